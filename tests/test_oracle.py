@@ -1,0 +1,155 @@
+"""CPU tests: the fp32 restatement (oracle/restatement.py) against (a) the vectors produced by the
+reference's own utils/model.py (tests/golden/model_utils_ref.npz), (b) independent float64 loop
+derivations (oracle/f64_loops.py), (c) SURVEY Appendix A/B structural facts."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import f64_loops as L
+from oracle import restatement as R
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.fixture(scope="module")
+def ref(golden_dir):
+    return np.load(os.path.join(golden_dir, "model_utils_ref.npz"))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_get_coord_matches_reference_file(ref, tag):
+    shape = tuple(ref["coord_%s_shape" % tag]); seed = int(ref["coord_%s_seed" % tag])
+    x = (np.random.RandomState(seed).randn(*shape) * float(ref["coord_%s_scale" % tag])).astype(np.float32)
+    xt = torch.from_numpy(x)
+    gy, yprob = R.get_coord(xt, 2, shape[1])
+    gx, xprob = R.get_coord(xt, 1, shape[2])
+    mu = torch.stack([gx, gy], dim=2).numpy()
+    # tolerance: abs 1e-6 on key-points in [-1,1] ("bit-pattern-close")
+    np.testing.assert_allclose(mu, ref["coord_%s_mu" % tag], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(yprob.numpy(), ref["coord_%s_yprob" % tag], atol=1e-7, rtol=1e-5)
+    np.testing.assert_allclose(xprob.numpy(), ref["coord_%s_xprob" % tag], atol=1e-7, rtol=1e-5)
+    np.testing.assert_allclose(mu, L.get_coord_xy(x), atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("tag", ["lo", "hi", "rect"])
+def test_gaussian_maps_match_reference_file(ref, tag):
+    mu = ref["gauss_%s_mu" % tag]; hw = [int(v) for v in ref["gauss_%s_hw" % tag]]
+    got = R.get_gaussian_maps(torch.from_numpy(mu), hw).numpy()
+    assert got.shape == ref["gauss_%s_map" % tag].shape           # [B,H,W,K]
+    np.testing.assert_allclose(got, ref["gauss_%s_map" % tag], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(got, L.gaussian_maps(mu, hw[0], hw[1]), atol=5e-6, rtol=1e-4)
+
+
+def test_n_iterations_reference_cases(ref):
+    import math
+    for total, bs, want in ref["n_iterations_cases"]:
+        assert math.ceil(total / bs) == want
+
+
+def test_same_pad_table():
+    for (n, k, s, pad), (before, after, out) in L.same_pad_table().items():
+        assert R.same_pad(n + 2 * pad, k, s) == (before, after, out)
+
+
+@pytest.mark.parametrize("h,w,cin,cout,k,s,pad", [
+    (8, 8, 5, 7, 3, 1, 0), (8, 8, 5, 7, 3, 2, 0), (9, 7, 4, 6, 3, 2, 0), (10, 10, 3, 8, 7, 1, 0),
+    (6, 6, 4, 3, 1, 1, 0), (12, 12, 3, 5, 4, 2, 1), (9, 9, 4, 5, 4, 2, 1), (4, 4, 6, 1, 3, 1, 1)])
+def test_conv_vs_f64_loops(h, w, cin, cout, k, s, pad):
+    rs = np.random.RandomState(h * 100 + k)
+    x = rs.randn(2, h, w, cin).astype(np.float32)
+    wt = rs.randn(k, k, cin, cout).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32)
+    got = R.conv(torch.from_numpy(x), torch.from_numpy(wt), torch.from_numpy(b), s, pad).numpy()
+    want = L.conv_same(x, wt, b, s, pad)
+    assert got.shape == want.shape
+    assert rel_l2(got, want) < 1e-6
+
+
+def test_bn_resize_pool_xent_vs_f64():
+    rs = np.random.RandomState(3)
+    x = rs.randn(3, 6, 5, 4).astype(np.float32) * 2 + 1
+    g = rs.rand(4).astype(np.float32) + 0.5; b = rs.randn(4).astype(np.float32)
+    y, mean, var = R.batch_norm_train(torch.from_numpy(x), torch.from_numpy(g), torch.from_numpy(b))
+    y64, m64, v64 = L.batch_norm_train(x, g, b)
+    assert rel_l2(y.numpy(), y64) < 1e-6 and rel_l2(mean.numpy(), m64) < 1e-6 and rel_l2(var.numpy(), v64) < 1e-6
+    mm, mv = R.moving_update(torch.zeros(4), torch.ones(4), mean, var, 90)
+    np.testing.assert_allclose(mm.numpy(), 0.001 * m64, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(mv.numpy(), 1 - 0.001 * (1 - v64 * 90 / 89), rtol=1e-5)
+    assert rel_l2(R.resize2x(torch.from_numpy(x)).numpy(), L.resize2x(x)) < 1e-7
+    xe = rs.randn(2, 6, 8, 3).astype(np.float32)
+    got = torch.nn.functional.max_pool2d(torch.from_numpy(xe).permute(0, 3, 1, 2), 2, 2, ceil_mode=True).permute(0, 2, 3, 1)
+    assert rel_l2(got.numpy(), L.maxpool2(xe)) == 0
+    z = rs.randn(50).astype(np.float32) * 4
+    for lab in (0.0, 1.0):
+        assert rel_l2(R.sigmoid_xent(torch.from_numpy(z), lab).numpy(), L.sigmoid_xent(z, lab)) < 1e-6
+
+
+def test_adam_and_lr_vs_f64():
+    rs = np.random.RandomState(5)
+    p0 = rs.randn(64).astype(np.float32)
+    params = {"w": torch.from_numpy(p0.copy())}
+    opt = R.AdamTF(["w"], params)
+    p64, m64, v64 = p0.astype(np.float64), np.zeros(64), np.zeros(64)
+    for t in range(1, 4):
+        g = rs.randn(64).astype(np.float32) * 0.1
+        opt.step(params, {"w": torch.from_numpy(g)}, 1e-4)
+        p64, m64, v64 = L.adam_tf(p64, g, m64, v64, t, 1e-4)
+        assert rel_l2(params["w"].numpy(), p64) < 1e-6
+        assert np.max(np.abs(params["w"].numpy() - p64)) < 6e-7   # 2 ulp at |p|~2.4
+    for step, want in ((0, 1e-4), (1, 1e-4 * 0.95 ** (1 / 20000)), (20000, 0.95e-4), (50000, 1e-4 * 0.95 ** 2.5)):
+        assert abs(float(R.exponential_decay(1e-4, step, 20000, 0.95)) - want) / want < 1e-6
+
+
+def test_manifest_counts_match_survey_appendix():
+    man = R.variable_manifest(15)
+    train = {n: s for n, s in man.items() if "moving_" not in n}
+    g = sum(int(np.prod(s)) for n, s in train.items() if "img_discr" not in n)
+    d = sum(int(np.prod(s)) for n, s in train.items() if "img_discr" in n)
+    assert g == 6419107 and d == 44721088          # SURVEY Appendix A totals (6.419 M / 44.721 M)
+    assert man["translator/conv_1_0/conv2d/kernel"] == (3, 3, 158, 256)
+    assert man["pose_encoder/conv_0/conv2d/kernel"] == (1, 1, 16, 15)
+    assert man["img_discr/D_logit/conv2d/kernel"] == (3, 3, 2048, 1)
+    assert "img_discr/D_logit/conv2d/bias" not in man
+    assert man["pose_encoder/conv_7_0/conv2d/kernel"] == (3, 3, 64, 16)
+
+
+def test_forward_shapes_and_discriminator_geometry():
+    torch.manual_seed(0)
+    v = R.init_variables(3, res=32)
+    net = R.Net({k: torch.from_numpy(a) for k, a in v.items()})
+    im, fut = R.synthetic_pair(2, res=32)
+    out = R.forward_pass(net, torch.from_numpy(im), torch.from_numpy(fut))
+    assert out["final_output"].shape == (2, 32, 32, 3) and out["mask"].shape == (2, 32, 32, 1)
+    assert out["current_points"].shape == (2, 3, 2) and out["current_map_lo"].shape == (2, 8, 8, 3)
+    assert out["current_keypoints_map"].shape == (2, 32, 32, 3)
+    # 128 -> 65 -> 34 -> 18 -> 10 -> 6 -> 4 -> logits 6x6
+    v128 = {k: torch.from_numpy(a) for k, a in R.init_variables(3, res=128).items() if k.startswith("img_discr")}
+    x = torch.zeros(1, 128, 128, 3)
+    sizes = []
+    for i in range(6):
+        x = R.conv(x, v128["img_discr/conv_%d/conv2d/kernel" % i], v128["img_discr/conv_%d/conv2d/bias" % i], 2, 1)
+        sizes.append(x.shape[1])
+    assert sizes == [65, 34, 18, 10, 6, 4]
+    assert R.conv(x, v128["img_discr/D_logit/conv2d/kernel"], None, 1, 1).shape == (1, 6, 6, 1)
+
+
+def test_tiny_e2e_golden(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "tiny_e2e_oracle.npz"))
+    torch.set_num_threads(1)
+    res, k, b = int(gold["res"]), int(gold["n_pts"]), int(gold["batch"])
+    st = R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=8))
+    im, fut = R.synthetic_pair(b, res=res)
+    r = R.train_step(st, im, fut)
+    assert abs(r["loss_D"] - float(gold["loss_D"])) < 1e-5
+    assert abs(r["loss_G"] - float(gold["loss_G"])) < 1e-4 * abs(float(gold["loss_G"]))
+    assert rel_l2(r["final_output"].numpy(), gold["final_output"]) < 1e-5
+    np.testing.assert_allclose(r["current_points"].numpy(), gold["current_points"], atol=1e-6)
+    g = {**r["grads_D"], **r["grads_G"]}
+    l2 = np.array([float(g[n].double().norm()) for n in gold["grad_names"]])
+    big = gold["grad_l2"] > 1e-6
+    np.testing.assert_allclose(l2[big], gold["grad_l2"][big], rtol=2e-3)
