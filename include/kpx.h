@@ -1,0 +1,150 @@
+/*
+ * kpx.h -- C ABI of libkpx_hip.so: the MI355X (gfx950) kernels behind the detector_translator
+ * per-frame hot path.
+ *
+ * The reference (YunjiKim/Unsupervised-Keypoint-Learning-...) has no FFI / custom-op boundary: its
+ * arithmetic is TensorFlow-1.12 ops called from Python.  Each entry point below therefore names the
+ * reference call site(s) (file:line under /root/reference) whose TF op it replaces.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers + sizes, no torch / C++ types; every pointer is DEVICE memory owned by the caller
+ *     (the library never allocates, frees or keeps global state);
+ *   - tensors are float32 NHWC; conv kernels HWIO [kh][kw][Cin][Cout]; "ld*" = pixel stride in floats
+ *     (>= channel count) so that producers can write into / consumers read from channel slices of a wider
+ *     buffer (this is how tf.concat(axis=-1) is realised without a copy);
+ *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return 0 on success, KPX_EINVAL (-1) for a bad argument, or -(hipError_t) if the launch failed;
+ *     nothing throws across the ABI; re-entrant, callable from any host thread.
+ */
+#ifndef KPX_H
+#define KPX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KPX_EINVAL (-1)
+#define KPX_ABI_VERSION 1
+
+enum { KPX_ACT_NONE = 0, KPX_ACT_RELU = 1, KPX_ACT_LRELU = 2 /* slope 0.01 */ };
+
+int kpx_abi_version(void);
+
+/* ---- convolution: replaces tf.pad + tf.layers.conv2d(padding='same') (models/networks/layers.py:6-9)
+ *      and tf.nn.conv2d + bias_add + relu (models/networks/vgg.py:51-54).
+ *      y[n,oh,ow,:] = act( sum_{r,q,c} x[n, oh*stride + r - pad_t, ow*stride + q - pad_l, c] * w[r,q,c,:] + bias )
+ *      pad_t/pad_l are the TOTAL top/left padding (explicit tf.pad + TF's SAME split, decided by the caller);
+ *      bottom/right padding is implied by Ho/Wo.  bias may be NULL.  fp32 MFMA implicit GEMM. */
+int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
+                       const float* w_hwio, int KH, int KW, const float* bias,
+                       float* y, int Ho, int Wo, int Cout, int ldy,
+                       int stride, int pad_t, int pad_l, int act, void* stream);
+
+/* dx = d(loss)/dx given dy (gradient of the conv output BEFORE activation).  Writes every element of dx. */
+int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int Cout, int lddy,
+                         const float* w_hwio, int KH, int KW,
+                         float* dx, int Hi, int Wi, int Cin, int lddx,
+                         int stride, int pad_t, int pad_l, void* stream);
+
+/* dw[r,q,c,k] = sum_{n,oh,ow} x[n, oh*s+r-pad_t, ow*s+q-pad_l, c] * dy[n,oh,ow,k].
+ * `workspace` holds split-K partial slabs; query its size with kpx_conv2d_wgrad_workspace_bytes. */
+size_t kpx_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
+int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
+                         const float* dy, int Ho, int Wo, int Cout, int lddy,
+                         float* dw_hwio, int KH, int KW, int stride, int pad_t, int pad_l,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* dy *= act'(y) in place (y = the activated conv output): relu / leaky_relu(0.01) backward
+ * (tf.nn.relu vgg.py:54, tf.nn.leaky_relu networks/__init__.py:145,148). */
+int kpx_act_bwd_f32(float* dy, const float* y, size_t n, int act, void* stream);
+
+/* ---- per-channel reductions over P pixels: sum[c] = sum_p x[p,c] (double accumulation).
+ *      Used for the conv bias gradient (tf.layers.conv2d use_bias, layers.py:9).
+ *      `scratch` (also for kpx_bn_stats_f32 / kpx_bn_bwd_f32) needs kpx_chan_reduce_scratch_bytes(C) bytes. */
+size_t kpx_chan_reduce_scratch_bytes(int C);
+int kpx_chan_sum_f32(const float* x, size_t P, int C, int ldx, float* sum_out, void* scratch, void* stream);
+
+/* ---- batch norm: replaces tf.contrib.layers.batch_norm(eps=1e-5, center, scale) (layers.py:13-14).
+ * train forward, step 1: batch mean / biased variance over P pixels (fp64 accumulation) ->
+ *   mean[C], invstd[C] = rsqrt(var+eps); if moving_mean/moving_var != NULL they are updated in place with
+ *   decay (TF fused-BN rule: unbiased variance, moving -= (moving-batch)*(1-decay)). */
+int kpx_bn_stats_f32(const float* x, size_t P, int C, int ldx, float eps,
+                     float* mean, float* invstd, float* var_biased,
+                     float* moving_mean, float* moving_var, float decay,
+                     void* scratch, void* stream);
+/* invstd[c] = rsqrt(moving_var[c]+eps) for inference-mode BN (models/keypoint_model.py:48-50). */
+int kpx_bn_invstd_f32(const float* var, int C, float eps, float* invstd, void* stream);
+/* step 2: y = act((x-mean)*invstd*gamma + beta), act in {NONE, RELU} (tf.nn.relu networks/__init__.py:12...). */
+int kpx_bn_apply_f32(const float* x, size_t P, int C, int ldx, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, float* y, int ldy, int act, void* stream);
+/* backward of y = act(BN_train(x)): dx, dgamma, dbeta from dy (gradient wrt y) and the saved x, mean, invstd. */
+int kpx_bn_bwd_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int C,
+                   const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                   float* dx, int lddx, float* dgamma, float* dbeta, void* scratch, void* stream);
+
+/* ---- tf.image.resize_images(x, 2x) legacy bilinear (models/networks/__init__.py:63,98). */
+int kpx_resize2x_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, void* stream);
+int kpx_resize2x_bwd_f32(const float* dy, int N, int H, int W, int C, int lddy, float* dx, int lddx, void* stream);
+
+/* ---- channel-slice copy: one half of tf.concat(axis=-1) (networks/__init__.py:44, detector_translator_model.py:170). */
+int kpx_copy_channels_f32(const float* src, int ldsrc, float* dst, int lddst, size_t P, int C, void* stream);
+
+/* ---- key-point head: model_utils.get_coord twice + tf.stack (utils/model.py:63-70, networks/__init__.py:68-72).
+ * logits [B,H,W,K] -> mu [B,K,2] (x,y) in [-1,1]; also the two softmax profiles prob_y [B,H,K], prob_x [B,W,K].
+ * scratch: kpx_keypoint_head_scratch_bytes(B,H,W,K). */
+size_t kpx_keypoint_head_scratch_bytes(int B, int H, int W, int K);
+int kpx_keypoint_head_fwd_f32(const float* logits, int B, int H, int W, int K,
+                              float* mu, float* prob_y, float* prob_x, void* scratch, void* stream);
+int kpx_keypoint_head_bwd_f32(const float* dmu, const float* mu, const float* prob_y, const float* prob_x,
+                              int B, int H, int W, int K, float* dlogits, void* stream);
+
+/* ---- Gaussian heat-map render: model_utils.get_gaussian_maps (utils/model.py:49-60).
+ * mu [B,K,2] (x,y) -> maps [B,H,W,K] written with pixel stride ldy (NHWC directly; no BKHW transpose pass). */
+int kpx_gaussian_maps_fwd_f32(const float* mu, int B, int K, int H, int W, double inv_std, float* maps, int ldy, void* stream);
+int kpx_gaussian_maps_bwd_f32(const float* dmaps, int lddy, const float* mu, int B, int K, int H, int W, double inv_std,
+                              float* dmu, void* stream);
+
+/* ---- translator heads + blend: mask = sigmoid(raw[...,3]); final = im*mask + crude*(1-mask)
+ *      (networks/__init__.py:87-89, detector_translator_model.py:174).  raw4 [P,4] = crude(3) ‖ mask logit(1). */
+int kpx_head_blend_fwd_f32(const float* im, const float* raw4, size_t P, float* final_out, float* crude_out, float* mask_out, void* stream);
+int kpx_head_blend_bwd_f32(const float* dfinal, const float* im, const float* raw4, size_t P, float* draw4, void* stream);
+
+/* ---- VGG input transform: rgb in [-1,1] -> (x+1)/2*255 -> BGR - mean
+ *      (detector_translator_model.py:262-263, vgg.py:16-19). */
+int kpx_vgg_prep_fwd_f32(const float* rgb, size_t P, float* bgr, void* stream);
+int kpx_vgg_prep_bwd_f32(const float* dbgr, size_t P, float* drgb, void* stream);
+
+/* ---- tf.nn.max_pool 2x2 s2 SAME (vgg.py:45-46). */
+int kpx_maxpool2_fwd_f32(const float* x, int N, int H, int W, int C, float* y, void* stream);
+int kpx_maxpool2_bwd_f32(const float* dy, const float* x, int N, int H, int W, int C, float* dx, void* stream);
+
+/* ---- perceptual L1 term: loss = mean|f[0:half] - f[half:2*half]| (detector_translator_model.py:280-284).
+ * fwd writes one float; bwd writes d/d f_pred (second half only) = -sign(gt-pred) * g,
+ * g = gscale_host * (gscale_dev ? *gscale_dev : 1).  scratch >= 8 KiB. */
+int kpx_l1_pair_fwd_f32(const float* f, size_t half, float* loss_out, void* scratch, void* stream);
+int kpx_l1_pair_bwd_f32(const float* f, size_t half, const float* gscale_dev, float gscale_host, float* dpred, void* stream);
+
+/* ---- tf.nn.sigmoid_cross_entropy_with_logits + reduce_mean (detector_translator_model.py:249-254,265-267).
+ * labels: the first n0 logits get label0, the next n1 get label1 (n1 may be 0).
+ * loss_out[3] = { mean(group0) + mean(group1), mean(group0), mean(group1) }.
+ * bwd: dlogits = (sigmoid(x) - label) * g / n_group, g = gscale_host * (gscale_dev ? *gscale_dev : 1). */
+int kpx_sigmoid_xent_fwd_f32(const float* logits, size_t n0, float label0, size_t n1, float label1, float* loss_out, void* stream);
+int kpx_sigmoid_xent_bwd_f32(const float* logits, size_t n0, float label0, size_t n1, float label1,
+                             const float* gscale_dev, float gscale_host, float* dlogits, void* stream);
+
+/* ---- tf.train.AdamOptimizer.apply (detector_translator_model.py:198-202) over one flat bucket.
+ * alpha = lr*sqrt(1-b2^t)/(1-b1^t) (host); g is pre-scaled by gscale (1/world_size for DP). */
+int kpx_adam_tf_flat_f32(float* p, const float* g, float* m, float* v, size_t n,
+                         float alpha, float beta1, float beta2, float eps, float gscale, void* stream);
+
+/* ---- utilities */
+int kpx_fill_f32(float* p, size_t n, float value, void* stream);
+int kpx_axpy_f32(float* y, const float* x, size_t n, float a, void* stream);   /* y += a*x (gradient accumulation) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KPX_H */

@@ -1,0 +1,105 @@
+"""GPU end-to-end parity: the detector_translator forward and full train step (HIP, through the C ABI) against the CPU
+oracle on identical seeded inputs and weights.  Tolerances: frames / losses rel 1e-4 (north-star bar), key-points abs
+1e-5 after the whole detector CNN, parameters after the Adam step abs 2e-6 (lr=1e-4: any sign flip of a ~0 gradient
+would show as 1e-4)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def make_model(res, k, b, dev, width_div=8, world=None):
+    import kpx_amd
+    cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': b},
+           'model': {'n_pts': k}, 'paths': {'log_dir': '/tmp/kpx_test', 'vggnet': None}}
+    vgg = kpx_amd.Vgg19(weights=kpx_amd.synthetic_vgg19_weights(seed=19, width_div=width_div), device=dev)
+    m = kpx_amd.DetectorTranslatorModel(cfg, device=dev, vgg=vgg, image_size=res)
+    m.build()
+    return m
+
+
+def test_tiny_train_steps_match_oracle():
+    dev = torch.device('cuda:0')
+    res, k, b = 32, 3, 2
+    model = make_model(res, k, b, dev)
+    st = R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=8))
+    # same initial weights by construction (same RandomState(1234) creation order)
+    exp = model.store.export_numpy()
+    for name, v in st.params.items():
+        assert np.array_equal(exp[name], v.numpy()), name
+    for step in range(2):
+        im, fut = R.synthetic_pair(b, res=res, seed0=10 + step, seed1=20 + step)
+        feed = {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}
+        model.train_step(None, feed, step, b)
+        got = model.loss_values()
+        want = R.train_step(st, im, fut)
+        for key in ('loss_D', 'loss_D_real', 'loss_D_fake', 'loss_G_recon', 'loss_G_adv', 'loss_G'):
+            assert abs(got[key] - want[key]) <= 1e-4 * max(1.0, abs(want[key])), (step, key, got[key], want[key])
+        fwd = model.last['fwd']
+        assert rel_l2(fwd['final_output'].cpu().numpy(), want['final_output'].numpy()) < 1e-4
+        np.testing.assert_allclose(fwd['current_points'].cpu().numpy(), want['current_points'].numpy(), atol=1e-5)
+        np.testing.assert_allclose(fwd['future_points'].cpu().numpy(), want['future_points'].numpy(), atol=1e-5)
+        # gradients (flat buckets still hold this step's G grads; D grads were taken before the G backward)
+        exp = model.store.export_numpy(include_slots=True)
+        for name, p in st.params.items():
+            assert np.max(np.abs(exp[name] - p.numpy())) < 2e-6 + 1e-5 * np.max(np.abs(p.numpy())), (step, name)
+        gnames = [n for n in want['grads_G'] if n.endswith('/kernel') and 'conv_6' not in n]
+        for n in gnames:
+            g = model.store.grad(n).cpu().numpy()
+            w = want['grads_G'][n].numpy()
+            if np.linalg.norm(w) > 1e-7:
+                assert rel_l2(g, w) < 2e-3, (step, n, rel_l2(g, w))
+    assert model.global_step == 2
+    assert abs(model.current_lr() - float(R.exponential_decay(1e-4, 2, 20000, 0.95))) < 1e-12
+
+
+def test_forward_128_k15_matches_oracle():
+    """BASELINE configs[0]-shaped forward (128x128, K=15) at B=2: key-points, heat-maps and frame."""
+    dev = torch.device('cuda:0')
+    res, k, b = 128, 15, 2
+    model = make_model(res, k, b, dev)
+    variables_np = R.init_variables(k, res=res, seed=1234)
+    net = R.Net({n: torch.from_numpy(a) for n, a in variables_np.items()}, train_mode=True)
+    im, fut = R.synthetic_pair(b, res=res)
+    torch.set_num_threads(os.cpu_count() or 1)
+    with torch.no_grad():
+        want = R.forward_pass(net, torch.from_numpy(im), torch.from_numpy(fut))
+    got = model.forward(torch.from_numpy(im).to(dev), torch.from_numpy(fut).to(dev), with_vis_maps=True)
+    np.testing.assert_allclose(got['current_points'].cpu().numpy(), want['current_points'].numpy(), atol=2e-5)
+    np.testing.assert_allclose(got['future_points'].cpu().numpy(), want['future_points'].numpy(), atol=2e-5)
+    assert rel_l2(got['current_keypoints_map'].cpu().numpy(), want['current_keypoints_map'].numpy()) < 1e-4
+    assert rel_l2(got['final_output'].cpu().numpy(), want['final_output'].numpy()) < 1e-4
+    assert rel_l2(got['mask'].cpu().numpy(), want['mask'].numpy()) < 1e-4
+    assert rel_l2(got['crude_output'].cpu().numpy(), want['crude_output'].numpy()) < 1e-4
+
+
+def test_checkpoint_roundtrip_uses_reference_names(tmp_path):
+    dev = torch.device('cuda:0')
+    model = make_model(32, 3, 2, dev)
+    model.initialize_loggers(str(tmp_path))
+    im, fut = R.synthetic_pair(2, res=32)
+    feed = {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}
+    model.train_step(None, feed, 0, 2)
+    path = model.save_checkpoint(None, 1)
+    assert path.endswith(os.path.join('detector_translator', 'model.ckpt-1.npz'))
+    arrays = model.checkpoint_arrays()
+    for name in ('global_step', 'beta1_power', 'beta2_power_1', 'translator/conv_6_0/conv2d/kernel', 'translator/conv_6_1/conv2d/bias',
+                 'pose_encoder/conv_0/conv2d/kernel', 'img_discr/D_logit/conv2d/kernel/Adam_1', 'image_encoder/encoder/b_norm_8/moving_variance'):
+        assert name in arrays, name
+    assert arrays['translator/conv_6_0/conv2d/kernel'].shape == (3, 3, 64, 3)
+    assert arrays['translator/conv_6_1/conv2d/kernel'].shape == (3, 3, 64, 1)
+    m2 = make_model(32, 3, 2, dev)
+    m2.restore(None, path)
+    a2 = m2.checkpoint_arrays()
+    for k_, v in arrays.items():
+        assert np.array_equal(np.asarray(v), np.asarray(a2[k_])), k_

@@ -1,0 +1,255 @@
+"""GPU parity tests: every HIP op (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances (stated here once): conv / features / frames rel-L2 <= 1e-5 (north-star bar is 1e-4); gradients rel-L2 <= 1e-4;
+key-points abs <= 2e-6 and heat-maps abs <= 2e-6 ("bit-pattern-close": the reduction order differs from numpy's).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def kpx():
+    import kpx_amd
+    return kpx_amd
+
+
+@pytest.fixture(scope='module')
+def dev():
+    return torch.device('cuda:0')
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, pad, act
+    (2, 16, 16, 32, 64, 3, 1, 0, 0),
+    (2, 16, 16, 32, 64, 3, 2, 0, 0),       # SAME pad (0,1)
+    (2, 17, 13, 16, 32, 3, 2, 0, 1),       # odd sizes, relu epilogue
+    (2, 32, 32, 3, 32, 7, 1, 0, 0),        # encoder conv_1
+    (2, 32, 32, 16, 15, 1, 1, 0, 0),       # 1x1 head, Cout=15
+    (2, 32, 32, 3, 64, 4, 2, 1, 2),        # img_discr conv_0 (pad 1 + SAME), lrelu
+    (2, 65, 65, 8, 16, 4, 2, 1, 2),        # img_discr conv_1 geometry: SAME (1,2)
+    (2, 4, 4, 64, 1, 3, 1, 1, 0),          # D_logit: 4 -> 6
+    (3, 8, 8, 158, 256, 3, 1, 0, 0),       # translator conv_1_0 channel count
+    (2, 8, 8, 256, 128, 3, 1, 0, 0),
+    (1, 32, 32, 64, 4, 3, 1, 0, 0),        # fused crude+mask head
+    (5, 9, 9, 130, 130, 3, 1, 0, 0),       # ragged channel tiles
+    (64, 4, 4, 128, 256, 4, 2, 1, 2),      # small-M / wide-N tile path
+]
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,k,s,pad,act', CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(kpx, dev, n, h, w, cin, cout, k, s, pad, act):
+    rs = np.random.RandomState(cin * 7 + cout)
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    wt = (rs.randn(k, k, cin, cout) / np.sqrt(k * k * cin)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32)
+    # oracle (+ autograd)
+    xo = torch.from_numpy(x).requires_grad_(True); wo = torch.from_numpy(wt).requires_grad_(True); bo = torch.from_numpy(b).requires_grad_(True)
+    yo = R.conv(xo, wo, bo, s, pad)
+    if act == 1: yo = torch.relu(yo)
+    if act == 2: yo = torch.nn.functional.leaky_relu(yo, 0.01)
+    gy = rs.randn(*yo.shape).astype(np.float32)
+    yo.backward(torch.from_numpy(gy))
+    # HIP
+    xg = torch.from_numpy(x).to(dev).requires_grad_(True); wg = torch.from_numpy(wt).to(dev).requires_grad_(True); bg = torch.from_numpy(b).to(dev).requires_grad_(True)
+    yg = kpx.ops.conv2d(xg, wg, bg, stride=s, pad=pad, act=act)
+    assert tuple(yg.shape) == tuple(yo.shape)
+    assert rel_l2(t2n(yg), t2n(yo)) < 1e-5
+    yg.backward(torch.from_numpy(gy).to(dev))
+    assert rel_l2(t2n(xg.grad), t2n(xo.grad)) < 1e-5
+    assert rel_l2(t2n(wg.grad), t2n(wo.grad)) < 1e-5
+    assert rel_l2(t2n(bg.grad), t2n(bo.grad)) < 1e-5
+
+
+def test_conv_reads_and_writes_channel_slices(kpx, dev):
+    rs = np.random.RandomState(0)
+    full = rs.randn(2, 8, 8, 160).astype(np.float32)
+    wt = (rs.randn(3, 3, 158, 32) * 0.05).astype(np.float32)
+    want = R.conv(torch.from_numpy(full[..., :158].copy()), torch.from_numpy(wt), None, 1)
+    got = kpx.ops.conv2d(torch.from_numpy(full).to(dev), torch.from_numpy(wt).to(dev), None, stride=1, cin=158)
+    assert rel_l2(t2n(got), t2n(want)) < 1e-5
+    sl = torch.from_numpy(full).to(dev)[..., 16:48]          # a strided channel slice as input
+    w2 = (rs.randn(3, 3, 32, 16) * 0.1).astype(np.float32)
+    want2 = R.conv(torch.from_numpy(full[..., 16:48].copy()), torch.from_numpy(w2), None, 1)
+    got2 = kpx.ops.conv2d(sl, torch.from_numpy(w2).to(dev), None, stride=1)
+    assert rel_l2(t2n(got2), t2n(want2)) < 1e-5
+
+
+@pytest.mark.parametrize('groups', [1, 2])
+def test_batch_norm_train_fwd_bwd_and_moving(kpx, dev, groups):
+    rs = np.random.RandomState(groups)
+    n, h, w, c = 4, 9, 7, 32
+    x = (rs.randn(n, h, w, c) * 2 + 0.5).astype(np.float32)
+    g = (rs.rand(c) + 0.5).astype(np.float32); b = rs.randn(c).astype(np.float32)
+    gy = rs.randn(n, h, w, c).astype(np.float32)
+    xo = torch.from_numpy(x).requires_grad_(True); go = torch.from_numpy(g).requires_grad_(True); bo = torch.from_numpy(b).requires_grad_(True)
+    ng = n // groups
+    ys, stats = [], []
+    for i in range(groups):
+        y, mean, var = R.batch_norm_train(xo[i * ng:(i + 1) * ng], go, bo)
+        ys.append(torch.relu(y)); stats.append((mean.detach(), var.detach()))
+    yo = torch.cat(ys, 0)
+    yo.backward(torch.from_numpy(gy))
+    mm, mv = torch.zeros(c), torch.ones(c)
+    for mean, var in stats:
+        mm, mv = R.moving_update(mm, mv, mean, var, ng * h * w)
+    xg = torch.from_numpy(x).to(dev).requires_grad_(True); gg = torch.from_numpy(g).to(dev).requires_grad_(True); bg = torch.from_numpy(b).to(dev).requires_grad_(True)
+    mmg, mvg = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    yg = kpx.ops.batch_norm(xg, gg, bg, mmg, mvg, train=True, act=1, groups=groups)
+    assert rel_l2(t2n(yg), t2n(yo)) < 1e-5
+    yg.backward(torch.from_numpy(gy).to(dev))
+    assert rel_l2(t2n(xg.grad), t2n(xo.grad)) < 1e-4
+    assert rel_l2(t2n(gg.grad), t2n(go.grad)) < 1e-5
+    assert rel_l2(t2n(bg.grad), t2n(bo.grad)) < 1e-5
+    np.testing.assert_allclose(t2n(mmg), mm.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(t2n(mvg), mv.numpy(), rtol=1e-6)
+    # inference mode uses the moving statistics
+    yi = kpx.ops.batch_norm(xg.detach(), gg.detach(), bg.detach(), mmg, mvg, train=False, act=0)
+    want = R.batch_norm_infer(torch.from_numpy(x), torch.from_numpy(g), torch.from_numpy(b), torch.from_numpy(t2n(mmg)), torch.from_numpy(t2n(mvg)))
+    assert rel_l2(t2n(yi), t2n(want)) < 1e-5
+
+
+def test_upsample_concat_fwd_bwd(kpx, dev):
+    rs = np.random.RandomState(4)
+    x = rs.randn(2, 5, 7, 16).astype(np.float32); sk = rs.randn(2, 10, 14, 8).astype(np.float32)
+    xo = torch.from_numpy(x).requires_grad_(True); so = torch.from_numpy(sk).requires_grad_(True)
+    yo = torch.cat([R.resize2x(xo), so], dim=-1)
+    gy = rs.randn(*yo.shape).astype(np.float32)
+    yo.backward(torch.from_numpy(gy))
+    xg = torch.from_numpy(x).to(dev).requires_grad_(True); sg = torch.from_numpy(sk).to(dev).requires_grad_(True)
+    yg = kpx.ops.upsample2x_concat(xg, sg)
+    assert rel_l2(t2n(yg), t2n(yo)) < 1e-7
+    yg.backward(torch.from_numpy(gy).to(dev))
+    assert rel_l2(t2n(xg.grad), t2n(xo.grad)) < 1e-6
+    assert rel_l2(t2n(sg.grad), t2n(so.grad)) == 0.0
+    y1 = kpx.ops.upsample2x_concat(torch.from_numpy(x).to(dev), None)
+    assert rel_l2(t2n(y1), t2n(R.resize2x(torch.from_numpy(x)))) < 1e-7
+
+
+@pytest.mark.parametrize('shape,scale', [((2, 128, 128, 15), 3.0), ((1, 24, 40, 5), 10.0), ((3, 32, 32, 40), 1.0)])
+def test_keypoint_head_fwd_bwd(kpx, dev, shape, scale):
+    rs = np.random.RandomState(shape[1])
+    x = (rs.randn(*shape) * scale).astype(np.float32)
+    xo = torch.from_numpy(x).requires_grad_(True)
+    gy, _ = R.get_coord(xo, 2, shape[1]); gx, _ = R.get_coord(xo, 1, shape[2])
+    muo = torch.stack([gx, gy], dim=2)
+    gm = rs.randn(*muo.shape).astype(np.float32)
+    muo.backward(torch.from_numpy(gm))
+    xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+    mug, py, px = kpx.ops.keypoint_head(xg)
+    np.testing.assert_allclose(t2n(mug), t2n(muo), atol=2e-6, rtol=0)
+    mug.backward(torch.from_numpy(gm).to(dev))
+    assert rel_l2(t2n(xg.grad), t2n(xo.grad)) < 1e-4
+
+
+def test_keypoint_head_and_renderer_match_reference_golden(kpx, dev, golden_dir):
+    ref = np.load(os.path.join(golden_dir, 'model_utils_ref.npz'))
+    for tag in ('a', 'b'):
+        shape = tuple(ref['coord_%s_shape' % tag]); seed = int(ref['coord_%s_seed' % tag])
+        x = (np.random.RandomState(seed).randn(*shape) * float(ref['coord_%s_scale' % tag])).astype(np.float32)
+        mu, py, px = kpx.ops.keypoint_head(torch.from_numpy(x).to(dev))
+        np.testing.assert_allclose(t2n(mu), ref['coord_%s_mu' % tag], atol=2e-6, rtol=0)
+        np.testing.assert_allclose(t2n(py), ref['coord_%s_yprob' % tag], atol=1e-7, rtol=2e-5)
+        np.testing.assert_allclose(t2n(px), ref['coord_%s_xprob' % tag], atol=1e-7, rtol=2e-5)
+        gy, _ = kpx.model_utils.get_coord(torch.from_numpy(x).to(dev), 2, shape[1])
+        np.testing.assert_allclose(t2n(gy), ref['coord_%s_mu' % tag][:, :, 1], atol=2e-6, rtol=0)
+    for tag in ('lo', 'hi', 'rect'):
+        mu = ref['gauss_%s_mu' % tag]; hw = [int(v) for v in ref['gauss_%s_hw' % tag]]
+        got = kpx.model_utils.get_gaussian_maps(torch.from_numpy(mu).to(dev), hw)
+        np.testing.assert_allclose(t2n(got), ref['gauss_%s_map' % tag], atol=2e-6, rtol=2e-5)
+
+
+def test_gaussian_maps_bwd_and_joint_embedding(kpx, dev):
+    rs = np.random.RandomState(9)
+    b, k, hh, c = 2, 15, 32, 128
+    cur = rs.uniform(-0.9, 0.9, (b, k, 2)).astype(np.float32); fut = rs.uniform(-0.9, 0.9, (b, k, 2)).astype(np.float32)
+    emb = rs.randn(b, hh, hh, c).astype(np.float32)
+    co = torch.from_numpy(cur).requires_grad_(True); fo = torch.from_numpy(fut).requires_grad_(True); eo = torch.from_numpy(emb).requires_grad_(True)
+    jo = torch.cat([eo, R.get_gaussian_maps(co, [hh, hh]), R.get_gaussian_maps(fo, [hh, hh])], dim=-1)
+    gy = rs.randn(b, hh, hh, 160).astype(np.float32)
+    jo.backward(torch.from_numpy(gy[..., :158].copy()))
+    cg = torch.from_numpy(cur).to(dev).requires_grad_(True); fg = torch.from_numpy(fut).to(dev).requires_grad_(True); eg = torch.from_numpy(emb).to(dev).requires_grad_(True)
+    jg = kpx.ops.joint_embedding(eg, cg, fg)
+    assert tuple(jg.shape) == (b, hh, hh, 160)
+    np.testing.assert_allclose(t2n(jg)[..., :158], t2n(jo), atol=2e-6, rtol=2e-5)
+    assert float(jg[..., 158:].abs().max()) == 0.0
+    jg.backward(torch.from_numpy(gy).to(dev))
+    assert rel_l2(t2n(cg.grad), t2n(co.grad)) < 1e-4
+    assert rel_l2(t2n(fg.grad), t2n(fo.grad)) < 1e-4
+    assert rel_l2(t2n(eg.grad), t2n(eo.grad)) == 0.0
+
+
+def test_head_blend_xent_adam(kpx, dev):
+    rs = np.random.RandomState(2)
+    im = rs.uniform(-1, 1, (2, 8, 8, 3)).astype(np.float32); raw = rs.randn(2, 8, 8, 4).astype(np.float32)
+    ro = torch.from_numpy(raw).requires_grad_(True)
+    mask = torch.sigmoid(ro[..., 3:]); fo = torch.from_numpy(im) * mask + ro[..., :3] * (1 - mask)
+    gy = rs.randn(2, 8, 8, 3).astype(np.float32)
+    fo.backward(torch.from_numpy(gy))
+    rg = torch.from_numpy(raw).to(dev).requires_grad_(True)
+    fg, crude, mk = kpx.ops.head_blend(torch.from_numpy(im).to(dev), rg)
+    assert rel_l2(t2n(fg), t2n(fo)) < 1e-6 and rel_l2(t2n(mk), t2n(mask)) < 1e-6
+    fg.backward(torch.from_numpy(gy).to(dev))
+    assert rel_l2(t2n(rg.grad), t2n(ro.grad)) < 1e-5
+    # sigmoid xent, two label groups
+    z = (rs.randn(144) * 3).astype(np.float32)
+    zo = torch.from_numpy(z).requires_grad_(True)
+    lo = R.sigmoid_xent(zo[:72], 1.0).mean() + R.sigmoid_xent(zo[72:], 0.0).mean()
+    lo.backward()
+    zg = torch.from_numpy(z).to(dev).requires_grad_(True)
+    lg = kpx.ops.sigmoid_xent(zg, 72, 1.0, 72, 0.0)
+    assert abs(float(lg[0]) - float(lo)) < 1e-6
+    torch.autograd.backward([lg], [torch.tensor([1.0, 0.0, 0.0], device=dev)])
+    assert rel_l2(t2n(zg.grad), t2n(zo.grad)) < 1e-6
+    # Adam: 3 steps against the oracle's ApplyAdam restatement
+    n = 1003
+    p0 = rs.randn(n).astype(np.float32)
+    params = {'w': torch.from_numpy(p0.copy())}
+    opt = R.AdamTF(['w'], params)
+    pad = (n + 3) // 4 * 4
+    p = torch.zeros(pad, device=dev); p[:n] = torch.from_numpy(p0).to(dev)
+    m = torch.zeros(pad, device=dev); v = torch.zeros(pad, device=dev)
+    b1p, b2p = np.float32(0.5), np.float32(0.999)
+    for _ in range(3):
+        g = (rs.randn(n) * 0.1).astype(np.float32)
+        opt.step(params, {'w': torch.from_numpy(g)}, 1e-4)
+        gd = torch.zeros(pad, device=dev); gd[:n] = torch.from_numpy(g).to(dev)
+        alpha = np.float32(np.float32(1e-4) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p))
+        kpx.ops.adam_tf_flat_(p, gd, m, v, alpha, 0.5, 0.999, 1e-8)
+        b1p, b2p = np.float32(b1p * np.float32(0.5)), np.float32(b2p * np.float32(0.999))
+        np.testing.assert_allclose(t2n(p)[:n], params['w'].numpy(), atol=3e-7, rtol=0)
+
+
+def test_vgg_perceptual_loss_fwd_bwd(kpx, dev):
+    rs = np.random.RandomState(7)
+    vggw = kpx.synthetic_vgg19_weights(seed=19, width_div=8)
+    gt = rs.uniform(-1, 1, (2, 32, 32, 3)).astype(np.float32); pred = rs.uniform(-1, 1, (2, 32, 32, 3)).astype(np.float32)
+    vo = {k: (torch.from_numpy(w), torch.from_numpy(b)) for k, (w, b) in R.synthetic_vgg(seed=19, width_div=8).items()}
+    po = torch.from_numpy(pred).requires_grad_(True)
+    lo = R.perceptual_loss(vo, (torch.from_numpy(gt) + 1) / 2.0 * 255.0, (po + 1) / 2.0 * 255.0)
+    lo.backward()
+    vgg = kpx.Vgg19(weights=vggw, device=dev)
+    pg = torch.from_numpy(pred).to(dev).requires_grad_(True)
+    lg = vgg.perceptual_loss(torch.from_numpy(gt).to(dev), pg)
+    assert abs(float(lg[0]) - float(lo)) < 1e-5 * abs(float(lo))
+    lg.backward(torch.ones(1, device=dev))
+    assert rel_l2(t2n(pg.grad), t2n(po.grad)) < 1e-4
+    feats = vgg.build(torch.from_numpy(np.concatenate([gt, pred])).to(dev))
+    fo = R.vgg19(vo, (torch.from_numpy(np.concatenate([gt, pred])) + 1) / 2.0 * 255.0)
+    for a, b in zip(feats, fo):
+        assert rel_l2(t2n(a), t2n(b)) < 1e-5

@@ -1,0 +1,80 @@
+"""ctypes binding of libkpx_hip.so (C ABI: include/kpx.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this module raises at
+import time, and every op raises ``KpxError`` on a non-zero return code.
+"""
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libkpx_hip.so')
+
+
+class KpxError(RuntimeError):
+    pass
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        'libkpx_hip.so not found at %s -- build it first: python -c "import __graft_entry__ as g; g.build()" '
+        '(or `make -C %s/csrc`). There is no CPU / PyTorch fallback for the hot path.' % (LIB_PATH, _HERE))
+
+lib = ctypes.CDLL(LIB_PATH)
+
+P = c_void_p
+# name -> (restype, argtypes); mirrors include/kpx.h one to one (tests/test_abi.py checks header vs this table)
+SIGNATURES = {
+    'kpx_abi_version': (c_int, []),
+    'kpx_conv2d_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P,
+                                   P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'kpx_conv2d_dgrad_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int,
+                                     P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'kpx_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'kpx_conv2d_wgrad_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int,
+                                     P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'kpx_act_bwd_f32': (c_int, [P, P, c_size_t, c_int, P]),
+    'kpx_chan_reduce_scratch_bytes': (c_size_t, [c_int]),
+    'kpx_chan_sum_f32': (c_int, [P, c_size_t, c_int, c_int, P, P, P]),
+    'kpx_bn_stats_f32': (c_int, [P, c_size_t, c_int, c_int, c_float, P, P, P, P, P, c_float, P, P]),
+    'kpx_bn_invstd_f32': (c_int, [P, c_int, c_float, P, P]),
+    'kpx_bn_apply_f32': (c_int, [P, c_size_t, c_int, c_int, P, P, P, P, P, c_int, c_int, P]),
+    'kpx_bn_bwd_f32': (c_int, [P, c_int, P, c_int, c_size_t, c_int, P, P, P, P, c_int, P, c_int, P, P, P, P]),
+    'kpx_resize2x_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
+    'kpx_resize2x_bwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
+    'kpx_copy_channels_f32': (c_int, [P, c_int, P, c_int, c_size_t, c_int, P]),
+    'kpx_keypoint_head_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
+    'kpx_keypoint_head_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P]),
+    'kpx_keypoint_head_bwd_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    'kpx_gaussian_maps_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_double, P, c_int, P]),
+    'kpx_gaussian_maps_bwd_f32': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_double, P, P]),
+    'kpx_head_blend_fwd_f32': (c_int, [P, P, c_size_t, P, P, P, P]),
+    'kpx_head_blend_bwd_f32': (c_int, [P, P, P, c_size_t, P, P]),
+    'kpx_vgg_prep_fwd_f32': (c_int, [P, c_size_t, P, P]),
+    'kpx_vgg_prep_bwd_f32': (c_int, [P, c_size_t, P, P]),
+    'kpx_maxpool2_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
+    'kpx_maxpool2_bwd_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
+    'kpx_l1_pair_fwd_f32': (c_int, [P, c_size_t, P, P, P]),
+    'kpx_l1_pair_bwd_f32': (c_int, [P, c_size_t, P, c_float, P, P]),
+    'kpx_sigmoid_xent_fwd_f32': (c_int, [P, c_size_t, c_float, c_size_t, c_float, P, P]),
+    'kpx_sigmoid_xent_bwd_f32': (c_int, [P, c_size_t, c_float, c_size_t, c_float, P, c_float, P, P]),
+    'kpx_adam_tf_flat_f32': (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),
+    'kpx_fill_f32': (c_int, [P, c_size_t, c_float, P]),
+    'kpx_axpy_f32': (c_int, [P, P, c_size_t, c_float, P]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError as e:  # pragma: no cover
+        raise ImportError('libkpx_hip.so does not export %s (stale build?)' % _name) from e
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.kpx_abi_version() != 1:
+    raise ImportError('libkpx_hip.so ABI version mismatch')
+
+
+def check(rc, what):
+    if rc != 0:
+        raise KpxError('%s failed with code %d (%s)' % (what, rc, 'bad argument' if rc == -1 else 'hipError %d' % -rc))

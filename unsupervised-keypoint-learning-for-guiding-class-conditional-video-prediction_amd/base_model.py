@@ -1,0 +1,64 @@
+"""Abstract model API with the reference's method names (reference: models/base_model.py:7-92).
+
+``sess`` arguments are kept for signature parity and ignored (there is no session: kernels are launched eagerly on the
+current HIP stream).  Checkpoints keep the reference's location ``<log_dir>/<name>/model.ckpt-<step>`` and variable
+names in an ``.npz`` container; the TF-V2 bundle byte format is a later row.
+"""
+import os
+from abc import ABC, abstractmethod
+from os import path as osp
+
+import numpy as np
+
+
+class BaseModel(ABC):
+    name = 'base_model'
+    trainable = True
+
+    def __init__(self, is_training=True):
+        super(BaseModel, self).__init__()
+        self.is_training = is_training
+        self.log_dir = None
+        self.store = None
+
+    @abstractmethod
+    def build(self, inputs):
+        raise NotImplementedError
+
+    @abstractmethod
+    def train_step(self, sess, feed_dict, step, batch_size, should_write_log=False, should_write_summary=False):
+        raise NotImplementedError
+
+    @abstractmethod
+    def test_step(self, sess, feed_dict, step, test_idx, batch_size):
+        raise NotImplementedError
+
+    @abstractmethod
+    def collect_test_results(self, results, step):
+        raise NotImplementedError
+
+    def initialize_loggers(self, log_dir, sess=None):
+        """reference :62-75 (the TensorBoard FileWriters are out of scope; the checkpoint directory is created)."""
+        self.log_dir = log_dir
+        os.makedirs(osp.join(log_dir, self.__class__.name), exist_ok=True)
+
+    def checkpoint_arrays(self):
+        """Everything tf.train.Saver(tf.global_variables()) would hold (reference :74)."""
+        return self.store.export_numpy(include_slots=self.is_training)
+
+    def save_checkpoint(self, sess, step):
+        """reference :77-81 -> <log_dir>/<name>/model.ckpt-<step>(.npz)."""
+        checkpoint_path = osp.join(self.log_dir, self.__class__.name, 'model.ckpt-%d.npz' % step)
+        np.savez(checkpoint_path, **{k.replace('/', '|'): v for k, v in self.checkpoint_arrays().items()})
+        return checkpoint_path
+
+    def restore(self, sess, checkpoint_path):
+        """reference :83-91: restore the intersection of checkpoint variables and model variables, by name."""
+        data = np.load(checkpoint_path)
+        arrays = {k.replace('|', '/'): data[k] for k in data.files}
+        self.store.load_numpy(arrays, strict=False)
+        self._restore_extra(arrays)
+        return sorted(arrays)
+
+    def _restore_extra(self, arrays):
+        pass

@@ -1,0 +1,580 @@
+// fp32 implicit-GEMM convolution for gfx950 (MI355X): forward, dgrad and wgrad on
+// v_mfma_f32_32x32x2_f32 (exact f32 fma chain, 157 TF peak).
+//
+// Replaces tf.layers.conv2d / tf.nn.conv2d of the reference (models/networks/layers.py:6-9,
+// models/networks/vgg.py:51) and their TF-generated gradients.
+//
+// One "gather conv" kernel serves forward and dgrad:
+//   out[n, a*osy+oy0, b*osx+ox0, j] = act( bias[j] + sum_{tr,tq,c} in[n, a*isy+tr*ity+iy0, b*isx+tq*itx+ix0, c] * B[tap(tr,tq)][c][j] )
+// forward : in = x, B = HWIO weights as stored ([c][j] row-major),   a,b = output pixel, input step = stride
+// dgrad   : in = dy, B = the same HWIO weights read transposed ([j][c]), one launch per stride-parity class of
+//           dx pixels so that no MFMA is spent on the zeros of a dilated gradient.
+// GEMM view: M = N*Ha*Wa pixels, N = output channels, K = taps*Cin; the A tile (pixels x 16 channels) is gathered
+// straight from NHWC (channels contiguous -> 16-B loads), staged in LDS [m][16+4] and read back as ds_read_b128;
+// the B tile is staged [k][n] and read as ds_read_b32.  Within a 16-wide K chunk lane-half h consumes channels
+// {8u+4h+j}: a K permutation shared by A and B, so the product is unchanged.
+#include "kpx_common.h"
+
+struct ConvGeom {
+    const float* x; float* y; const float* w; const float* bias;
+    int N, Hi, Wi, Cin, ldx;
+    int Ho, Wo, Cout, ldy;
+    int Ha, Wa;
+    int osy, oy0, osx, ox0;
+    int isy, iy0, isx, ix0;
+    int Tr, Tq, ity, itx;
+    int wr0, wrs, wq0, wqs, KW;
+    int wts, ldw;
+    int act, vecA, vecB;
+    int M, mt, nt;
+};
+
+template <int BM, int BN, int WM, int WN, bool BT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
+    constexpr int BK = 16, SA = BK + 4;
+    constexpr int SB = BT ? (BN + 2) : BN;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int RA = BM / 64;
+    constexpr int BU = BN * 4;
+    constexpr int RB = (BU + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) float As[2][BM * SA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * SB];
+    __shared__ int rowpix[BM];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (L / g.nt) * BM, n0 = (L % g.nt) * BN;
+    const int HW = g.Ha * g.Wa;
+
+    if (t < BM) {
+        const int m = m0 + t;
+        int pix = -1;
+        if (m < g.M) {
+            const int n = m / HW, rem = m - n * HW, a = rem / g.Wa, b = rem - a * g.Wa;
+            pix = (n * g.Ho + a * g.osy + g.oy0) * g.Wo + b * g.osx + g.ox0;
+        }
+        rowpix[t] = pix;
+    }
+
+    // per-thread A rows
+    const int kq = t & 3;
+    int a_ih0[RA], a_iw0[RA], a_base[RA];
+    bool a_ok[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + (t >> 2) + 64 * i;
+        a_ok[i] = m < g.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int n = mm / HW, rem = mm - n * HW, a = rem / g.Wa, b = rem - a * g.Wa;
+        a_ih0[i] = a * g.isy + g.iy0;
+        a_iw0[i] = b * g.isx + g.ix0;
+        a_base[i] = n * g.Hi * g.Wi;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nck = (g.Cin + BK - 1) / BK;
+    const int nchunks = g.Tr * g.Tq * nck;
+    int tr = 0, tq = 0, c0 = 0;
+    f32x4 ra[RA], rb[RB];
+
+    auto load_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int ih = a_ih0[i] + tr * g.ity, iw = a_iw0[i] + tq * g.itx;
+            const int c = c0 + kq * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a_ok[i] && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi && c < g.Cin) {
+                const float* p = g.x + (size_t)(a_base[i] + ih * g.Wi + iw) * g.ldx + c;
+                if (g.vecA) {
+                    v = *reinterpret_cast<const f32x4*>(p);
+                    if (c + 3 >= g.Cin) {
+                        if (c + 1 >= g.Cin) v[1] = 0.f;
+                        if (c + 2 >= g.Cin) v[2] = 0.f;
+                        v[3] = 0.f;
+                    }
+                } else {
+                    v[0] = p[0];
+                    if (c + 1 < g.Cin) v[1] = p[1];
+                    if (c + 2 < g.Cin) v[2] = p[2];
+                    if (c + 3 < g.Cin) v[3] = p[3];
+                }
+            }
+            ra[i] = v;
+        }
+        const int tap = (g.wr0 + tr * g.wrs) * g.KW + (g.wq0 + tq * g.wqs);
+        const float* wp = g.w + (size_t)tap * g.wts;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int u = t + 256 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (u < BU) {
+                if (!BT) {
+                    const int k = u / (BN / 4), n = n0 + (u % (BN / 4)) * 4, c = c0 + k;
+                    if (c < g.Cin && n < g.Cout) {
+                        const float* p = wp + (size_t)c * g.ldw + n;
+                        if (g.vecB) {
+                            v = *reinterpret_cast<const f32x4*>(p);
+                            if (n + 3 >= g.Cout) {
+                                if (n + 1 >= g.Cout) v[1] = 0.f;
+                                if (n + 2 >= g.Cout) v[2] = 0.f;
+                                v[3] = 0.f;
+                            }
+                        } else {
+                            v[0] = p[0];
+                            if (n + 1 < g.Cout) v[1] = p[1];
+                            if (n + 2 < g.Cout) v[2] = p[2];
+                            if (n + 3 < g.Cout) v[3] = p[3];
+                        }
+                    }
+                } else {
+                    const int n = n0 + (u >> 2), c = c0 + (u & 3) * 4;
+                    if (n < g.Cout && c < g.Cin) {
+                        const float* p = wp + (size_t)n * g.ldw + c;
+                        if (g.vecB) {
+                            v = *reinterpret_cast<const f32x4*>(p);
+                            if (c + 3 >= g.Cin) {
+                                if (c + 1 >= g.Cin) v[1] = 0.f;
+                                if (c + 2 >= g.Cin) v[2] = 0.f;
+                                v[3] = 0.f;
+                            }
+                        } else {
+                            v[0] = p[0];
+                            if (c + 1 < g.Cin) v[1] = p[1];
+                            if (c + 2 < g.Cin) v[2] = p[2];
+                            if (c + 3 < g.Cin) v[3] = p[3];
+                        }
+                    }
+                }
+            }
+            rb[i] = v;
+        }
+        // advance (tr,tq,c0) to the next chunk
+        c0 += BK;
+        if (c0 >= g.Cin) {
+            c0 = 0;
+            if (++tq == g.Tq) { tq = 0; ++tr; }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+            *reinterpret_cast<f32x4*>(&As[buf][((t >> 2) + 64 * i) * SA + kq * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int u = t + 256 * i;
+            if (u < BU) {
+                if (!BT) {
+                    *reinterpret_cast<f32x4*>(&Bs[buf][(u / (BN / 4)) * SB + (u % (BN / 4)) * 4]) = rb[i];
+                } else {
+                    const int nn = u >> 2, kk = (u & 3) * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Bs[buf][(kk + j) * SB + nn] = rb[i][j];
+                }
+            }
+        }
+    };
+
+    if (nchunks > 0) {
+        load_chunk();
+        store_chunk(0);
+    }
+    __syncthreads();
+
+    const int wrow = wm * TM * 32, wcol = wn * TN * 32;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        const bool more = ch + 1 < nchunks;
+        if (more) load_chunk();
+        const float* Ab = As[buf];
+        const float* Bb = Bs[buf];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 a[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(&Ab[(wrow + i * 32 + li) * SA + (2 * u + lh) * 4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float b[TN];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) b[n] = Bb[(8 * u + 4 * lh + j) * SB + wcol + n * 32 + li];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n], acc[i][n], 0, 0, 0);
+            }
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: bias + activation, 32 consecutive channels per half-wave store
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+        const int col = n0 + wcol + n * 32 + li;
+        const bool cok = col < g.Cout;
+        const float bv = (cok && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int pix = rowpix[row];
+                if (cok && pix >= 0) {
+                    float v = acc[i][n][r] + bv;
+                    if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+                    g.y[(size_t)pix * g.ldy + col] = v;
+                }
+            }
+        }
+    }
+}
+
+template <bool BT>
+static int launch_gather_conv(ConvGeom g, hipStream_t s) {
+    g.M = g.N * g.Ha * g.Wa;
+    if (g.M <= 0 || g.Cout <= 0) return 0;
+    // N tile: smallest padded width, ties -> wider tile
+    int BN = 128;
+    {
+        auto pad = [&](int b) { return (g.Cout + b - 1) / b * b; };
+        if (pad(64) < pad(BN)) BN = 64;
+        if (pad(32) < pad(BN)) BN = 32;
+    }
+    auto blocks = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.Cout + bn - 1) / bn); };
+    const long want = 512;
+    int BM;
+    if (BN == 128) BM = blocks(128, 128) >= want ? 128 : 64;
+    else if (BN == 64) BM = blocks(256, 64) >= want ? 256 : (blocks(128, 64) >= want ? 128 : 64);
+    else BM = blocks(256, 32) >= want ? 256 : 128;
+    if (BN == 128 && BM == 64) BN = 64;   // small-M, wide-N: 64x64 tiles for occupancy
+    g.mt = (g.M + BM - 1) / BM;
+    g.nt = (g.Cout + BN - 1) / BN;
+    const dim3 grid((unsigned)(g.mt * g.nt)), block(256);
+#define KPX_LAUNCH(bm, bn, wm, wn) \
+    hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn, BT>), grid, block, 0, s, g)
+    if (BM == 128 && BN == 128) KPX_LAUNCH(128, 128, 2, 2);
+    else if (BM == 256 && BN == 64) KPX_LAUNCH(256, 64, 4, 1);
+    else if (BM == 128 && BN == 64) KPX_LAUNCH(128, 64, 2, 2);
+    else if (BM == 64 && BN == 64) KPX_LAUNCH(64, 64, 2, 2);
+    else if (BM == 256 && BN == 32) KPX_LAUNCH(256, 32, 4, 1);
+    else KPX_LAUNCH(128, 32, 4, 1);
+#undef KPX_LAUNCH
+    return kpx_launch_status();
+}
+
+static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
+                                  const float* w, int KH, int KW, const float* bias,
+                                  float* y, int Ho, int Wo, int Cout, int ldy,
+                                  int stride, int pad_t, int pad_l, int act, void* stream) {
+    if (!x || !w || !y || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
+        KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || ldy < Cout || act < 0 || act > 2)
+        return KPX_EINVAL;
+    ConvGeom g{};
+    g.x = x; g.y = y; g.w = w; g.bias = bias;
+    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.ldx = ldx;
+    g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
+    g.Ha = Ho; g.Wa = Wo; g.osy = 1; g.oy0 = 0; g.osx = 1; g.ox0 = 0;
+    g.isy = stride; g.iy0 = -pad_t; g.isx = stride; g.ix0 = -pad_l;
+    g.Tr = KH; g.Tq = KW; g.ity = 1; g.itx = 1;
+    g.wr0 = 0; g.wrs = 1; g.wq0 = 0; g.wqs = 1; g.KW = KW;
+    g.wts = Cin * Cout; g.ldw = Cout; g.act = act;
+    g.vecA = (ldx % 4 == 0) && aligned16(x);
+    g.vecB = (Cout % 4 == 0) && aligned16(w);
+    return launch_gather_conv<false>(g, kpx_stream(stream));
+}
+
+extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int Cout, int lddy,
+                                    const float* w, int KH, int KW,
+                                    float* dx, int Hi, int Wi, int Cin, int lddx,
+                                    int stride, int pad_t, int pad_l, void* stream) {
+    if (!dy || !w || !dx || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
+        KH <= 0 || KW <= 0 || stride <= 0 || lddy < Cout || lddx < Cin)
+        return KPX_EINVAL;
+    for (int ph = 0; ph < stride; ++ph) {
+        for (int pw = 0; pw < stride; ++pw) {
+            if (ph >= Hi || pw >= Wi) continue;
+            ConvGeom g{};
+            g.x = dy; g.y = dx; g.w = w; g.bias = nullptr;
+            g.N = N; g.Hi = Ho; g.Wi = Wo; g.Cin = Cout; g.ldx = lddy;       // "input" of the gather = dy
+            g.Ho = Hi; g.Wo = Wi; g.Cout = Cin; g.ldy = lddx;                // "output" = dx
+            g.Ha = (Hi - ph + stride - 1) / stride; g.Wa = (Wi - pw + stride - 1) / stride;
+            g.osy = stride; g.oy0 = ph; g.osx = stride; g.ox0 = pw;
+            const int r0 = (ph + pad_t) % stride, q0 = (pw + pad_l) % stride;
+            g.Tr = r0 < KH ? (KH - r0 + stride - 1) / stride : 0;
+            g.Tq = q0 < KW ? (KW - q0 + stride - 1) / stride : 0;
+            if (g.Tr == 0 || g.Tq == 0) { g.Tr = 0; g.Tq = 0; }
+            g.isy = 1; g.iy0 = (ph + pad_t - r0) / stride; g.ity = -1;
+            g.isx = 1; g.ix0 = (pw + pad_l - q0) / stride; g.itx = -1;
+            g.wr0 = r0; g.wrs = stride; g.wq0 = q0; g.wqs = stride; g.KW = KW;
+            g.wts = Cin * Cout; g.ldw = Cout; g.act = KPX_ACT_NONE;
+            g.vecA = (lddy % 4 == 0) && aligned16(dy);
+            g.vecB = (Cout % 4 == 0) && aligned16(w);
+            const int rc = launch_gather_conv<true>(g, kpx_stream(stream));
+            if (rc) return rc;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------ wgrad
+// dw[tap][c][k] = sum_p x[p shifted by tap][c] * dy[p][k]: GEMM with M = Cin, N = Cout, K = pixels.
+// Both operands are pixel-major in memory, so the LDS tiles are plain [pixel][channel] copies of NHWC
+// and the MFMA operands are ds_read_b32 (32 consecutive channels per half-wave, conflict-free).
+// The pixel range is split over blocks (split-K); partial slabs are summed by wgrad_reduce_kernel in a
+// fixed order, so the result is bitwise reproducible (no float atomics).
+struct WgradGeom {
+    const float* x; const float* dy; float* out;
+    int N, Hi, Wi, Cin, ldx;
+    int Ho, Wo, Cout, lddy;
+    int KH, KW, stride, pad_t, pad_l;
+    int P, S, pps;          // pixels, splits, pixels per split (multiple of 16)
+    int ct, kt;             // channel tiles
+    int vecA, vecB;
+    size_t slab;            // floats per slab = KH*KW*Cin*Cout
+};
+
+template <int BMc, int BNk>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
+    constexpr int BKP = 16;
+    constexpr int TM = BMc / 64, TN = BNk / 64;
+    constexpr int RA = BMc / 64, RB = BNk / 64;     // float4 units per thread (16*BMc/4/256)
+    __shared__ __attribute__((aligned(16))) float As[2][BKP * BMc];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BKP * BNk];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    const int taps = g.KH * g.KW;
+    const int kti = L % g.kt; L /= g.kt;
+    const int cti = L % g.ct; L /= g.ct;
+    const int tap = L % taps; L /= taps;
+    const int split = L;
+    const int r = tap / g.KW, q = tap - r * g.KW;
+    const int cbase = cti * BMc, kbase = kti * BNk;
+    const int pbeg = split * g.pps;
+    const int pend = min(g.P, pbeg + g.pps);
+
+    // per-thread loader coordinates: A unit -> (pixel-in-chunk, channel group)
+    int apx[RA], ac[RA], an[RA], aho[RA], awo[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int u = t + 256 * i;
+        apx[i] = u / (BMc / 4);
+        ac[i] = cbase + (u % (BMc / 4)) * 4;
+        const int p = pbeg + apx[i];
+        an[i] = p / (g.Ho * g.Wo);
+        const int rem = p - an[i] * g.Ho * g.Wo;
+        aho[i] = rem / g.Wo;
+        awo[i] = rem - aho[i] * g.Wo;
+    }
+    int bpx[RB], bk[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int u = t + 256 * i;
+        bpx[i] = u / (BNk / 4);
+        bk[i] = kbase + (u % (BNk / 4)) * 4;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[RA], rb[RB];
+    int p0 = pbeg;
+    auto load_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int p = p0 + apx[i];
+            const int ih = aho[i] * g.stride + r - g.pad_t, iw = awo[i] * g.stride + q - g.pad_l;
+            const int c = ac[i];
+            if (p < pend && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi && c < g.Cin) {
+                const float* ptr = g.x + ((size_t)(an[i] * g.Hi + ih) * g.Wi + iw) * g.ldx + c;
+                if (g.vecA) {
+                    v = *reinterpret_cast<const f32x4*>(ptr);
+                    if (c + 3 >= g.Cin) {
+                        if (c + 1 >= g.Cin) v[1] = 0.f;
+                        if (c + 2 >= g.Cin) v[2] = 0.f;
+                        v[3] = 0.f;
+                    }
+                } else {
+                    v[0] = ptr[0];
+                    if (c + 1 < g.Cin) v[1] = ptr[1];
+                    if (c + 2 < g.Cin) v[2] = ptr[2];
+                    if (c + 3 < g.Cin) v[3] = ptr[3];
+                }
+            }
+            ra[i] = v;
+            // advance this unit's pixel by one chunk
+            awo[i] += BKP;
+            while (awo[i] >= g.Wo) {
+                awo[i] -= g.Wo;
+                if (++aho[i] == g.Ho) { aho[i] = 0; ++an[i]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int p = p0 + bpx[i];
+            const int k = bk[i];
+            if (p < pend && k < g.Cout) {
+                const float* ptr = g.dy + (size_t)p * g.lddy + k;
+                if (g.vecB) {
+                    v = *reinterpret_cast<const f32x4*>(ptr);
+                    if (k + 3 >= g.Cout) {
+                        if (k + 1 >= g.Cout) v[1] = 0.f;
+                        if (k + 2 >= g.Cout) v[2] = 0.f;
+                        v[3] = 0.f;
+                    }
+                } else {
+                    v[0] = ptr[0];
+                    if (k + 1 < g.Cout) v[1] = ptr[1];
+                    if (k + 2 < g.Cout) v[2] = ptr[2];
+                    if (k + 3 < g.Cout) v[3] = ptr[3];
+                }
+            }
+            rb[i] = v;
+        }
+        p0 += BKP;
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[buf][(t + 256 * i) * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(t + 256 * i) * 4]) = rb[i];
+    };
+
+    const int nchunks = pend > pbeg ? (pend - pbeg + BKP - 1) / BKP : 0;
+    if (nchunks > 0) { load_chunk(); store_chunk(0); }
+    __syncthreads();
+    const int wrow = wm * TM * 32, wcol = wn * TN * 32;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        const bool more = ch + 1 < nchunks;
+        if (more) load_chunk();
+        const float* Ab = As[buf];
+        const float* Bb = Bs[buf];
+#pragma unroll
+        for (int s2 = 0; s2 < BKP / 2; ++s2) {
+            const int kp = 2 * s2 + lh;
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Ab[kp * BMc + wrow + i * 32 + li];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bb[kp * BNk + wcol + j * 32 + li];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = g.out + (size_t)split * g.slab + (size_t)tap * g.Cin * g.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int k = kbase + wcol + j * 32 + li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = cbase + wrow + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (c < g.Cin && k < g.Cout) out[(size_t)c * g.Cout + k] = acc[i][j][e];
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           size_t n, int S) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += ws[(size_t)k * n + i];
+        dw[i] = s;
+    }
+}
+
+static void wgrad_tiles(int Cin, int Cout, int& bm, int& bn) {
+    auto pick = [](int c) { return ((c + 127) / 128 * 128 == (c + 63) / 64 * 64) ? 128 : 64; };
+    bm = pick(Cin); bn = pick(Cout);
+    if (bm != bn) { bm = 64; bn = 64; }   // only the square tiles are instantiated
+}
+
+static int wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
+    int bm, bn;
+    wgrad_tiles(Cin, Cout, bm, bn);
+    const long tiles = (long)KH * KW * ((Cin + bm - 1) / bm) * ((Cout + bn - 1) / bn);
+    const long P = (long)N * Ho * Wo;
+    long S = (1024 + tiles - 1) / tiles;
+    const long maxS_pix = P / 128 > 0 ? P / 128 : 1;
+    if (S > maxS_pix) S = maxS_pix;
+    const size_t slab_bytes = (size_t)KH * KW * Cin * Cout * 4;
+    const size_t cap = (size_t)256 << 20;
+    if ((size_t)S * slab_bytes > cap) S = (long)(cap / slab_bytes);
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+extern "C" size_t kpx_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
+    const int S = wgrad_splits(N, Ho, Wo, Cin, Cout, KH, KW);
+    return S > 1 ? (size_t)S * KH * KW * Cin * Cout * 4 : 0;
+}
+
+extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
+                                    const float* dy, int Ho, int Wo, int Cout, int lddy,
+                                    float* dw, int KH, int KW, int stride, int pad_t, int pad_l,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
+        KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || lddy < Cout)
+        return KPX_EINVAL;
+    WgradGeom g{};
+    g.x = x; g.dy = dy;
+    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.ldx = ldx;
+    g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.lddy = lddy;
+    g.KH = KH; g.KW = KW; g.stride = stride; g.pad_t = pad_t; g.pad_l = pad_l;
+    g.P = N * Ho * Wo;
+    g.S = wgrad_splits(N, Ho, Wo, Cin, Cout, KH, KW);
+    g.slab = (size_t)KH * KW * Cin * Cout;
+    if (g.S > 1 && (!workspace || workspace_bytes < (size_t)g.S * g.slab * 4)) return KPX_EINVAL;
+    g.pps = ((g.P + g.S - 1) / g.S + 15) / 16 * 16;
+    g.out = g.S > 1 ? (float*)workspace : dw;
+    int bm, bn;
+    wgrad_tiles(Cin, Cout, bm, bn);
+    g.ct = (Cin + bm - 1) / bm; g.kt = (Cout + bn - 1) / bn;
+    g.vecA = (ldx % 4 == 0) && aligned16(x);
+    g.vecB = (lddy % 4 == 0) && aligned16(dy);
+    hipStream_t s = kpx_stream(stream);
+    const dim3 grid((unsigned)(g.S * KH * KW * g.ct * g.kt)), block(256);
+    if (bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, s, g);
+    int rc = kpx_launch_status();
+    if (rc) return rc;
+    if (g.S > 1) {
+        const size_t n = g.slab;
+        const unsigned nb = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, s, (const float*)workspace, dw, n, g.S);
+        rc = kpx_launch_status();
+    }
+    return rc;
+}

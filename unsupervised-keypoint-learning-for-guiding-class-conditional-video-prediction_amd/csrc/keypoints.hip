@@ -1,0 +1,255 @@
+// Key-point head (separable softmax expectation) and Gaussian heat-map renderer.
+//
+// Head: model_utils.get_coord applied twice + tf.stack (utils/model.py:63-70, networks/__init__.py:68-72):
+//   y: mean over W -> softmax over H -> sum(p * linspace(-1,1,H));  x: mean over H -> softmax over W -> ...
+// The logits [B,H,W,K] are read ONCE (TF reads them twice, once per axis): stage 1 streams row stripes and emits
+// row sums + per-stripe column sums; stage 2 gives one wavefront to each (b,k,axis) profile and does max / sum /
+// expectation with wave shuffles.
+// Renderer: model_utils.get_gaussian_maps (utils/model.py:49-60) written straight in NHWC (the reference builds BKHW
+// and transposes): a pure write stream, 16 B per lane.
+// linspace follows tf.linspace in fp32 (start + step*i, two roundings) via __fmul_rn/__fadd_rn so that hipcc's
+// default fp-contraction cannot fuse it.
+#include "kpx_common.h"
+
+#define KP_RS 8   // rows per stripe in stage 1
+
+__device__ __forceinline__ float kpx_linspace(int i, int n) {
+    const float step = __fdiv_rn(2.0f, (float)(n - 1));
+    return __fadd_rn(-1.0f, __fmul_rn(step, (float)i));
+}
+
+__global__ __launch_bounds__(256) void kp_stage1_kernel(const float* __restrict__ x, int H, int W, int K,
+                                                        float* __restrict__ rowsum, float* __restrict__ colpart, int nstripes) {
+    const int b = blockIdx.x, stripe = blockIdx.y;
+    const int T = (256 / K) * K, t = threadIdx.x;
+    const int WK = W * K;
+    const int h0 = stripe * KP_RS;
+    const float* xb = x + ((size_t)b * H + h0) * WK;
+    float racc[KP_RS];
+#pragma unroll
+    for (int r = 0; r < KP_RS; ++r) racc[r] = 0.f;
+    if (t < T) {
+        for (int e = t; e < WK; e += T) {          // T % K == 0, so this thread's channel k = t % K is fixed
+            float v[KP_RS];
+#pragma unroll
+            for (int r = 0; r < KP_RS; ++r) v[r] = (h0 + r < H) ? xb[(size_t)r * WK + e] : 0.f;
+            float c = 0.f;
+#pragma unroll
+            for (int r = 0; r < KP_RS; ++r) { c += v[r]; racc[r] += v[r]; }
+            colpart[((size_t)b * nstripes + stripe) * WK + e] = c;
+        }
+    }
+    __shared__ float sm[KP_RS][256];
+#pragma unroll
+    for (int r = 0; r < KP_RS; ++r) sm[r][t] = (t < T) ? racc[r] : 0.f;
+    __syncthreads();
+    if (t < K) {
+        const int groups = T / K;
+#pragma unroll
+        for (int r = 0; r < KP_RS; ++r) {
+            if (h0 + r >= H) break;
+            float s = 0.f;
+            for (int g2 = 0; g2 < groups; ++g2) s += sm[r][g2 * K + t];
+            rowsum[((size_t)b * H + h0 + r) * K + t] = s;
+        }
+    }
+}
+
+// one wavefront per (b, k, axis)
+__global__ __launch_bounds__(256) void kp_stage2_kernel(const float* __restrict__ rowsum, const float* __restrict__ colpart,
+                                                        int B, int H, int W, int K, int nstripes,
+                                                        float* __restrict__ mu, float* __restrict__ prob_y, float* __restrict__ prob_x) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wid >= B * K * 2) return;
+    const int axis = wid & 1;                 // 0 -> x (profile over W), 1 -> y (profile over H)
+    const int k = (wid >> 1) % K, b = (wid >> 1) / K;
+    const int n = axis ? H : W;
+    const int WK = W * K;
+    // pass 1: means (kept in registers: up to 8 per lane -> n <= 512) and max
+    float v[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = lane + 64 * j;
+        float m = -INFINITY;
+        if (i < n) {
+            if (axis) m = rowsum[((size_t)b * H + i) * K + k] / (float)W;
+            else {
+                float s = 0.f;
+                for (int st = 0; st < nstripes; ++st) s += colpart[((size_t)b * nstripes + st) * WK + (size_t)i * K + k];
+                m = s / (float)H;
+            }
+        }
+        v[j] = m;
+        mx = fmaxf(mx, m);
+    }
+    mx = kpx_wave_max(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = (i < n) ? expf(v[j] - mx) : 0.f;
+        se += v[j];
+    }
+    se = kpx_wave_sum(se);
+    const float inv = 1.0f / se;                // tf.nn.softmax: e * (1/sum)
+    float ex = 0.f;
+    float* pout = axis ? prob_y : prob_x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = lane + 64 * j;
+        if (i < n) {
+            const float p = v[j] * inv;
+            pout[((size_t)b * n + i) * K + k] = p;
+            ex += p * kpx_linspace(i, n);
+        }
+    }
+    ex = kpx_wave_sum(ex);
+    if (lane == 0) mu[((size_t)b * K + k) * 2 + axis] = ex;
+}
+
+extern "C" size_t kpx_keypoint_head_scratch_bytes(int B, int H, int W, int K) {
+    const size_t nstripes = (size_t)(H + KP_RS - 1) / KP_RS;
+    return ((size_t)B * H * K + (size_t)B * nstripes * W * K) * sizeof(float);
+}
+
+extern "C" int kpx_keypoint_head_fwd_f32(const float* logits, int B, int H, int W, int K,
+                                         float* mu, float* prob_y, float* prob_x, void* scratch, void* stream) {
+    if (!logits || !mu || !prob_y || !prob_x || !scratch || B <= 0 || H < 2 || W < 2 || K <= 0 || K > 256 || H > 512 || W > 512)
+        return KPX_EINVAL;
+    hipStream_t s = kpx_stream(stream);
+    const int nstripes = (H + KP_RS - 1) / KP_RS;
+    float* rowsum = (float*)scratch;
+    float* colpart = rowsum + (size_t)B * H * K;
+    hipLaunchKernelGGL(kp_stage1_kernel, dim3(B, nstripes), dim3(256), 0, s, logits, H, W, K, rowsum, colpart, nstripes);
+    int rc = kpx_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(kp_stage2_kernel, dim3((B * K * 2 + 3) / 4), dim3(256), 0, s, (const float*)rowsum, (const float*)colpart,
+                       B, H, W, K, nstripes, mu, prob_y, prob_x);
+    return kpx_launch_status();
+}
+
+// dlogits[b,h,w,k] = dRow[b,h,k]/W + dCol[b,w,k]/H, dRow[h] = dmu_y * p_y[h] * (lin_H[h] - mu_y), dCol likewise
+__global__ __launch_bounds__(256) void kp_bwd_kernel(const float* __restrict__ dmu, const float* __restrict__ mu,
+                                                     const float* __restrict__ prob_y, const float* __restrict__ prob_x,
+                                                     int B, int H, int W, int K, float* __restrict__ dl) {
+    const size_t total = (size_t)B * H * W * K;
+    const float iw = 1.0f / (float)W, ih = 1.0f / (float)H;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int k = (int)(i % K);
+        size_t p = i / K;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int b = (int)(p / H);
+        const size_t bk = ((size_t)b * K + k) * 2;
+        const float drow = dmu[bk + 1] * prob_y[((size_t)b * H + h) * K + k] * (kpx_linspace(h, H) - mu[bk + 1]);
+        const float dcol = dmu[bk + 0] * prob_x[((size_t)b * W + w) * K + k] * (kpx_linspace(w, W) - mu[bk + 0]);
+        dl[i] = drow * iw + dcol * ih;
+    }
+}
+extern "C" int kpx_keypoint_head_bwd_f32(const float* dmu, const float* mu, const float* prob_y, const float* prob_x,
+                                         int B, int H, int W, int K, float* dlogits, void* stream) {
+    if (!dmu || !mu || !prob_y || !prob_x || !dlogits || B <= 0 || H < 2 || W < 2 || K <= 0) return KPX_EINVAL;
+    const size_t total = (size_t)B * H * W * K;
+    size_t nb = (total + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(kp_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, kpx_stream(stream), dmu, mu, prob_y, prob_x, B, H, W, K, dlogits);
+    return kpx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ Gaussian maps
+__device__ __forceinline__ float kpx_gauss(float yv, float xv, float my, float mx, float inv2) {
+    const float dy = __fsub_rn(yv, my), dx = __fsub_rn(xv, mx);
+    const float dist = __fmul_rn(__fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dx, dx)), inv2);
+    return expf(-dist);
+}
+
+// contiguous output (ldy == K): flat float4 stores, element e -> (pixel = e / K, k = e % K)
+__global__ __launch_bounds__(256) void gauss_fwd_flat_kernel(const float* __restrict__ mu, int K, int H, int W, float inv2,
+                                                             float* __restrict__ out, size_t total4, size_t total) {
+    const size_t HWK = (size_t)H * W * K;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        f32x4 r;
+        const size_t e0 = i * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const size_t e = e0 + j;
+            float g = 0.f;
+            if (e < total) {
+                const int b = (int)(e / HWK);
+                const size_t rem = e - (size_t)b * HWK;
+                const int pix = (int)(rem / K), k = (int)(rem - (size_t)pix * K);
+                const int h = pix / W, w = pix - h * W;
+                const float mx = mu[((size_t)b * K + k) * 2], my = mu[((size_t)b * K + k) * 2 + 1];
+                g = kpx_gauss(kpx_linspace(h, H), kpx_linspace(w, W), my, mx, inv2);
+            }
+            r[j] = g;
+        }
+        if (e0 + 3 < total) reinterpret_cast<f32x4*>(out)[i] = r;
+        else for (int j = 0; j < 4 && e0 + j < total; ++j) out[e0 + j] = r[j];
+    }
+}
+// strided output (channel slice of a wider concat buffer)
+__global__ __launch_bounds__(256) void gauss_fwd_strided_kernel(const float* __restrict__ mu, int B, int K, int H, int W, float inv2,
+                                                                float* __restrict__ out, int ldy) {
+    const size_t total = (size_t)B * H * W * K;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int k = (int)(e % K);
+        const size_t pixg = e / K;
+        const int w = (int)(pixg % W);
+        const size_t t2 = pixg / W;
+        const int h = (int)(t2 % H), b = (int)(t2 / H);
+        const float mx = mu[((size_t)b * K + k) * 2], my = mu[((size_t)b * K + k) * 2 + 1];
+        out[pixg * ldy + k] = kpx_gauss(kpx_linspace(h, H), kpx_linspace(w, W), my, mx, inv2);
+    }
+}
+extern "C" int kpx_gaussian_maps_fwd_f32(const float* mu, int B, int K, int H, int W, double inv_std, float* maps, int ldy, void* stream) {
+    if (!mu || !maps || B <= 0 || K <= 0 || H < 2 || W < 2 || ldy < K) return KPX_EINVAL;
+    const float inv2 = (float)(inv_std * inv_std);      // python: inv_std ** 2 in float64, then cast (utils/model.py:58)
+    const size_t total = (size_t)B * H * W * K;
+    hipStream_t s = kpx_stream(stream);
+    if (ldy == K && (((uintptr_t)maps) & 15) == 0) {
+        const size_t total4 = (total + 3) / 4;
+        size_t nb = (total4 + 255) / 256; if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(gauss_fwd_flat_kernel, dim3((unsigned)nb), dim3(256), 0, s, mu, K, H, W, inv2, maps, total4, total);
+    } else {
+        size_t nb = (total + 255) / 256; if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(gauss_fwd_strided_kernel, dim3((unsigned)nb), dim3(256), 0, s, mu, B, K, H, W, inv2, maps, ldy);
+    }
+    return kpx_launch_status();
+}
+
+// dmu_x[b,k] = sum_{h,w} dmaps * g * 2*inv2*(x_w - mu_x); dmu_y likewise.  One block per image.
+__global__ __launch_bounds__(256) void gauss_bwd_kernel(const float* __restrict__ dmaps, int lddy, const float* __restrict__ mu,
+                                                        int K, int H, int W, float inv2, float* __restrict__ dmu) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int T = (256 / K) * K, groups = T / K;
+    const int k = t % K, g0 = t / K;
+    float sx = 0.f, sy = 0.f;
+    if (t < T) {
+        const float mx = mu[((size_t)b * K + k) * 2], my = mu[((size_t)b * K + k) * 2 + 1];
+        for (int pix = g0; pix < H * W; pix += groups) {
+            const int h = pix / W, w = pix - h * W;
+            const float yv = kpx_linspace(h, H), xv = kpx_linspace(w, W);
+            const float g = kpx_gauss(yv, xv, my, mx, inv2);
+            const float d = dmaps[((size_t)b * H * W + pix) * lddy + k] * g * (2.0f * inv2);
+            sx = fmaf(d, xv - mx, sx);
+            sy = fmaf(d, yv - my, sy);
+        }
+    }
+    __shared__ float sm[2][256];
+    sm[0][t] = sx; sm[1][t] = sy;
+    __syncthreads();
+    if (t < K) {
+        float ax = 0.f, ay = 0.f;
+        for (int g2 = 0; g2 < groups; ++g2) { ax += sm[0][g2 * K + t]; ay += sm[1][g2 * K + t]; }
+        dmu[((size_t)b * K + t) * 2] = ax;
+        dmu[((size_t)b * K + t) * 2 + 1] = ay;
+    }
+}
+extern "C" int kpx_gaussian_maps_bwd_f32(const float* dmaps, int lddy, const float* mu, int B, int K, int H, int W, double inv_std,
+                                         float* dmu, void* stream) {
+    if (!dmaps || !mu || !dmu || B <= 0 || K <= 0 || K > 256 || H < 2 || W < 2 || lddy < K) return KPX_EINVAL;
+    const float inv2 = (float)(inv_std * inv_std);
+    hipLaunchKernelGGL(gauss_bwd_kernel, dim3(B), dim3(256), 0, kpx_stream(stream), dmaps, lddy, mu, K, H, W, inv2, dmu);
+    return kpx_launch_status();
+}

@@ -1,0 +1,582 @@
+// HBM-bound NHWC kernels of the detector_translator path: batch-norm (stats / apply / backward), activation
+// backward, bilinear x2 (TF-1.12 legacy sampling), channel-slice copy, head blend, VGG input transform, max-pool.
+// All are streaming kernels: 16-B per-lane accesses along the contiguous channel axis, grid-stride loops capped
+// at 2048 blocks, per-channel reductions accumulated in fp64 and finished by a second tiny kernel (no atomics,
+// bitwise reproducible).
+#include "kpx_common.h"
+
+#define KPX_MAX_BLOCKS 2048
+#define KPX_RED_BLOCKS 1024
+
+static inline unsigned grid_for(size_t work_items) {
+    size_t b = (work_items + 255) / 256;
+    if (b < 1) b = 1;
+    if (b > KPX_MAX_BLOCKS) b = KPX_MAX_BLOCKS;
+    return (unsigned)b;
+}
+
+// ------------------------------------------------------------------------------------------ utilities
+__global__ __launch_bounds__(256) void fill_kernel(float* p, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+extern "C" int kpx_fill_f32(float* p, size_t n, float value, void* stream) {
+    if (!p) return KPX_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, kpx_stream(stream), p, n, value);
+    return kpx_launch_status();
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, size_t n, float a) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = fmaf(a, x[i], y[i]);
+}
+extern "C" int kpx_axpy_f32(float* y, const float* x, size_t n, float a, void* stream) {
+    if (!y || !x) return KPX_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, kpx_stream(stream), y, x, n, a);
+    return kpx_launch_status();
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* src, int lds_, float* dst, int ldd, size_t P, int C) {
+    const int G = VEC ? C / 4 : C;
+    const size_t total = P * (size_t)G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t p = i / G;
+        const int c = (int)(i - p * G);
+        if (VEC) *reinterpret_cast<f32x4*>(dst + p * ldd + c * 4) = *reinterpret_cast<const f32x4*>(src + p * lds_ + c * 4);
+        else dst[p * ldd + c] = src[p * lds_ + c];
+    }
+}
+extern "C" int kpx_copy_channels_f32(const float* src, int ldsrc, float* dst, int lddst, size_t P, int C, void* stream) {
+    if (!src || !dst || C <= 0 || ldsrc < C || lddst < C) return KPX_EINVAL;
+    if (P == 0) return 0;
+    const bool vec = (C % 4 == 0) && (ldsrc % 4 == 0) && (lddst % 4 == 0) && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(copy_channels_kernel<true>, dim3(grid_for(P * (C / 4))), dim3(256), 0, kpx_stream(stream), src, ldsrc, dst, lddst, P, C);
+    else hipLaunchKernelGGL(copy_channels_kernel<false>, dim3(grid_for(P * C)), dim3(256), 0, kpx_stream(stream), src, ldsrc, dst, lddst, P, C);
+    return kpx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ activation backward
+__global__ __launch_bounds__(256) void act_bwd_kernel(float* dy, const float* y, size_t n, int act) {
+    const float neg = act == KPX_ACT_RELU ? 0.f : 0.01f;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 g = reinterpret_cast<f32x4*>(dy)[i];
+        const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = v[j] > 0.f ? g[j] : g[j] * neg;
+        reinterpret_cast<f32x4*>(dy)[i] = g;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dy[i] = y[i] > 0.f ? dy[i] : dy[i] * neg;
+}
+extern "C" int kpx_act_bwd_f32(float* dy, const float* y, size_t n, int act, void* stream) {
+    if (!dy || !y || act < 0 || act > 2 || (((uintptr_t)dy | (uintptr_t)y) & 15)) return KPX_EINVAL;
+    if (act == KPX_ACT_NONE || n == 0) return 0;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, kpx_stream(stream), dy, y, n, act);
+    return kpx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ per-channel reductions
+// MODE 0: sum x            (bias gradient)
+// MODE 1: sum x, sum x^2   (batch-norm statistics)
+// MODE 2: sum dz, sum dz*xhat with dz = dy*[act'(y)], y = (x-mean)*invstd*gamma+beta   (batch-norm backward)
+struct RedArgs {
+    const float* x; int ldx; const float* dy; int lddy;
+    size_t P; int C;
+    const float* mean; const float* invstd; const float* gamma; const float* beta; int act;
+    double* part;       // [gridDim.x][2][C]
+};
+
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256) void chan_reduce_kernel(const RedArgs a) {
+    constexpr int W = VEC ? 4 : 1;
+    const int G = VEC ? a.C / 4 : a.C;               // channel groups
+    const int Gb = G < 256 ? G : 256;                // groups handled per blockIdx.y slice
+    const int PPB = 256 / Gb;
+    const int t = threadIdx.x;
+    const int cgl = t % Gb, prow = t / Gb;
+    const int cg = blockIdx.y * Gb + cgl;
+    const bool active = prow < PPB && cg < G;
+    double s0[W], s1[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
+    float mu[W], is[W], ga[W], be[W];
+    if (MODE == 2 && active) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const int c = cg * W + j;
+            mu[j] = a.mean[c]; is[j] = a.invstd[c]; ga[j] = a.gamma[c]; be[j] = a.beta[c];
+        }
+    }
+    if (active) {
+        for (size_t p = (size_t)blockIdx.x * PPB + prow; p < a.P; p += (size_t)gridDim.x * PPB) {
+            float xv[W], gv[W];
+            if (VEC) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + p * a.ldx + cg * 4);
+#pragma unroll
+                for (int j = 0; j < W; ++j) xv[j] = v[j];
+                if (MODE == 2) {
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + p * a.lddy + cg * 4);
+#pragma unroll
+                    for (int j = 0; j < W; ++j) gv[j] = d[j];
+                }
+            } else {
+                xv[0] = a.x[p * a.ldx + cg];
+                if (MODE == 2) gv[0] = a.dy[p * a.lddy + cg];
+            }
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                if (MODE == 0) s0[j] += (double)xv[j];
+                if (MODE == 1) { s0[j] += (double)xv[j]; s1[j] += (double)xv[j] * (double)xv[j]; }
+                if (MODE == 2) {
+                    const float xh = (xv[j] - mu[j]) * is[j];
+                    const float yv = fmaf(xh, ga[j], be[j]);
+                    const float dz = (a.act == KPX_ACT_RELU && !(yv > 0.f)) ? 0.f : gv[j];
+                    s0[j] += (double)dz; s1[j] += (double)dz * (double)xh;
+                }
+            }
+        }
+    }
+    __shared__ double sm[2][256 * W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) { sm[0][t * W + j] = s0[j]; sm[1][t * W + j] = s1[j]; }
+    __syncthreads();
+    if (t < Gb && blockIdx.y * Gb + t < G) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            double r0 = 0.0, r1 = 0.0;
+            for (int pr = 0; pr < PPB; ++pr) { r0 += sm[0][(pr * Gb + t) * W + j]; r1 += sm[1][(pr * Gb + t) * W + j]; }
+            const int c = (blockIdx.y * Gb + t) * W + j;
+            a.part[((size_t)blockIdx.x * 2 + 0) * a.C + c] = r0;
+            a.part[((size_t)blockIdx.x * 2 + 1) * a.C + c] = r1;
+        }
+    }
+}
+
+static int launch_chan_reduce(int mode, RedArgs a, int* nb_out, hipStream_t s) {
+    const bool vec = (a.C % 4 == 0) && (a.ldx % 4 == 0) && (((uintptr_t)a.x) & 15) == 0 &&
+                     (mode != 2 || ((a.lddy % 4 == 0) && (((uintptr_t)a.dy) & 15) == 0));
+    const int G = vec ? a.C / 4 : a.C;
+    const int Gb = G < 256 ? G : 256;
+    const int PPB = 256 / Gb;
+    size_t nb = a.P / ((size_t)PPB * 8);
+    if (nb < 1) nb = 1;
+    if (nb > KPX_RED_BLOCKS) nb = KPX_RED_BLOCKS;
+    *nb_out = (int)nb;
+    const dim3 grid((unsigned)nb, (unsigned)((G + Gb - 1) / Gb)), block(256);
+#define KPX_RED(M) \
+    do { if (vec) hipLaunchKernelGGL((chan_reduce_kernel<M, true>), grid, block, 0, s, a); \
+         else hipLaunchKernelGGL((chan_reduce_kernel<M, false>), grid, block, 0, s, a); } while (0)
+    if (mode == 0) KPX_RED(0); else if (mode == 1) KPX_RED(1); else KPX_RED(2);
+#undef KPX_RED
+    return kpx_launch_status();
+}
+
+// partial sums [KPX_RED_BLOCKS][2][C] doubles, then 2*C floats where bn_bwd parks the finished channel sums
+extern "C" size_t kpx_chan_reduce_scratch_bytes(int C) {
+    const size_t c = (size_t)(C > 0 ? C : 1);
+    return (size_t)KPX_RED_BLOCKS * 2 * c * sizeof(double) + ((2 * c * sizeof(float) + 15) & ~(size_t)15);
+}
+
+__global__ void chan_sum_finalize_kernel(const double* part, int nb, int C, float* out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += part[((size_t)b * 2) * C + c];
+    out[c] = (float)s;
+}
+extern "C" int kpx_chan_sum_f32(const float* x, size_t P, int C, int ldx, float* sum_out, void* scratch, void* stream) {
+    if (!x || !sum_out || !scratch || C <= 0 || ldx < C || P == 0) return KPX_EINVAL;
+    RedArgs a{}; a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.part = (double*)scratch;
+    int nb; int rc = launch_chan_reduce(0, a, &nb, kpx_stream(stream));
+    if (rc) return rc;
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, kpx_stream(stream), (const double*)scratch, nb, C, sum_out);
+    return kpx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ batch norm
+__global__ void bn_stats_finalize_kernel(const double* part, int nb, int C, double count, float eps,
+                                         float* mean, float* invstd, float* var_biased,
+                                         float* mm, float* mv, float decay) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nb; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+    const double m = s / count;
+    double v = q / count - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mf = (float)m, vf = (float)v;
+    mean[c] = mf;
+    if (var_biased) var_biased[c] = vf;
+    invstd[c] = 1.0f / sqrtf(vf + eps);
+    if (mm && mv) {   // TF fused batch norm: moving -= (moving - batch) * (1 - decay), variance Bessel-corrected
+        const float one_minus = 1.0f - decay;
+        const float unb = (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+        mm[c] = mm[c] - (mm[c] - mf) * one_minus;
+        mv[c] = mv[c] - (mv[c] - unb) * one_minus;
+    }
+}
+extern "C" int kpx_bn_stats_f32(const float* x, size_t P, int C, int ldx, float eps,
+                                float* mean, float* invstd, float* var_biased,
+                                float* moving_mean, float* moving_var, float decay, void* scratch, void* stream) {
+    if (!x || !mean || !invstd || !scratch || C <= 0 || ldx < C || P == 0) return KPX_EINVAL;
+    RedArgs a{}; a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.part = (double*)scratch;
+    int nb; int rc = launch_chan_reduce(1, a, &nb, kpx_stream(stream));
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, kpx_stream(stream), (const double*)scratch, nb, C,
+                       (double)P, eps, mean, invstd, var_biased, moving_mean, moving_var, decay);
+    return kpx_launch_status();
+}
+
+__global__ void bn_invstd_kernel(const float* var, int C, float eps, float* invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);
+}
+extern "C" int kpx_bn_invstd_f32(const float* var, int C, float eps, float* invstd, void* stream) {
+    if (!var || !invstd || C <= 0) return KPX_EINVAL;
+    hipLaunchKernelGGL(bn_invstd_kernel, dim3((C + 63) / 64), dim3(64), 0, kpx_stream(stream), var, C, eps, invstd);
+    return kpx_launch_status();
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, size_t P, int C, int ldx, const float* mean, const float* invstd,
+                                                       const float* gamma, const float* beta, float* y, int ldy, int act) {
+    constexpr int W = VEC ? 4 : 1;
+    const int G = C / W;
+    const size_t total = P * (size_t)G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t p = i / G;
+        const int c0 = (int)(i - p * G) * W;
+        float v[W];
+        if (VEC) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + p * ldx + c0);
+#pragma unroll
+            for (int j = 0; j < W; ++j) v[j] = xv[j];
+        } else v[0] = x[p * ldx + c0];
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const float xh = (v[j] - mean[c0 + j]) * invstd[c0 + j];
+            float r = fmaf(xh, gamma[c0 + j], beta[c0 + j]);
+            if (act == KPX_ACT_RELU) r = fmaxf(r, 0.f);
+            v[j] = r;
+        }
+        if (VEC) {
+            f32x4 o = {v[0], v[W > 1 ? 1 : 0], v[W > 2 ? 2 : 0], v[W > 3 ? 3 : 0]};
+            *reinterpret_cast<f32x4*>(y + p * ldy + c0) = o;
+        } else y[p * ldy + c0] = v[0];
+    }
+}
+extern "C" int kpx_bn_apply_f32(const float* x, size_t P, int C, int ldx, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, float* y, int ldy, int act, void* stream) {
+    if (!x || !y || !mean || !invstd || !gamma || !beta || C <= 0 || ldx < C || ldy < C || act < 0 || act > 1) return KPX_EINVAL;
+    if (P == 0) return 0;
+    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid_for(P * (C / 4))), dim3(256), 0, kpx_stream(stream), x, P, C, ldx, mean, invstd, gamma, beta, y, ldy, act);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(P * C)), dim3(256), 0, kpx_stream(stream), x, P, C, ldx, mean, invstd, gamma, beta, y, ldy, act);
+    return kpx_launch_status();
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* part, int nb, int C, float* dgamma, float* dbeta, float* sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nb; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+    dbeta[c] = (float)s; dgamma[c] = (float)q;
+    sums[c] = (float)s; sums[C + c] = (float)q;
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int lddy, const float* x, int ldx, size_t P, int C,
+                                                           const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                                           int act, const float* sums, float inv_count, float* dx, int lddx) {
+    constexpr int W = VEC ? 4 : 1;
+    const int G = C / W;
+    const size_t total = P * (size_t)G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t p = i / G;
+        const int c0 = (int)(i - p * G) * W;
+        float xv[W], gv[W];
+        if (VEC) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + p * ldx + c0);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dy + p * lddy + c0);
+#pragma unroll
+            for (int j = 0; j < W; ++j) { xv[j] = a[j]; gv[j] = d[j]; }
+        } else { xv[0] = x[p * ldx + c0]; gv[0] = dy[p * lddy + c0]; }
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const int c = c0 + j;
+            const float xh = (xv[j] - mean[c]) * invstd[c];
+            const float yv = fmaf(xh, gamma[c], beta[c]);
+            const float dz = (act == KPX_ACT_RELU && !(yv > 0.f)) ? 0.f : gv[j];
+            xv[j] = gamma[c] * invstd[c] * (dz - sums[c] * inv_count - xh * (sums[C + c] * inv_count));
+        }
+        if (VEC) {
+            f32x4 o = {xv[0], xv[W > 1 ? 1 : 0], xv[W > 2 ? 2 : 0], xv[W > 3 ? 3 : 0]};
+            *reinterpret_cast<f32x4*>(dx + p * lddx + c0) = o;
+        } else dx[p * lddx + c0] = xv[0];
+    }
+}
+extern "C" int kpx_bn_bwd_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int C,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                              float* dx, int lddx, float* dgamma, float* dbeta, void* scratch, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !scratch || C <= 0 ||
+        ldx < C || lddy < C || lddx < C || act < 0 || act > 1 || P == 0)
+        return KPX_EINVAL;
+    hipStream_t s = kpx_stream(stream);
+    RedArgs a{}; a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.P = P; a.C = C;
+    a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.act = act; a.part = (double*)scratch;
+    int nb; int rc = launch_chan_reduce(2, a, &nb, s);
+    if (rc) return rc;
+    // the per-channel sums are parked (as floats) behind the partials in the scratch buffer
+    float* sums = reinterpret_cast<float*>((double*)scratch + (size_t)KPX_RED_BLOCKS * 2 * C);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, (const double*)scratch, nb, C, dgamma, dbeta, sums);
+    rc = kpx_launch_status();
+    if (rc) return rc;
+    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) &&
+                     ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
+    const float inv_count = (float)(1.0 / (double)P);
+    if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(P * (C / 4))), dim3(256), 0, s, dy, lddy, x, ldx, P, C, mean, invstd, gamma, beta, act, sums, inv_count, dx, lddx);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(P * C)), dim3(256), 0, s, dy, lddy, x, ldx, P, C, mean, invstd, gamma, beta, act, sums, inv_count, dx, lddx);
+    return kpx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ bilinear x2 (legacy TF sampling)
+template <bool VEC>
+__global__ __launch_bounds__(256) void resize2x_fwd_kernel(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy) {
+    constexpr int V = VEC ? 4 : 1;
+    const int G = C / V, W2 = 2 * W, H2 = 2 * H;
+    const size_t total = (size_t)N * H2 * W2 * G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % G) * V;
+        size_t p = i / G;
+        const int ox = (int)(p % W2); p /= W2;
+        const int oy = (int)(p % H2);
+        const int n = (int)(p / H2);
+        const int iy = oy >> 1, ix = ox >> 1;
+        const int iy1 = min(iy + 1, H - 1), ix1 = min(ix + 1, W - 1);
+        const float ty = (oy & 1) ? 0.5f : 0.f, tx = (ox & 1) ? 0.5f : 0.f;
+        const float* r0 = x + ((size_t)(n * H + iy) * W) * ldx + c;
+        const float* r1 = x + ((size_t)(n * H + iy1) * W) * ldx + c;
+        float* o = y + ((size_t)(n * H2 + oy) * W2 + ox) * ldy + c;
+        if (VEC) {
+            const f32x4 tl = *reinterpret_cast<const f32x4*>(r0 + (size_t)ix * ldx), tr = *reinterpret_cast<const f32x4*>(r0 + (size_t)ix1 * ldx);
+            const f32x4 bl = *reinterpret_cast<const f32x4*>(r1 + (size_t)ix * ldx), br = *reinterpret_cast<const f32x4*>(r1 + (size_t)ix1 * ldx);
+            f32x4 r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float top = tl[j] + (tr[j] - tl[j]) * tx, bot = bl[j] + (br[j] - bl[j]) * tx;
+                r[j] = top + (bot - top) * ty;
+            }
+            *reinterpret_cast<f32x4*>(o) = r;
+        } else {
+            const float tl = r0[(size_t)ix * ldx], tr = r0[(size_t)ix1 * ldx], bl = r1[(size_t)ix * ldx], br = r1[(size_t)ix1 * ldx];
+            const float top = tl + (tr - tl) * tx, bot = bl + (br - bl) * tx;
+            *o = top + (bot - top) * ty;
+        }
+    }
+}
+extern "C" int kpx_resize2x_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || ldx < C || ldy < C) return KPX_EINVAL;
+    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    const size_t items = (size_t)N * 4 * H * W * (vec ? C / 4 : C);
+    if (vec) hipLaunchKernelGGL(resize2x_fwd_kernel<true>, dim3(grid_for(items)), dim3(256), 0, kpx_stream(stream), x, N, H, W, C, ldx, y, ldy);
+    else hipLaunchKernelGGL(resize2x_fwd_kernel<false>, dim3(grid_for(items)), dim3(256), 0, kpx_stream(stream), x, N, H, W, C, ldx, y, ldy);
+    return kpx_launch_status();
+}
+
+// dx[i] gathers out rows {2i-1 (w .5, i>=1), 2i (w 1), 2i+1 (w .5, or 1 at the clamped last row)} x the same in x.
+template <bool VEC>
+__global__ __launch_bounds__(256) void resize2x_bwd_kernel(const float* dy, int N, int H, int W, int C, int lddy, float* dx, int lddx) {
+    constexpr int V = VEC ? 4 : 1;
+    const int G = C / V, W2 = 2 * W, H2 = 2 * H;
+    const size_t total = (size_t)N * H * W * G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % G) * V;
+        size_t p = i / G;
+        const int ix = (int)(p % W); p /= W;
+        const int iy = (int)(p % H);
+        const int n = (int)(p / H);
+        float wy[3], wx[3];
+        wy[0] = iy >= 1 ? 0.5f : 0.f; wy[1] = 1.f; wy[2] = iy == H - 1 ? 1.f : 0.5f;
+        wx[0] = ix >= 1 ? 0.5f : 0.f; wx[1] = 1.f; wx[2] = ix == W - 1 ? 1.f : 0.5f;
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int oy = 2 * iy - 1 + a;
+            if (oy < 0) continue;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int ox = 2 * ix - 1 + b;
+                if (ox < 0) continue;
+                const float wgt = wy[a] * wx[b];
+                const float* q = dy + ((size_t)(n * H2 + oy) * W2 + ox) * lddy + c;
+                if (VEC) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(q);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) acc[j] = fmaf(wgt, v[j], acc[j]);
+                } else acc[0] = fmaf(wgt, *q, acc[0]);
+            }
+        }
+        float* o = dx + ((size_t)(n * H + iy) * W + ix) * lddx + c;
+        if (VEC) {
+            f32x4 r = {acc[0], acc[V > 1 ? 1 : 0], acc[V > 2 ? 2 : 0], acc[V > 3 ? 3 : 0]};
+            *reinterpret_cast<f32x4*>(o) = r;
+        } else *o = acc[0];
+    }
+}
+extern "C" int kpx_resize2x_bwd_f32(const float* dy, int N, int H, int W, int C, int lddy, float* dx, int lddx, void* stream) {
+    if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || lddy < C || lddx < C) return KPX_EINVAL;
+    const bool vec = (C % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && ((((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
+    const size_t items = (size_t)N * H * W * (vec ? C / 4 : C);
+    if (vec) hipLaunchKernelGGL(resize2x_bwd_kernel<true>, dim3(grid_for(items)), dim3(256), 0, kpx_stream(stream), dy, N, H, W, C, lddy, dx, lddx);
+    else hipLaunchKernelGGL(resize2x_bwd_kernel<false>, dim3(grid_for(items)), dim3(256), 0, kpx_stream(stream), dy, N, H, W, C, lddy, dx, lddx);
+    return kpx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ translator heads + blend
+__global__ __launch_bounds__(256) void head_blend_fwd_kernel(const float* im, const float* raw4, size_t P, float* fin, float* crude, float* mask) {
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (size_t)gridDim.x * 256) {
+        const f32x4 r = reinterpret_cast<const f32x4*>(raw4)[p];
+        const float m = 1.0f / (1.0f + expf(-r[3]));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            fin[p * 3 + j] = im[p * 3 + j] * m + r[j] * (1.0f - m);
+            if (crude) crude[p * 3 + j] = r[j];
+        }
+        if (mask) mask[p] = m;
+    }
+}
+extern "C" int kpx_head_blend_fwd_f32(const float* im, const float* raw4, size_t P, float* final_out, float* crude_out, float* mask_out, void* stream) {
+    if (!im || !raw4 || !final_out || (((uintptr_t)raw4) & 15)) return KPX_EINVAL;
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(head_blend_fwd_kernel, dim3(grid_for(P)), dim3(256), 0, kpx_stream(stream), im, raw4, P, final_out, crude_out, mask_out);
+    return kpx_launch_status();
+}
+__global__ __launch_bounds__(256) void head_blend_bwd_kernel(const float* dfin, const float* im, const float* raw4, size_t P, float* draw4) {
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (size_t)gridDim.x * 256) {
+        const f32x4 r = reinterpret_cast<const f32x4*>(raw4)[p];
+        const float m = 1.0f / (1.0f + expf(-r[3]));
+        f32x4 d;
+        float dm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float g = dfin[p * 3 + j];
+            d[j] = g * (1.0f - m);
+            dm = fmaf(g, im[p * 3 + j] - r[j], dm);
+        }
+        d[3] = dm * m * (1.0f - m);
+        reinterpret_cast<f32x4*>(draw4)[p] = d;
+    }
+}
+extern "C" int kpx_head_blend_bwd_f32(const float* dfinal, const float* im, const float* raw4, size_t P, float* draw4, void* stream) {
+    if (!dfinal || !im || !raw4 || !draw4 || ((((uintptr_t)raw4) | ((uintptr_t)draw4)) & 15)) return KPX_EINVAL;
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(head_blend_bwd_kernel, dim3(grid_for(P)), dim3(256), 0, kpx_stream(stream), dfinal, im, raw4, P, draw4);
+    return kpx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ VGG input transform
+__global__ __launch_bounds__(256) void vgg_prep_fwd_kernel(const float* rgb, size_t P, float* bgr) {
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (size_t)gridDim.x * 256) {
+        const float r = (rgb[p * 3 + 0] + 1.0f) / 2.0f * 255.0f;
+        const float g = (rgb[p * 3 + 1] + 1.0f) / 2.0f * 255.0f;
+        const float b = (rgb[p * 3 + 2] + 1.0f) / 2.0f * 255.0f;
+        bgr[p * 3 + 0] = b - 103.939f; bgr[p * 3 + 1] = g - 116.779f; bgr[p * 3 + 2] = r - 123.68f;
+    }
+}
+extern "C" int kpx_vgg_prep_fwd_f32(const float* rgb, size_t P, float* bgr, void* stream) {
+    if (!rgb || !bgr) return KPX_EINVAL;
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(vgg_prep_fwd_kernel, dim3(grid_for(P)), dim3(256), 0, kpx_stream(stream), rgb, P, bgr);
+    return kpx_launch_status();
+}
+__global__ __launch_bounds__(256) void vgg_prep_bwd_kernel(const float* dbgr, size_t P, float* drgb) {
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (size_t)gridDim.x * 256) {
+        drgb[p * 3 + 0] = dbgr[p * 3 + 2] * 127.5f;
+        drgb[p * 3 + 1] = dbgr[p * 3 + 1] * 127.5f;
+        drgb[p * 3 + 2] = dbgr[p * 3 + 0] * 127.5f;
+    }
+}
+extern "C" int kpx_vgg_prep_bwd_f32(const float* dbgr, size_t P, float* drgb, void* stream) {
+    if (!dbgr || !drgb) return KPX_EINVAL;
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(vgg_prep_bwd_kernel, dim3(grid_for(P)), dim3(256), 0, kpx_stream(stream), dbgr, P, drgb);
+    return kpx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ max-pool 2x2 s2 SAME
+template <bool VEC>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* x, int N, int H, int W, int C, float* y) {
+    constexpr int V = VEC ? 4 : 1;
+    const int G = C / V, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const size_t total = (size_t)N * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % G) * V;
+        size_t p = i / G;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float m[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) m[j] = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int iy = 2 * oy + a, ix = 2 * ox + b;
+                if (iy >= H || ix >= W) continue;
+                const float* q = x + ((size_t)(n * H + iy) * W + ix) * C + c;
+                if (VEC) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(q);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) m[j] = fmaxf(m[j], v[j]);
+                } else m[0] = fmaxf(m[0], *q);
+            }
+        float* o = y + ((size_t)(n * Ho + oy) * Wo + ox) * C + c;
+        if (VEC) { f32x4 r = {m[0], m[V > 1 ? 1 : 0], m[V > 2 ? 2 : 0], m[V > 3 ? 3 : 0]}; *reinterpret_cast<f32x4*>(o) = r; }
+        else *o = m[0];
+    }
+}
+extern "C" int kpx_maxpool2_fwd_f32(const float* x, int N, int H, int W, int C, float* y, void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) return KPX_EINVAL;
+    const bool vec = (C % 4 == 0) && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    const size_t items = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * (vec ? C / 4 : C);
+    if (vec) hipLaunchKernelGGL(maxpool2_fwd_kernel<true>, dim3(grid_for(items)), dim3(256), 0, kpx_stream(stream), x, N, H, W, C, y);
+    else hipLaunchKernelGGL(maxpool2_fwd_kernel<false>, dim3(grid_for(items)), dim3(256), 0, kpx_stream(stream), x, N, H, W, C, y);
+    return kpx_launch_status();
+}
+// gradient goes to the first maximum of each window in row-major scan order (TF / Eigen argmax rule)
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* dy, const float* x, int N, int H, int W, int C, float* dx) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const size_t total = (size_t)N * Ho * Wo * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        size_t p = i / C;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float best = -INFINITY; int bi = 0;
+        float v[4]; bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int iy = 2 * oy + (k >> 1), ix = 2 * ox + (k & 1);
+            ok[k] = iy < H && ix < W;
+            v[k] = ok[k] ? x[((size_t)(n * H + iy) * W + ix) * C + c] : -INFINITY;
+            if (ok[k] && v[k] > best) { best = v[k]; bi = k; }
+        }
+        const float g = dy[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int iy = 2 * oy + (k >> 1), ix = 2 * ox + (k & 1);
+            if (ok[k]) dx[((size_t)(n * H + iy) * W + ix) * C + c] = (k == bi) ? g : 0.f;
+        }
+    }
+}
+extern "C" int kpx_maxpool2_bwd_f32(const float* dy, const float* x, int N, int H, int W, int C, float* dx, void* stream) {
+    if (!dy || !x || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return KPX_EINVAL;
+    const size_t items = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C;
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(items)), dim3(256), 0, kpx_stream(stream), dy, x, N, H, W, C, dx);
+    return kpx_launch_status();
+}

@@ -1,0 +1,215 @@
+"""Stage-1 model: key-point detector + translator + GAN / perceptual losses
+(reference: models/detector_translator_model.py).
+
+The step is the reference's D-run followed by its G-run (train_step :79-117) on ONE batch, restructured so that the
+generator forward -- identical in both runs because the D update does not touch generator variables -- is computed once
+(SURVEY 8d "restructured step"); the discriminator is re-run with its UPDATED weights for the generator's adversarial
+term exactly as the second sess.run would.  Data parallelism: one process per GPU, per-replica BN statistics, one
+all-reduce (RCCL) per flat gradient bucket per optimiser update, 1/world scaling inside the fused Adam kernel.
+"""
+import logging
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+
+from . import model_utils, networks, ops, variables
+from .base_model import BaseModel
+from .variables import Sym
+from .vgg import Vgg19
+
+log = logging.getLogger('kpx')
+
+
+class DetectorTranslatorModel(BaseModel):
+    name = 'detector_translator'       # reference :15 (checkpoint sub-directory)
+
+    def __init__(self, config, global_step=None, is_training=True, device='cuda', vgg=None, process_group=None,
+                 image_size=128, seed=1234):
+        super(DetectorTranslatorModel, self).__init__(is_training)
+        train_config, model_config, paths_config = config['training'], config['model'], config['paths']
+        self.lr = train_config['lr'] if self.is_training else None      # reference :24-27
+        self.batch_size = train_config['batch_size']
+        self.n_points = model_config['n_pts']
+        self.log_dir = paths_config['log_dir']
+        self.vgg19_path = paths_config.get('vggnet')
+        self.image_size = image_size            # literal 128 in the reference loaders (image_pair_dataloader.py:13)
+        self.heat_size = image_size // 4        # literal [32, 32] (:168-169)
+        self.device = torch.device(device)
+        self.global_step = int(global_step or 0)
+        self.process_group = process_group
+        self.world_size = torch.distributed.get_world_size(process_group) if (
+            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        self.store = variables.VariableStore(device=self.device, seed=seed)
+        self.vgg = vgg
+        # Adam state (two optimisers, reference :198 and :201): fp32 beta powers like TF's beta{1,2}_power variables
+        self.beta1, self.beta2, self.adam_eps = np.float32(0.5), np.float32(0.999), np.float32(1e-8)
+        self.beta_power = {'D': [np.float32(0.5), np.float32(0.999)], 'G': [np.float32(0.5), np.float32(0.999)]}
+        self.last = {}
+
+    # ------------------------------------------------------------------------------------------------ build
+    def build(self, inputs=None):
+        """Declare every variable with a shape-only pass over the same network code (the analogue of TF graph
+        construction, reference :68-77), then allocate the flat buckets on the device."""
+        b, r = 2, self.image_size
+        with variables.as_default(self.store):
+            self._define_forward_pass(Sym(b, r, r, 3), Sym(b, r, r, 3))
+            networks.img_discr(Sym(b, r, r, 3))
+        self.store.materialise()
+        dev = self.device
+        if dev.type == 'cuda':
+            self._e0 = torch.tensor([1.0, 0.0, 0.0], dtype=torch.float32, device=dev)
+            self._one = torch.ones(1, dtype=torch.float32, device=dev)
+        if self.is_training and self.vgg is None and dev.type == 'cuda':
+            self.vgg = Vgg19(self.vgg19_path, device=dev)             # raises like vgg.py:9-10 when the file is missing
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def _define_forward_pass(self, im, future_im, with_vis_maps=False, update_moving=True):
+        """reference _define_forward_pass (:160-184)."""
+        train = self.is_training
+        sym = variables.is_sym(im)
+        b = im.shape[0]
+        embeddings = networks.image_encoder(im, train)                                     # :165
+        # :166-167 -- the two weight-sharing pose_encoder calls as one batched launch, BN statistics per call
+        both = Sym(2 * b, *im.shape[1:]) if sym else ops.concat_batch(im, future_im)
+        pts, logits = networks.pose_encoder(both, self.n_points, train, final_res=self.image_size, bn_groups=2,
+                                            return_logits=True)
+        if sym:
+            joint = Sym(b, self.heat_size, self.heat_size, (embeddings[-2].shape[-1] + 2 * self.n_points + 3) // 4 * 4)
+            cur_pt = fut_pt = None
+        else:
+            cur_pt, fut_pt = pts[:b], pts[b:]
+            joint = ops.joint_embedding(embeddings[-2], cur_pt, fut_pt)                    # :168-170
+        raw4 = networks.translator(joint, train, final_res=self.image_size,
+                                   cin=embeddings[-2].shape[-1] + 2 * self.n_points)       # :173
+        if sym:
+            return None
+        final_output, crude_output, mask = ops.head_blend(im, raw4)                        # :174
+        out = dict(final_output=final_output, crude_output=crude_output, mask=mask,
+                   current_points=cur_pt, future_points=fut_pt)
+        if with_vis_maps:                                                                  # :176-177
+            hw = [self.image_size, self.image_size]
+            out['current_keypoints_map'] = model_utils.get_gaussian_maps(cur_pt.detach(), hw)
+            out['future_keypoints_map'] = model_utils.get_gaussian_maps(fut_pt.detach(), hw)
+        return out
+
+    def forward(self, im, future_im, with_vis_maps=True):
+        with variables.as_default(self.store), torch.no_grad():
+            return self._define_forward_pass(im, future_im, with_vis_maps=with_vis_maps)
+
+    # ------------------------------------------------------------------------------------------------ losses
+    def _loss_D(self, future_im_pred, future_im):
+        """reference _compute_loss_D (:246-259); real and fake go through img_discr as one batch."""
+        n = future_im.shape[0]
+        logits = networks.img_discr(ops.concat_batch(future_im, future_im_pred))
+        per = logits.numel() // (2 * n)
+        return ops.sigmoid_xent(logits, n * per, 1.0, n * per, 0.0)       # [loss_D, D_real, D_fake]
+
+    def _loss_G(self, future_im_pred, future_im):
+        """reference _compute_loss_G (:261-272): perceptual + adversarial (vs ones)."""
+        recon = self.vgg.perceptual_loss(future_im, future_im_pred)        # [1]
+        with self.store.freeze('img_discr'):
+            logits = networks.img_discr(future_im_pred)
+        adv = ops.sigmoid_xent(logits, logits.numel(), 1.0)                # [adv, adv, 0]
+        return recon, adv
+
+    def current_lr(self):
+        """tf.train.exponential_decay, non-staircase, fp32 (reference :193-195)."""
+        p = np.float32(self.global_step) / np.float32(self.lr['step'])
+        return np.float32(np.float32(self.lr['start_val']) * np.power(np.float32(self.lr['decay']), p, dtype=np.float32))
+
+    def _apply_adam(self, which, lr):
+        bucket = self.store.buckets[which]
+        if self.world_size > 1:                                           # the ONE collective of the data-parallel step
+            torch.distributed.all_reduce(bucket.grads, group=self.process_group)
+        b1p, b2p = self.beta_power[which]
+        alpha = np.float32(np.float32(lr) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p))
+        ops.adam_tf_flat_(bucket.params, bucket.grads, bucket.m, bucket.v, alpha, self.beta1, self.beta2, self.adam_eps,
+                          gscale=1.0 / self.world_size)
+        self.beta_power[which] = [np.float32(b1p * self.beta1), np.float32(b2p * self.beta2)]
+
+    # ------------------------------------------------------------------------------------------------ steps
+    def train_step(self, sess, feed_dict, step, batch_size, should_write_log=False, should_write_summary=False):
+        """reference train_step (:79-117).  feed_dict = {'image': [B,H,W,3], 'future_image': [B,H,W,3]} in [-1,1]."""
+        im, future_im = feed_dict['image'], feed_dict['future_image']
+        start_time = time.time()
+        lr = self.current_lr()
+        with variables.as_default(self.store):
+            fwd = self._define_forward_pass(im, future_im)
+            final = fwd['final_output']
+            # ---- D run (:93)
+            d_losses = self._loss_D(final.detach(), future_im)
+            torch.autograd.backward([d_losses], [self._e0])
+            self._apply_adam('D', lr)
+            # ---- G run (:94) with the updated discriminator
+            recon, adv = self._loss_G(final, future_im)
+            torch.autograd.backward([recon, adv], [self._one, self._e0])
+            self._apply_adam('G', lr)
+        self.global_step += 1                                             # incremented by the G optimiser (:201-202)
+        self.last = dict(d_losses=d_losses.detach(), recon=recon.detach(), adv=adv.detach(), lr=float(lr), fwd=fwd)
+        if should_write_log:
+            vals = self.loss_values()
+            duration = time.time() - start_time
+            log.info('%s: step %d, loss_D = %.4f, loss_G = %.4f (%.1f examples/sec) %.3f sec/batch',
+                     datetime.now(), step, vals['loss_D'], vals['loss_G'], batch_size / float(duration), duration)
+
+    def loss_values(self):
+        """Host copies of the last step's scalars (synchronises)."""
+        d = self.last['d_losses'].cpu().numpy()
+        recon = float(self.last['recon'].cpu()[0])
+        adv = float(self.last['adv'].cpu()[0])
+        return dict(loss_D=float(d[0]), loss_D_real=float(d[1]), loss_D_fake=float(d[2]),
+                    loss_G_recon=recon, loss_G_adv=adv, loss_G=recon + adv, lr=self.last['lr'])
+
+    def test_step(self, sess, feed_dict, step, test_idx, batch_size):
+        """reference test_step (:119-141): losses only, BN in batch-statistics mode, no updates."""
+        im, future_im = feed_dict['image'], feed_dict['future_image']
+        start_time = time.time()
+        with variables.as_default(self.store), torch.no_grad():
+            fwd = self._define_forward_pass(im, future_im, update_moving=False)
+            d = self._loss_D(fwd['final_output'], future_im)
+            recon, adv = self._loss_G(fwd['final_output'], future_im)
+        loss_d = float(d.cpu()[0])
+        loss_g = float(recon.cpu()[0]) + float(adv.cpu()[0])
+        return loss_d, loss_g, time.time() - start_time, batch_size
+
+    def collect_test_results(self, results, step):
+        """reference collect_test_results (:143-158)."""
+        average_loss_D = sum(x[0] for x in results) / len(results)
+        average_loss_G = sum(x[1] for x in results) / len(results)
+        total_duration = sum(x[2] for x in results)
+        num_examples = sum(x[3] for x in results)
+        log.info('test: %s: step %d, loss_D = %.4f, loss_G = %.4f (%.1f examples/sec) %.3f sec/batch', datetime.now(), step,
+                 average_loss_D, average_loss_G, num_examples / total_duration, total_duration / len(results))
+        return average_loss_D, average_loss_G
+
+    # ------------------------------------------------------------------------------------------------ checkpoints
+    def checkpoint_arrays(self):
+        powers = {'beta1_power': self.beta_power['D'][0], 'beta2_power': self.beta_power['D'][1],     # D optimiser first (:198)
+                  'beta1_power_1': self.beta_power['G'][0], 'beta2_power_1': self.beta_power['G'][1],
+                  'global_step': np.int32(self.global_step)}
+        return self.store.export_numpy(include_slots=self.is_training, beta_powers={k: np.asarray(v) for k, v in powers.items()})
+
+    def _restore_extra(self, arrays):
+        if 'global_step' in arrays:
+            self.global_step = int(arrays['global_step'])
+        for which, sfx in (('D', ''), ('G', '_1')):
+            if 'beta1_power' + sfx in arrays:
+                self.beta_power[which] = [np.float32(arrays['beta1_power' + sfx]), np.float32(arrays['beta2_power' + sfx])]
+        if self.is_training:
+            with torch.no_grad():
+                for b in self.store.buckets.values():
+                    for name in b.entries:
+                        for slot, flat in (('/Adam', b.m), ('/Adam_1', b.v)):
+                            if '_0+1/' in name:
+                                k0, k1 = name.replace('_0+1/', '_0/') + slot, name.replace('_0+1/', '_1/') + slot
+                                if k0 in arrays and k1 in arrays:
+                                    src = np.concatenate([arrays[k0], arrays[k1]], axis=-1)
+                                else:
+                                    continue
+                            elif name + slot in arrays:
+                                src = arrays[name + slot]
+                            else:
+                                continue
+                            b.view(flat, name).copy_(torch.from_numpy(np.ascontiguousarray(src, np.float32)).to(flat.device))

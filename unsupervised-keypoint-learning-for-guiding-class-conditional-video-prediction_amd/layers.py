@@ -1,0 +1,52 @@
+"""Layer wrappers with the reference's signatures (reference: models/networks/layers.py).
+
+``conv`` and ``batch_norm`` keep the reference's argument names / defaults and variable naming
+(``<scope>/conv2d/{kernel,bias}``, ``<scope>/{beta,gamma,moving_mean,moving_variance}``); the arithmetic is the HIP
+kernels of libkpx_hip.so.  Extra keyword arguments (``act``, ``cin``, ``groups``...) expose fusions the TF graph did as
+separate ops (bias+activation epilogue, BN+ReLU, batched weight-sharing calls).
+"""
+from . import ops
+from .variables import Sym, default_store, is_sym
+
+ACT_NONE, ACT_RELU, ACT_LRELU = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LRELU
+
+
+def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', act=ACT_NONE, cin=None, head31=False):
+    """reference layers.conv (layers.py:4-10): tf.pad(pad) + tf.layers.conv2d(padding='same', xavier, bias)."""
+    st = default_store()
+    channels = int(channels)          # the reference passes float filter counts after `filters /= 2` ([TF-sem 9])
+    cin_ = int(cin) if cin is not None else int(x.shape[-1])
+    with st.variable_scope(scope), st.variable_scope('conv2d'):
+        kname = st.get_variable('kernel', (kernel, kernel, cin_, channels), 'kernel_head31' if head31 else 'kernel')
+        bname = st.get_variable('bias', (channels,), 'zeros') if use_bias else None
+    if is_sym(x):
+        n, h, w, _ = x.shape
+        _, _, ho = ops.same_pad(h + 2 * pad, kernel, stride)
+        _, _, wo = ops.same_pad(w + 2 * pad, kernel, stride)
+        return Sym(n, ho, wo, channels)
+    w_, wg = st.param(kname)
+    b_, bg = st.param(bname) if use_bias else (None, None)
+    return ops.conv2d(x, w_, b_, stride=stride, pad=pad, act=act, cin=cin, w_grad_out=wg, b_grad_out=bg)
+
+
+def batch_norm(x, train_mode, scope='batch_norm', act=ACT_NONE, groups=1, update_moving=True):
+    """reference layers.batch_norm (layers.py:13-14): contrib batch_norm(eps=1e-5, center, scale, is_training)."""
+    st = default_store()
+    c = int(x.shape[-1])
+    with st.variable_scope(scope):
+        beta = st.get_variable('beta', (c,), 'zeros')
+        gamma = st.get_variable('gamma', (c,), 'ones')
+        mm = st.get_variable('moving_mean', (c,), 'moving_zeros')
+        mv = st.get_variable('moving_variance', (c,), 'moving_ones')
+    if is_sym(x):
+        return Sym(*x.shape)
+    g_, gg = st.param(gamma)
+    b_, bg = st.param(beta)
+    return ops.batch_norm(x, g_, b_, st[mm], st[mv], train=bool(train_mode), act=act, groups=groups,
+                          update_moving=update_moving and bool(train_mode), g_grad_out=gg, b_grad_out=bg)
+
+
+def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, groups=1, update_moving=True, cin=None):
+    """conv -> batch_norm -> relu, the repeating unit of every generator network (reference networks/__init__.py:10-12)."""
+    x = conv(x, channels, kernel=kernel, stride=stride, scope=conv_scope, cin=cin)
+    return batch_norm(x, train_mode, scope=bn_scope, act=ACT_RELU, groups=groups, update_moving=update_moving)

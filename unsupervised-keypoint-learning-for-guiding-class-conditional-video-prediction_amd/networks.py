@@ -1,0 +1,103 @@
+"""Network builders with the reference's names and scopes (reference: models/networks/__init__.py).
+
+Same layer order, filter schedule and variable scopes as the reference; differences are fusions only:
+BN+ReLU in one kernel, resize written straight into the skip-concat buffer, one 4-channel conv for the crude+mask
+heads, and ``bn_groups`` so that weight-sharing calls on different images run as one batched launch with separate
+batch-norm statistics per call.
+"""
+from . import layers, ops
+from . import model_utils
+from .layers import ACT_LRELU, ACT_NONE
+from .variables import Sym, default_store, is_sym
+
+
+def _upsample_concat(x, skip):
+    if is_sym(x):
+        n, h, w, c = x.shape
+        return Sym(n, 2 * h, 2 * w, c + (skip.shape[-1] if skip is not None else 0))
+    return ops.upsample2x_concat(x, skip)
+
+
+def encoder(x, train_mode, filters=32, bn_groups=1, skip_last_block=False):
+    """reference encoder (networks/__init__.py:7-26).  Returns the 4 block features."""
+    st = default_store()
+    with st.variable_scope('encoder'):
+        feats = []
+        x = layers.conv_bn_relu(x, filters, 7, 1, train_mode, 'conv_1', 'b_norm_1', bn_groups)
+        x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_2', 'b_norm_2', bn_groups)
+        feats.append(x)
+        for i in range(3):
+            filters *= 2
+            x = layers.conv_bn_relu(x, filters, 3, 2, train_mode, 'conv_%d' % (i * 2 + 3), 'b_norm_%d' % (i * 2 + 3), bn_groups)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d' % (i * 2 + 4), 'b_norm_%d' % (i * 2 + 4), bn_groups)
+            feats.append(x)
+        return feats
+
+
+def image_encoder(x, train_mode):
+    """reference image_encoder (:29-33): [x] + the 4 encoder blocks."""
+    st = default_store()
+    with st.variable_scope('image_encoder'):
+        return [x] + encoder(x, train_mode)
+
+
+def pose_encoder(x, n_pts, train_mode, final_res=128, filters=128, bn_groups=1, return_logits=False):
+    """reference pose_encoder (:36-72): encoder + U-Net decoder + 1x1 head -> separable-softmax key-points [B,K,2]."""
+    st = default_store()
+    with st.variable_scope('pose_encoder'):
+        block_features = encoder(x, train_mode, bn_groups=bn_groups)
+        x = block_features[-1]
+        size = x.shape[1]
+        conv_id = 1
+        for i in range(4):
+            # i > 0: x is already the [up-sampled ‖ skip] concat buffer written by the previous stage (:44)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % conv_id, 'b_norm_%d_0' % conv_id, bn_groups)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id, bn_groups)
+            if size == final_res:
+                x = layers.conv(x, n_pts, kernel=1, stride=1)        # default scope 'conv_0' (:54)
+                break
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1), bn_groups)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % (conv_id + 1), 'b_norm_%d_1' % (conv_id + 1), bn_groups)
+            x = _upsample_concat(x, block_features[-1 * (i + 2)])     # resize (:63) + next stage's concat (:44)
+            size = 2 * size
+            conv_id += 2
+            if filters >= 8:
+                filters //= 2
+        gauss_mu, _, _ = model_utils.get_coords_xy(x)                 # :68-71
+        return (gauss_mu, x) if return_logits else gauss_mu
+
+
+def translator(x, train_mode, final_res=128, filters=256, cin=None):
+    """reference translator (:75-102).  Returns the fused 4-channel head output raw4 = crude(3) ‖ mask-logit(1);
+    sigmoid + blend happen in ops.head_blend."""
+    st = default_store()
+    with st.variable_scope('translator'):
+        size = x.shape[1]
+        conv_id = 1
+        while size <= final_res:
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % conv_id, 'b_norm_%d_0' % conv_id, cin=cin)
+            cin = None
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id)
+            if size == final_res:
+                # conv_N_0 (crude, 3 ch, :87) and conv_N_1 (mask, 1 ch, :88) as one 4-channel conv
+                return layers.conv(x, 4, kernel=3, stride=1, scope='conv_%d_0+1' % (conv_id + 1), head31=True)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1))
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % (conv_id + 1), 'b_norm_%d_1' % (conv_id + 1))
+            x = _upsample_concat(x, None)                              # :98
+            size = 2 * size
+            conv_id += 2
+            if filters >= 8:
+                filters //= 2
+    raise ValueError('translator input (%d) larger than final_res (%d)' % (size, final_res))
+
+
+def img_discr(x):
+    """reference img_discr (:141-151): 6x [pad 1 + conv4x4 s2 + bias + leaky_relu(0.01)] + D_logit 3x3 (no bias)."""
+    st = default_store()
+    with st.variable_scope('img_discr'):
+        channel = 64
+        x = layers.conv(x, channel, kernel=4, stride=2, pad=1, use_bias=True, scope='conv_0', act=ACT_LRELU)
+        for i in range(1, 6):
+            x = layers.conv(x, channel * 2, kernel=4, stride=2, pad=1, use_bias=True, scope='conv_' + str(i), act=ACT_LRELU)
+            channel = channel * 2
+        return layers.conv(x, channels=1, kernel=3, stride=1, pad=1, use_bias=False, scope='D_logit', act=ACT_NONE)

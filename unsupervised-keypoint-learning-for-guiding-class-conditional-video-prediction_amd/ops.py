@@ -1,0 +1,540 @@
+"""torch.autograd.Function wrappers around the C ABI (include/kpx.h).
+
+PyTorch is used as plumbing only: device buffers (caching allocator), the current HIP stream and the autograd tape.
+Every tensor op on the hot path is a kernel from libkpx_hip.so; there is no eager-PyTorch fallback -- a missing
+library fails at import (``_lib``) and a failed launch raises ``KpxError``.
+
+Weight / bias / gamma / beta gradients are written by the kernels straight into caller-provided views of the
+flat gradient bucket (``*_grad_out``), so the RCCL all-reduce and the fused Adam step run on one contiguous buffer
+without a gather pass.
+"""
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+BN_EPS = 1e-5        # reference: models/networks/layers.py:14
+BN_DECAY = 0.999     # tf.contrib.layers.batch_norm default
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise _lib.KpxError('kpx ops run on MI355X only (got a %s tensor); there is no CPU fallback' % t.device)
+    if t.dtype != torch.float32:
+        raise _lib.KpxError('kpx ops are fp32 (got %s)' % t.dtype)
+
+
+def same_pad(in_size, k, s):
+    """TF SAME padding: out = ceil(in/s); the extra pixel goes to the bottom/right."""
+    out = -(-in_size // s)
+    total = max((out - 1) * s + k - in_size, 0)
+    return total // 2, total - total // 2, out
+
+
+def _nhwc(t):
+    """Return (tensor, pixel stride) for an NHWC tensor that may be a channel slice of a wider buffer."""
+    _require_gpu(t)
+    assert t.dim() == 4
+    n, h, w, c = t.shape
+    ld = t.stride(2) if w > 1 else (t.stride(1) if h > 1 else (t.stride(0) if n > 1 else c))
+    ok = (c == 1 or t.stride(3) == 1) and ld >= c
+    ok = ok and (w == 1 or t.stride(2) == ld) and (h == 1 or t.stride(1) == w * ld) and (n == 1 or t.stride(0) == h * w * ld)
+    if not ok:
+        t = t.contiguous()
+        ld = c
+    return t, ld
+
+
+class _Scratch:
+    """Per-device scratch buffers; all kernels are stream-ordered so consecutive ops may share them."""
+
+    def __init__(self):
+        self._bufs = {}
+
+    def get(self, key, nbytes, device):
+        k = (key, device)
+        b = self._bufs.get(k)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(int(max(nbytes, 1 << 16)), dtype=torch.uint8, device=device)
+            self._bufs[k] = b
+        return b
+
+    def reduce(self, c, device):
+        return self.get('reduce', lib.kpx_chan_reduce_scratch_bytes(int(c)), device)
+
+
+scratch = _Scratch()
+
+
+# ----------------------------------------------------------------------------------------------- raw launchers
+def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act):
+    n, hi, wi = x.shape[0], x.shape[1], x.shape[2]
+    kh, kw, _, cout = w.shape
+    check(lib.kpx_conv2d_fwd_f32(x.data_ptr(), n, hi, wi, cin, ldx, w.data_ptr(), kh, kw,
+                                 bias.data_ptr() if bias is not None else None,
+                                 y.data_ptr(), y.shape[1], y.shape[2], cout, ldy, stride, pad_t, pad_l, act, _stream()),
+          'kpx_conv2d_fwd_f32')
+
+
+def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l):
+    n, ho, wo = dy.shape[0], dy.shape[1], dy.shape[2]
+    kh, kw, _, cout = w.shape
+    check(lib.kpx_conv2d_dgrad_f32(dy.data_ptr(), n, ho, wo, cout, lddy, w.data_ptr(), kh, kw,
+                                   dx.data_ptr(), dx.shape[1], dx.shape[2], cin, lddx, stride, pad_t, pad_l, _stream()),
+          'kpx_conv2d_dgrad_f32')
+
+
+def conv_wgrad_raw(x, ldx, cin, dy, lddy, dw, stride, pad_t, pad_l):
+    n, hi, wi = x.shape[0], x.shape[1], x.shape[2]
+    ho, wo = dy.shape[1], dy.shape[2]
+    kh, kw, _, cout = dw.shape
+    nbytes = lib.kpx_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, cout, kh, kw)
+    ws = scratch.get('wgrad', nbytes, x.device) if nbytes else None
+    check(lib.kpx_conv2d_wgrad_f32(x.data_ptr(), n, hi, wi, cin, ldx, dy.data_ptr(), ho, wo, cout, lddy,
+                                   dw.data_ptr(), kh, kw, stride, pad_t, pad_l,
+                                   ws.data_ptr() if ws is not None else None, nbytes, _stream()),
+          'kpx_conv2d_wgrad_f32')
+
+
+def chan_sum_raw(x, ldx, pixels, c, out):
+    check(lib.kpx_chan_sum_f32(x.data_ptr(), pixels, c, ldx, out.data_ptr(), scratch.reduce(c, x.device).data_ptr(), _stream()),
+          'kpx_chan_sum_f32')
+
+
+def act_bwd_raw_(dy, y, act):
+    check(lib.kpx_act_bwd_f32(dy.data_ptr(), y.data_ptr(), dy.numel(), act, _stream()), 'kpx_act_bwd_f32')
+
+
+def axpy_raw_(y, x, a=1.0):
+    check(lib.kpx_axpy_f32(y.data_ptr(), x.data_ptr(), y.numel(), a, _stream()), 'kpx_axpy_f32')
+
+
+def fill_raw_(t, v=0.0):
+    check(lib.kpx_fill_f32(t.data_ptr(), t.numel(), v, _stream()), 'kpx_fill_f32')
+
+
+def copy_channels_raw(src_ptr, ldsrc, dst_ptr, lddst, pixels, c):
+    check(lib.kpx_copy_channels_f32(src_ptr, ldsrc, dst_ptr, lddst, pixels, c, _stream()), 'kpx_copy_channels_f32')
+
+
+def flat_copy_raw(src_ptr, dst_ptr, n):
+    """dst[0:n] = src[0:n] (floats): a degenerate channel copy, 16 B per lane when alignment allows."""
+    if n % 4 == 0 and src_ptr % 16 == 0 and dst_ptr % 16 == 0:
+        copy_channels_raw(src_ptr, 4, dst_ptr, 4, n // 4, 4)
+    else:
+        copy_channels_raw(src_ptr, 1, dst_ptr, 1, n, 1)
+
+
+# ----------------------------------------------------------------------------------------------- conv
+class Conv2dFn(torch.autograd.Function):
+    """layers.conv: tf.pad(pad) + conv2d(SAME) + bias [+ activation] (reference models/networks/layers.py:4-10)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin):
+        x, ldx = _nhwc(x)
+        _require_gpu(w)
+        w = w.contiguous()
+        n, h, wd, cx = x.shape
+        kh, kw, wcin, cout = w.shape
+        cin = cx if cin is None else cin
+        assert wcin == cin and cin <= cx
+        pt, _, ho = same_pad(h + 2 * pad, kh, stride)
+        pl, _, wo = same_pad(wd + 2 * pad, kw, stride)
+        pad_t, pad_l = pad + pt, pad + pl
+        y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+        conv_fwd_raw(x, ldx, cin, w, b, y, cout, stride, pad_t, pad_l, act)
+        ctx.geom = (stride, pad_t, pad_l, act, cin, ldx)
+        ctx.has_bias = b is not None
+        ctx.w_grad_out, ctx.b_grad_out = w_grad_out, b_grad_out
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad_t, pad_l, act, cin, ldx = ctx.geom
+        dy = dy.contiguous()
+        cout = w.shape[3]
+        if act != ACT_NONE:
+            dy = dy.clone()
+            act_bwd_raw_(dy, y, act)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            cx = x.shape[3]
+            dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            if cin < cx:
+                fill_raw_(dx, 0.0)
+            conv_dgrad_raw(dy, cout, w, dx, cx, cin, stride, pad_t, pad_l)
+        if ctx.needs_input_grad[1]:
+            dw_buf = ctx.w_grad_out if ctx.w_grad_out is not None else torch.empty_like(w)
+            conv_wgrad_raw(x, ldx, cin, dy, cout, dw_buf, stride, pad_t, pad_l)
+            dw = None if ctx.w_grad_out is not None else dw_buf
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db_buf = ctx.b_grad_out if ctx.b_grad_out is not None else torch.empty(cout, dtype=torch.float32, device=x.device)
+            chan_sum_raw(dy, cout, dy.shape[0] * dy.shape[1] * dy.shape[2], cout, db_buf)
+            db = None if ctx.b_grad_out is not None else db_buf
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, cin=None, w_grad_out=None, b_grad_out=None):
+    return Conv2dFn.apply(x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin)
+
+
+# ----------------------------------------------------------------------------------------------- batch norm
+class BatchNormFn(torch.autograd.Function):
+    """layers.batch_norm (+ fused ReLU) -- tf.contrib.layers.batch_norm(eps=1e-5) (reference layers.py:13-14).
+
+    ``groups`` > 1 computes separate batch statistics for consecutive batch slices: this is how the two weight-sharing
+    pose_encoder calls of the reference (detector_translator_model.py:166-167, separate BN statistics per call) run as
+    ONE launch over the concatenated batch.  Moving statistics are updated once per group, in order.
+    """
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving):
+        _require_gpu(x)
+        x = x.contiguous()
+        n, h, w, c = x.shape
+        assert n % groups == 0
+        y = torch.empty_like(x)
+        dev = x.device
+        sc = scratch.reduce(c, dev)
+        if train:
+            mean = torch.empty((groups, c), dtype=torch.float32, device=dev)
+            invstd = torch.empty((groups, c), dtype=torch.float32, device=dev)
+            ng = n // groups
+            pix = ng * h * w
+            for g in range(groups):
+                xg, yg = x[g * ng:(g + 1) * ng], y[g * ng:(g + 1) * ng]
+                check(lib.kpx_bn_stats_f32(xg.data_ptr(), pix, c, c, BN_EPS, mean[g].data_ptr(), invstd[g].data_ptr(), None,
+                                           moving_mean.data_ptr() if update_moving else None,
+                                           moving_var.data_ptr() if update_moving else None,
+                                           BN_DECAY, sc.data_ptr(), _stream()), 'kpx_bn_stats_f32')
+                check(lib.kpx_bn_apply_f32(xg.data_ptr(), pix, c, c, mean[g].data_ptr(), invstd[g].data_ptr(),
+                                           gamma.data_ptr(), beta.data_ptr(), yg.data_ptr(), c, act, _stream()), 'kpx_bn_apply_f32')
+        else:
+            mean = moving_mean.reshape(1, c)
+            invstd = torch.empty((1, c), dtype=torch.float32, device=dev)
+            check(lib.kpx_bn_invstd_f32(moving_var.data_ptr(), c, BN_EPS, invstd.data_ptr(), _stream()), 'kpx_bn_invstd_f32')
+            check(lib.kpx_bn_apply_f32(x.data_ptr(), n * h * w, c, c, mean.data_ptr(), invstd.data_ptr(),
+                                       gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), c, act, _stream()), 'kpx_bn_apply_f32')
+        ctx.train, ctx.act, ctx.groups = train, act, groups
+        ctx.g_grad_out, ctx.b_grad_out = g_grad_out, b_grad_out
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.train:
+            raise _lib.KpxError('backward through inference-mode batch norm is not part of the hot path')
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, h, w, c = x.shape
+        groups = ctx.groups
+        ng = n // groups
+        pix = ng * h * w
+        dev = x.device
+        dx = torch.empty_like(x)
+        dg = ctx.g_grad_out if ctx.g_grad_out is not None else torch.empty(c, dtype=torch.float32, device=dev)
+        db = ctx.b_grad_out if ctx.b_grad_out is not None else torch.empty(c, dtype=torch.float32, device=dev)
+        sc = scratch.reduce(c, dev)
+        tmp = torch.empty((2, c), dtype=torch.float32, device=dev) if groups > 1 else None
+        for g in range(groups):
+            sl = slice(g * ng, (g + 1) * ng)
+            dgo, dbo = (dg, db) if g == 0 else (tmp[0], tmp[1])
+            check(lib.kpx_bn_bwd_f32(dy[sl].data_ptr(), c, x[sl].data_ptr(), c, pix, c, mean[g].data_ptr(), invstd[g].data_ptr(),
+                                     gamma.data_ptr(), beta.data_ptr(), ctx.act, dx[sl].data_ptr(), c,
+                                     dgo.data_ptr(), dbo.data_ptr(), sc.data_ptr(), _stream()), 'kpx_bn_bwd_f32')
+            if g > 0:
+                axpy_raw_(dg, tmp[0])
+                axpy_raw_(db, tmp[1])
+        return (dx, None if ctx.g_grad_out is not None else dg, None if ctx.b_grad_out is not None else db,
+                None, None, None, None, None, None, None, None)
+
+
+def batch_norm(x, gamma, beta, moving_mean, moving_var, train=True, act=ACT_RELU, groups=1, update_moving=True,
+               g_grad_out=None, b_grad_out=None):
+    return BatchNormFn.apply(x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving)
+
+
+# ----------------------------------------------------------------------------------------------- resize + concat
+class UpsampleConcatFn(torch.autograd.Function):
+    """tf.image.resize_images(x, 2x) [+ tf.concat([up, skip], -1)] (reference networks/__init__.py:63,98 and :44).
+    The up-sampled tensor is written straight into its channel slice of the concat buffer."""
+
+    @staticmethod
+    def forward(ctx, x, skip):
+        _require_gpu(x)
+        x = x.contiguous()
+        n, h, w, c1 = x.shape
+        c2 = 0
+        if skip is not None:
+            skip = skip.contiguous()
+            assert skip.shape[:3] == (n, 2 * h, 2 * w)
+            c2 = skip.shape[3]
+        ld = c1 + c2
+        out = torch.empty((n, 2 * h, 2 * w, ld), dtype=torch.float32, device=x.device)
+        check(lib.kpx_resize2x_fwd_f32(x.data_ptr(), n, h, w, c1, c1, out.data_ptr(), ld, _stream()), 'kpx_resize2x_fwd_f32')
+        if c2:
+            copy_channels_raw(skip.data_ptr(), c2, out.data_ptr() + 4 * c1, ld, n * 4 * h * w, c2)
+        ctx.dims = (n, h, w, c1, c2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, h, w, c1, c2 = ctx.dims
+        dout = dout.contiguous()
+        ld = c1 + c2
+        dx = dskip = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((n, h, w, c1), dtype=torch.float32, device=dout.device)
+            check(lib.kpx_resize2x_bwd_f32(dout.data_ptr(), n, h, w, c1, ld, dx.data_ptr(), c1, _stream()), 'kpx_resize2x_bwd_f32')
+        if c2 and ctx.needs_input_grad[1]:
+            dskip = torch.empty((n, 2 * h, 2 * w, c2), dtype=torch.float32, device=dout.device)
+            copy_channels_raw(dout.data_ptr() + 4 * c1, ld, dskip.data_ptr(), c2, n * 4 * h * w, c2)
+        return dx, dskip
+
+
+def upsample2x_concat(x, skip=None):
+    return UpsampleConcatFn.apply(x, skip)
+
+
+class ConcatChannelsFn(torch.autograd.Function):
+    """tf.concat([a, b], axis=-1) for two NHWC tensors (batch-norm'd feature + skip) without resize."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        _require_gpu(a)
+        n, h, w, c1 = a.shape
+        c2 = b.shape[3]
+        out = torch.empty((n, h, w, c1 + c2), dtype=torch.float32, device=a.device)
+        copy_channels_raw(a.data_ptr(), c1, out.data_ptr(), c1 + c2, n * h * w, c1)
+        copy_channels_raw(b.data_ptr(), c2, out.data_ptr() + 4 * c1, c1 + c2, n * h * w, c2)
+        ctx.dims = (n, h, w, c1, c2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, h, w, c1, c2 = ctx.dims
+        dout = dout.contiguous()
+        da = torch.empty((n, h, w, c1), dtype=torch.float32, device=dout.device)
+        db = torch.empty((n, h, w, c2), dtype=torch.float32, device=dout.device)
+        copy_channels_raw(dout.data_ptr(), c1 + c2, da.data_ptr(), c1, n * h * w, c1)
+        copy_channels_raw(dout.data_ptr() + 4 * c1, c1 + c2, db.data_ptr(), c2, n * h * w, c2)
+        return da, db
+
+
+def concat_channels(a, b):
+    return ConcatChannelsFn.apply(a, b)
+
+
+class ConcatBatchFn(torch.autograd.Function):
+    """tf.concat([a, b], axis=0): used to run the two pose_encoder calls / the real+fake discriminator passes batched."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        _require_gpu(a)
+        assert a.shape[1:] == b.shape[1:]
+        out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), dtype=torch.float32, device=a.device)
+        flat_copy_raw(a.data_ptr(), out.data_ptr(), a.numel())
+        flat_copy_raw(b.data_ptr(), out.data_ptr() + 4 * a.numel(), b.numel())
+        ctx.na = a.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        return dout[:ctx.na], dout[ctx.na:]
+
+
+def concat_batch(a, b):
+    return ConcatBatchFn.apply(a, b)
+
+
+# ----------------------------------------------------------------------------------------------- key-points
+class KeypointHeadFn(torch.autograd.Function):
+    """get_coord x2 + stack (reference utils/model.py:63-70, networks/__init__.py:68-72): logits -> [B,K,2] (x,y)."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        _require_gpu(logits)
+        logits = logits.contiguous()
+        b, h, w, k = logits.shape
+        dev = logits.device
+        mu = torch.empty((b, k, 2), dtype=torch.float32, device=dev)
+        py = torch.empty((b, h, k), dtype=torch.float32, device=dev)
+        px = torch.empty((b, w, k), dtype=torch.float32, device=dev)
+        sc = scratch.get('kphead', lib.kpx_keypoint_head_scratch_bytes(b, h, w, k), dev)
+        check(lib.kpx_keypoint_head_fwd_f32(logits.data_ptr(), b, h, w, k, mu.data_ptr(), py.data_ptr(), px.data_ptr(),
+                                            sc.data_ptr(), _stream()), 'kpx_keypoint_head_fwd_f32')
+        ctx.dims = (b, h, w, k)
+        ctx.save_for_backward(mu, py, px)
+        ctx.mark_non_differentiable(py, px)
+        return mu, py, px
+
+    @staticmethod
+    def backward(ctx, dmu, _dpy, _dpx):
+        mu, py, px = ctx.saved_tensors
+        b, h, w, k = ctx.dims
+        dmu = dmu.contiguous()
+        dl = torch.empty((b, h, w, k), dtype=torch.float32, device=dmu.device)
+        check(lib.kpx_keypoint_head_bwd_f32(dmu.data_ptr(), mu.data_ptr(), py.data_ptr(), px.data_ptr(), b, h, w, k,
+                                            dl.data_ptr(), _stream()), 'kpx_keypoint_head_bwd_f32')
+        return dl
+
+
+def keypoint_head(logits):
+    return KeypointHeadFn.apply(logits)
+
+
+class GaussianMapsFn(torch.autograd.Function):
+    """get_gaussian_maps (reference utils/model.py:49-60): [B,K,2] -> [B,H,W,K]."""
+
+    @staticmethod
+    def forward(ctx, mu, h, w, inv_std):
+        _require_gpu(mu)
+        mu = mu.contiguous()
+        b, k, _ = mu.shape
+        out = torch.empty((b, h, w, k), dtype=torch.float32, device=mu.device)
+        check(lib.kpx_gaussian_maps_fwd_f32(mu.data_ptr(), b, k, h, w, float(inv_std), out.data_ptr(), k, _stream()),
+              'kpx_gaussian_maps_fwd_f32')
+        ctx.dims = (b, k, h, w, float(inv_std))
+        ctx.save_for_backward(mu)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (mu,) = ctx.saved_tensors
+        b, k, h, w, inv_std = ctx.dims
+        dout = dout.contiguous()
+        dmu = torch.empty_like(mu)
+        check(lib.kpx_gaussian_maps_bwd_f32(dout.data_ptr(), k, mu.data_ptr(), b, k, h, w, inv_std, dmu.data_ptr(), _stream()),
+              'kpx_gaussian_maps_bwd_f32')
+        return dmu, None, None, None
+
+
+def gaussian_maps(mu, h, w, inv_std=14.3):
+    return GaussianMapsFn.apply(mu, h, w, inv_std)
+
+
+class JointEmbeddingFn(torch.autograd.Function):
+    """tf.concat([embedding, current_map, future_map], -1) (reference detector_translator_model.py:168-170) with the
+    two heat-maps rendered straight into their channel slices.  Output pixel stride is padded to a multiple of 4
+    (16-B aligned pixels); the consumer conv reads only the first C+2K channels (``cin``)."""
+
+    @staticmethod
+    def forward(ctx, emb, cur_pt, fut_pt, inv_std):
+        _require_gpu(emb)
+        emb, cur_pt, fut_pt = emb.contiguous(), cur_pt.contiguous(), fut_pt.contiguous()
+        b, h, w, c = emb.shape
+        k = cur_pt.shape[1]
+        ld = (c + 2 * k + 3) // 4 * 4
+        out = torch.empty((b, h, w, ld), dtype=torch.float32, device=emb.device)
+        if ld > c + 2 * k:
+            fill_raw_(out, 0.0)
+        copy_channels_raw(emb.data_ptr(), c, out.data_ptr(), ld, b * h * w, c)
+        for i, pt in enumerate((cur_pt, fut_pt)):
+            check(lib.kpx_gaussian_maps_fwd_f32(pt.data_ptr(), b, k, h, w, float(inv_std), out.data_ptr() + 4 * (c + i * k), ld, _stream()),
+                  'kpx_gaussian_maps_fwd_f32')
+        ctx.dims = (b, h, w, c, k, ld, float(inv_std))
+        ctx.save_for_backward(cur_pt, fut_pt)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cur_pt, fut_pt = ctx.saved_tensors
+        b, h, w, c, k, ld, inv_std = ctx.dims
+        dout = dout.contiguous()
+        demb = torch.empty((b, h, w, c), dtype=torch.float32, device=dout.device)
+        copy_channels_raw(dout.data_ptr(), ld, demb.data_ptr(), c, b * h * w, c)
+        grads = []
+        for i, pt in enumerate((cur_pt, fut_pt)):
+            d = torch.empty_like(pt)
+            check(lib.kpx_gaussian_maps_bwd_f32(dout.data_ptr() + 4 * (c + i * k), ld, pt.data_ptr(), b, k, h, w, inv_std,
+                                                d.data_ptr(), _stream()), 'kpx_gaussian_maps_bwd_f32')
+            grads.append(d)
+        return demb, grads[0], grads[1], None
+
+
+def joint_embedding(emb, cur_pt, fut_pt, inv_std=14.3):
+    return JointEmbeddingFn.apply(emb, cur_pt, fut_pt, inv_std)
+
+
+# ----------------------------------------------------------------------------------------------- heads / losses
+class HeadBlendFn(torch.autograd.Function):
+    """mask = sigmoid(raw[...,3]); final = im*mask + crude*(1-mask) (reference networks/__init__.py:87-89,
+    detector_translator_model.py:174).  raw4 = crude(3) ‖ mask-logit(1) from ONE 4-channel conv."""
+
+    @staticmethod
+    def forward(ctx, im, raw4):
+        _require_gpu(raw4)
+        im, raw4 = im.contiguous(), raw4.contiguous()
+        n, h, w, _ = raw4.shape
+        dev = raw4.device
+        final = torch.empty((n, h, w, 3), dtype=torch.float32, device=dev)
+        crude = torch.empty((n, h, w, 3), dtype=torch.float32, device=dev)
+        mask = torch.empty((n, h, w, 1), dtype=torch.float32, device=dev)
+        check(lib.kpx_head_blend_fwd_f32(im.data_ptr(), raw4.data_ptr(), n * h * w, final.data_ptr(), crude.data_ptr(),
+                                         mask.data_ptr(), _stream()), 'kpx_head_blend_fwd_f32')
+        ctx.save_for_backward(im, raw4)
+        ctx.mark_non_differentiable(crude, mask)
+        return final, crude, mask
+
+    @staticmethod
+    def backward(ctx, dfinal, _dc, _dm):
+        im, raw4 = ctx.saved_tensors
+        dfinal = dfinal.contiguous()
+        draw = torch.empty_like(raw4)
+        n, h, w, _ = raw4.shape
+        check(lib.kpx_head_blend_bwd_f32(dfinal.data_ptr(), im.data_ptr(), raw4.data_ptr(), n * h * w, draw.data_ptr(), _stream()),
+              'kpx_head_blend_bwd_f32')
+        return None, draw
+
+
+def head_blend(im, raw4):
+    return HeadBlendFn.apply(im, raw4)
+
+
+class SigmoidXentFn(torch.autograd.Function):
+    """reduce_mean(sigmoid_cross_entropy_with_logits) for one or two label groups
+    (reference detector_translator_model.py:249-254, 265-267).  Returns [total, mean_group0, mean_group1]."""
+
+    @staticmethod
+    def forward(ctx, logits, n0, label0, n1, label1):
+        _require_gpu(logits)
+        logits = logits.contiguous()
+        assert logits.numel() == n0 + n1
+        out = torch.empty(3, dtype=torch.float32, device=logits.device)
+        check(lib.kpx_sigmoid_xent_fwd_f32(logits.data_ptr(), n0, label0, n1, label1, out.data_ptr(), _stream()), 'kpx_sigmoid_xent_fwd_f32')
+        ctx.args = (n0, label0, n1, label1)
+        ctx.save_for_backward(logits)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (logits,) = ctx.saved_tensors
+        n0, label0, n1, label1 = ctx.args
+        dout = dout.contiguous()          # only dout[0] (the summed loss) is differentiated
+        dl = torch.empty_like(logits)
+        check(lib.kpx_sigmoid_xent_bwd_f32(logits.data_ptr(), n0, label0, n1, label1, dout.data_ptr(), 1.0, dl.data_ptr(), _stream()),
+              'kpx_sigmoid_xent_bwd_f32')
+        return dl, None, None, None, None
+
+
+def sigmoid_xent(logits, n0, label0, n1=0, label1=0.0):
+    return SigmoidXentFn.apply(logits, n0, float(label0), n1, float(label1))
+
+
+# ----------------------------------------------------------------------------------------------- optimiser
+def adam_tf_flat_(p, g, m, v, alpha, beta1, beta2, eps, gscale=1.0):
+    """In-place tf.train.AdamOptimizer update of one flat bucket (reference detector_translator_model.py:198-202)."""
+    for t in (p, g, m, v):
+        _require_gpu(t)
+    check(lib.kpx_adam_tf_flat_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                   float(alpha), float(beta1), float(beta2), float(eps), float(gscale), _stream()), 'kpx_adam_tf_flat_f32')

@@ -1,0 +1,219 @@
+"""Variable store: the stand-in for TF1's graph-level variable scopes of the reference.
+
+The reference identifies every weight by its ``tf.variable_scope`` path (e.g.
+``pose_encoder/encoder/conv_3/conv2d/kernel``) and trains two variable sets split by the substring ``img_discr``
+(models/detector_translator_model.py:191-192).  Here the same names index views into two flat fp32 buckets in HBM
+(generator / discriminator): parameters, gradients and the two Adam slots are each ONE contiguous buffer per bucket, so
+the data-parallel exchange is a single RCCL all-reduce and the optimiser a single fused kernel launch per bucket.
+"""
+import contextlib
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+class Bucket:
+    """One flat parameter bucket with matching flat gradient and Adam-slot buffers."""
+
+    def __init__(self, name):
+        self.name = name
+        self.entries = OrderedDict()     # var name -> (offset, shape)
+        self.size = 0
+        self.params = self.grads = self.m = self.v = None
+
+    def add(self, name, shape):
+        n = int(np.prod(shape))
+        self.entries[name] = (self.size, tuple(shape))
+        self.size += (n + 3) // 4 * 4      # keep every view 16-B aligned for the vectorised kernels
+
+    def allocate(self, device):
+        z = lambda: torch.zeros(max(self.size, 4), dtype=torch.float32, device=device)
+        self.params, self.grads, self.m, self.v = z(), z(), z(), z()
+
+    def view(self, flat, name):
+        off, shape = self.entries[name]
+        return flat[off:off + int(np.prod(shape))].view(shape)
+
+
+class VariableStore:
+    """name -> tensor, created on first use under the current scope (tf.get_variable semantics with AUTO_REUSE)."""
+
+    def __init__(self, device='cpu', seed=1234):
+        self.device = torch.device(device)
+        self.rng = np.random.RandomState(seed)       # RandomState(1234), creation order
+        self.specs = OrderedDict()                   # name -> (shape, kind)
+        self.init_values = OrderedDict()             # name -> np array (until materialised)
+        self.vars = OrderedDict()                    # name -> torch tensor (views into buckets once materialised)
+        self.grad_views = {}
+        self.buckets = OrderedDict((k, Bucket(k)) for k in ('G', 'D'))
+        self._scope = []
+        self.materialised = False
+        self.frozen = ()                             # name substrings whose variables are used without gradients
+
+    @contextlib.contextmanager
+    def freeze(self, *substrings):
+        """Use the matching variables as constants (the discriminator inside the generator update)."""
+        old, self.frozen = self.frozen, tuple(substrings)
+        try:
+            yield
+        finally:
+            self.frozen = old
+
+    def param(self, name):
+        """(tensor, gradient destination) for a variable, honouring freeze()."""
+        v = self.vars[name]
+        if any(s in name for s in self.frozen):
+            return v.detach(), None
+        return v, self.grad_views.get(name)
+
+    # ---- scopes ------------------------------------------------------------------------------------------------
+    @contextlib.contextmanager
+    def variable_scope(self, name):
+        self._scope.append(name)
+        try:
+            yield
+        finally:
+            self._scope.pop()
+
+    def scoped(self, name):
+        return '/'.join(self._scope + [name])
+
+    # ---- creation ----------------------------------------------------------------------------------------------
+    def get_variable(self, name, shape, kind):
+        """kind: 'kernel' (xavier-uniform), 'zeros', 'ones'; non-trainable kinds: 'moving_zeros', 'moving_ones'."""
+        full = self.scoped(name)
+        if full in self.specs:
+            assert self.specs[full][0] == tuple(shape), (full, self.specs[full][0], shape)
+            return full
+        assert not self.materialised, 'variable %s requested after materialise()' % full
+        self.specs[full] = (tuple(shape), kind)
+        if kind == 'kernel':                          # tf.contrib.layers.xavier_initializer (layers.py:8)
+            val = self._xavier(shape)
+        elif kind == 'kernel_head31':                 # fused crude(3) + mask(1) head: two reference variables
+            kh, kw, ci, co = shape
+            assert co == 4
+            val = np.concatenate([self._xavier((kh, kw, ci, 3)), self._xavier((kh, kw, ci, 1))], axis=-1)
+        elif kind in ('ones', 'moving_ones'):
+            val = np.ones(shape, np.float32)
+        else:
+            val = np.zeros(shape, np.float32)
+        self.init_values[full] = val
+        return full
+
+    def _xavier(self, shape):
+        kh, kw, ci, co = shape
+        lim = math.sqrt(6.0 / (kh * kw * ci + kh * kw * co))
+        return self.rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+    @staticmethod
+    def is_trainable(kind):
+        return not kind.startswith('moving')
+
+    def materialise(self):
+        """Allocate the buckets on the device and turn every variable into a view of them."""
+        for name, (shape, kind) in self.specs.items():
+            if self.is_trainable(kind):
+                self.buckets['D' if 'img_discr' in name else 'G'].add(name, shape)   # reference :191-192
+        for b in self.buckets.values():
+            b.allocate(self.device)
+        for name, (shape, kind) in self.specs.items():
+            val = torch.from_numpy(self.init_values[name])
+            if self.is_trainable(kind):
+                b = self.buckets['D' if 'img_discr' in name else 'G']
+                v = b.view(b.params, name)
+                v.copy_(val)
+                v.requires_grad_(True)
+                self.vars[name] = v
+                self.grad_views[name] = b.view(b.grads, name)
+            else:
+                self.vars[name] = val.to(self.device)
+        self.init_values.clear()
+        self.materialised = True
+
+    # ---- access ------------------------------------------------------------------------------------------------
+    def __getitem__(self, name):
+        return self.vars[name]
+
+    def grad(self, name):
+        return self.grad_views.get(name)
+
+    def load_numpy(self, arrays, strict=True):
+        """Copy {TF name: array} into the store; the fused translator head 'translator/conv_N_0+1' is assembled from the
+        reference's separate conv_N_0 (crude, 3 ch) and conv_N_1 (mask, 1 ch) variables."""
+        arrays = dict(arrays)
+        with torch.no_grad():
+            for name, v in self.vars.items():
+                if '_0+1/' in name:
+                    a = arrays.get(name.replace('_0+1/', '_0/'))
+                    b = arrays.get(name.replace('_0+1/', '_1/'))
+                    if a is None or b is None:
+                        if strict:
+                            raise KeyError(name)
+                        continue
+                    src = np.concatenate([np.asarray(a), np.asarray(b)], axis=-1)
+                elif name in arrays:
+                    src = np.asarray(arrays[name])
+                else:
+                    if strict:
+                        raise KeyError(name)
+                    continue
+                v.copy_(torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)).to(v.device))
+
+    def export_numpy(self, include_slots=False, beta_powers=None):
+        """{TF name: array} in the reference's checkpoint naming, splitting the fused head."""
+        out = OrderedDict()
+
+        def put(name, t, suffix=''):
+            a = t.detach().cpu().numpy().copy()
+            if '_0+1/' in name:
+                out[name.replace('_0+1/', '_0/') + suffix] = a[..., :3].copy()
+                out[name.replace('_0+1/', '_1/') + suffix] = a[..., 3:].copy()
+            else:
+                out[name + suffix] = a
+
+        for name, v in self.vars.items():
+            put(name, v)
+        if include_slots:
+            for b in self.buckets.values():
+                for name in b.entries:
+                    put(name, b.view(b.m, name), '/Adam')
+                    put(name, b.view(b.v, name), '/Adam_1')
+        if beta_powers:
+            out.update(beta_powers)
+        return out
+
+
+_default_store = []
+
+
+@contextlib.contextmanager
+def as_default(store):
+    """The analogue of TF1's default graph: layers.* create / look up variables in the innermost default store."""
+    _default_store.append(store)
+    try:
+        yield store
+    finally:
+        _default_store.pop()
+
+
+def default_store():
+    if not _default_store:
+        raise RuntimeError('no default VariableStore: wrap the network call in `with variables.as_default(store):`')
+    return _default_store[-1]
+
+
+class Sym:
+    """Shape-only stand-in for a tensor, used for the build pass that declares variables (the analogue of TF1 graph
+    construction: models/base_model.py build() creates variables without running anything)."""
+
+    def __init__(self, *shape):
+        self.shape = tuple(int(s) for s in shape)
+
+    def __repr__(self):
+        return 'Sym%s' % (self.shape,)
+
+
+def is_sym(x):
+    return isinstance(x, Sym)
