@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""Benchmark of the detector_translator train step (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = the reference's D-run + G-run (models/detector_translator_model.py:79-117) on one synthetic batch of
+image pairs: generator forward, discriminator update (Adam), generator update (VGG19 perceptual + adversarial loss,
+Adam), BN moving-average update -- nothing skipped.  Workload at every N: BASELINE configs[1] per GPU (128x128, K=15,
+fp32, batch 32 per GPU, weak scaling); gradients are all-reduced over RCCL once per bucket per update.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+RES, K_PTS, BATCH = 128, 15, 32
+# forward MACs per image pair
+GMAC_GEN_FWD, GMAC_D_PASS, GMAC_VGG_IMG = 11.370 + 0.227, 1.384, 6.370
+
+
+def step_gmac_per_pair():
+    """Algorithmic MACs of the restructured step per pair (shared generator forward; conv fwd = dgrad = wgrad):
+    G fwd + bwd(dgrad+wgrad) ; D-run: 2 D fwd + 2 x (dgrad+wgrad) ; G-run: D fwd + D dgrad ; VGG: 2 fwd + 1 dgrad."""
+    gen = 11.370 * 3 + 0.227          # the dead image_encoder conv_7/8 branch runs forward only (BN moving stats)
+    d_run = 2 * GMAC_D_PASS * 3
+    g_adv = GMAC_D_PASS * 2
+    vgg = GMAC_VGG_IMG * 3
+    return gen + d_run + g_adv + vgg
+
+
+def time_kernel(fn, iters, warm=3):
+    """Average device time of fn() in ms, HIP events on the stream the kernels are launched on (torch's current)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def roofline_conv(dev):
+    """Dominant kernel: conv_igemm (fp32 MFMA) on the translator's 3x3 128->128 layer at 64x64 (conv_3_1 / 4_0 / 4_1,
+    SURVEY Appendix A: 603 979 776 MAC per image), batch 32."""
+    from kpx_amd import ops
+    n, h, c = BATCH, 64, 128
+    x = torch.randn(n, h, h, c, device=dev)
+    w = torch.randn(3, 3, c, c, device=dev) * 0.03
+    b = torch.zeros(c, device=dev)
+    y = torch.empty(n, h, h, c, device=dev)
+    ms = time_kernel(lambda: ops.conv_fwd_raw(x, c, c, w, b, y, c, 1, 1, 1, 0), iters=20)
+    flops = 2.0 * 603979776 * n
+    ach = flops / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,128> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
+            'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4), 'traffic': None,
+            'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops}
+
+
+def roofline_render(dev):
+    """HBM-bound kernel the north star singles out: Gaussian heat-map render at [128,128,K=15], batch 32:
+    algorithmic bytes = B*H*W*K*4 written (+ K*8 read) per launch (983 040 B per image)."""
+    from kpx_amd import ops
+    from kpx_amd._lib import lib, check
+    b = BATCH
+    mu = (torch.rand(b, K_PTS, 2, device=dev) * 2 - 1).contiguous()
+    out = torch.empty(b, RES, RES, K_PTS, device=dev)
+
+    def run():
+        check(lib.kpx_gaussian_maps_fwd_f32(mu.data_ptr(), b, K_PTS, RES, RES, 14.3, out.data_ptr(), K_PTS, ops._stream()), 'gauss')
+    ms = time_kernel(run, iters=50)
+    nbytes = b * (RES * RES * K_PTS * 4 + K_PTS * 8)
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'kernel': 'gauss_fwd_flat_kernel [32,128,128,15]', 'achieved': round(ach, 1), 'peak': 8000.0,
+            'unit': 'GB/s', 'frac': round(ach / 8000.0, 4), 'traffic': None, 'avg_launch_ms': round(ms, 5), 'bytes_per_launch': nbytes}
+
+
+def host_cores():
+    """Cores this process may actually use: min(affinity mask, cgroup-v2 cpu.max quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline():
+    """The CPU restatement of the reference (oracle/restatement.py; NOT TF 1.12 -- it cannot be installed)
+    timed on this box's host cores: full train steps of BASELINE configs[0] (B=4, 128x128, K=15, VGG19 perceptual loss)."""
+    from oracle import restatement as R
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    b = 4
+    st = R.TrainState(R.init_variables(K_PTS, res=RES, seed=1234), R.synthetic_vgg(seed=19))
+    im, fut = R.synthetic_pair(b, res=RES)
+    R.train_step(st, im, fut)                      # warm-up
+    times = []
+    t_end = time.time() + 25.0
+    while len(times) < 5 and (time.time() < t_end or len(times) < 2):
+        t0 = time.time()
+        R.train_step(st, im, fut)
+        times.append(time.time() - t0)
+    med = float(np.median(times))
+    return {'value': round(b / med, 3), 'unit': 'image pairs/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d full train steps (D+G update, VGG19 loss) of batch 4 at 128x128 K=15, median; torch-CPU fp32 '
+                      'restatement of the reference, not TF 1.12' % len(times),
+            'sec_per_step': round(med, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=BATCH, help='image pairs per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
+                         '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.distributed.init_process_group('nccl', device_id=dev)   # RCCL over xGMI
+
+    import kpx_amd
+    from kpx_amd.synthetic import synthetic_pair
+    cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': args.batch},
+           'model': {'n_pts': K_PTS}, 'paths': {'log_dir': '/tmp/kpx_bench', 'vggnet': None}}
+    vgg = kpx_amd.Vgg19(weights=kpx_amd.synthetic_vgg19_weights(seed=19), device=dev)
+    model = kpx_amd.DetectorTranslatorModel(cfg, device=dev, vgg=vgg, image_size=RES)
+    model.build()
+    pair = synthetic_pair(args.batch, res=RES, seed0=2 * rank, seed1=2 * rank + 1)
+    feed = {k: torch.from_numpy(v).to(dev) for k, v in pair.items()}
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    tw = time.perf_counter()
+    for i in range(args.warmup):
+        model.train_step(None, feed, i, args.batch)
+    sync()
+    if rank == 0:
+        print('[bench] warmup %d steps: %.2fs' % (args.warmup, time.perf_counter() - tw), file=sys.stderr, flush=True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        model.train_step(None, feed, args.warmup + i, args.batch)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = model.loss_values()
+    assert np.isfinite(losses['loss_D']) and np.isfinite(losses['loss_G']), losses
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * args.batch * args.steps / dt
+        gmac = step_gmac_per_pair()
+        out = {'metric': 'detector_translator train frames/sec @128x128 K=15', 'value': round(value, 2),
+               'unit': 'image pairs/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+               'dtype': 'f32', 'data': 'synthetic',
+               'config': {'workload': 'Penn 128x128 K=15 detector_translator fp32, batch=%d per GPU (BASELINE configs[1])' % args.batch,
+                          'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
+                          'step': 'D update + G update on one batch (generator forward shared, SURVEY 8d restructured step), '
+                                  'VGG19 perceptual loss with synthetic He-normal weights, two fused Adam updates',
+                          'algorithmic_gmac_per_pair': round(gmac, 2)},
+               'step_tflops': round(2 * gmac * 1e9 * value / 1e12, 2),
+               'step_mfma_frac_of_f32_peak': round(2 * gmac * 1e9 * value / world / 157.3e12, 4),
+               'loss_D': round(losses['loss_D'], 5), 'loss_G': round(losses['loss_G'], 5)}
+        if world == 1:
+            out['roofline'] = roofline_conv(dev)
+            out['roofline_hbm_render'] = roofline_render(dev)
+            if not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

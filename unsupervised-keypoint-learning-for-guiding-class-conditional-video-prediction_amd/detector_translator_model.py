@@ -147,7 +147,8 @@ class DetectorTranslatorModel(BaseModel):
             torch.autograd.backward([recon, adv], [self._one, self._e0])
             self._apply_adam('G', lr)
         self.global_step += 1                                             # incremented by the G optimiser (:201-202)
-        self.last = dict(d_losses=d_losses.detach(), recon=recon.detach(), adv=adv.detach(), lr=float(lr), fwd=fwd)
+        self.last = dict(d_losses=d_losses.detach(), recon=recon.detach(), adv=adv.detach(), lr=float(lr),
+                         fwd={k: v.detach() for k, v in fwd.items()})
         if should_write_log:
             vals = self.loss_values()
             duration = time.time() - start_time
