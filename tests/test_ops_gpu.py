@@ -49,6 +49,9 @@ CONV_CASES = [
     (1, 32, 32, 64, 4, 3, 1, 0, 0),        # fused crude+mask head
     (5, 9, 9, 130, 130, 3, 1, 0, 0),       # ragged channel tiles
     (64, 4, 4, 128, 256, 4, 2, 1, 2),      # small-M / wide-N tile path
+    (2, 4, 4, 256, 1, 3, 1, 1, 0),         # D_logit-shaped: wave-per-pixel small-Cout kernel
+    (2, 6, 6, 512, 4, 3, 1, 0, 1),         # small-Cout kernel, Cout=4, relu
+    (2, 20, 20, 3, 64, 3, 1, 0, 1),        # VGG conv1_1 shape (row-merged Cin=3)
 ]
 
 

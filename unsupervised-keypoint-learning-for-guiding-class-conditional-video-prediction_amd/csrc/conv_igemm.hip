@@ -27,6 +27,8 @@ struct ConvGeom {
     int wts, ldw;
     int act, vecA, vecB;
     int M, mt, nt;
+    int merge;      // >0: row-merged taps for tiny Cin (= original Cin): the KW*Cin floats of one filter row are
+                    // contiguous in NHWC, so they are treated as one tap with KW*Cin channels (per-element x bounds)
 };
 
 template <int BM, int BN, int WM, int WN, bool BT>
@@ -93,7 +95,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
             const int ih = a_ih0[i] + tr * g.ity, iw = a_iw0[i] + tq * g.itx;
             const int c = c0 + kq * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a_ok[i] && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi && c < g.Cin) {
+            if (g.merge) {
+                if (a_ok[i] && (unsigned)ih < (unsigned)g.Hi && c < g.Cin) {
+                    const float* p = g.x + (ptrdiff_t)(a_base[i] + ih * g.Wi + iw) * g.ldx + c;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cc = c + j;
+                        if (cc < g.Cin && (unsigned)(iw + cc / g.merge) < (unsigned)g.Wi) v[j] = p[j];
+                    }
+                }
+            } else if (a_ok[i] && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi && c < g.Cin) {
                 const float* p = g.x + (size_t)(a_base[i] + ih * g.Wi + iw) * g.ldx + c;
                 if (g.vecA) {
                     v = *reinterpret_cast<const f32x4*>(p);
@@ -275,6 +286,49 @@ static int launch_gather_conv(ConvGeom g, hipStream_t s) {
     return kpx_launch_status();
 }
 
+// Tiny-Cout / long-K forward (img_discr D_logit: 3x3x2048 -> 1, reference networks/__init__.py:150): one wavefront
+// per output pixel, lanes stride over the contiguous channel axis, shuffle-tree reduction.  An MFMA tile would idle
+// 31/32 of its columns and serialise 18432-deep K loops on a handful of workgroups.
+__global__ __launch_bounds__(256) void conv_small_cout_kernel(const ConvGeom g) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= g.M) return;
+    const int HW = g.Ha * g.Wa;
+    const int n = m / HW, rem = m - n * HW, a = rem / g.Wa, b = rem - a * g.Wa;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int tr = 0; tr < g.Tr; ++tr) {
+        const int ih = a * g.isy + g.iy0 + tr * g.ity;
+        if ((unsigned)ih >= (unsigned)g.Hi) continue;
+        for (int tq = 0; tq < g.Tq; ++tq) {
+            const int iw = b * g.isx + g.ix0 + tq * g.itx;
+            if ((unsigned)iw >= (unsigned)g.Wi) continue;
+            const float* xp = g.x + ((size_t)(n * g.Hi + ih) * g.Wi + iw) * g.ldx;
+            const float* wp = g.w + (size_t)((g.wr0 + tr * g.wrs) * g.KW + g.wq0 + tq * g.wqs) * g.wts;
+            for (int c = lane * 4; c < g.Cin; c += 256) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    for (int o = 0; o < g.Cout; ++o) acc[o] = fmaf(xv[j], wp[(size_t)(c + j) * g.ldw + o], acc[o]);
+            }
+        }
+    }
+    const int pix = (n * g.Ho + a * g.osy + g.oy0) * g.Wo + b * g.osx + g.ox0;
+    for (int o = 0; o < g.Cout; ++o) {
+        float v = kpx_wave_sum(acc[o]);
+        if (lane == 0) {
+            v += g.bias ? g.bias[o] : 0.f;
+            if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+            g.y[(size_t)pix * g.ldy + o] = v;
+        }
+    }
+}
+static int launch_small_cout(ConvGeom g, hipStream_t s) {
+    g.M = g.N * g.Ha * g.Wa;
+    hipLaunchKernelGGL(conv_small_cout_kernel, dim3((unsigned)((g.M + 3) / 4)), dim3(256), 0, s, g);
+    return kpx_launch_status();
+}
+
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
@@ -295,6 +349,11 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
     g.wts = Cin * Cout; g.ldw = Cout; g.act = act;
     g.vecA = (ldx % 4 == 0) && aligned16(x);
     g.vecB = (Cout % 4 == 0) && aligned16(w);
+    if (Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64) {      // image inputs (Cin = 3): merge each filter row
+        g.merge = Cin; g.Tq = 1; g.KW = 1; g.Cin = KW * Cin; g.wts = KW * Cin * Cout; g.vecA = 0;
+    }
+    if (Cout <= 4 && Cin % 4 == 0 && Cin >= 256 && g.vecA && g.vecB == (Cout == 4))
+        return launch_small_cout(g, kpx_stream(stream));
     return launch_gather_conv<false>(g, kpx_stream(stream));
 }
 
@@ -345,6 +404,7 @@ struct WgradGeom {
     int P, S, pps;          // pixels, splits, pixels per split (multiple of 16)
     int ct, kt;             // channel tiles
     int vecA, vecB;
+    int merge;              // >0: row-merged taps (see ConvGeom::merge); Cin/KW below are the merged values
     size_t slab;            // floats per slab = KH*KW*Cin*Cout
 };
 
@@ -371,12 +431,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     const int pend = min(g.P, pbeg + g.pps);
 
     // per-thread loader coordinates: A unit -> (pixel-in-chunk, channel group)
-    int apx[RA], ac[RA], an[RA], aho[RA], awo[RA];
+    int apx[RA], ac[RA], an[RA], aho[RA], awo[RA], aq[RA][4];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int u = t + 256 * i;
         apx[i] = u / (BMc / 4);
         ac[i] = cbase + (u % (BMc / 4)) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aq[i][j] = g.merge ? (ac[i] + j) / g.merge : 0;
         const int p = pbeg + apx[i];
         an[i] = p / (g.Ho * g.Wo);
         const int rem = p - an[i] * g.Ho * g.Wo;
@@ -408,7 +470,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
             const int p = p0 + apx[i];
             const int ih = aho[i] * g.stride + r - g.pad_t, iw = awo[i] * g.stride + q - g.pad_l;
             const int c = ac[i];
-            if (p < pend && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi && c < g.Cin) {
+            if (g.merge) {
+                if (p < pend && (unsigned)ih < (unsigned)g.Hi && c < g.Cin) {
+                    const float* ptr = g.x + ((ptrdiff_t)(an[i] * g.Hi + ih) * g.Wi + iw) * g.ldx + c;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c + j < g.Cin && (unsigned)(iw + aq[i][j]) < (unsigned)g.Wi) v[j] = ptr[j];
+                }
+            } else if (p < pend && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi && c < g.Cin) {
                 const float* ptr = g.x + ((size_t)(an[i] * g.Hi + ih) * g.Wi + iw) * g.ldx + c;
                 if (g.vecA) {
                     v = *reinterpret_cast<const f32x4*>(ptr);
@@ -521,10 +590,13 @@ static void wgrad_tiles(int Cin, int Cout, int& bm, int& bn) {
     if (bm != bn) { bm = 64; bn = 64; }   // only the square tiles are instantiated
 }
 
+static inline bool wgrad_merge(int Cin, int ldx, int KW) { return Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64; }
+
 static int wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
     int bm, bn;
     wgrad_tiles(Cin, Cout, bm, bn);
-    const long tiles = (long)KH * KW * ((Cin + bm - 1) / bm) * ((Cout + bn - 1) / bn);
+    long tiles = (long)KH * KW * ((Cin + bm - 1) / bm) * ((Cout + bn - 1) / bn);
+    if (wgrad_merge(Cin, Cin, KW)) tiles = (long)KH * ((Cout + bn - 1) / bn);
     const long P = (long)N * Ho * Wo;
     long S = (1024 + tiles - 1) / tiles;
     const long maxS_pix = P / 128 > 0 ? P / 128 : 1;
@@ -564,8 +636,13 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     g.ct = (Cin + bm - 1) / bm; g.kt = (Cout + bn - 1) / bn;
     g.vecA = (ldx % 4 == 0) && aligned16(x);
     g.vecB = (lddy % 4 == 0) && aligned16(dy);
+    int taps = KH * KW;
+    if (wgrad_merge(Cin, ldx, KW)) {     // image inputs (Cin = 3): one tap per filter row, KW*Cin merged channels
+        g.merge = Cin; g.Cin = KW * Cin; g.KW = 1; g.vecA = 0; taps = KH;
+        g.ct = (g.Cin + bm - 1) / bm;
+    }
     hipStream_t s = kpx_stream(stream);
-    const dim3 grid((unsigned)(g.S * KH * KW * g.ct * g.kt)), block(256);
+    const dim3 grid((unsigned)(g.S * taps * g.ct * g.kt)), block(256);
     if (bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, s, g);
     int rc = kpx_launch_status();

@@ -179,30 +179,40 @@ extern "C" size_t kpx_chan_reduce_scratch_bytes(int C) {
     return (size_t)KPX_RED_BLOCKS * 2 * c * sizeof(double) + ((2 * c * sizeof(float) + 15) & ~(size_t)15);
 }
 
-__global__ void chan_sum_finalize_kernel(const double* part, int nb, int C, float* out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += part[((size_t)b * 2) * C + c];
-    out[c] = (float)s;
+// Finalize kernels: one wavefront per channel; lanes stride over the (up to 1024) block partials, then a shuffle tree.
+__device__ __forceinline__ void kpx_sum_partials(const double* part, int nb, int C, int c, double& s, double& q) {
+    s = 0.0; q = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 64) {
+        s += part[((size_t)b * 2) * C + c];
+        q += part[((size_t)b * 2 + 1) * C + c];
+    }
+    s = kpx_wave_sum_d(s);
+    q = kpx_wave_sum_d(q);
+}
+
+__global__ __launch_bounds__(64) void chan_sum_finalize_kernel(const double* part, int nb, int C, float* out) {
+    const int c = blockIdx.x;
+    double s, q;
+    kpx_sum_partials(part, nb, C, c, s, q);
+    if (threadIdx.x == 0) out[c] = (float)s;
 }
 extern "C" int kpx_chan_sum_f32(const float* x, size_t P, int C, int ldx, float* sum_out, void* scratch, void* stream) {
     if (!x || !sum_out || !scratch || C <= 0 || ldx < C || P == 0) return KPX_EINVAL;
     RedArgs a{}; a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.part = (double*)scratch;
     int nb; int rc = launch_chan_reduce(0, a, &nb, kpx_stream(stream));
     if (rc) return rc;
-    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, kpx_stream(stream), (const double*)scratch, nb, C, sum_out);
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(C), dim3(64), 0, kpx_stream(stream), (const double*)scratch, nb, C, sum_out);
     return kpx_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------ batch norm
-__global__ void bn_stats_finalize_kernel(const double* part, int nb, int C, double count, float eps,
-                                         float* mean, float* invstd, float* var_biased,
-                                         float* mm, float* mv, float decay) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nb; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const double* part, int nb, int C, double count, float eps,
+                                                               float* mean, float* invstd, float* var_biased,
+                                                               float* mm, float* mv, float decay) {
+    const int c = blockIdx.x;
+    double s, q;
+    kpx_sum_partials(part, nb, C, c, s, q);
+    if (threadIdx.x != 0) return;
     const double m = s / count;
     double v = q / count - m * m;
     if (v < 0.0) v = 0.0;
@@ -224,7 +234,7 @@ extern "C" int kpx_bn_stats_f32(const float* x, size_t P, int C, int ldx, float 
     RedArgs a{}; a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.part = (double*)scratch;
     int nb; int rc = launch_chan_reduce(1, a, &nb, kpx_stream(stream));
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, kpx_stream(stream), (const double*)scratch, nb, C,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, kpx_stream(stream), (const double*)scratch, nb, C,
                        (double)P, eps, mean, invstd, var_biased, moving_mean, moving_var, decay);
     return kpx_launch_status();
 }
@@ -277,11 +287,11 @@ extern "C" int kpx_bn_apply_f32(const float* x, size_t P, int C, int ldx, const 
     return kpx_launch_status();
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* part, int nb, int C, float* dgamma, float* dbeta, float* sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nb; ++b) { s += part[((size_t)b * 2) * C + c]; q += part[((size_t)b * 2 + 1) * C + c]; }
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* part, int nb, int C, float* dgamma, float* dbeta, float* sums) {
+    const int c = blockIdx.x;
+    double s, q;
+    kpx_sum_partials(part, nb, C, c, s, q);
+    if (threadIdx.x != 0) return;
     dbeta[c] = (float)s; dgamma[c] = (float)q;
     sums[c] = (float)s; sums[C + c] = (float)q;
 }
@@ -329,7 +339,7 @@ extern "C" int kpx_bn_bwd_f32(const float* dy, int lddy, const float* x, int ldx
     if (rc) return rc;
     // the per-channel sums are parked (as floats) behind the partials in the scratch buffer
     float* sums = reinterpret_cast<float*>((double*)scratch + (size_t)KPX_RED_BLOCKS * 2 * C);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, (const double*)scratch, nb, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)scratch, nb, C, dgamma, dbeta, sums);
     rc = kpx_launch_status();
     if (rc) return rc;
     const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) &&
