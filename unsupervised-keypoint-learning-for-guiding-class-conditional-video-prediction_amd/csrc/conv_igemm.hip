@@ -14,6 +14,7 @@
 // the B tile is staged [k][n] and read as ds_read_b32.  Within a 16-wide K chunk lane-half h consumes channels
 // {8u+4h+j}: a K permutation shared by A and B, so the product is unchanged.
 #include "kpx_common.h"
+#include <stdlib.h>
 
 struct ConvGeom {
     const float* x; float* y; const float* w; const float* bias;
@@ -349,10 +350,10 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
     g.wts = Cin * Cout; g.ldw = Cout; g.act = act;
     g.vecA = (ldx % 4 == 0) && aligned16(x);
     g.vecB = (Cout % 4 == 0) && aligned16(w);
-    if (Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64) {      // image inputs (Cin = 3): merge each filter row
+    if (!(getenv("KPX_NO_MERGE") && atoi(getenv("KPX_NO_MERGE")) == KH) && Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64) {      // image inputs (Cin = 3): merge each filter row
         g.merge = Cin; g.Tq = 1; g.KW = 1; g.Cin = KW * Cin; g.wts = KW * Cin * Cout; g.vecA = 0;
     }
-    if (Cout <= 4 && Cin % 4 == 0 && Cin >= 256 && g.vecA && g.vecB == (Cout == 4))
+    if (!getenv("KPX_NO_SMALLCOUT") && Cout <= 4 && Cin % 4 == 0 && Cin >= 256 && g.vecA && g.vecB == (Cout == 4))
         return launch_small_cout(g, kpx_stream(stream));
     return launch_gather_conv<false>(g, kpx_stream(stream));
 }
@@ -590,7 +591,7 @@ static void wgrad_tiles(int Cin, int Cout, int& bm, int& bn) {
     if (bm != bn) { bm = 64; bn = 64; }   // only the square tiles are instantiated
 }
 
-static inline bool wgrad_merge(int Cin, int ldx, int KW) { return Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64; }
+static inline bool wgrad_merge(int Cin, int ldx, int KW) { return !getenv("KPX_NO_WMERGE") && Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64; }
 
 static int wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
     int bm, bn;
