@@ -1,0 +1,116 @@
+"""CPU tests of the host logic: variable declaration pass (shape-only build), reference naming / checkpoint layout,
+config surface, LR schedule, and the data-parallel gradient exchange on 2 gloo processes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import restatement as R
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': 4},
+       'model': {'n_pts': 15}, 'paths': {'log_dir': '/tmp/kpx_cpu', 'vggnet': None}}
+
+
+def build_cpu_model(n_pts=15, res=128):
+    import kpx_amd
+    cfg = {**CFG, 'model': {'n_pts': n_pts}}
+    m = kpx_amd.DetectorTranslatorModel(cfg, device='cpu', image_size=res)
+    m.build()
+    return m
+
+
+def test_build_declares_the_reference_variable_manifest():
+    m = build_cpu_model()
+    exp = m.store.export_numpy()
+    man = R.variable_manifest(15)
+    assert list(exp.keys()).sort() == list(man.keys()).sort() and set(exp) == set(man)
+    for k, shape in man.items():
+        assert tuple(exp[k].shape) == tuple(shape), k
+    # same RandomState(1234) creation order as SURVEY 8d / the oracle -> bit-identical initial weights
+    init = R.init_variables(15)
+    for k in man:
+        assert np.array_equal(exp[k], init[k]), k
+    # variable split by the substring 'img_discr' (reference detector_translator_model.py:191-192)
+    assert sum(int(np.prod(s)) for n, (o, s) in m.store.buckets['G'].entries.items()) == 6419107
+    assert sum(int(np.prod(s)) for n, (o, s) in m.store.buckets['D'].entries.items()) == 44721088
+    for b in m.store.buckets.values():
+        for name, (off, shape) in b.entries.items():
+            assert off % 4 == 0                      # 16-B aligned views for the vectorised kernels
+
+
+def test_checkpoint_arrays_follow_tf_saver_naming():
+    m = build_cpu_model(n_pts=3, res=32)
+    arrays = m.checkpoint_arrays()
+    for name in ('global_step', 'beta1_power', 'beta2_power', 'beta1_power_1', 'beta2_power_1',
+                 'translator/conv_6_0/conv2d/kernel', 'translator/conv_6_1/conv2d/kernel', 'translator/conv_6_0/conv2d/kernel/Adam',
+                 'pose_encoder/conv_0/conv2d/bias/Adam_1', 'img_discr/D_logit/conv2d/kernel', 'pose_encoder/b_norm_7_1/moving_variance'):
+        assert name in arrays, name
+    assert not any(k.startswith('content_vgg') or 'vgg' in k for k in arrays)        # VGG weights are constants, not saved
+    assert not any('moving_mean/Adam' in k for k in arrays)
+    assert arrays['translator/conv_6_1/conv2d/kernel'].shape == (3, 3, 64, 1)
+
+
+def test_lr_schedule_and_config_surface():
+    m = build_cpu_model(n_pts=3, res=32)
+    for step in (0, 1, 20000, 50000):
+        m.global_step = step
+        assert abs(float(m.current_lr()) - float(R.exponential_decay(1e-4, step, 20000, 0.95))) == 0.0
+    cfg = yaml.load(open(os.path.join(REPO, 'configs', 'penn.yaml')), Loader=yaml.FullLoader)
+    assert set(cfg) == {'paths', 'training', 'model'}
+    assert set(cfg['training']) == {'n_steps', 'summary_interval', 'test_interval', 'checkpoint_interval', 'log_interval', 'batch_size', 'lr'}
+    assert cfg['model']['n_pts'] == 40 and cfg['training']['batch_size'] == 16 and cfg['training']['lr'] == {'start_val': 0.0001, 'step': 20000, 'decay': 0.95}
+    import train
+    with pytest.raises(Exception, match='unknown model|motion_generator'):
+        train._get_model_by_mode('motion_generator', cfg, 0)
+
+
+def test_synthetic_pairs_follow_the_loader_contract():
+    from kpx_amd.synthetic import synthetic_pair
+    p = synthetic_pair(3, res=16, seed0=4, seed1=5)
+    assert set(p) == {'image', 'future_image'}
+    for v in p.values():
+        assert v.shape == (3, 16, 16, 3) and v.dtype == np.float32 and v.min() >= -1 and v.max() <= 1
+    a, b = R.synthetic_pair(3, res=16, seed0=4, seed1=5)
+    assert np.array_equal(p['image'], a) and np.array_equal(p['future_image'], b)
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, REPO)
+    torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+    m = build_cpu_model(n_pts=3, res=32)
+    assert m.world_size == world
+    out = {}
+    for which in ('D', 'G'):
+        b = m.store.buckets[which]
+        b.grads.copy_(torch.arange(b.grads.numel(), dtype=torch.float32) * 1e-3 + (rank + 1))
+        g = m.exchange_gradients(which)
+        want = torch.arange(b.grads.numel(), dtype=torch.float32) * 1e-3 * world + sum(range(1, world + 1))
+        out[which] = bool(torch.allclose(g, want, rtol=1e-6))
+        # parameter views alias the flat bucket: a bucket update is visible through every named variable
+        b.params.add_(1.0)
+    name = 'translator/conv_1_0/conv2d/kernel'
+    out['alias'] = bool(torch.allclose(m.store[name], torch.from_numpy(R.init_variables(3, res=32)[name]) + 1.0))
+    q.put((rank, out))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_gradient_exchange_two_gloo_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in results:
+        assert out == {'D': True, 'G': True, 'alias': True}, (rank, out)

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Training entry point with the reference's CLI (reference: train.py:12-114):
+
+    python train.py --mode detector_translator --config configs/penn.yaml [--synthetic] [--steps N]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --mode ... (data parallel)
+
+Only the stage-1 ``detector_translator`` mode is built (BASELINE.json hot path); ``motion_generator`` is out of scope and
+raises.  The JPEG input pipeline of the reference (data/image_pair_dataloader.py) is out of scope too: ``--synthetic``
+feeds Penn-shaped random pairs with the same output contract (float32 NHWC in [-1,1], keys image / future_image).
+"""
+import logging
+import os
+import sys
+from argparse import ArgumentParser
+
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def load_config(config_path):
+    """reference utils/__init__.py:8-10"""
+    with open(config_path, 'r') as f:
+        return yaml.load(f, Loader=yaml.FullLoader)
+
+
+def _get_model_by_mode(mode, config, global_step, **kw):
+    """reference train.py:117-123"""
+    if mode == 'detector_translator':
+        from kpx_amd import DetectorTranslatorModel
+        return DetectorTranslatorModel(config, global_step, is_training=True, **kw)
+    if mode == 'motion_generator':
+        raise Exception('mode motion_generator (stage 2) is outside the MI355X hot-path build; see DESIGN.md')
+    raise Exception('unknown model %s' % mode)
+
+
+def main(argv=None):
+    parser = ArgumentParser()
+    parser.add_argument('--mode', type=str, choices=['detector_translator', 'motion_generator'], help='which mode to train')
+    parser.add_argument('--config', type=str, help='path of the configuration file')
+    parser.add_argument('--synthetic', action='store_true', help='synthetic Penn-shaped pairs instead of the JPEG pipeline')
+    parser.add_argument('--synthetic-vgg', action='store_true', help='He-normal VGG19 weights when paths.vggnet is absent')
+    parser.add_argument('--steps', type=int, default=None, help='override training.n_steps')
+    args = parser.parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format='%(message)s')
+
+    config = load_config(args.config)
+    paths_config, train_config = config['paths'], config['training']
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        torch.distributed.init_process_group('nccl', device_id=dev)
+
+    import kpx_amd
+    from kpx_amd.synthetic import synthetic_pair
+    vgg = None
+    if args.synthetic_vgg or not os.path.exists(str(paths_config.get('vggnet'))):
+        if not args.synthetic_vgg:
+            raise Exception('file of pretrained vgg19 does not exist at: %s (pass --synthetic-vgg for benchmarking)' % paths_config.get('vggnet'))
+        vgg = kpx_amd.Vgg19(weights=kpx_amd.synthetic_vgg19_weights(), device=dev)
+    model = _get_model_by_mode(args.mode, config, 0, device=dev, vgg=vgg)
+    print('model initialized')
+    model.build(None)
+    if not args.synthetic:
+        raise Exception('the Penn Action JPEG pipeline (data/image_pair_dataloader.py) is out of scope; run with --synthetic')
+
+    batch_size = train_config['batch_size']          # per process, like the reference's single-device batch
+    n_steps = args.steps if args.steps is not None else train_config['n_steps']
+    model.initialize_loggers(paths_config['log_dir'], None)
+    print('training start')
+    for step in range(model.global_step, n_steps):   # reference train.py:84-113
+        should_write_log = step % train_config['log_interval'] == 0
+        pair = synthetic_pair(batch_size, res=model.image_size, seed0=2 * (step * world + rank), seed1=2 * (step * world + rank) + 1)
+        feed_dict = {k: torch.from_numpy(v).to(dev) for k, v in pair.items()}
+        model.train_step(None, feed_dict, step, batch_size, should_write_log=should_write_log and rank == 0,
+                         should_write_summary=False)
+        if step % train_config['checkpoint_interval'] == 0 and rank == 0:
+            model.save_checkpoint(None, step)
+        if step % train_config['test_interval'] == 0 and rank == 0:
+            tp = synthetic_pair(batch_size, res=model.image_size, seed0=10 ** 6, seed1=10 ** 6 + 1)
+            result = model.test_step(None, {k: torch.from_numpy(v).to(dev) for k, v in tp.items()}, step, 0, batch_size)
+            model.collect_test_results([result], step)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

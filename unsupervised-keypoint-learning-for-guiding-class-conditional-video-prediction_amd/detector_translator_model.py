@@ -119,10 +119,17 @@ class DetectorTranslatorModel(BaseModel):
         p = np.float32(self.global_step) / np.float32(self.lr['step'])
         return np.float32(np.float32(self.lr['start_val']) * np.power(np.float32(self.lr['decay']), p, dtype=np.float32))
 
+    def exchange_gradients(self, which):
+        """Data-parallel exchange: ONE all-reduce(sum) of the bucket's flat fp32 gradient buffer (RCCL over xGMI on the
+        GPUs; gloo in the CPU tests).  The 1/world scaling happens inside the fused Adam kernel."""
+        bucket = self.store.buckets[which]
+        if self.world_size > 1:
+            torch.distributed.all_reduce(bucket.grads, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
+        return bucket.grads
+
     def _apply_adam(self, which, lr):
         bucket = self.store.buckets[which]
-        if self.world_size > 1:                                           # the ONE collective of the data-parallel step
-            torch.distributed.all_reduce(bucket.grads, group=self.process_group)
+        self.exchange_gradients(which)
         b1p, b2p = self.beta_power[which]
         alpha = np.float32(np.float32(lr) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p))
         ops.adam_tf_flat_(bucket.params, bucket.grads, bucket.m, bucket.v, alpha, self.beta1, self.beta2, self.adam_eps,
