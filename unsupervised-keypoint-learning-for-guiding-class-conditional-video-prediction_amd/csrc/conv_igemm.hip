@@ -32,18 +32,22 @@ struct ConvGeom {
                     // contiguous in NHWC, so they are treated as one tap with KW*Cin channels (per-element x bounds)
 };
 
-template <int BM, int BN, int WM, int WN, bool BT>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
-    constexpr int BK = 16, SA = BK + 4;
-    constexpr int SB = BT ? (BN + 2) : BN;
+// Tile geometry: BM x BN outputs per workgroup, WM x WN wavefronts each owning (BM/WM) x (BN/WN) as 32x32 MFMA
+// accumulators, K chunks of 32 channels.  LDS (double buffered): A [BM][32] with the 16-B slot index XOR-swizzled by
+// ((row>>1)&7) -- conflict-free for both the 8-lane ds_write_b128 groups (one row = 128 contiguous bytes = one full cache
+// line of the pixel's channels) and the 16-lane ds_read_b128 groups; B [32][BN], for dgrad (weights read transposed) the
+// column index is XORed with ((k>>2)&7)<<2 so the scalar transposing writes spread over all banks.
+template <int BM, int BN, int WM, int WN, bool BT, bool VEC, bool MERGE>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BK = 32;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-    constexpr int RA = BM / 64;
-    constexpr int BU = BN * 4;
-    constexpr int RB = (BU + 255) / 256;
-    static_assert(WM * WN == 4, "4 waves");
-    __shared__ __attribute__((aligned(16))) float As[2][BM * SA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * SB];
-    __shared__ int rowpix[BM];
+    constexpr int RA = (BM * 8) / NT;              // A float4 units per thread (BM rows x 8 slots)
+    constexpr int RB = (BN * 8 + NT - 1) / NT;     // B float4 units per thread (32 x BN/4, or BN rows x 8 slots when BT)
+    constexpr int BU = BN * 8;
+    static_assert(TM >= 1 && TN >= 1 && RA >= 1 && (BM * 8) % NT == 0, "tile/wave shape");
+    __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -52,23 +56,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
     const int m0 = (L / g.nt) * BM, n0 = (L % g.nt) * BN;
     const int HW = g.Ha * g.Wa;
 
-    if (t < BM) {
-        const int m = m0 + t;
-        int pix = -1;
-        if (m < g.M) {
-            const int n = m / HW, rem = m - n * HW, a = rem / g.Wa, b = rem - a * g.Wa;
-            pix = (n * g.Ho + a * g.osy + g.oy0) * g.Wo + b * g.osx + g.ox0;
-        }
-        rowpix[t] = pix;
-    }
-
     // per-thread A rows
-    const int kq = t & 3;
+    const int kq = t & 7;
     int a_ih0[RA], a_iw0[RA], a_base[RA];
     bool a_ok[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + (t >> 2) + 64 * i;
+        const int m = m0 + (t >> 3) + (NT / 8) * i;
         a_ok[i] = m < g.M;
         const int mm = a_ok[i] ? m : 0;
         const int n = mm / HW, rem = mm - n * HW, a = rem / g.Wa, b = rem - a * g.Wa;
@@ -89,108 +83,96 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
     const int nchunks = g.Tr * g.Tq * nck;
     int tr = 0, tq = 0, c0 = 0;
     f32x4 ra[RA], rb[RB];
+    unsigned am[RA], bm[RB];
 
+    // Loads are issued unconditionally from a clamped (always readable) address and masked when they are written to
+    // LDS one chunk later, so nothing in the chunk's MFMA phase depends on them: the global-load latency hides under the
+    // MFMAs of the current chunk instead of being waited for right after issue.
+    auto tail4 = [](int c, int lim) -> unsigned {      // bit j set iff c + j < lim
+        const int r = lim - c;
+        return r >= 4 ? 15u : (r <= 0 ? 0u : (15u >> (4 - r)));
+    };
+    auto load4 = [&](const float* p, unsigned mask, const float* safe) -> f32x4 {
+        f32x4 v;
+        if (VEC) {
+            v = *reinterpret_cast<const f32x4*>(mask ? p : safe);
+        } else {
+            v[0] = *((mask & 1u) ? p : safe);
+            v[1] = *((mask & 2u) ? p + 1 : safe);
+            v[2] = *((mask & 4u) ? p + 2 : safe);
+            v[3] = *((mask & 8u) ? p + 3 : safe);
+        }
+        return v;
+    };
     auto load_chunk = [&]() {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int ih = a_ih0[i] + tr * g.ity, iw = a_iw0[i] + tq * g.itx;
             const int c = c0 + kq * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (g.merge) {
-                if (a_ok[i] && (unsigned)ih < (unsigned)g.Hi && c < g.Cin) {
-                    const float* p = g.x + (ptrdiff_t)(a_base[i] + ih * g.Wi + iw) * g.ldx + c;
+            unsigned mask = 0;
+            const float* p = g.x + (ptrdiff_t)(a_base[i] + ih * g.Wi + iw) * g.ldx + c;
+            if (a_ok[i] && (unsigned)ih < (unsigned)g.Hi) {
+                if (MERGE) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int cc = c + j;
-                        if (cc < g.Cin && (unsigned)(iw + cc / g.merge) < (unsigned)g.Wi) v[j] = p[j];
-                    }
-                }
-            } else if (a_ok[i] && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi && c < g.Cin) {
-                const float* p = g.x + (size_t)(a_base[i] + ih * g.Wi + iw) * g.ldx + c;
-                if (g.vecA) {
-                    v = *reinterpret_cast<const f32x4*>(p);
-                    if (c + 3 >= g.Cin) {
-                        if (c + 1 >= g.Cin) v[1] = 0.f;
-                        if (c + 2 >= g.Cin) v[2] = 0.f;
-                        v[3] = 0.f;
-                    }
-                } else {
-                    v[0] = p[0];
-                    if (c + 1 < g.Cin) v[1] = p[1];
-                    if (c + 2 < g.Cin) v[2] = p[2];
-                    if (c + 3 < g.Cin) v[3] = p[3];
+                    for (int j = 0; j < 4; ++j)
+                        if (c + j < g.Cin && (unsigned)(iw + (c + j) / g.merge) < (unsigned)g.Wi) mask |= 1u << j;
+                } else if ((unsigned)iw < (unsigned)g.Wi) {
+                    mask = tail4(c, g.Cin);
                 }
             }
-            ra[i] = v;
+            am[i] = mask;
+            ra[i] = load4(p, mask, g.x);
         }
         const int tap = (g.wr0 + tr * g.wrs) * g.KW + (g.wq0 + tq * g.wqs);
         const float* wp = g.w + (size_t)tap * g.wts;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int u = t + 256 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int u = t + NT * i;
+            unsigned mask = 0;
+            const float* p = g.w;
             if (u < BU) {
                 if (!BT) {
                     const int k = u / (BN / 4), n = n0 + (u % (BN / 4)) * 4, c = c0 + k;
-                    if (c < g.Cin && n < g.Cout) {
-                        const float* p = wp + (size_t)c * g.ldw + n;
-                        if (g.vecB) {
-                            v = *reinterpret_cast<const f32x4*>(p);
-                            if (n + 3 >= g.Cout) {
-                                if (n + 1 >= g.Cout) v[1] = 0.f;
-                                if (n + 2 >= g.Cout) v[2] = 0.f;
-                                v[3] = 0.f;
-                            }
-                        } else {
-                            v[0] = p[0];
-                            if (n + 1 < g.Cout) v[1] = p[1];
-                            if (n + 2 < g.Cout) v[2] = p[2];
-                            if (n + 3 < g.Cout) v[3] = p[3];
-                        }
-                    }
+                    p = wp + (size_t)c * g.ldw + n;
+                    if (c < g.Cin) mask = tail4(n, g.Cout);
                 } else {
-                    const int n = n0 + (u >> 2), c = c0 + (u & 3) * 4;
-                    if (n < g.Cout && c < g.Cin) {
-                        const float* p = wp + (size_t)n * g.ldw + c;
-                        if (g.vecB) {
-                            v = *reinterpret_cast<const f32x4*>(p);
-                            if (c + 3 >= g.Cin) {
-                                if (c + 1 >= g.Cin) v[1] = 0.f;
-                                if (c + 2 >= g.Cin) v[2] = 0.f;
-                                v[3] = 0.f;
-                            }
-                        } else {
-                            v[0] = p[0];
-                            if (c + 1 < g.Cin) v[1] = p[1];
-                            if (c + 2 < g.Cin) v[2] = p[2];
-                            if (c + 3 < g.Cin) v[3] = p[3];
-                        }
-                    }
+                    const int n = n0 + (u >> 3), c = c0 + (u & 7) * 4;
+                    p = wp + (size_t)n * g.ldw + c;
+                    if (n < g.Cout) mask = tail4(c, g.Cin);
                 }
             }
-            rb[i] = v;
+            bm[i] = mask;
+            rb[i] = load4(p, mask, g.w);
         }
-        // advance (tr,tq,c0) to the next chunk
         c0 += BK;
         if (c0 >= g.Cin) {
             c0 = 0;
             if (++tq == g.Tq) { tq = 0; ++tr; }
         }
     };
+    auto masked = [](f32x4 v, unsigned m) -> f32x4 {
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = (m >> j) & 1u ? v[j] : 0.f;
+        return r;
+    };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i)
-            *reinterpret_cast<f32x4*>(&As[buf][((t >> 2) + 64 * i) * SA + kq * 4]) = ra[i];
+        for (int i = 0; i < RA; ++i) {
+            const int row = (t >> 3) + (NT / 8) * i;
+            *reinterpret_cast<f32x4*>(&As[buf][row * BK + ((kq ^ ((row >> 1) & 7)) << 2)]) = masked(ra[i], am[i]);
+        }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int u = t + 256 * i;
+            const int u = t + NT * i;
             if (u < BU) {
+                const f32x4 v = masked(rb[i], bm[i]);
                 if (!BT) {
-                    *reinterpret_cast<f32x4*>(&Bs[buf][(u / (BN / 4)) * SB + (u % (BN / 4)) * 4]) = rb[i];
+                    *reinterpret_cast<f32x4*>(&Bs[buf][(u / (BN / 4)) * BN + (u % (BN / 4)) * 4]) = v;
                 } else {
-                    const int nn = u >> 2, kk = (u & 3) * 4;
+                    const int nn = u >> 3, ks = u & 7;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) Bs[buf][(kk + j) * SB + nn] = rb[i][j];
+                    for (int j = 0; j < 4; ++j) Bs[buf][(ks * 4 + j) * BN + (nn ^ (ks << 2))] = v[j];
                 }
             }
         }
@@ -210,16 +192,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
         const float* Ab = As[buf];
         const float* Bb = Bs[buf];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
+            const int ks = 2 * u + lh;                       // this lane-half's 16-B slot = channels 4*ks .. 4*ks+3
             f32x4 a[TM];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(&Ab[(wrow + i * 32 + li) * SA + (2 * u + lh) * 4]);
+            for (int i = 0; i < TM; ++i) {
+                const int row = wrow + i * 32 + li;
+                a[i] = *reinterpret_cast<const f32x4*>(&Ab[row * BK + ((ks ^ ((row >> 1) & 7)) << 2)]);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float b[TN];
 #pragma unroll
-                for (int n = 0; n < TN; ++n) b[n] = Bb[(8 * u + 4 * lh + j) * SB + wcol + n * 32 + li];
+                for (int n = 0; n < TN; ++n) {
+                    const int col = wcol + n * 32 + li;
+                    b[n] = Bb[(ks * 4 + j) * BN + (BT ? (col ^ (ks << 2)) : col)];
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -231,7 +219,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
         __syncthreads();
     }
 
-    // epilogue: bias + activation, 32 consecutive channels per half-wave store
+    // epilogue: the output pixel of every tile row goes through LDS (the A buffers are free now)
+    int* rowpix = reinterpret_cast<int*>(&As[0][0]);
+    if (t < BM) {
+        const int m = m0 + t;
+        int pix = -1;
+        if (m < g.M) {
+            const int n = m / HW, rem = m - n * HW, a = rem / g.Wa, b = rem - a * g.Wa;
+            pix = (n * g.Ho + a * g.osy + g.oy0) * g.Wo + b * g.osx + g.ox0;
+        }
+        rowpix[t] = pix;
+    }
+    __syncthreads();
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
         const int col = n0 + wcol + n * 32 + li;
@@ -254,8 +253,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvGeom g) {
     }
 }
 
-template <bool BT>
-static int launch_gather_conv(ConvGeom g, hipStream_t s) {
+template <bool BT, bool VEC, bool MERGE>
+static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
     g.M = g.N * g.Ha * g.Wa;
     if (g.M <= 0 || g.Cout <= 0) return 0;
     // N tile: smallest padded width, ties -> wider tile
@@ -267,24 +266,28 @@ static int launch_gather_conv(ConvGeom g, hipStream_t s) {
     }
     auto blocks = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.Cout + bn - 1) / bn); };
     const long want = 512;
-    int BM;
-    if (BN == 128) BM = blocks(128, 128) >= want ? 128 : 64;
-    else if (BN == 64) BM = blocks(256, 64) >= want ? 256 : (blocks(128, 64) >= want ? 128 : 64);
-    else BM = blocks(256, 32) >= want ? 256 : 128;
-    if (BN == 128 && BM == 64) BN = 64;   // small-M, wide-N: 64x64 tiles for occupancy
+    int BM = 128;
+    if (BN == 128 && blocks(128, 128) < want) { BM = 64; }
+    else if (BN == 64 && blocks(128, 64) < want) BM = 64;
     g.mt = (g.M + BM - 1) / BM;
     g.nt = (g.Cout + BN - 1) / BN;
-    const dim3 grid((unsigned)(g.mt * g.nt)), block(256);
+    const unsigned nblk = (unsigned)(g.mt * g.nt);
 #define KPX_LAUNCH(bm, bn, wm, wn) \
-    hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn, BT>), grid, block, 0, s, g)
-    if (BM == 128 && BN == 128) KPX_LAUNCH(128, 128, 2, 2);
-    else if (BM == 256 && BN == 64) KPX_LAUNCH(256, 64, 4, 1);
-    else if (BM == 128 && BN == 64) KPX_LAUNCH(128, 64, 2, 2);
-    else if (BM == 64 && BN == 64) KPX_LAUNCH(64, 64, 2, 2);
-    else if (BM == 256 && BN == 32) KPX_LAUNCH(256, 32, 4, 1);
-    else KPX_LAUNCH(128, 32, 4, 1);
+    hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn, BT, VEC, MERGE>), dim3(nblk), dim3((wm) * (wn) * 64), 0, s, g)
+    if (BM == 128 && BN == 128) KPX_LAUNCH(128, 128, 2, 4);        // 8 waves of 64x32
+    else if (BM == 64 && BN == 128) KPX_LAUNCH(64, 128, 2, 4);     // 8 waves of 32x32 (small M, wide N)
+    else if (BM == 128 && BN == 64) KPX_LAUNCH(128, 64, 4, 2);     // 8 waves of 32x32
+    else if (BM == 64 && BN == 64) KPX_LAUNCH(64, 64, 2, 2);       // 4 waves of 32x32
+    else KPX_LAUNCH(128, 32, 4, 1);                                // 4 waves of 32x32
 #undef KPX_LAUNCH
     return kpx_launch_status();
+}
+
+template <bool BT>
+static int launch_gather_conv(const ConvGeom& g, hipStream_t s) {
+    if (g.merge) return launch_gather_conv_v<false, false, true>(g, s);
+    if (g.vecA && g.vecB) return launch_gather_conv_v<BT, true, false>(g, s);
+    return launch_gather_conv_v<BT, false, false>(g, s);
 }
 
 // Tiny-Cout / long-K forward (img_discr D_logit: 3x3x2048 -> 1, reference networks/__init__.py:150): one wavefront
@@ -409,7 +412,7 @@ struct WgradGeom {
     size_t slab;            // floats per slab = KH*KW*Cin*Cout
 };
 
-template <int BMc, int BNk>
+template <int BMc, int BNk, bool VEC, bool MERGE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     constexpr int BKP = 16;
     constexpr int TM = BMc / 64, TN = BNk / 64;
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
         apx[i] = u / (BMc / 4);
         ac[i] = cbase + (u % (BMc / 4)) * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) aq[i][j] = g.merge ? (ac[i] + j) / g.merge : 0;
+        for (int j = 0; j < 4; ++j) aq[i][j] = MERGE ? (ac[i] + j) / g.merge : 0;
         const int p = pbeg + apx[i];
         an[i] = p / (g.Ho * g.Wo);
         const int rem = p - an[i] * g.Ho * g.Wo;
@@ -463,39 +466,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     f32x4 ra[RA], rb[RB];
+    unsigned am[RA], bm[RB];
     int p0 = pbeg;
+    auto tail4 = [](int c, int lim) -> unsigned {
+        const int r_ = lim - c;
+        return r_ >= 4 ? 15u : (r_ <= 0 ? 0u : (15u >> (4 - r_)));
+    };
+    // unconditional loads from a clamped address, masked when written to LDS (see conv_igemm_kernel)
     auto load_chunk = [&]() {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int p = p0 + apx[i];
             const int ih = aho[i] * g.stride + r - g.pad_t, iw = awo[i] * g.stride + q - g.pad_l;
             const int c = ac[i];
-            if (g.merge) {
-                if (p < pend && (unsigned)ih < (unsigned)g.Hi && c < g.Cin) {
-                    const float* ptr = g.x + ((ptrdiff_t)(an[i] * g.Hi + ih) * g.Wi + iw) * g.ldx + c;
+            unsigned mask = 0;
+            const float* ptr = g.x + ((ptrdiff_t)(an[i] * g.Hi + ih) * g.Wi + iw) * g.ldx + c;
+            if (p < pend && (unsigned)ih < (unsigned)g.Hi) {
+                if (MERGE) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (c + j < g.Cin && (unsigned)(iw + aq[i][j]) < (unsigned)g.Wi) v[j] = ptr[j];
-                }
-            } else if (p < pend && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi && c < g.Cin) {
-                const float* ptr = g.x + ((size_t)(an[i] * g.Hi + ih) * g.Wi + iw) * g.ldx + c;
-                if (g.vecA) {
-                    v = *reinterpret_cast<const f32x4*>(ptr);
-                    if (c + 3 >= g.Cin) {
-                        if (c + 1 >= g.Cin) v[1] = 0.f;
-                        if (c + 2 >= g.Cin) v[2] = 0.f;
-                        v[3] = 0.f;
-                    }
-                } else {
-                    v[0] = ptr[0];
-                    if (c + 1 < g.Cin) v[1] = ptr[1];
-                    if (c + 2 < g.Cin) v[2] = ptr[2];
-                    if (c + 3 < g.Cin) v[3] = ptr[3];
+                        if (c + j < g.Cin && (unsigned)(iw + aq[i][j]) < (unsigned)g.Wi) mask |= 1u << j;
+                } else if ((unsigned)iw < (unsigned)g.Wi) {
+                    mask = tail4(c, g.Cin);
                 }
             }
+            am[i] = mask;
+            f32x4 v;
+            if (VEC) {
+                v = *reinterpret_cast<const f32x4*>(mask ? ptr : g.x);
+            } else {
+                v[0] = *((mask & 1u) ? ptr : g.x);
+                v[1] = *((mask & 2u) ? ptr + 1 : g.x);
+                v[2] = *((mask & 4u) ? ptr + 2 : g.x);
+                v[3] = *((mask & 8u) ? ptr + 3 : g.x);
+            }
             ra[i] = v;
-            // advance this unit's pixel by one chunk
             awo[i] += BKP;
             while (awo[i] >= g.Wo) {
                 awo[i] -= g.Wo;
@@ -504,34 +509,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             const int p = p0 + bpx[i];
             const int k = bk[i];
-            if (p < pend && k < g.Cout) {
-                const float* ptr = g.dy + (size_t)p * g.lddy + k;
-                if (g.vecB) {
-                    v = *reinterpret_cast<const f32x4*>(ptr);
-                    if (k + 3 >= g.Cout) {
-                        if (k + 1 >= g.Cout) v[1] = 0.f;
-                        if (k + 2 >= g.Cout) v[2] = 0.f;
-                        v[3] = 0.f;
-                    }
-                } else {
-                    v[0] = ptr[0];
-                    if (k + 1 < g.Cout) v[1] = ptr[1];
-                    if (k + 2 < g.Cout) v[2] = ptr[2];
-                    if (k + 3 < g.Cout) v[3] = ptr[3];
-                }
+            const unsigned mask = p < pend ? tail4(k, g.Cout) : 0u;
+            const float* ptr = g.dy + (size_t)p * g.lddy + k;
+            bm[i] = mask;
+            f32x4 v;
+            if (VEC) {
+                v = *reinterpret_cast<const f32x4*>(mask ? ptr : g.dy);
+            } else {
+                v[0] = *((mask & 1u) ? ptr : g.dy);
+                v[1] = *((mask & 2u) ? ptr + 1 : g.dy);
+                v[2] = *((mask & 4u) ? ptr + 2 : g.dy);
+                v[3] = *((mask & 8u) ? ptr + 3 : g.dy);
             }
             rb[i] = v;
         }
         p0 += BKP;
     };
+    auto masked = [](f32x4 v, unsigned m) -> f32x4 {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (m >> j) & 1u ? v[j] : 0.f;
+        return o;
+    };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[buf][(t + 256 * i) * 4]) = ra[i];
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[buf][(t + 256 * i) * 4]) = masked(ra[i], am[i]);
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(t + 256 * i) * 4]) = rb[i];
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(t + 256 * i) * 4]) = masked(rb[i], bm[i]);
     };
 
     const int nchunks = pend > pbeg ? (pend - pbeg + BKP - 1) / BKP : 0;
@@ -644,8 +650,12 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     }
     hipStream_t s = kpx_stream(stream);
     const dim3 grid((unsigned)(g.S * taps * g.ct * g.kt)), block(256);
-    if (bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, s, g);
+    const bool vec = g.vecA && g.vecB && !g.merge;
+    if (g.merge) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, false, true>), grid, block, 0, s, g);
+    else if (bm == 128 && vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, false>), grid, block, 0, s, g);
+    else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, false, false>), grid, block, 0, s, g);
+    else if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true, false>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, false, false>), grid, block, 0, s, g);
     int rc = kpx_launch_status();
     if (rc) return rc;
     if (g.S > 1) {
