@@ -52,6 +52,11 @@ CONV_CASES = [
     (2, 4, 4, 256, 1, 3, 1, 1, 0),         # D_logit-shaped: wave-per-pixel small-Cout kernel
     (2, 6, 6, 512, 4, 3, 1, 0, 1),         # small-Cout kernel, Cout=4, relu
     (2, 20, 20, 3, 64, 3, 1, 0, 1),        # VGG conv1_1 shape (row-merged Cin=3)
+    (4, 128, 128, 16, 16, 3, 1, 0, 0),     # multi-tap small-channel wgrad kernel (pose conv_7_1)
+    (4, 128, 128, 64, 16, 3, 1, 0, 1),     # same, two 32-channel input tiles per wave (pose conv_7_0)
+    (16, 64, 64, 128, 32, 3, 1, 0, 0),     # same, two channel tiles of 64 (pose conv_5_0)
+    (4, 128, 128, 64, 4, 3, 1, 0, 0),      # same, translator crude+mask head
+    (2, 64, 64, 256, 128, 3, 1, 0, 0),     # 8-wave 128x128 wgrad tiles
 ]
 
 

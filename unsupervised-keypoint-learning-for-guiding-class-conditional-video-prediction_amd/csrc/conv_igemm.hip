@@ -412,17 +412,19 @@ struct WgradGeom {
     size_t slab;            // floats per slab = KH*KW*Cin*Cout
 };
 
-template <int BMc, int BNk, bool VEC, bool MERGE>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
-    constexpr int BKP = 16;
-    constexpr int TM = BMc / 64, TN = BNk / 64;
-    constexpr int RA = BMc / 64, RB = BNk / 64;     // float4 units per thread (16*BMc/4/256)
+template <int BMc, int BNk, int WM, int WN, bool VEC, bool MERGE>
+__global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradGeom g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BKP = 32;                          // pixels per K chunk
+    constexpr int TM = BMc / (WM * 32), TN = BNk / (WN * 32);
+    constexpr int RA = (BKP * BMc / 4) / NT, RB = (BKP * BNk / 4) / NT;     // float4 units per thread
+    static_assert(RA >= 1 && RB >= 1 && TM >= 1 && TN >= 1, "tile/wave shape");
     __shared__ __attribute__((aligned(16))) float As[2][BKP * BMc];
     __shared__ __attribute__((aligned(16))) float Bs[2][BKP * BNk];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
     const int taps = g.KH * g.KW;
     const int kti = L % g.kt; L /= g.kt;
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     int apx[RA], ac[RA], an[RA], aho[RA], awo[RA], aq[RA][4];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int u = t + 256 * i;
+        const int u = t + NT * i;
         apx[i] = u / (BMc / 4);
         ac[i] = cbase + (u % (BMc / 4)) * 4;
 #pragma unroll
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     int bpx[RB], bk[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int u = t + 256 * i;
+        const int u = t + NT * i;
         bpx[i] = u / (BNk / 4);
         bk[i] = kbase + (u % (BNk / 4)) * 4;
     }
@@ -535,9 +537,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[buf][(t + 256 * i) * 4]) = masked(ra[i], am[i]);
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[buf][(t + NT * i) * 4]) = masked(ra[i], am[i]);
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(t + 256 * i) * 4]) = masked(rb[i], bm[i]);
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[buf][(t + NT * i) * 4]) = masked(rb[i], bm[i]);
     };
 
     const int nchunks = pend > pbeg ? (pend - pbeg + BKP - 1) / BKP : 0;
@@ -582,13 +584,184 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradGeom g) {
     }
 }
 
+// dw[i] = sum_s ws[s][i] in a fixed order: a workgroup owns 64 consecutive elements, its 4 wavefronts stride over the
+// slabs (256 contiguous bytes per slab and wave -> coalesced), 8 loads in flight per lane, then a 4-way LDS combine.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                            size_t n, int S) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < S; ++k) s += ws[(size_t)k * n + i];
-        dw[i] = s;
+    const int e = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + e;
+    float acc = 0.f;
+    if (i < n) {
+        int k = sg;
+        for (; k + 28 < S; k += 32) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ws[(size_t)(k + 4 * j) * n + i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+        for (; k < S; k += 4) acc += ws[(size_t)k * n + i];
     }
+    __shared__ float sm[4][64];
+    sm[sg][e] = acc;
+    __syncthreads();
+    if (sg == 0 && i < n) dw[i] = (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
+}
+
+static inline void launch_wgrad_reduce(const float* ws, float* dw, size_t n, int S, hipStream_t s) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, ws, dw, n, S);
+}
+
+// ------------------------------------------------------------------------------------------ wgrad, small channel counts
+// High-resolution layers with <= 64 input and <= 32 output channels (pose_encoder tail, translator head, encoder conv_2):
+// the generic kernel above gives every filter tap its own workgroups, so x and dy are re-read KH*KW times and most of each
+// 64x64 MFMA tile is padding.  Here one workgroup walks chunks of 32 consecutive output pixels of one image row, stages
+// the KH x (32+KW-1) input halo and the 32 dy pixels ONCE in LDS, and its 4 wavefronts split the taps (wave w owns taps
+// w, w+4, w+8), each tap a 32*CT x 32 accumulator.  Partial slabs per workgroup, same fixed-order reduce.
+struct WgradRowsGeom {
+    const float* x; const float* dy; float* out;
+    int N, Hi, Wi, Cin, ldx;
+    int Ho, Wo, Cout, lddy;
+    int KH, KW, pad_t, pad_l;
+    int total_chunks, cpb, ct;
+    size_t slab;
+};
+
+template <int CT>
+__global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(const WgradRowsGeom g) {
+    constexpr int CW = 32, HALO = CW + 2, CinT = 32 * CT, CoutT = 32;
+    constexpr int XU = 3 * HALO * (CinT / 4);          // x float4 units per chunk (3 rows max)
+    constexpr int RX = (XU + 255) / 256;
+    constexpr int RY = (CW * CoutT / 4) / 256;         // = 1
+    __shared__ __attribute__((aligned(16))) float xs[2][3 * HALO * CinT];
+    __shared__ __attribute__((aligned(16))) float dys[2][CW * CoutT];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    const int cti = L % g.ct; L /= g.ct;
+    const int split = L;
+    const int cbase = cti * CinT;
+    const int T = g.KH * g.KW;
+    const int wpr = g.Wo / CW;                          // chunks per output row
+    const int cbeg = split * g.cpb, cend = min(g.total_chunks, cbeg + g.cpb);
+
+    f32x16 acc[3][CT];
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[sl][i][e] = 0.f;
+
+    f32x4 rx[RX], ry[RY];
+    unsigned mx[RX], my[RY];
+    auto load_chunk = [&](int chunk) {
+        const int wc = chunk % wpr, rest = chunk / wpr, ho = rest % g.Ho, n = rest / g.Ho;
+#pragma unroll
+        for (int i = 0; i < RX; ++i) {
+            const int u = t + 256 * i;
+            const int c4 = u % (CinT / 4), col = (u / (CinT / 4)) % HALO, r = u / ((CinT / 4) * HALO);
+            const int ih = ho + r - g.pad_t, iw = wc * CW + col - g.pad_l, c = cbase + c4 * 4;
+            unsigned mask = 0;
+            if (u < XU && r < g.KH && (unsigned)ih < (unsigned)g.Hi && (unsigned)iw < (unsigned)g.Wi && c < g.Cin) {
+                const int rem = g.Cin - c;
+                mask = rem >= 4 ? 15u : (15u >> (4 - rem));
+            }
+            const float* p = g.x + ((ptrdiff_t)(n * g.Hi + ih) * g.Wi + iw) * g.ldx + c;
+            mx[i] = mask;
+            rx[i] = *reinterpret_cast<const f32x4*>(mask ? p : g.x);
+        }
+#pragma unroll
+        for (int i = 0; i < RY; ++i) {
+            const int u = t + 256 * i;
+            const int k4 = u % (CoutT / 4), px = u / (CoutT / 4);
+            const int k = k4 * 4;
+            unsigned mask = 0;
+            if (k < g.Cout) { const int rem = g.Cout - k; mask = rem >= 4 ? 15u : (15u >> (4 - rem)); }
+            const float* p = g.dy + ((size_t)(n * g.Ho + ho) * g.Wo + wc * CW + px) * g.lddy + k;
+            my[i] = mask;
+            ry[i] = *reinterpret_cast<const f32x4*>(mask ? p : g.dy);
+        }
+    };
+    auto masked = [](f32x4 v, unsigned m) -> f32x4 {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (m >> j) & 1u ? v[j] : 0.f;
+        return o;
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RX; ++i) {
+            const int u = t + 256 * i;
+            if (u < XU) *reinterpret_cast<f32x4*>(&xs[buf][u * 4]) = masked(rx[i], mx[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < RY; ++i) *reinterpret_cast<f32x4*>(&dys[buf][(t + 256 * i) * 4]) = masked(ry[i], my[i]);
+    };
+
+    const int nch = cend > cbeg ? cend - cbeg : 0;
+    if (nch > 0) { load_chunk(cbeg); store_chunk(0); }
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int buf = ch & 1;
+        const bool more = ch + 1 < nch;
+        if (more) load_chunk(cbeg + ch + 1);
+        const float* X = xs[buf];
+        const float* Y = dys[buf];
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {
+            const int tap = wave + 4 * sl;
+            if (tap < T) {
+                const int r = tap / g.KW, q = tap - r * g.KW;
+                const float* Xr = X + (r * HALO + q) * CinT;
+#pragma unroll
+                for (int s2 = 0; s2 < CW / 2; ++s2) {
+                    const int kp = 2 * s2 + lh;
+                    const float b = Y[kp * CoutT + li];
+#pragma unroll
+                    for (int i = 0; i < CT; ++i)
+                        acc[sl][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Xr[kp * CinT + i * 32 + li], b, acc[sl][i], 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = g.out + (size_t)split * g.slab;
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+        const int tap = wave + 4 * sl;
+        if (tap < T) {
+#pragma unroll
+            for (int i = 0; i < CT; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int c = cbase + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                    if (c < g.Cin && li < g.Cout) out[((size_t)tap * g.Cin + c) * g.Cout + li] = acc[sl][i][e];
+                }
+        }
+    }
+}
+
+// shape-only eligibility + split plan of the rows kernel (alignment / stride are checked by the caller)
+static bool wgrad_rows_plan(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int* S, int* cpb, int* CT) {
+    if (getenv("KPX_NO_WROWS")) return false;
+    if (KH > 3 || KW > 3 || KH * KW < 2 || Wo % 32 != 0 || Cout > 32 || Cin > 128 || (long)N * Ho * Wo < 65536) return false;
+    *CT = Cin > 32 ? 2 : 1;
+    const int ct = (Cin + 32 * *CT - 1) / (32 * *CT);
+    const long total = (long)N * Ho * (Wo / 32);
+    long want = 768 / ct;
+    if (want < 1) want = 1;
+    long s = total < want ? total : want;
+    const size_t slab_bytes = (size_t)KH * KW * Cin * Cout * 4;
+    const size_t cap = (size_t)256 << 20;
+    if ((size_t)s * slab_bytes > cap) s = (long)(cap / slab_bytes);
+    if (s < 1) s = 1;
+    *cpb = (int)((total + s - 1) / s);
+    *S = (int)((total + *cpb - 1) / *cpb);
+    return true;
 }
 
 static void wgrad_tiles(int Cin, int Cout, int& bm, int& bn) {
@@ -617,7 +790,13 @@ static int wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW
 
 extern "C" size_t kpx_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
     const int S = wgrad_splits(N, Ho, Wo, Cin, Cout, KH, KW);
-    return S > 1 ? (size_t)S * KH * KW * Cin * Cout * 4 : 0;
+    size_t need = S > 1 ? (size_t)S * KH * KW * Cin * Cout * 4 : 0;
+    int S2, cpb, CT;
+    if (wgrad_rows_plan(N, Ho, Wo, Cin, Cout, KH, KW, &S2, &cpb, &CT)) {
+        const size_t n2 = (size_t)S2 * KH * KW * Cin * Cout * 4;
+        if (n2 > need) need = n2;
+    }
+    return need;
 }
 
 extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
@@ -627,6 +806,32 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     if (!x || !dy || !dw || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || lddy < Cout)
         return KPX_EINVAL;
+    {
+        int S2, cpb, CT;
+        const bool vec = (ldx % 4 == 0) && (lddy % 4 == 0) && (Cin % 4 == 0) && aligned16(x) && aligned16(dy);
+        if (stride == 1 && vec && wgrad_rows_plan(N, Ho, Wo, Cin, Cout, KH, KW, &S2, &cpb, &CT)) {
+            WgradRowsGeom r{};
+            r.x = x; r.dy = dy;
+            r.N = N; r.Hi = Hi; r.Wi = Wi; r.Cin = Cin; r.ldx = ldx;
+            r.Ho = Ho; r.Wo = Wo; r.Cout = Cout; r.lddy = lddy;
+            r.KH = KH; r.KW = KW; r.pad_t = pad_t; r.pad_l = pad_l;
+            r.total_chunks = N * Ho * (Wo / 32); r.cpb = cpb; r.ct = (Cin + 32 * CT - 1) / (32 * CT);
+            r.slab = (size_t)KH * KW * Cin * Cout;
+            if (S2 > 1 && (!workspace || workspace_bytes < (size_t)S2 * r.slab * 4)) return KPX_EINVAL;
+            r.out = S2 > 1 ? (float*)workspace : dw;
+            hipStream_t s = kpx_stream(stream);
+            const dim3 grid((unsigned)(S2 * r.ct));
+            if (CT == 2) hipLaunchKernelGGL((conv_wgrad_rows_kernel<2>), grid, dim3(256), 0, s, r);
+            else hipLaunchKernelGGL((conv_wgrad_rows_kernel<1>), grid, dim3(256), 0, s, r);
+            int rc = kpx_launch_status();
+            if (rc) return rc;
+            if (S2 > 1) {
+                launch_wgrad_reduce((const float*)workspace, dw, r.slab, S2, s);
+                rc = kpx_launch_status();
+            }
+            return rc;
+        }
+    }
     WgradGeom g{};
     g.x = x; g.dy = dy;
     g.N = N; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.ldx = ldx;
@@ -636,7 +841,7 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     g.S = wgrad_splits(N, Ho, Wo, Cin, Cout, KH, KW);
     g.slab = (size_t)KH * KW * Cin * Cout;
     if (g.S > 1 && (!workspace || workspace_bytes < (size_t)g.S * g.slab * 4)) return KPX_EINVAL;
-    g.pps = ((g.P + g.S - 1) / g.S + 15) / 16 * 16;
+    g.pps = ((g.P + g.S - 1) / g.S + 31) / 32 * 32;
     g.out = g.S > 1 ? (float*)workspace : dw;
     int bm, bn;
     wgrad_tiles(Cin, Cout, bm, bn);
@@ -649,19 +854,17 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
         g.ct = (g.Cin + bm - 1) / bm;
     }
     hipStream_t s = kpx_stream(stream);
-    const dim3 grid((unsigned)(g.S * taps * g.ct * g.kt)), block(256);
+    const dim3 grid((unsigned)(g.S * taps * g.ct * g.kt));
     const bool vec = g.vecA && g.vecB && !g.merge;
-    if (g.merge) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, false, true>), grid, block, 0, s, g);
-    else if (bm == 128 && vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, true, false>), grid, block, 0, s, g);
-    else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, false, false>), grid, block, 0, s, g);
-    else if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true, false>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, false, false>), grid, block, 0, s, g);
+    if (g.merge) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false, true>), grid, dim3(256), 0, s, g);
+    else if (bm == 128 && vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 4, true, false>), grid, dim3(512), 0, s, g);
+    else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 4, false, false>), grid, dim3(512), 0, s, g);
+    else if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, true, false>), grid, dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false, false>), grid, dim3(256), 0, s, g);
     int rc = kpx_launch_status();
     if (rc) return rc;
     if (g.S > 1) {
-        const size_t n = g.slab;
-        const unsigned nb = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, s, (const float*)workspace, dw, n, g.S);
+        launch_wgrad_reduce((const float*)workspace, dw, g.slab, g.S, s);
         rc = kpx_launch_status();
     }
     return rc;
