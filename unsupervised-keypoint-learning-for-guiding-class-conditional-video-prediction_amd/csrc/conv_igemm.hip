@@ -16,6 +16,9 @@
 #include "kpx_common.h"
 #include <stdlib.h>
 
+// per stride-parity class of output pixels (dgrad of a strided conv); forward has exactly one class
+struct ConvClass { int Ha, Wa, oy0, ox0, Tr, Tq, iy0, ix0, wr0, wq0, M, mt; };
+
 struct ConvGeom {
     const float* x; float* y; const float* w; const float* bias;
     int N, Hi, Wi, Cin, ldx;
@@ -28,6 +31,7 @@ struct ConvGeom {
     int wts, ldw;
     int act, vecA, vecB;
     int M, mt, nt;
+    ConvClass cls[4]; int ncls;   // blockIdx.y selects the class
     int merge;      // >0: row-merged taps for tiny Cin (= original Cin): the KW*Cin floats of one filter row are
                     // contiguous in NHWC, so they are treated as one tap with KW*Cin channels (per-element x bounds)
 };
@@ -52,9 +56,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+    const ConvClass k = g.cls[blockIdx.y];
     const int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    if (L >= k.mt * g.nt) return;                  // this class has fewer tiles than the widest one
     const int m0 = (L / g.nt) * BM, n0 = (L % g.nt) * BN;
-    const int HW = g.Ha * g.Wa;
+    const int HW = k.Ha * k.Wa;
 
     // per-thread A rows
     const int kq = t & 7;
@@ -63,11 +69,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + (t >> 3) + (NT / 8) * i;
-        a_ok[i] = m < g.M;
+        a_ok[i] = m < k.M;
         const int mm = a_ok[i] ? m : 0;
-        const int n = mm / HW, rem = mm - n * HW, a = rem / g.Wa, b = rem - a * g.Wa;
-        a_ih0[i] = a * g.isy + g.iy0;
-        a_iw0[i] = b * g.isx + g.ix0;
+        const int n = mm / HW, rem = mm - n * HW, a = rem / k.Wa, b = rem - a * k.Wa;
+        a_ih0[i] = a * g.isy + k.iy0;
+        a_iw0[i] = b * g.isx + k.ix0;
         a_base[i] = n * g.Hi * g.Wi;
     }
 
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nck = (g.Cin + BK - 1) / BK;
-    const int nchunks = g.Tr * g.Tq * nck;
+    const int nchunks = k.Tr * k.Tq * nck;
     int tr = 0, tq = 0, c0 = 0;
     f32x4 ra[RA], rb[RB];
     unsigned am[RA], bm[RB];
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
             am[i] = mask;
             ra[i] = load4(p, mask, g.x);
         }
-        const int tap = (g.wr0 + tr * g.wrs) * g.KW + (g.wq0 + tq * g.wqs);
+        const int tap = (k.wr0 + tr * g.wrs) * g.KW + (k.wq0 + tq * g.wqs);
         const float* wp = g.w + (size_t)tap * g.wts;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -132,7 +138,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
             const float* p = g.w;
             if (u < BU) {
                 if (!BT) {
-                    const int k = u / (BN / 4), n = n0 + (u % (BN / 4)) * 4, c = c0 + k;
+                    const int kr = u / (BN / 4), n = n0 + (u % (BN / 4)) * 4, c = c0 + kr;
                     p = wp + (size_t)c * g.ldw + n;
                     if (c < g.Cin) mask = tail4(n, g.Cout);
                 } else {
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
         c0 += BK;
         if (c0 >= g.Cin) {
             c0 = 0;
-            if (++tq == g.Tq) { tq = 0; ++tr; }
+            if (++tq == k.Tq) { tq = 0; ++tr; }
         }
     };
     auto masked = [](f32x4 v, unsigned m) -> f32x4 {
@@ -224,9 +230,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
     if (t < BM) {
         const int m = m0 + t;
         int pix = -1;
-        if (m < g.M) {
-            const int n = m / HW, rem = m - n * HW, a = rem / g.Wa, b = rem - a * g.Wa;
-            pix = (n * g.Ho + a * g.osy + g.oy0) * g.Wo + b * g.osx + g.ox0;
+        if (m < k.M) {
+            const int n = m / HW, rem = m - n * HW, a = rem / k.Wa, b = rem - a * k.Wa;
+            pix = (n * g.Ho + a * g.osy + k.oy0) * g.Wo + b * g.osx + k.ox0;
         }
         rowpix[t] = pix;
     }
@@ -255,7 +261,9 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
 
 template <bool BT, bool VEC, bool MERGE>
 static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
-    g.M = g.N * g.Ha * g.Wa;
+    if (g.ncls <= 0) { g.ncls = 1; g.cls[0] = ConvClass{g.Ha, g.Wa, g.oy0, g.ox0, g.Tr, g.Tq, g.iy0, g.ix0, g.wr0, g.wq0, 0, 0}; }
+    g.M = 0;
+    for (int i = 0; i < g.ncls; ++i) { g.cls[i].M = g.N * g.cls[i].Ha * g.cls[i].Wa; if (g.cls[i].M > g.M) g.M = g.cls[i].M; }
     if (g.M <= 0 || g.Cout <= 0) return 0;
     // N tile: smallest padded width, ties -> wider tile
     int BN = 128;
@@ -264,16 +272,34 @@ static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
         if (pad(64) < pad(BN)) BN = 64;
         if (pad(32) < pad(BN)) BN = 32;
     }
-    auto blocks = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.Cout + bn - 1) / bn); };
-    const long want = 512;
+    auto blocks = [&](int bm, int bn) {
+        long b = 0;
+        for (int i = 0; i < g.ncls; ++i) b += (long)((g.cls[i].M + bm - 1) / bm) * ((g.Cout + bn - 1) / bn);
+        return b;
+    };
+    // pick the tile by how well its workgroup count fills 256 CUs x resident workgroups per CU (LDS-limited)
     int BM = 128;
-    if (BN == 128 && blocks(128, 128) < want) { BM = 64; }
-    else if (BN == 64 && blocks(128, 64) < want) BM = 64;
-    g.mt = (g.M + BM - 1) / BM;
+    if (BN != 32) {
+        struct Cand { int bm, bn, occ; double eff; };
+        const Cand c128[] = {{128, 128, 2, 1.0}, {64, 128, 3, 0.92}, {128, 64, 3, 0.92}, {64, 64, 5, 0.85}};
+        const Cand c64[] = {{128, 64, 3, 1.0}, {64, 64, 5, 0.92}};
+        const Cand* cs = BN == 128 ? c128 : c64;
+        const int nc = BN == 128 ? 4 : 2;
+        double best = -1;
+        for (int i = 0; i < nc; ++i) {
+            const long nb = blocks(cs[i].bm, cs[i].bn), slots = 256L * cs[i].occ;
+            const long rounds = (nb + slots - 1) / slots;
+            const double score = cs[i].eff * (double)nb / (double)(rounds * slots);
+            if (score > best) { best = score; BM = cs[i].bm; BN = cs[i].bn; }
+        }
+    }
     g.nt = (g.Cout + BN - 1) / BN;
-    const unsigned nblk = (unsigned)(g.mt * g.nt);
+    int mtmax = 0;
+    for (int i = 0; i < g.ncls; ++i) { g.cls[i].mt = (g.cls[i].M + BM - 1) / BM; if (g.cls[i].mt > mtmax) mtmax = g.cls[i].mt; }
+    g.mt = mtmax;
+    const dim3 nblk((unsigned)(g.mt * g.nt), (unsigned)g.ncls);
 #define KPX_LAUNCH(bm, bn, wm, wn) \
-    hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn, BT, VEC, MERGE>), dim3(nblk), dim3((wm) * (wn) * 64), 0, s, g)
+    hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn, BT, VEC, MERGE>), nblk, dim3((wm) * (wn) * 64), 0, s, g)
     if (BM == 128 && BN == 128) KPX_LAUNCH(128, 128, 2, 4);        // 8 waves of 64x32
     else if (BM == 64 && BN == 128) KPX_LAUNCH(64, 128, 2, 4);     // 8 waves of 32x32 (small M, wide N)
     else if (BM == 128 && BN == 64) KPX_LAUNCH(128, 64, 4, 2);     // 8 waves of 32x32
@@ -368,30 +394,35 @@ extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int 
     if (!dy || !w || !dx || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || lddy < Cout || lddx < Cin)
         return KPX_EINVAL;
+    if (stride > 2) return KPX_EINVAL;             // at most 4 parity classes per launch (the path has strides 1 and 2)
+    ConvGeom g{};
+    g.x = dy; g.y = dx; g.w = w; g.bias = nullptr;
+    g.N = N; g.Hi = Ho; g.Wi = Wo; g.Cin = Cout; g.ldx = lddy;       // "input" of the gather = dy
+    g.Ho = Hi; g.Wo = Wi; g.Cout = Cin; g.ldy = lddx;                // "output" = dx
+    g.osy = stride; g.osx = stride;
+    g.isy = 1; g.ity = -1; g.isx = 1; g.itx = -1;
+    g.wrs = stride; g.wqs = stride; g.KW = KW;
+    g.wts = Cin * Cout; g.ldw = Cout; g.act = KPX_ACT_NONE;
+    g.vecA = (lddy % 4 == 0) && aligned16(dy);
+    g.vecB = (Cout % 4 == 0) && aligned16(w);
+    g.ncls = 0;
     for (int ph = 0; ph < stride; ++ph) {
         for (int pw = 0; pw < stride; ++pw) {
             if (ph >= Hi || pw >= Wi) continue;
-            ConvGeom g{};
-            g.x = dy; g.y = dx; g.w = w; g.bias = nullptr;
-            g.N = N; g.Hi = Ho; g.Wi = Wo; g.Cin = Cout; g.ldx = lddy;       // "input" of the gather = dy
-            g.Ho = Hi; g.Wo = Wi; g.Cout = Cin; g.ldy = lddx;                // "output" = dx
-            g.Ha = (Hi - ph + stride - 1) / stride; g.Wa = (Wi - pw + stride - 1) / stride;
-            g.osy = stride; g.oy0 = ph; g.osx = stride; g.ox0 = pw;
+            ConvClass c{};
+            c.Ha = (Hi - ph + stride - 1) / stride; c.Wa = (Wi - pw + stride - 1) / stride;
+            c.oy0 = ph; c.ox0 = pw;
             const int r0 = (ph + pad_t) % stride, q0 = (pw + pad_l) % stride;
-            g.Tr = r0 < KH ? (KH - r0 + stride - 1) / stride : 0;
-            g.Tq = q0 < KW ? (KW - q0 + stride - 1) / stride : 0;
-            if (g.Tr == 0 || g.Tq == 0) { g.Tr = 0; g.Tq = 0; }
-            g.isy = 1; g.iy0 = (ph + pad_t - r0) / stride; g.ity = -1;
-            g.isx = 1; g.ix0 = (pw + pad_l - q0) / stride; g.itx = -1;
-            g.wr0 = r0; g.wrs = stride; g.wq0 = q0; g.wqs = stride; g.KW = KW;
-            g.wts = Cin * Cout; g.ldw = Cout; g.act = KPX_ACT_NONE;
-            g.vecA = (lddy % 4 == 0) && aligned16(dy);
-            g.vecB = (Cout % 4 == 0) && aligned16(w);
-            const int rc = launch_gather_conv<true>(g, kpx_stream(stream));
-            if (rc) return rc;
+            c.Tr = r0 < KH ? (KH - r0 + stride - 1) / stride : 0;
+            c.Tq = q0 < KW ? (KW - q0 + stride - 1) / stride : 0;
+            if (c.Tr == 0 || c.Tq == 0) { c.Tr = 0; c.Tq = 0; }
+            c.iy0 = (ph + pad_t - r0) / stride;
+            c.ix0 = (pw + pad_l - q0) / stride;
+            c.wr0 = r0; c.wq0 = q0;
+            g.cls[g.ncls++] = c;
         }
     }
-    return 0;
+    return launch_gather_conv<true>(g, kpx_stream(stream));
 }
 
 // ------------------------------------------------------------------------------------------ wgrad
