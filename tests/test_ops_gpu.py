@@ -57,6 +57,7 @@ CONV_CASES = [
     (16, 64, 64, 128, 32, 3, 1, 0, 0),     # same, two channel tiles of 64 (pose conv_5_0)
     (4, 128, 128, 64, 4, 3, 1, 0, 0),      # same, translator crude+mask head
     (2, 64, 64, 256, 128, 3, 1, 0, 0),     # 8-wave 128x128 wgrad tiles
+    (4, 128, 128, 3, 32, 7, 1, 0, 0),      # row-merged multi-tap wgrad (encoder conv_1 at full resolution)
 ]
 
 

@@ -776,6 +776,113 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(const WgradRowsGeo
     }
 }
 
+// Same idea for the image-input convs (Cin = 3, 7x7): with dense NHWC the KW*Cin floats under one filter row are
+// contiguous, so filter row r is ONE tap whose operand for output pixel p is the float window seg[r][p*Cin .. p*Cin+KW*Cin).
+// The workgroup stages KH raw row segments of (32+KW-1)*Cin floats; wave w owns filter rows w and w+4.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void conv_wgrad_rows_merged_kernel(const WgradRowsGeom g) {
+    constexpr int CW = 32, SEG = 128, CoutT = 32, KHMAX = 8;
+    constexpr int RX = KHMAX * SEG / 256;              // 4 scalar units per thread
+    __shared__ float xs[2][KHMAX * SEG];
+    __shared__ __attribute__((aligned(16))) float dys[2][CW * CoutT];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int split = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    const int KWC = g.KW * g.Cin;                       // merged channels per filter row (<= 32)
+    const int segf = (CW + g.KW - 1) * g.Cin;           // valid floats per staged row (<= SEG)
+    const int wpr = g.Wo / CW;
+    const int cbeg = split * g.cpb, cend = min(g.total_chunks, cbeg + g.cpb);
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[sl][e] = 0.f;
+
+    int xr[RX], xf[RX], xcol[RX];
+#pragma unroll
+    for (int i = 0; i < RX; ++i) {
+        const int u = t + 256 * i;
+        xr[i] = u / SEG; xf[i] = u % SEG; xcol[i] = xf[i] / g.Cin;
+    }
+    float rx[RX];
+    f32x4 ry;
+    unsigned my;
+    auto load_chunk = [&](int chunk) {
+        const int wc = chunk % wpr, rest = chunk / wpr, ho = rest % g.Ho, n = rest / g.Ho;
+        const int iw0 = wc * CW - g.pad_l;
+#pragma unroll
+        for (int i = 0; i < RX; ++i) {
+            const int ih = ho + xr[i] - g.pad_t;
+            const bool ok = xr[i] < g.KH && xf[i] < segf && (unsigned)ih < (unsigned)g.Hi && (unsigned)(iw0 + xcol[i]) < (unsigned)g.Wi;
+            const float* p = g.x + ((ptrdiff_t)(n * g.Hi + ih) * g.Wi + iw0) * g.Cin + xf[i];
+            const float v = *(ok ? p : g.x);
+            rx[i] = ok ? v : 0.f;
+        }
+        {
+            const int k4 = t % (CoutT / 4), px = t / (CoutT / 4), k = k4 * 4;
+            my = 0;
+            if (k < g.Cout) { const int rem = g.Cout - k; my = rem >= 4 ? 15u : (15u >> (4 - rem)); }
+            const float* p = g.dy + ((size_t)(n * g.Ho + ho) * g.Wo + wc * CW + px) * g.lddy + k;
+            ry = *reinterpret_cast<const f32x4*>(my ? p : g.dy);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RX; ++i) xs[buf][t + 256 * i] = rx[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (my >> j) & 1u ? ry[j] : 0.f;
+        *reinterpret_cast<f32x4*>(&dys[buf][t * 4]) = o;
+    };
+    const int nch = cend > cbeg ? cend - cbeg : 0;
+    if (nch > 0) { load_chunk(cbeg); store_chunk(0); }
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int buf = ch & 1;
+        const bool more = ch + 1 < nch;
+        if (more) load_chunk(cbeg + ch + 1);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int r = wave + 4 * sl;
+            if (r < g.KH) {
+                const float* Xr = &xs[buf][r * SEG];
+#pragma unroll
+                for (int s2 = 0; s2 < CW / 2; ++s2) {
+                    const int kp = 2 * s2 + lh;
+                    acc[sl] = __builtin_amdgcn_mfma_f32_32x32x2f32(Xr[kp * g.Cin + li], dys[buf][kp * CoutT + li], acc[sl], 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = g.out + (size_t)split * g.slab;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int r = wave + 4 * sl;
+        if (r < g.KH) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (c < KWC && li < g.Cout) out[((size_t)r * KWC + c) * g.Cout + li] = acc[sl][e];
+            }
+        }
+    }
+}
+
+static bool wgrad_rows_merged_plan(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int* S, int* cpb) {
+    if (getenv("KPX_NO_WROWS")) return false;
+    if (Cin % 4 == 0 || KW * Cin > 32 || (32 + KW - 1) * Cin > 128 || KH > 8 || KW < 2 || Wo % 32 != 0 || Cout > 32 ||
+        (long)N * Ho * Wo < 65536)
+        return false;
+    const long total = (long)N * Ho * (Wo / 32);
+    long s = total < 768 ? total : 768;
+    *cpb = (int)((total + s - 1) / s);
+    *S = (int)((total + *cpb - 1) / *cpb);
+    return true;
+}
+
 // shape-only eligibility + split plan of the rows kernel (alignment / stride are checked by the caller)
 static bool wgrad_rows_plan(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int* S, int* cpb, int* CT) {
     if (getenv("KPX_NO_WROWS")) return false;
@@ -827,6 +934,10 @@ extern "C" size_t kpx_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Ci
         const size_t n2 = (size_t)S2 * KH * KW * Cin * Cout * 4;
         if (n2 > need) need = n2;
     }
+    if (wgrad_rows_merged_plan(N, Ho, Wo, Cin, Cout, KH, KW, &S2, &cpb)) {
+        const size_t n2 = (size_t)S2 * KH * KW * Cin * Cout * 4;
+        if (n2 > need) need = n2;
+    }
     return need;
 }
 
@@ -837,6 +948,26 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     if (!x || !dy || !dw || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || lddy < Cout)
         return KPX_EINVAL;
+    {
+        int S2, cpb;
+        if (stride == 1 && ldx == Cin && lddy % 4 == 0 && aligned16(dy) && wgrad_rows_merged_plan(N, Ho, Wo, Cin, Cout, KH, KW, &S2, &cpb)) {
+            WgradRowsGeom r{};
+            r.x = x; r.dy = dy;
+            r.N = N; r.Hi = Hi; r.Wi = Wi; r.Cin = Cin; r.ldx = ldx;
+            r.Ho = Ho; r.Wo = Wo; r.Cout = Cout; r.lddy = lddy;
+            r.KH = KH; r.KW = KW; r.pad_t = pad_t; r.pad_l = pad_l;
+            r.total_chunks = N * Ho * (Wo / 32); r.cpb = cpb; r.ct = 1;
+            r.slab = (size_t)KH * KW * Cin * Cout;
+            if (S2 > 1 && (!workspace || workspace_bytes < (size_t)S2 * r.slab * 4)) return KPX_EINVAL;
+            r.out = S2 > 1 ? (float*)workspace : dw;
+            hipStream_t s = kpx_stream(stream);
+            hipLaunchKernelGGL((conv_wgrad_rows_merged_kernel<0>), dim3((unsigned)S2), dim3(256), 0, s, r);
+            int rc = kpx_launch_status();
+            if (rc) return rc;
+            if (S2 > 1) { launch_wgrad_reduce((const float*)workspace, dw, r.slab, S2, s); rc = kpx_launch_status(); }
+            return rc;
+        }
+    }
     {
         int S2, cpb, CT;
         const bool vec = (ldx % 4 == 0) && (lddy % 4 == 0) && (Cin % 4 == 0) && aligned16(x) && aligned16(dy);
