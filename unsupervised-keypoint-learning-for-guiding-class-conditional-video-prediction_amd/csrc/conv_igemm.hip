@@ -15,6 +15,9 @@
 // {8u+4h+j}: a K permutation shared by A and B, so the product is unchanged.
 #include "kpx_common.h"
 #include <stdlib.h>
+#ifndef KPX_EXP
+#define KPX_EXP 0
+#endif
 
 // per stride-parity class of output pixels (dgrad of a strided conv); forward has exactly one class
 struct ConvClass { int Ha, Wa, oy0, ox0, Tr, Tq, iy0, ix0, wr0, wq0, M, mt; };
@@ -41,7 +44,11 @@ struct ConvGeom {
 // ((row>>1)&7) -- conflict-free for both the 8-lane ds_write_b128 groups (one row = 128 contiguous bytes = one full cache
 // line of the pixel's channels) and the 16-lane ds_read_b128 groups; B [32][BN], for dgrad (weights read transposed) the
 // column index is XORed with ((k>>2)&7)<<2 so the scalar transposing writes spread over all banks.
-template <int BM, int BN, int WM, int WN, bool BT, bool VEC, bool MERGE>
+// 16 zero bytes in the code object: invalid (out-of-image / out-of-range) 16-B units are loaded from here, so the
+// TAIL=false kernels need no per-element select between the load and the LDS write.
+__device__ __attribute__((aligned(16))) float kpx_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int BM, int BN, int WM, int WN, bool BT, bool VEC, bool MERGE, bool TAIL>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom g) {
     constexpr int NT = WM * WN * 64;
     constexpr int BK = 32;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
                 }
             }
             am[i] = mask;
-            ra[i] = load4(p, mask, g.x);
+            ra[i] = load4(p, mask, TAIL ? g.x : kpx_zero16);
         }
         const int tap = (k.wr0 + tr * g.wrs) * g.KW + (k.wq0 + tq * g.wqs);
         const float* wp = g.w + (size_t)tap * g.wts;
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
                 }
             }
             bm[i] = mask;
-            rb[i] = load4(p, mask, g.w);
+            rb[i] = load4(p, mask, TAIL ? g.w : kpx_zero16);
         }
         c0 += BK;
         if (c0 >= g.Cin) {
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
         }
     };
     auto masked = [](f32x4 v, unsigned m) -> f32x4 {
+        if (!TAIL) return v;                 // invalid units were loaded from the zero page; no partial units exist
         f32x4 r;
 #pragma unroll
         for (int j = 0; j < 4; ++j) r[j] = (m >> j) & 1u ? v[j] : 0.f;
@@ -191,38 +199,58 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
     __syncthreads();
 
     const int wrow = wm * TM * 32, wcol = wn * TN * 32;
+    // One chunk = 4 groups of 8 k-steps.  The next chunk's global loads are issued after the first group and written to
+    // the other LDS buffer after the third, so their address arithmetic, the wait and the ds_writes sit between MFMAs
+    // (the pipe is busy for 64 cycles per MFMA) instead of in the serial gap around the barrier.
+    auto mfma_group = [&](const float* Ab, const float* Bb, int u) {
+        const int ks = 2 * u + lh;                       // this lane-half's 16-B slot = channels 4*ks .. 4*ks+3
+        f32x4 a[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wrow + i * 32 + li;
+#if KPX_EXP == 1
+            a[i] = f32x4{(float)row, 1.f, 2.f, (float)u};
+#else
+            a[i] = *reinterpret_cast<const f32x4*>(&Ab[row * BK + ((ks ^ ((row >> 1) & 7)) << 2)]);
+#endif
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float b[TN];
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const int col = wcol + n * 32 + li;
+#if KPX_EXP == 1
+                b[n] = (float)(col + j);
+#else
+                b[n] = Bb[(ks * 4 + j) * BN + (BT ? (col ^ (ks << 2)) : col)];
+#endif
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n], acc[i][n], 0, 0, 0);
+        }
+    };
     for (int ch = 0; ch < nchunks; ++ch) {
         const int buf = ch & 1;
         const bool more = ch + 1 < nchunks;
-        if (more) load_chunk();
         const float* Ab = As[buf];
         const float* Bb = Bs[buf];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int ks = 2 * u + lh;                       // this lane-half's 16-B slot = channels 4*ks .. 4*ks+3
-            f32x4 a[TM];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wrow + i * 32 + li;
-                a[i] = *reinterpret_cast<const f32x4*>(&Ab[row * BK + ((ks ^ ((row >> 1) & 7)) << 2)]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float b[TN];
-#pragma unroll
-                for (int n = 0; n < TN; ++n) {
-                    const int col = wcol + n * 32 + li;
-                    b[n] = Bb[(ks * 4 + j) * BN + (BT ? (col ^ (ks << 2)) : col)];
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int n = 0; n < TN; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n], acc[i][n], 0, 0, 0);
-            }
-        }
+        mfma_group(Ab, Bb, 0);
+#if KPX_EXP != 2
+        if (more) load_chunk();
+#endif
+        mfma_group(Ab, Bb, 1);
+        mfma_group(Ab, Bb, 2);
+#if KPX_EXP != 2
         if (more) store_chunk(buf ^ 1);
+#endif
+        mfma_group(Ab, Bb, 3);
+#if KPX_EXP != 3
         __syncthreads();
+#endif
     }
 
     // epilogue: the output pixel of every tile row goes through LDS (the A buffers are free now)
@@ -259,7 +287,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
     }
 }
 
-template <bool BT, bool VEC, bool MERGE>
+template <bool BT, bool VEC, bool MERGE, bool TAIL>
 static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
     if (g.ncls <= 0) { g.ncls = 1; g.cls[0] = ConvClass{g.Ha, g.Wa, g.oy0, g.ox0, g.Tr, g.Tq, g.iy0, g.ix0, g.wr0, g.wq0, 0, 0}; }
     g.M = 0;
@@ -299,7 +327,7 @@ static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
     g.mt = mtmax;
     const dim3 nblk((unsigned)(g.mt * g.nt), (unsigned)g.ncls);
 #define KPX_LAUNCH(bm, bn, wm, wn) \
-    hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn, BT, VEC, MERGE>), nblk, dim3((wm) * (wn) * 64), 0, s, g)
+    hipLaunchKernelGGL((conv_igemm_kernel<bm, bn, wm, wn, BT, VEC, MERGE, TAIL>), nblk, dim3((wm) * (wn) * 64), 0, s, g)
     if (BM == 128 && BN == 128) KPX_LAUNCH(128, 128, 2, 4);        // 8 waves of 64x32
     else if (BM == 64 && BN == 128) KPX_LAUNCH(64, 128, 2, 4);     // 8 waves of 32x32 (small M, wide N)
     else if (BM == 128 && BN == 64) KPX_LAUNCH(128, 64, 4, 2);     // 8 waves of 32x32
@@ -311,9 +339,12 @@ static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
 
 template <bool BT>
 static int launch_gather_conv(const ConvGeom& g, hipStream_t s) {
-    if (g.merge) return launch_gather_conv_v<false, false, true>(g, s);
-    if (g.vecA && g.vecB) return launch_gather_conv_v<BT, true, false>(g, s);
-    return launch_gather_conv_v<BT, false, false>(g, s);
+    if (g.merge) return launch_gather_conv_v<false, false, true, true>(g, s);
+    if (g.vecA && g.vecB) {
+        if (g.Cin % 4 == 0 && g.Cout % 4 == 0) return launch_gather_conv_v<BT, true, false, false>(g, s);
+        return launch_gather_conv_v<BT, true, false, true>(g, s);
+    }
+    return launch_gather_conv_v<BT, false, false, true>(g, s);
 }
 
 // Tiny-Cout / long-K forward (img_discr D_logit: 3x3x2048 -> 1, reference networks/__init__.py:150): one wavefront
