@@ -15,9 +15,6 @@
 // {8u+4h+j}: a K permutation shared by A and B, so the product is unchanged.
 #include "kpx_common.h"
 #include <stdlib.h>
-#ifndef KPX_EXP
-#define KPX_EXP 0
-#endif
 
 // per stride-parity class of output pixels (dgrad of a strided conv); forward has exactly one class
 struct ConvClass { int Ha, Wa, oy0, ox0, Tr, Tq, iy0, ix0, wr0, wq0, M, mt; };
@@ -48,6 +45,8 @@ struct ConvGeom {
 // TAIL=false kernels need no per-element select between the load and the LDS write.
 __device__ __attribute__((aligned(16))) float kpx_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
+template <int V> struct kpx_ic { static constexpr int value = V; };
+
 template <int BM, int BN, int WM, int WN, bool BT, bool VEC, bool MERGE, bool TAIL>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom g) {
     constexpr int NT = WM * WN * 64;
@@ -56,9 +55,10 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
     constexpr int RA = (BM * 8) / NT;              // A float4 units per thread (BM rows x 8 slots)
     constexpr int RB = (BN * 8 + NT - 1) / NT;     // B float4 units per thread (32 x BN/4, or BN rows x 8 slots when BT)
     constexpr int BU = BN * 8;
+    constexpr int ASZ = BM * BK, BSZ = BK * BN;    // floats per LDS stage
     static_assert(TM >= 1 && TN >= 1 && RA >= 1 && (BM * 8) % NT == 0, "tile/wave shape");
-    __shared__ __attribute__((aligned(16))) float As[2][BM * BK];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+    __shared__ __attribute__((aligned(16))) float As[2 * ASZ];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -68,20 +68,62 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
     if (L >= k.mt * g.nt) return;                  // this class has fewer tiles than the widest one
     const int m0 = (L / g.nt) * BM, n0 = (L % g.nt) * BN;
     const int HW = k.Ha * k.Wa;
+    const int wrow = wm * TM * 32, wcol = wn * TN * 32;
 
-    // per-thread A rows
+    // ---- everything that does not change over the K loop is computed once per thread: pointers of the A / B units at
+    // tap (0,0) / channel 0, their validity as bit masks over the taps, and all LDS addresses.  Per chunk only wave-uniform
+    // (scalar) offsets are added, so the loop carries ~2 VALU per MFMA instead of ~6.
     const int kq = t & 7;
-    int a_ih0[RA], a_iw0[RA], a_base[RA];
-    bool a_ok[RA];
+    const float* a_ptr[RA];
+    unsigned a_vr[RA], a_vq[RA];
+    int a_iw0[RA], a_st[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + (t >> 3) + (NT / 8) * i;
-        a_ok[i] = m < k.M;
-        const int mm = a_ok[i] ? m : 0;
+        const int row = (t >> 3) + (NT / 8) * i;
+        const int m = m0 + row;
+        const bool ok = m < k.M;
+        const int mm = ok ? m : 0;
         const int n = mm / HW, rem = mm - n * HW, a = rem / k.Wa, b = rem - a * k.Wa;
-        a_ih0[i] = a * g.isy + k.iy0;
-        a_iw0[i] = b * g.isx + k.ix0;
-        a_base[i] = n * g.Hi * g.Wi;
+        const int ih0 = a * g.isy + k.iy0, iw0 = b * g.isx + k.ix0;
+        a_ptr[i] = g.x + (ptrdiff_t)(n * g.Hi * g.Wi + ih0 * g.Wi + iw0) * g.ldx + kq * 4;
+        unsigned vr = 0, vq = 0;
+        for (int r = 0; r < k.Tr; ++r) if (ok && (unsigned)(ih0 + r * g.ity) < (unsigned)g.Hi) vr |= 1u << r;
+        for (int q = 0; q < k.Tq; ++q) if (MERGE || (unsigned)(iw0 + q * g.itx) < (unsigned)g.Wi) vq |= 1u << q;
+        a_vr[i] = vr; a_vq[i] = vq; a_iw0[i] = iw0;
+        a_st[i] = row * BK + ((kq ^ ((row >> 1) & 7)) << 2);
+    }
+    const float* b_ptr[RB];
+    bool b_ok[RB];
+    int b_k[RB], b_n[RB], b_st[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int u = t + NT * i;
+        if (!BT) {
+            const int kr = u / (BN / 4), n4 = u % (BN / 4), n = n0 + n4 * 4;
+            b_k[i] = kr; b_n[i] = n; b_ok[i] = u < BU && n < g.Cout;
+            b_ptr[i] = g.w + (size_t)kr * g.ldw + n;
+            b_st[i] = kr * BN + n4 * 4;
+        } else {
+            const int nn = u >> 3, ks = u & 7, n = n0 + nn;
+            b_k[i] = ks * 4; b_n[i] = n; b_ok[i] = u < BU && n < g.Cout;
+            b_ptr[i] = g.w + (size_t)n * g.ldw + ks * 4;
+            b_st[i] = (ks * 4) * BN + (nn ^ (ks << 2));
+        }
+    }
+    int a_rd[TM][4], b_rd[TN][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ks = 2 * u + lh;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wrow + i * 32 + li;
+            a_rd[i][u] = row * BK + ((ks ^ ((row >> 1) & 7)) << 2);
+        }
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = wcol + n * 32 + li;
+            b_rd[n][u] = (ks * 4) * BN + (BT ? (col ^ (ks << 2)) : col);
+        }
     }
 
     f32x16 acc[TM][TN];
@@ -98,9 +140,6 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
     f32x4 ra[RA], rb[RB];
     unsigned am[RA], bm[RB];
 
-    // Loads are issued unconditionally from a clamped (always readable) address and masked when they are written to
-    // LDS one chunk later, so nothing in the chunk's MFMA phase depends on them: the global-load latency hides under the
-    // MFMAs of the current chunk instead of being waited for right after issue.
     auto tail4 = [](int c, int lim) -> unsigned {      // bit j set iff c + j < lim
         const int r = lim - c;
         return r >= 4 ? 15u : (r <= 0 ? 0u : (15u >> (4 - r)));
@@ -117,45 +156,40 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
         }
         return v;
     };
+    // Loads go out unconditionally: an invalid unit reads the 16 zero bytes of kpx_zero16 (or, with TAIL, a clamped
+    // address that is masked when the registers are written to LDS), so nothing in the MFMA phase depends on them.
     auto load_chunk = [&]() {
+        const int a_off = ((tr * g.ity) * g.Wi + tq * g.itx) * g.ldx + c0;          // wave-uniform
+        const int tap = (k.wr0 + tr * g.wrs) * g.KW + (k.wq0 + tq * g.wqs);
+        const size_t b_off = (size_t)tap * g.wts + (BT ? (size_t)c0 : (size_t)c0 * g.ldw);
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int ih = a_ih0[i] + tr * g.ity, iw = a_iw0[i] + tq * g.itx;
             const int c = c0 + kq * 4;
-            unsigned mask = 0;
-            const float* p = g.x + (ptrdiff_t)(a_base[i] + ih * g.Wi + iw) * g.ldx + c;
-            if (a_ok[i] && (unsigned)ih < (unsigned)g.Hi) {
+            const bool v = (((a_vr[i] >> tr) & (a_vq[i] >> tq)) & 1u) != 0 && c < g.Cin;
+            const float* p = a_ptr[i] + a_off;
+            unsigned mask = v ? 15u : 0u;
+            if (TAIL) {
                 if (MERGE) {
+                    mask = 0;
+                    if (v) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (c + j < g.Cin && (unsigned)(iw + (c + j) / g.merge) < (unsigned)g.Wi) mask |= 1u << j;
-                } else if ((unsigned)iw < (unsigned)g.Wi) {
+                        for (int j = 0; j < 4; ++j)
+                            if (c + j < g.Cin && (unsigned)(a_iw0[i] + (c + j) / g.merge) < (unsigned)g.Wi) mask |= 1u << j;
+                    }
+                } else if (v) {
                     mask = tail4(c, g.Cin);
                 }
             }
             am[i] = mask;
             ra[i] = load4(p, mask, TAIL ? g.x : kpx_zero16);
         }
-        const int tap = (k.wr0 + tr * g.wrs) * g.KW + (k.wq0 + tq * g.wqs);
-        const float* wp = g.w + (size_t)tap * g.wts;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int u = t + NT * i;
-            unsigned mask = 0;
-            const float* p = g.w;
-            if (u < BU) {
-                if (!BT) {
-                    const int kr = u / (BN / 4), n = n0 + (u % (BN / 4)) * 4, c = c0 + kr;
-                    p = wp + (size_t)c * g.ldw + n;
-                    if (c < g.Cin) mask = tail4(n, g.Cout);
-                } else {
-                    const int n = n0 + (u >> 3), c = c0 + (u & 7) * 4;
-                    p = wp + (size_t)n * g.ldw + c;
-                    if (n < g.Cout) mask = tail4(c, g.Cin);
-                }
-            }
+            const bool v = b_ok[i] && c0 + b_k[i] < g.Cin;
+            unsigned mask = v ? 15u : 0u;
+            if (TAIL && v) mask = BT ? tail4(c0 + b_k[i], g.Cin) : tail4(b_n[i], g.Cout);
             bm[i] = mask;
-            rb[i] = load4(p, mask, TAIL ? g.w : kpx_zero16);
+            rb[i] = load4(b_ptr[i] + b_off, mask, TAIL ? g.w : kpx_zero16);
         }
         c0 += BK;
         if (c0 >= g.Cin) {
@@ -164,68 +198,39 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
         }
     };
     auto masked = [](f32x4 v, unsigned m) -> f32x4 {
-        if (!TAIL) return v;                 // invalid units were loaded from the zero page; no partial units exist
+        if (!TAIL) return v;
         f32x4 r;
 #pragma unroll
         for (int j = 0; j < 4; ++j) r[j] = (m >> j) & 1u ? v[j] : 0.f;
         return r;
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf) {                  // buf is a compile-time constant at every call site
 #pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int row = (t >> 3) + (NT / 8) * i;
-            *reinterpret_cast<f32x4*>(&As[buf][row * BK + ((kq ^ ((row >> 1) & 7)) << 2)]) = masked(ra[i], am[i]);
-        }
+        for (int i = 0; i < RA; ++i)
+            *reinterpret_cast<f32x4*>(&As[buf * ASZ + a_st[i]]) = masked(ra[i], am[i]);
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            const int u = t + NT * i;
-            if (u < BU) {
+            if (t + NT * i < BU) {
                 const f32x4 v = masked(rb[i], bm[i]);
                 if (!BT) {
-                    *reinterpret_cast<f32x4*>(&Bs[buf][(u / (BN / 4)) * BN + (u % (BN / 4)) * 4]) = v;
+                    *reinterpret_cast<f32x4*>(&Bs[buf * BSZ + b_st[i]]) = v;
                 } else {
-                    const int nn = u >> 3, ks = u & 7;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) Bs[buf][(ks * 4 + j) * BN + (nn ^ (ks << 2))] = v[j];
+                    for (int j = 0; j < 4; ++j) Bs[buf * BSZ + b_st[i] + j * BN] = v[j];
                 }
             }
         }
     };
-
-    if (nchunks > 0) {
-        load_chunk();
-        store_chunk(0);
-    }
-    __syncthreads();
-
-    const int wrow = wm * TM * 32, wcol = wn * TN * 32;
-    // One chunk = 4 groups of 8 k-steps.  The next chunk's global loads are issued after the first group and written to
-    // the other LDS buffer after the third, so their address arithmetic, the wait and the ds_writes sit between MFMAs
-    // (the pipe is busy for 64 cycles per MFMA) instead of in the serial gap around the barrier.
-    auto mfma_group = [&](const float* Ab, const float* Bb, int u) {
-        const int ks = 2 * u + lh;                       // this lane-half's 16-B slot = channels 4*ks .. 4*ks+3
+    // one group = 8 k-steps: lane-half lh consumes channels 4*(2u+lh) .. +3 of the chunk (a K permutation shared by A and B)
+    auto mfma_group = [&](int buf, int u) {
         f32x4 a[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = wrow + i * 32 + li;
-#if KPX_EXP == 1
-            a[i] = f32x4{(float)row, 1.f, 2.f, (float)u};
-#else
-            a[i] = *reinterpret_cast<const f32x4*>(&Ab[row * BK + ((ks ^ ((row >> 1) & 7)) << 2)]);
-#endif
-        }
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf * ASZ + a_rd[i][u]]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float b[TN];
 #pragma unroll
-            for (int n = 0; n < TN; ++n) {
-                const int col = wcol + n * 32 + li;
-#if KPX_EXP == 1
-                b[n] = (float)(col + j);
-#else
-                b[n] = Bb[(ks * 4 + j) * BN + (BT ? (col ^ (ks << 2)) : col)];
-#endif
-            }
+            for (int n = 0; n < TN; ++n) b[n] = Bs[buf * BSZ + b_rd[n][u] + j * BN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -233,28 +238,33 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n], acc[i][n], 0, 0, 0);
         }
     };
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int buf = ch & 1;
-        const bool more = ch + 1 < nchunks;
-        const float* Ab = As[buf];
-        const float* Bb = Bs[buf];
-        mfma_group(Ab, Bb, 0);
-#if KPX_EXP != 2
+    // The next chunk's global loads are issued after the first group and written to the other LDS buffer after the third,
+    // so their address arithmetic, the wait and the ds_writes sit between MFMAs instead of in the gap around the barrier.
+    auto chunk = [&](auto bufc, bool more) {
+        constexpr int buf = decltype(bufc)::value;
+        mfma_group(buf, 0);
         if (more) load_chunk();
-#endif
-        mfma_group(Ab, Bb, 1);
-        mfma_group(Ab, Bb, 2);
-#if KPX_EXP != 2
+        mfma_group(buf, 1);
+        mfma_group(buf, 2);
         if (more) store_chunk(buf ^ 1);
-#endif
-        mfma_group(Ab, Bb, 3);
-#if KPX_EXP != 3
+        mfma_group(buf, 3);
         __syncthreads();
-#endif
+    };
+
+    if (nchunks > 0) {
+        load_chunk();
+        store_chunk(0);
     }
+    __syncthreads();
+    int ch = 0;
+    for (; ch + 1 < nchunks; ch += 2) {                // unrolled by two: the LDS buffer index is an immediate
+        chunk(kpx_ic<0>{}, true);
+        chunk(kpx_ic<1>{}, ch + 2 < nchunks);
+    }
+    if (ch < nchunks) chunk(kpx_ic<0>{}, false);
 
     // epilogue: the output pixel of every tile row goes through LDS (the A buffers are free now)
-    int* rowpix = reinterpret_cast<int*>(&As[0][0]);
+    int* rowpix = reinterpret_cast<int*>(&As[0]);
     if (t < BM) {
         const int m = m0 + t;
         int pix = -1;
