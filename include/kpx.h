@@ -57,9 +57,9 @@ int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx
                          float* dw_hwio, int KH, int KW, int stride, int pad_t, int pad_l,
                          void* workspace, size_t workspace_bytes, void* stream);
 
-/* dy *= act'(y) in place (y = the activated conv output): relu / leaky_relu(0.01) backward
+/* dz = dy * act'(y) (y = the activated conv output; dz may alias dy): relu / leaky_relu(0.01) backward
  * (tf.nn.relu vgg.py:54, tf.nn.leaky_relu networks/__init__.py:145,148). */
-int kpx_act_bwd_f32(float* dy, const float* y, size_t n, int act, void* stream);
+int kpx_act_bwd_f32(const float* dy, const float* y, float* dz, size_t n, int act, void* stream);
 
 /* ---- per-channel reductions over P pixels: sum[c] = sum_p x[p,c] (double accumulation).
  *      Used for the conv bias gradient (tf.layers.conv2d use_bias, layers.py:9).

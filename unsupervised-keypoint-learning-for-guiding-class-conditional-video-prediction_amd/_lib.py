@@ -33,7 +33,7 @@ SIGNATURES = {
     'kpx_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_wgrad_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int,
                                      P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
-    'kpx_act_bwd_f32': (c_int, [P, P, c_size_t, c_int, P]),
+    'kpx_act_bwd_f32': (c_int, [P, P, P, c_size_t, c_int, P]),
     'kpx_chan_reduce_scratch_bytes': (c_size_t, [c_int]),
     'kpx_chan_sum_f32': (c_int, [P, c_size_t, c_int, c_int, P, P, P]),
     'kpx_bn_stats_f32': (c_int, [P, c_size_t, c_int, c_int, c_float, P, P, P, P, P, c_float, P, P]),

@@ -656,6 +656,146 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradGeo
     }
 }
 
+// Fast path of the per-tap wgrad for Wo % 32 == 0 (every generator layer at 32/64/128 pixels): a K chunk is 32 consecutive
+// output pixels of ONE image row, so (n, ho, row validity, base addresses) are wave-uniform scalars and each thread only adds
+// a fixed offset; invalid units read the zero page; chunk loop unrolled by two for immediate LDS buffer offsets.
+struct WgradTapGeom {
+    const float* x; const float* dy; float* out;
+    int N, Hi, Wi, Cin, ldx;
+    int Ho, Wo, Cout, lddy;
+    int KH, KW, stride, pad_t, pad_l;
+    int total_chunks, cpb, S, ct, kt;
+    size_t slab;
+};
+
+template <int BMc, int BNk, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tap_rows_kernel(const WgradTapGeom g) {
+    constexpr int NT = WM * WN * 64, CW = 32;
+    constexpr int TM = BMc / (WM * 32), TN = BNk / (WN * 32);
+    constexpr int RA = (CW * BMc / 4) / NT, RB = (CW * BNk / 4) / NT;
+    constexpr int ASZ = CW * BMc, BSZ = CW * BNk;
+    static_assert(RA >= 1 && RB >= 1 && TM >= 1 && TN >= 1, "tile/wave shape");
+    __shared__ __attribute__((aligned(16))) float As[2 * ASZ];
+    __shared__ __attribute__((aligned(16))) float Bs[2 * BSZ];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    const int taps = g.KH * g.KW;
+    const int kti = L % g.kt; L /= g.kt;
+    const int cti = L % g.ct; L /= g.ct;
+    const int tap = L % taps; L /= taps;
+    const int split = L;
+    const int r = tap / g.KW, q = tap - r * g.KW;
+    const int cbase = cti * BMc, kbase = kti * BNk;
+    const int wpr = g.Wo / CW;
+    const int cbeg = split * g.cpb, cend = min(g.total_chunks, cbeg + g.cpb);
+    const int nch = cend > cbeg ? cend - cbeg : 0;
+
+    // fixed per-thread parts
+    int a_off[RA], a_px[RA];
+    bool a_cok[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int u = t + NT * i;
+        const int px = u / (BMc / 4), c = cbase + (u % (BMc / 4)) * 4;
+        a_px[i] = px * g.stride;
+        a_off[i] = px * g.stride * g.ldx + c;
+        a_cok[i] = c < g.Cin;
+    }
+    int b_off[RB];
+    bool b_kok[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int u = t + NT * i;
+        const int px = u / (BNk / 4), kk = kbase + (u % (BNk / 4)) * 4;
+        b_off[i] = px * g.lddy + kk;
+        b_kok[i] = kk < g.Cout;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // wave-uniform chunk cursor
+    int wc = cbeg % wpr, ho = (cbeg / wpr) % g.Ho, n = cbeg / (wpr * g.Ho);
+    f32x4 ra[RA], rb[RB];
+    auto load_chunk = [&]() {
+        const int ih = ho * g.stride + r - g.pad_t;
+        const int iwb = wc * CW * g.stride + q - g.pad_l;
+        const bool rowok = (unsigned)ih < (unsigned)g.Hi;
+        const float* xb = g.x + ((ptrdiff_t)(n * g.Hi + ih) * g.Wi + iwb) * g.ldx;
+        const float* yb = g.dy + ((size_t)(n * g.Ho + ho) * g.Wo + wc * CW) * g.lddy;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const bool v = rowok && a_cok[i] && (unsigned)(iwb + a_px[i]) < (unsigned)g.Wi;
+            ra[i] = *reinterpret_cast<const f32x4*>(v ? xb + a_off[i] : kpx_zero16);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            rb[i] = *reinterpret_cast<const f32x4*>(b_kok[i] ? yb + b_off[i] : kpx_zero16);
+        if (++wc == wpr) { wc = 0; if (++ho == g.Ho) { ho = 0; ++n; } }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[buf * ASZ + (t + NT * i) * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[buf * BSZ + (t + NT * i) * 4]) = rb[i];
+    };
+    const int wrow = wm * TM * 32, wcol = wn * TN * 32;
+    const int a_rd = lh * BMc + wrow + li, b_rd = lh * BNk + wcol + li;
+    auto mfma_steps = [&](int buf, int s0, int s1) {
+#pragma unroll
+        for (int s2 = s0; s2 < s1; ++s2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = As[buf * ASZ + a_rd + 2 * s2 * BMc + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = Bs[buf * BSZ + b_rd + 2 * s2 * BNk + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto chunk = [&](auto bufc, bool more) {
+        constexpr int buf = decltype(bufc)::value;
+        mfma_steps(buf, 0, 4);
+        if (more) load_chunk();
+        mfma_steps(buf, 4, 12);
+        if (more) store_chunk(buf ^ 1);
+        mfma_steps(buf, 12, 16);
+        __syncthreads();
+    };
+    if (nch > 0) { load_chunk(); store_chunk(0); }
+    __syncthreads();
+    int ch = 0;
+    for (; ch + 1 < nch; ch += 2) {
+        chunk(kpx_ic<0>{}, true);
+        chunk(kpx_ic<1>{}, ch + 2 < nch);
+    }
+    if (ch < nch) chunk(kpx_ic<0>{}, false);
+
+    float* out = g.out + (size_t)split * g.slab + (size_t)tap * g.Cin * g.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int kk = kbase + wcol + j * 32 + li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = cbase + wrow + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (c < g.Cin && kk < g.Cout) out[(size_t)c * g.Cout + kk] = acc[i][j][e];
+            }
+    }
+}
+
 // dw[i] = sum_s ws[s][i] in a fixed order: a workgroup owns 64 consecutive elements, its 4 wavefronts stride over the
 // slabs (256 contiguous bytes per slab and wave -> coalesced), 8 loads in flight per lane, then a 4-way LDS combine.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
@@ -1051,6 +1191,27 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     g.ct = (Cin + bm - 1) / bm; g.kt = (Cout + bn - 1) / bn;
     g.vecA = (ldx % 4 == 0) && aligned16(x);
     g.vecB = (lddy % 4 == 0) && aligned16(dy);
+    if (!getenv("KPX_NO_WTAPROWS") && g.vecA && g.vecB && Cin % 4 == 0 && Cout % 4 == 0 && Wo % 32 == 0 && !wgrad_merge(Cin, ldx, KW)) {
+        // chunk-aligned split: same S as the generic plan, but in units of 32-pixel row chunks
+        WgradTapGeom r{};
+        r.x = x; r.dy = dy;
+        r.N = N; r.Hi = Hi; r.Wi = Wi; r.Cin = Cin; r.ldx = ldx;
+        r.Ho = Ho; r.Wo = Wo; r.Cout = Cout; r.lddy = lddy;
+        r.KH = KH; r.KW = KW; r.stride = stride; r.pad_t = pad_t; r.pad_l = pad_l;
+        r.total_chunks = N * Ho * (Wo / 32);
+        r.cpb = (r.total_chunks + g.S - 1) / g.S;
+        r.S = (r.total_chunks + r.cpb - 1) / r.cpb;             // <= g.S, so the workspace query still covers it
+        r.ct = g.ct; r.kt = g.kt; r.slab = g.slab;
+        r.out = r.S > 1 ? (float*)workspace : dw;
+        hipStream_t s = kpx_stream(stream);
+        const dim3 grid((unsigned)(r.S * KH * KW * r.ct * r.kt));
+        if (bm == 128) hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<128, 128, 2, 4>), grid, dim3(512), 0, s, r);
+        else hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, r);
+        int rc = kpx_launch_status();
+        if (rc) return rc;
+        if (r.S > 1) { launch_wgrad_reduce((const float*)workspace, dw, r.slab, r.S, s); rc = kpx_launch_status(); }
+        return rc;
+    }
     int taps = KH * KW;
     if (wgrad_merge(Cin, ldx, KW)) {     // image inputs (Cin = 3): one tap per filter row, KW*Cin merged channels
         g.merge = Cin; g.Cin = KW * Cin; g.KW = 1; g.vecA = 0; taps = KH;

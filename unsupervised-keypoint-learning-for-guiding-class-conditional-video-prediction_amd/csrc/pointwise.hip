@@ -57,23 +57,24 @@ extern "C" int kpx_copy_channels_f32(const float* src, int ldsrc, float* dst, in
 }
 
 // ------------------------------------------------------------------------------------------ activation backward
-__global__ __launch_bounds__(256) void act_bwd_kernel(float* dy, const float* y, size_t n, int act) {
-    const float neg = act == KPX_ACT_RELU ? 0.f : 0.01f;
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* dy, const float* y, float* dz, size_t n, int act) {
+    const float neg = act == KPX_ACT_RELU ? 0.f : (act == KPX_ACT_LRELU ? 0.01f : 1.f);
     const size_t n4 = n / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        f32x4 g = reinterpret_cast<f32x4*>(dy)[i];
+        f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
         const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[j] = v[j] > 0.f ? g[j] : g[j] * neg;
-        reinterpret_cast<f32x4*>(dy)[i] = g;
+        reinterpret_cast<f32x4*>(dz)[i] = g;
     }
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        dy[i] = y[i] > 0.f ? dy[i] : dy[i] * neg;
+        dz[i] = y[i] > 0.f ? dy[i] : dy[i] * neg;
 }
-extern "C" int kpx_act_bwd_f32(float* dy, const float* y, size_t n, int act, void* stream) {
-    if (!dy || !y || act < 0 || act > 2 || (((uintptr_t)dy | (uintptr_t)y) & 15)) return KPX_EINVAL;
-    if (act == KPX_ACT_NONE || n == 0) return 0;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, kpx_stream(stream), dy, y, n, act);
+extern "C" int kpx_act_bwd_f32(const float* dy, const float* y, float* dz, size_t n, int act, void* stream) {
+    if (!dy || !y || !dz || act < 0 || act > 2 || (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dz) & 15)) return KPX_EINVAL;
+    if (n == 0) return 0;
+    if (act == KPX_ACT_NONE && dz == dy) return 0;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, kpx_stream(stream), dy, y, dz, n, act);
     return kpx_launch_status();
 }
 

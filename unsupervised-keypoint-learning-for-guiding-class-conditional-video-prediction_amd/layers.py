@@ -9,9 +9,10 @@ from . import ops
 from .variables import Sym, default_store, is_sym
 
 ACT_NONE, ACT_RELU, ACT_LRELU = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LRELU
+EXACT_ZERO_BIAS_GRAD = True      # see conv_bn_relu
 
 
-def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', act=ACT_NONE, cin=None, head31=False):
+def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', act=ACT_NONE, cin=None, head31=False, bias_grad=True):
     """reference layers.conv (layers.py:4-10): tf.pad(pad) + tf.layers.conv2d(padding='same', xavier, bias)."""
     st = default_store()
     channels = int(channels)          # the reference passes float filter counts after `filters /= 2` ([TF-sem 9])
@@ -26,7 +27,7 @@ def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', 
         return Sym(n, ho, wo, channels)
     w_, wg = st.param(kname)
     b_, bg = st.param(bname) if use_bias else (None, None)
-    return ops.conv2d(x, w_, b_, stride=stride, pad=pad, act=act, cin=cin, w_grad_out=wg, b_grad_out=bg)
+    return ops.conv2d(x, w_, b_, stride=stride, pad=pad, act=act, cin=cin, w_grad_out=wg, b_grad_out=bg, bias_grad=bias_grad)
 
 
 def batch_norm(x, train_mode, scope='batch_norm', act=ACT_NONE, groups=1, update_moving=True):
@@ -47,6 +48,11 @@ def batch_norm(x, train_mode, scope='batch_norm', act=ACT_NONE, groups=1, update
 
 
 def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, groups=1, update_moving=True, cin=None):
-    """conv -> batch_norm -> relu, the repeating unit of every generator network (reference networks/__init__.py:10-12)."""
-    x = conv(x, channels, kernel=kernel, stride=stride, scope=conv_scope, cin=cin)
+    """conv -> batch_norm -> relu, the repeating unit of every generator network (reference networks/__init__.py:10-12).
+
+    The conv keeps its bias variable (reference layers.py:4 default use_bias=True), but d(loss)/d(bias) is exactly
+    zero when a train-mode batch norm follows (the batch mean removes any per-channel constant), so it is not computed: the
+    flat gradient bucket holds 0 there and Adam leaves those biases at their initial value.  The reference computes fp32
+    rounding noise for them, which its Adam turns into a +-lr random walk that batch norm again cancels in the forward."""
+    x = conv(x, channels, kernel=kernel, stride=stride, scope=conv_scope, cin=cin, bias_grad=not (EXACT_ZERO_BIAS_GRAD and train_mode))
     return batch_norm(x, train_mode, scope=bn_scope, act=ACT_RELU, groups=groups, update_moving=update_moving)

@@ -106,8 +106,13 @@ def chan_sum_raw(x, ldx, pixels, c, out):
           'kpx_chan_sum_f32')
 
 
+def act_bwd_raw(dy, y, dz, act):
+    """dz = dy * act'(y); dz may be dy itself (in place)."""
+    check(lib.kpx_act_bwd_f32(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), act, _stream()), 'kpx_act_bwd_f32')
+
+
 def act_bwd_raw_(dy, y, act):
-    check(lib.kpx_act_bwd_f32(dy.data_ptr(), y.data_ptr(), dy.numel(), act, _stream()), 'kpx_act_bwd_f32')
+    act_bwd_raw(dy, y, dy, act)
 
 
 def axpy_raw_(y, x, a=1.0):
@@ -135,7 +140,7 @@ class Conv2dFn(torch.autograd.Function):
     """layers.conv: tf.pad(pad) + conv2d(SAME) + bias [+ activation] (reference models/networks/layers.py:4-10)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin):
+    def forward(ctx, x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad):
         x, ldx = _nhwc(x)
         _require_gpu(w)
         w = w.contiguous()
@@ -149,7 +154,7 @@ class Conv2dFn(torch.autograd.Function):
         y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
         conv_fwd_raw(x, ldx, cin, w, b, y, cout, stride, pad_t, pad_l, act)
         ctx.geom = (stride, pad_t, pad_l, act, cin, ldx)
-        ctx.has_bias = b is not None
+        ctx.has_bias = b is not None and bias_grad
         ctx.w_grad_out, ctx.b_grad_out = w_grad_out, b_grad_out
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         return y
@@ -161,8 +166,9 @@ class Conv2dFn(torch.autograd.Function):
         dy = dy.contiguous()
         cout = w.shape[3]
         if act != ACT_NONE:
-            dy = dy.clone()
-            act_bwd_raw_(dy, y, act)
+            dz = torch.empty_like(dy)          # the incoming gradient tensor is not ours to overwrite
+            act_bwd_raw(dy, y, dz, act)
+            dy = dz
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             cx = x.shape[3]
@@ -178,11 +184,12 @@ class Conv2dFn(torch.autograd.Function):
             db_buf = ctx.b_grad_out if ctx.b_grad_out is not None else torch.empty(cout, dtype=torch.float32, device=x.device)
             chan_sum_raw(dy, cout, dy.shape[0] * dy.shape[1] * dy.shape[2], cout, db_buf)
             db = None if ctx.b_grad_out is not None else db_buf
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, cin=None, w_grad_out=None, b_grad_out=None):
-    return Conv2dFn.apply(x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin)
+def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, cin=None, w_grad_out=None, b_grad_out=None, bias_grad=True):
+    """bias_grad=False: the bias gradient is known to be exactly zero (conv feeding a batch norm) and is not computed."""
+    return Conv2dFn.apply(x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad)
 
 
 # ----------------------------------------------------------------------------------------------- batch norm
