@@ -61,10 +61,10 @@ def roofline_conv(dev):
     w = torch.randn(3, 3, c, c, device=dev) * 0.03
     b = torch.zeros(c, device=dev)
     y = torch.empty(n, h, h, c, device=dev)
-    ms = time_kernel(lambda: ops.conv_fwd_raw(x, c, c, w, b, y, c, 1, 1, 1, 0), iters=20)
+    ms = time_kernel(lambda: ops.conv_fwd_raw(x, c, c, w, b, y, c, 1, 1, 1, 0), iters=100, warm=20)
     flops = 2.0 * 603979776 * n
     ach = flops / (ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,128> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
+    return {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,128,2,4> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
             'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4), 'traffic': None,
             'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops}
 
@@ -74,16 +74,16 @@ def roofline_render(dev):
     algorithmic bytes = B*H*W*K*4 written (+ K*8 read) per launch (983 040 B per image)."""
     from kpx_amd import ops
     from kpx_amd._lib import lib, check
-    b = BATCH
+    b = 2 * BATCH                      # current + future key-point maps of one batch of 32 pairs
     mu = (torch.rand(b, K_PTS, 2, device=dev) * 2 - 1).contiguous()
     out = torch.empty(b, RES, RES, K_PTS, device=dev)
 
     def run():
         check(lib.kpx_gaussian_maps_fwd_f32(mu.data_ptr(), b, K_PTS, RES, RES, 14.3, out.data_ptr(), K_PTS, ops._stream()), 'gauss')
-    ms = time_kernel(run, iters=50)
+    ms = time_kernel(run, iters=200, warm=20)
     nbytes = b * (RES * RES * K_PTS * 4 + K_PTS * 8)
     ach = nbytes / (ms * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': 'gauss_fwd_flat_kernel [32,128,128,15]', 'achieved': round(ach, 1), 'peak': 8000.0,
+    return {'bound': 'hbm', 'kernel': 'gauss_fwd_flat_kernel [64,128,128,15] (current+future maps of 32 pairs)', 'achieved': round(ach, 1), 'peak': 8000.0,
             'unit': 'GB/s', 'frac': round(ach / 8000.0, 4), 'traffic': None, 'avg_launch_ms': round(ms, 5), 'bytes_per_launch': nbytes}
 
 
