@@ -64,8 +64,13 @@ def roofline_conv(dev):
     ms = time_kernel(lambda: ops.conv_fwd_raw(x, c, c, w, b, y, c, 1, 1, 1, 0), iters=100, warm=20)
     flops = 2.0 * 603979776 * n
     ach = flops / (ms * 1e-3) / 1e12
+    traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes of this same kernel / shape
+    try:
+        traffic = int(json.load(open(os.path.join(ROOT, 'profiles', 'r01_conv_pmc.json')))['traffic_bytes_per_launch'])
+    except (OSError, KeyError, ValueError):
+        pass
     return {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,128,2,4> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
-            'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4), 'traffic': None,
+            'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4), 'traffic': traffic,
             'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops}
 
 
