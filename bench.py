@@ -134,6 +134,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH, help='image pairs per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--roofline-only', action='store_true', help='only the two kernel microbenchmarks (used for the rocprofv3 cross-check)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -150,6 +151,9 @@ def main():
 
     import kpx_amd
     from kpx_amd.synthetic import synthetic_pair
+    if args.roofline_only:
+        print(json.dumps({'roofline': roofline_conv(dev), 'roofline_hbm_render': roofline_render(dev)}), flush=True)
+        return
     cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': args.batch},
            'model': {'n_pts': K_PTS}, 'paths': {'log_dir': '/tmp/kpx_bench', 'vggnet': None}}
     vgg = kpx_amd.Vgg19(weights=kpx_amd.synthetic_vgg19_weights(seed=19), device=dev)
