@@ -88,7 +88,10 @@ def _dp_worker(rank, world, port, q):
     for which in ('D', 'G'):
         b = m.store.buckets[which]
         b.grads.copy_(torch.arange(b.grads.numel(), dtype=torch.float32) * 1e-3 + (rank + 1))
-        g = m.exchange_gradients(which)
+        work = m.exchange_gradients(which, async_op=(which == 'D'))      # D: asynchronous handle, G: blocking
+        if work is not None:
+            work.wait()
+        g = b.grads
         want = torch.arange(b.grads.numel(), dtype=torch.float32) * 1e-3 * world + sum(range(1, world + 1))
         out[which] = bool(torch.allclose(g, want, rtol=1e-6))
         # parameter views alias the flat bucket: a bucket update is visible through every named variable

@@ -141,3 +141,47 @@ def test_checkpoint_roundtrip_uses_reference_names(tmp_path):
     a2 = m2.checkpoint_arrays()
     for k_, v in arrays.items():
         assert np.array_equal(np.asarray(v), np.asarray(a2[k_])), k_
+
+
+def _dp_gpu_worker(rank, world, port, q):
+    import sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)     # both ranks share cuda:0 here; RCCL needs one GPU per rank
+    dev = torch.device('cuda:0')
+    res, k, b = 32, 3, 2
+    model = make_model(res, k, b, dev)
+    assert model.world_size == world
+    for step in range(2):
+        im, fut = R.synthetic_pair(b, res=res, seed0=100 + 2 * (step * world + rank), seed1=101 + 2 * (step * world + rank))
+        model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, step, b)
+    out = {}
+    for which in ('D', 'G'):
+        p = model.store.buckets[which].params.detach().cpu()
+        gathered = [torch.empty_like(p) for _ in range(world)]
+        dist.all_gather(gathered, p)
+        out[which] = bool(all(torch.equal(gathered[0], g) for g in gathered)) and bool(torch.isfinite(p).all())
+    lv = model.loss_values()
+    out['finite'] = bool(np.isfinite(lv['loss_D']) and np.isfinite(lv['loss_G']))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_train_steps_keep_replicas_identical():
+    """Two ranks (gloo, sharing cuda:0), different data per rank: after the all-reduced Adam updates both replicas must
+    hold bit-identical parameters (the summation order of a 2-rank all-reduce is symmetric)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, out in results:
+        assert out == {'D': True, 'G': True, 'finite': True}, (rank, out)

@@ -106,30 +106,42 @@ class DetectorTranslatorModel(BaseModel):
         per = logits.numel() // (2 * n)
         return ops.sigmoid_xent(logits, n * per, 1.0, n * per, 0.0)       # [loss_D, D_real, D_fake]
 
-    def _loss_G(self, future_im_pred, future_im):
-        """reference _compute_loss_G (:261-272): perceptual + adversarial (vs ones)."""
-        recon = self.vgg.perceptual_loss(future_im, future_im_pred)        # [1]
+    def _loss_G_recon(self, future_im_pred, future_im):
+        """reference _compute_loss_G (:261-263): VGG19 perceptual term (independent of the discriminator)."""
+        return self.vgg.perceptual_loss(future_im, future_im_pred)         # [1]
+
+    def _loss_G_adv(self, future_im_pred):
+        """reference _compute_loss_G (:264-267): adversarial term vs ones, discriminator weights as constants."""
         with self.store.freeze('img_discr'):
             logits = networks.img_discr(future_im_pred)
-        adv = ops.sigmoid_xent(logits, logits.numel(), 1.0)                # [adv, adv, 0]
-        return recon, adv
+        return ops.sigmoid_xent(logits, logits.numel(), 1.0)               # [adv, adv, 0]
+
+    def _loss_G(self, future_im_pred, future_im):
+        return self._loss_G_recon(future_im_pred, future_im), self._loss_G_adv(future_im_pred)
 
     def current_lr(self):
         """tf.train.exponential_decay, non-staircase, fp32 (reference :193-195)."""
         p = np.float32(self.global_step) / np.float32(self.lr['step'])
         return np.float32(np.float32(self.lr['start_val']) * np.power(np.float32(self.lr['decay']), p, dtype=np.float32))
 
-    def exchange_gradients(self, which):
+    def exchange_gradients(self, which, async_op=False):
         """Data-parallel exchange: ONE all-reduce(sum) of the bucket's flat fp32 gradient buffer (RCCL over xGMI on the
-        GPUs; gloo in the CPU tests).  The 1/world scaling happens inside the fused Adam kernel."""
+        GPUs; gloo in the CPU tests).  The 1/world scaling happens inside the fused Adam kernel.  With ``async_op`` the
+        collective runs on RCCL's own stream and the returned handle is waited for just before the Adam update, so the
+        178.9 MB discriminator exchange overlaps the VGG19 forward of the generator's perceptual loss."""
         bucket = self.store.buckets[which]
         if self.world_size > 1:
-            torch.distributed.all_reduce(bucket.grads, op=torch.distributed.ReduceOp.SUM, group=self.process_group)
-        return bucket.grads
+            work = torch.distributed.all_reduce(bucket.grads, op=torch.distributed.ReduceOp.SUM, group=self.process_group,
+                                                async_op=async_op)
+            return work if async_op else None
+        return None
 
-    def _apply_adam(self, which, lr):
+    def _apply_adam(self, which, lr, pending=None, exchanged=False):
         bucket = self.store.buckets[which]
-        self.exchange_gradients(which)
+        if pending is not None:
+            pending.wait()                      # stream-level wait for the asynchronous all-reduce
+        elif not exchanged:
+            self.exchange_gradients(which)
         b1p, b2p = self.beta_power[which]
         alpha = np.float32(np.float32(lr) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p))
         ops.adam_tf_flat_(bucket.params, bucket.grads, bucket.m, bucket.v, alpha, self.beta1, self.beta2, self.adam_eps,
@@ -148,9 +160,12 @@ class DetectorTranslatorModel(BaseModel):
             # ---- D run (:93)
             d_losses = self._loss_D(final.detach(), future_im)
             torch.autograd.backward([d_losses], [self._e0])
-            self._apply_adam('D', lr)
-            # ---- G run (:94) with the updated discriminator
-            recon, adv = self._loss_G(final, future_im)
+            pending = self.exchange_gradients('D', async_op=True)          # overlaps the VGG forward below
+            # ---- G run (:94): the perceptual forward does not involve the discriminator, so it runs first ...
+            recon = self._loss_G_recon(final, future_im)
+            self._apply_adam('D', lr, pending=pending, exchanged=True)
+            # ... and the adversarial term sees the UPDATED discriminator, exactly as the reference's second sess.run
+            adv = self._loss_G_adv(final)
             torch.autograd.backward([recon, adv], [self._one, self._e0])
             self._apply_adam('G', lr)
         self.global_step += 1                                             # incremented by the G optimiser (:201-202)
