@@ -185,3 +185,21 @@ def test_data_parallel_train_steps_keep_replicas_identical():
         assert p.exitcode == 0
     for rank, out in results:
         assert out == {'D': True, 'G': True, 'finite': True}, (rank, out)
+
+
+def test_forward_256_k40_matches_oracle():
+    """BASELINE configs[3]-shaped forward (256x256, K=40; SURVEY 8d generalisation: low-res maps H/4, vis maps H) at B=1."""
+    dev = torch.device('cuda:0')
+    res, k, b = 256, 40, 1
+    model = make_model(res, k, b, dev)
+    net = R.Net({n: torch.from_numpy(a) for n, a in R.init_variables(k, res=res, seed=1234).items()}, train_mode=True)
+    im, fut = R.synthetic_pair(b, res=res, seed0=5, seed1=6)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    with torch.no_grad():
+        want = R.forward_pass(net, torch.from_numpy(im), torch.from_numpy(fut))
+    got = model.forward(torch.from_numpy(im).to(dev), torch.from_numpy(fut).to(dev), with_vis_maps=True)
+    assert tuple(got['current_keypoints_map'].shape) == (b, 256, 256, 40)
+    np.testing.assert_allclose(got['current_points'].cpu().numpy(), want['current_points'].numpy(), atol=2e-5)
+    np.testing.assert_allclose(got['future_points'].cpu().numpy(), want['future_points'].numpy(), atol=2e-5)
+    assert rel_l2(got['future_keypoints_map'].cpu().numpy(), want['future_keypoints_map'].numpy()) < 1e-4
+    assert rel_l2(got['final_output'].cpu().numpy(), want['final_output'].numpy()) < 1e-4
