@@ -37,17 +37,24 @@ int kpx_abi_version(void);
  *      and tf.nn.conv2d + bias_add + relu (models/networks/vgg.py:51-54).
  *      y[n,oh,ow,:] = act( sum_{r,q,c} x[n, oh*stride + r - pad_t, ow*stride + q - pad_l, c] * w[r,q,c,:] + bias )
  *      pad_t/pad_l are the TOTAL top/left padding (explicit tf.pad + TF's SAME split, decided by the caller);
- *      bottom/right padding is implied by Ho/Wo.  bias may be NULL.  fp32 MFMA implicit GEMM. */
+ *      bottom/right padding is implied by Ho/Wo.  bias may be NULL.  fp32 MFMA implicit GEMM.
+ *      `workspace` (optional, may be NULL): split-K scratch for small-M / long-K layers; size from
+ *      kpx_conv2d_fwd_workspace_bytes (0 = not needed).  Without it the layer runs unsplit. */
+size_t kpx_conv2d_fwd_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
                        const float* w_hwio, int KH, int KW, const float* bias,
                        float* y, int Ho, int Wo, int Cout, int ldy,
-                       int stride, int pad_t, int pad_l, int act, void* stream);
+                       int stride, int pad_t, int pad_l, int act,
+                       void* workspace, size_t workspace_bytes, void* stream);
 
-/* dx = d(loss)/dx given dy (gradient of the conv output BEFORE activation).  Writes every element of dx. */
+/* dx = d(loss)/dx given dy (gradient of the conv output BEFORE activation).  Writes every element of dx.
+ * stride <= 2.  `workspace`: optional split-K scratch, see kpx_conv2d_fwd_f32. */
+size_t kpx_conv2d_dgrad_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride);
 int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int Cout, int lddy,
                          const float* w_hwio, int KH, int KW,
                          float* dx, int Hi, int Wi, int Cin, int lddx,
-                         int stride, int pad_t, int pad_l, void* stream);
+                         int stride, int pad_t, int pad_l,
+                         void* workspace, size_t workspace_bytes, void* stream);
 
 /* dw[r,q,c,k] = sum_{n,oh,ow} x[n, oh*s+r-pad_t, ow*s+q-pad_l, c] * dy[n,oh,ow,k].
  * `workspace` holds split-K partial slabs; query its size with kpx_conv2d_wgrad_workspace_bytes. */

@@ -58,6 +58,8 @@ CONV_CASES = [
     (4, 128, 128, 64, 4, 3, 1, 0, 0),      # same, translator crude+mask head
     (2, 64, 64, 256, 128, 3, 1, 0, 0),     # 8-wave 128x128 wgrad tiles
     (4, 128, 128, 3, 32, 7, 1, 0, 0),      # row-merged multi-tap wgrad (encoder conv_1 at full resolution)
+    (8, 8, 8, 512, 512, 3, 1, 0, 1),       # split-K forward/dgrad (VGG conv5 shape), relu epilogue in the reduce
+    (16, 10, 10, 256, 512, 4, 2, 1, 2),    # split-K with stride-2 parity classes (img_discr conv_4 geometry)
 ]
 
 

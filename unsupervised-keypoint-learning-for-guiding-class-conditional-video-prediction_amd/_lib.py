@@ -26,10 +26,12 @@ P = c_void_p
 # name -> (restype, argtypes); mirrors include/kpx.h one to one (tests/test_abi.py checks header vs this table)
 SIGNATURES = {
     'kpx_abi_version': (c_int, []),
+    'kpx_conv2d_fwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P,
-                                   P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+                                   P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'kpx_conv2d_dgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_dgrad_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int,
-                                     P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+                                     P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'kpx_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_wgrad_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int,
                                      P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),

@@ -32,6 +32,8 @@ struct ConvGeom {
     int act, vecA, vecB;
     int M, mt, nt;
     ConvClass cls[4]; int ncls;   // blockIdx.y selects the class
+    int ksplit; float* ws;        // split-K: blockIdx.z owns an equal slice of the K chunks; raw partials go to ws[z][pixel][Cout]
+    size_t ws_slab;               // floats per split slab = N*Ho*Wo*Cout
     int merge;      // >0: row-merged taps for tiny Cin (= original Cin): the KW*Cin floats of one filter row are
                     // contiguous in NHWC, so they are treated as one tap with KW*Cin channels (per-element x bounds)
 };
@@ -135,8 +137,15 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nck = (g.Cin + BK - 1) / BK;
-    const int nchunks = k.Tr * k.Tq * nck;
+    int nchunks = k.Tr * k.Tq * nck;
     int tr = 0, tq = 0, c0 = 0;
+    if (g.ksplit > 1) {                                 // this workgroup's slice of the K loop
+        const int cps = (nchunks + g.ksplit - 1) / g.ksplit;
+        const int cb = blockIdx.z * cps, ce = min(nchunks, cb + cps);
+        const int tap0 = cb / nck;
+        c0 = (cb - tap0 * nck) * BK; tr = tap0 / k.Tq; tq = tap0 - tr * k.Tq;
+        nchunks = ce > cb ? ce - cb : 0;
+    }
     f32x4 ra[RA], rb[RB];
     unsigned am[RA], bm[RB];
 
@@ -275,6 +284,21 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
         rowpix[t] = pix;
     }
     __syncthreads();
+    if (g.ksplit > 1) {                                 // raw partial sums; bias / activation happen in splitk_reduce_kernel
+        float* wsl = g.ws + (size_t)blockIdx.z * g.ws_slab;
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = n0 + wcol + n * 32 + li;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pix = rowpix[wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+                    if (col < g.Cout && pix >= 0) wsl[(size_t)pix * g.Cout + col] = acc[i][n][r];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
         const int col = n0 + wcol + n * 32 + li;
@@ -297,12 +321,66 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
     }
 }
 
+// y[pix][c] = act( bias[c] + sum_s ws[s][pix][c] ), fixed summation order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, size_t slab, int S, size_t npix, int C,
+                                                            const float* __restrict__ bias, int act, float* __restrict__ y, int ldy) {
+    const int C4 = C >> 2;                              // C % 4 == 0 is a precondition of the split-K path
+    const size_t total = npix * (size_t)C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t pix = i / C4;
+        const int c = (int)(i - pix * C4) * 4;
+        f32x4 a = *reinterpret_cast<const f32x4*>(ws + pix * C + c);
+        for (int s2 = 1; s2 < S; ++s2) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(ws + (size_t)s2 * slab + pix * C + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += b[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = a[j] + (bias ? bias[c + j] : 0.f);
+            if (act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+            a[j] = v;
+        }
+        *reinterpret_cast<f32x4*>(y + pix * ldy + c) = a;
+    }
+}
+
+// Split-K plan (shape only): used when the 128x128 tiling would leave most CUs idle (small M, long K).
+static int conv_splitk_plan(long M, int Cout, long nchunks_total) {
+    if (getenv("KPX_NO_SPLITK") || Cout % 4 != 0 || Cout < 64) return 1;
+    const long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
+    if (tiles >= 384) return 1;
+    long S = 512 / tiles;
+    if (S > 8) S = 8;
+    while (S > 1 && nchunks_total / S < 6) --S;         // keep >= 6 chunks (192 channels-taps) per split
+    if ((double)S * (double)M * Cout * 4.0 > (double)((size_t)256 << 20)) return 1;
+    return (int)(S < 1 ? 1 : S);
+}
+
 template <bool BT, bool VEC, bool MERGE, bool TAIL>
 static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
     if (g.ncls <= 0) { g.ncls = 1; g.cls[0] = ConvClass{g.Ha, g.Wa, g.oy0, g.ox0, g.Tr, g.Tq, g.iy0, g.ix0, g.wr0, g.wq0, 0, 0}; }
     g.M = 0;
     for (int i = 0; i < g.ncls; ++i) { g.cls[i].M = g.N * g.cls[i].Ha * g.cls[i].Wa; if (g.cls[i].M > g.M) g.M = g.cls[i].M; }
     if (g.M <= 0 || g.Cout <= 0) return 0;
+    if (g.ksplit > 1) {                                 // decided by the entry point (needs the caller's workspace)
+        const int BMs = 128, BNs = g.Cout > 64 ? 128 : 64;
+        g.nt = (g.Cout + BNs - 1) / BNs;
+        int mtmax = 0;
+        for (int i = 0; i < g.ncls; ++i) { g.cls[i].mt = (g.cls[i].M + BMs - 1) / BMs; if (g.cls[i].mt > mtmax) mtmax = g.cls[i].mt; }
+        g.mt = mtmax;
+        const dim3 nblk((unsigned)(g.mt * g.nt), (unsigned)g.ncls, (unsigned)g.ksplit);
+        if (BNs == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 128, 2, 4, BT, VEC, MERGE, TAIL>), nblk, dim3(512), 0, s, g);
+        else hipLaunchKernelGGL((conv_igemm_kernel<128, 64, 4, 2, BT, VEC, MERGE, TAIL>), nblk, dim3(512), 0, s, g);
+        int rc = kpx_launch_status();
+        if (rc) return rc;
+        const size_t npix = (size_t)g.N * g.Ho * g.Wo;
+        size_t nb = (npix * (g.Cout / 4) + 255) / 256; if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)g.ws, g.ws_slab, g.ksplit, npix, g.Cout,
+                           g.bias, g.act, g.y, g.ldy);
+        return kpx_launch_status();
+    }
     // N tile: smallest padded width, ties -> wider tile
     int BN = 128;
     {
@@ -402,10 +480,29 @@ static int launch_small_cout(ConvGeom g, hipStream_t s) {
 
 static inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+static int dgrad_splitk_plan(int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride) {
+    const long Mcls = (long)N * ((Hi + stride - 1) / stride) * ((Wi + stride - 1) / stride);      // largest parity class
+    const long chunks = (long)(KH / stride > 0 ? KH / stride : 1) * (KW / stride > 0 ? KW / stride : 1) * ((Cout + 31) / 32);   // smallest class
+    if (Cin % 4 != 0) return 1;
+    int S = conv_splitk_plan(Mcls * stride * stride, Cin, chunks);   // tiles are counted over all classes of the launch
+    return S;
+}
+
+extern "C" size_t kpx_conv2d_fwd_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
+    if (Cin % 4 != 0) return 0;
+    const int S = conv_splitk_plan((long)N * Ho * Wo, Cout, (long)KH * KW * ((Cin + 31) / 32));
+    return S > 1 ? (size_t)S * N * Ho * Wo * Cout * 4 : 0;
+}
+
+extern "C" size_t kpx_conv2d_dgrad_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride) {
+    const int S = dgrad_splitk_plan(N, Hi, Wi, Cin, Cout, KH, KW, stride);
+    return S > 1 ? (size_t)S * N * Hi * Wi * Cin * 4 : 0;
+}
+
 extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
                                   const float* w, int KH, int KW, const float* bias,
                                   float* y, int Ho, int Wo, int Cout, int ldy,
-                                  int stride, int pad_t, int pad_l, int act, void* stream) {
+                                  int stride, int pad_t, int pad_l, int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !w || !y || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || ldy < Cout || act < 0 || act > 2)
         return KPX_EINVAL;
@@ -431,7 +528,7 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
 extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int Cout, int lddy,
                                     const float* w, int KH, int KW,
                                     float* dx, int Hi, int Wi, int Cin, int lddx,
-                                    int stride, int pad_t, int pad_l, void* stream) {
+                                    int stride, int pad_t, int pad_l, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dy || !w || !dx || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || lddy < Cout || lddx < Cin)
         return KPX_EINVAL;
@@ -462,6 +559,11 @@ extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int 
             c.wr0 = r0; c.wq0 = q0;
             g.cls[g.ncls++] = c;
         }
+    }
+    if (g.vecA && g.vecB && Cout % 4 == 0) {
+        const int S = dgrad_splitk_plan(N, Hi, Wi, Cin, Cout, KH, KW, stride);
+        g.ws_slab = (size_t)N * Hi * Wi * Cin;
+        if (S > 1 && workspace && workspace_bytes >= (size_t)S * g.ws_slab * 4) { g.ksplit = S; g.ws = (float*)workspace; }
     }
     return launch_gather_conv<true>(g, kpx_stream(stream));
 }

@@ -75,17 +75,23 @@ scratch = _Scratch()
 def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act):
     n, hi, wi = x.shape[0], x.shape[1], x.shape[2]
     kh, kw, _, cout = w.shape
+    nbytes = lib.kpx_conv2d_fwd_workspace_bytes(n, y.shape[1], y.shape[2], cin, cout, kh, kw)
+    ws = scratch.get('splitk', nbytes, x.device) if nbytes else None
     check(lib.kpx_conv2d_fwd_f32(x.data_ptr(), n, hi, wi, cin, ldx, w.data_ptr(), kh, kw,
                                  bias.data_ptr() if bias is not None else None,
-                                 y.data_ptr(), y.shape[1], y.shape[2], cout, ldy, stride, pad_t, pad_l, act, _stream()),
+                                 y.data_ptr(), y.shape[1], y.shape[2], cout, ldy, stride, pad_t, pad_l, act,
+                                 ws.data_ptr() if ws is not None else None, nbytes, _stream()),
           'kpx_conv2d_fwd_f32')
 
 
 def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l):
     n, ho, wo = dy.shape[0], dy.shape[1], dy.shape[2]
     kh, kw, _, cout = w.shape
+    nbytes = lib.kpx_conv2d_dgrad_workspace_bytes(n, dx.shape[1], dx.shape[2], cin, cout, kh, kw, stride)
+    ws = scratch.get('splitk', nbytes, dy.device) if nbytes else None
     check(lib.kpx_conv2d_dgrad_f32(dy.data_ptr(), n, ho, wo, cout, lddy, w.data_ptr(), kh, kw,
-                                   dx.data_ptr(), dx.shape[1], dx.shape[2], cin, lddx, stride, pad_t, pad_l, _stream()),
+                                   dx.data_ptr(), dx.shape[1], dx.shape[2], cin, lddx, stride, pad_t, pad_l,
+                                   ws.data_ptr() if ws is not None else None, nbytes, _stream()),
           'kpx_conv2d_dgrad_f32')
 
 
