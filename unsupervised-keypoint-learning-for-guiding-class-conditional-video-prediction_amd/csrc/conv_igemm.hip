@@ -230,33 +230,42 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
             }
         }
     };
-    // one group = 8 k-steps: lane-half lh consumes channels 4*(2u+lh) .. +3 of the chunk (a K permutation shared by A and B)
-    auto mfma_group = [&](int buf, int u) {
-        f32x4 a[TM];
+    // one group = 8 k-steps: lane-half lh consumes channels 4*(2u+lh) .. +3 of the chunk (a K permutation shared by A and B).
+    // The fragments of group u+1 are read from LDS before the MFMAs of group u are issued (register double buffering), so
+    // only the first group of a chunk exposes the LDS latency.
+    struct Frag { f32x4 a[TM]; float b[4][TN]; };
+    auto read_frag = [&](int buf, int u, Frag& f) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&As[buf * ASZ + a_rd[i][u]]);
+        for (int i = 0; i < TM; ++i) f.a[i] = *reinterpret_cast<const f32x4*>(&As[buf * ASZ + a_rd[i][u]]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float b[TN];
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int n = 0; n < TN; ++n) b[n] = Bs[buf * BSZ + b_rd[n][u] + j * BN];
+            for (int n = 0; n < TN; ++n) f.b[j][n] = Bs[buf * BSZ + b_rd[n][u] + j * BN];
+    };
+    auto mfma_frag = [&](const Frag& f) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int n = 0; n < TN; ++n)
-                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n], acc[i][n], 0, 0, 0);
-        }
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][j], f.b[j][n], acc[i][n], 0, 0, 0);
     };
     // The next chunk's global loads are issued after the first group and written to the other LDS buffer after the third,
     // so their address arithmetic, the wait and the ds_writes sit between MFMAs instead of in the gap around the barrier.
     auto chunk = [&](auto bufc, bool more) {
         constexpr int buf = decltype(bufc)::value;
-        mfma_group(buf, 0);
+        Frag f0, f1;
+        read_frag(buf, 0, f0);
+        read_frag(buf, 1, f1);
+        mfma_frag(f0);
         if (more) load_chunk();
-        mfma_group(buf, 1);
-        mfma_group(buf, 2);
+        read_frag(buf, 2, f0);
+        mfma_frag(f1);
+        read_frag(buf, 3, f1);
+        mfma_frag(f0);
         if (more) store_chunk(buf ^ 1);
-        mfma_group(buf, 3);
+        mfma_frag(f1);
         __syncthreads();
     };
 
