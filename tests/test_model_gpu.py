@@ -203,3 +203,33 @@ def test_forward_256_k40_matches_oracle():
     np.testing.assert_allclose(got['future_points'].cpu().numpy(), want['future_points'].numpy(), atol=2e-5)
     assert rel_l2(got['future_keypoints_map'].cpu().numpy(), want['future_keypoints_map'].numpy()) < 1e-4
     assert rel_l2(got['final_output'].cpu().numpy(), want['final_output'].numpy()) < 1e-4
+
+
+def test_keypoint_model_inference_matches_oracle(tmp_path):
+    """KeypointModel = pose_encoder with batch norm on the moving statistics (keypoint_model.py:48-50),
+    restored by name from a stage-1 checkpoint."""
+    import kpx_amd
+    dev = torch.device('cuda:0')
+    res, k, b = 32, 3, 2
+    stage1 = make_model(res, k, b, dev)
+    stage1.initialize_loggers(str(tmp_path))
+    for step in range(2):                       # move the weights and the moving statistics away from their initial values
+        im, fut = R.synthetic_pair(b, res=res, seed0=30 + step, seed1=40 + step)
+        stage1.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, step, b)
+    path = stage1.save_checkpoint(None, 2)
+    cfg = {'model': {'n_pts': k}, 'paths': {'log_dir': str(tmp_path)}}
+    km = kpx_amd.KeypointModel(cfg, device=dev, image_size=res, frames_per_launch=3)
+    km.build()
+    km.restore(None, path)
+    video = np.random.RandomState(3).uniform(-1, 1, (1, 7, res, res, 3)).astype(np.float32)
+    out = km.run(None, {'image': torch.from_numpy(video).to(dev), 'idx': np.array([5]), 'len': np.array([6])})
+    assert tuple(out['pts'].shape) == (1, 7, k, 2)
+    params = {n: torch.from_numpy(np.asarray(a)) for n, a in stage1.store.export_numpy().items()}
+    net = R.Net(params, train_mode=False)
+    with torch.no_grad():
+        want = R.pose_encoder(net, torch.from_numpy(video[0]), final_res=res)
+    np.testing.assert_allclose(out['pts'][0].cpu().numpy(), want.numpy(), atol=2e-5)
+    import make_pseudo_labels
+    make_pseudo_labels._save_output(str(tmp_path), out)
+    saved = np.load(os.path.join(str(tmp_path), '0005.npy'))
+    assert saved.shape == (6, k, 2) and saved.dtype == np.float32

@@ -6,7 +6,8 @@ from . import _lib  # noqa: F401  (raises ImportError when the HIP library is mi
 from . import layers, model_utils, networks, ops, variables  # noqa: F401
 from .base_model import BaseModel  # noqa: F401
 from .detector_translator_model import DetectorTranslatorModel  # noqa: F401
+from .keypoint_model import KeypointModel  # noqa: F401
 from .vgg import Vgg19, synthetic_vgg19_weights  # noqa: F401
 
-__all__ = ['BaseModel', 'DetectorTranslatorModel', 'Vgg19', 'synthetic_vgg19_weights', 'layers', 'model_utils',
+__all__ = ['BaseModel', 'DetectorTranslatorModel', 'KeypointModel', 'Vgg19', 'synthetic_vgg19_weights', 'layers', 'model_utils',
            'networks', 'ops', 'variables']
