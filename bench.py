@@ -143,11 +143,16 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit('for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
                          '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+    local_rank %= max(1, torch.cuda.device_count())     # (several ranks may share one GPU only in the gloo self-test below)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.distributed.init_process_group('nccl', device_id=dev)   # RCCL over xGMI
+        backend = os.environ.get('KPX_DIST_BACKEND', 'nccl')          # nccl = RCCL over xGMI; gloo only to self-test on one GPU
+        if backend == 'nccl':
+            torch.distributed.init_process_group('nccl', device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     import kpx_amd
     from kpx_amd.synthetic import synthetic_pair
