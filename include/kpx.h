@@ -29,7 +29,7 @@ extern "C" {
 #define KPX_EINVAL (-1)
 #define KPX_ABI_VERSION 1
 
-enum { KPX_ACT_NONE = 0, KPX_ACT_RELU = 1, KPX_ACT_LRELU = 2 /* slope 0.01 */ };
+enum { KPX_ACT_NONE = 0, KPX_ACT_RELU = 1, KPX_ACT_LRELU = 2 /* slope 0.01 */, KPX_ACT_TANH = 3 /* forward only */ };
 
 int kpx_abi_version(void);
 
@@ -146,6 +146,16 @@ int kpx_sigmoid_xent_bwd_f32(const float* logits, size_t n0, float label0, size_
  * alpha = lr*sqrt(1-b2^t)/(1-b1^t) (host); g is pre-scaled by gscale (1/world_size for DP). */
 int kpx_adam_tf_flat_f32(float* p, const float* g, float* m, float* v, size_t n,
                          float alpha, float beta1, float beta2, float eps, float gscale, void* stream);
+
+/* ---- evaluate.py / FinalModel rollout (forward only).  Dense layers run as 1x1 kpx_conv2d_fwd_f32.
+ * LSTMCell pointwise part (models/networks/layers.py:17-21): gates [B,4U] = (i,j,f,o) pre-activations. */
+int kpx_lstm_pointwise_f32(const float* gates, const float* c_prev, float forget_bias, float* c_out, float* h_out,
+                           int B, int U, void* stream);
+/* tf.tile over a new time axis (models/final_model.py:58-66,85-87): dst[((b*T+t)*pix+p)*lddst+c] = src[(b*pix+p)*ldsrc+c]. */
+int kpx_tile_batch_f32(const float* src, int ldsrc, int B, int T, int pix, int C, float* dst, int lddst, void* stream);
+/* blend with the T-times tiled source image + optional clip_by_value(-1,1) of crude and final (final_model.py:95-99). */
+int kpx_head_blend_tiled_fwd_f32(const float* im, const float* raw4, size_t P, int HW, int T, int clip,
+                                 float* final_out, float* crude_out, float* mask_out, void* stream);
 
 /* ---- utilities */
 int kpx_fill_f32(float* p, size_t n, float value, void* stream);

@@ -522,3 +522,84 @@ def train_step(state, im, future_im, same_batch=True, im_G=None, future_im_G=Non
                 final_output=fwd['final_output'].detach(),
                 current_points=fwd['current_points'].detach(),
                 future_points=fwd['future_points'].detach())
+
+
+# --------------------------------------------------------------------------- stage-2 decoder + evaluate.py rollout
+N_FUTURE_FRAMES = 32      # models/final_model.py:11
+
+
+def stage2_decoder_manifest(n_pts, n_action=9, cell_info=(1024, 1024), vae_dim=64):
+    """Variables of networks.vae_decoder (models/networks/__init__.py:116-129) [TF-sem naming]."""
+    out = OrderedDict()
+    fc_in = vae_dim + 2 * n_pts + n_action
+    out['vae_decoder/fully_connected/weights'] = (fc_in, 32)                 # tf.contrib.layers.fully_connected(.., 32) :120
+    out['vae_decoder/fully_connected/biases'] = (32,)
+    prev = 32
+    for i, units in enumerate(cell_info):                                      # layers.lstm_model (layers.py:17-21)
+        out['vae_decoder/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel' % i] = (prev + units, 4 * units)
+        out['vae_decoder/multi_rnn_cell/cell_%d/basic_lstm_cell/bias' % i] = (4 * units,)
+        prev = units
+    out['vae_decoder/fully_connected/W'] = (cell_info[-1], 2 * n_pts)         # layers.to_coord (layers.py:24-28)
+    out['vae_decoder/fully_connected/b'] = (2 * n_pts,)
+    return out
+
+
+def init_stage2_decoder(n_pts, n_action=9, cell_info=(1024, 1024), vae_dim=64, seed=4321):
+    rs = np.random.RandomState(seed)
+    out = OrderedDict()
+    for name, shape in stage2_decoder_manifest(n_pts, n_action, cell_info, vae_dim).items():
+        if name.endswith('/W'):
+            out[name] = (rs.randn(*shape) * 0.02).astype(np.float32)           # random_normal_initializer(stddev=0.02)
+        elif len(shape) == 2:
+            lim = math.sqrt(6.0 / (shape[0] + shape[1]))                       # glorot_uniform / xavier
+            out[name] = rs.uniform(-lim, lim, size=shape).astype(np.float32)
+        else:
+            out[name] = np.zeros(shape, np.float32)
+    return out
+
+
+def vae_decoder(p, x, f_pt, act_code, cell_info, n_pts):
+    """networks.vae_decoder (models/networks/__init__.py:116-129): fc(relu) -> 2-layer LSTMCell x 32 steps (zero inputs after
+    step 0) -> to_coord tanh.  LSTMCell [TF-sem]: gates i,j,f,o; forget_bias 1.0; state (c,h) zero-initialised."""
+    s = 'vae_decoder'
+    inp = F.relu(torch.cat([x, f_pt, act_code], dim=-1) @ p[s + '/fully_connected/weights'] + p[s + '/fully_connected/biases'])
+    b = x.shape[0]
+    c = [torch.zeros(b, u) for u in cell_info]
+    h = [torch.zeros(b, u) for u in cell_info]
+    outs = []
+    for step in range(N_FUTURE_FRAMES):
+        xin = inp if step == 0 else torch.zeros_like(inp)
+        for l, u in enumerate(cell_info):
+            g = torch.cat([xin, h[l]], dim=-1) @ p[s + '/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel' % l] + \
+                p[s + '/multi_rnn_cell/cell_%d/basic_lstm_cell/bias' % l]
+            i, j, f, o = torch.split(g, u, dim=-1)
+            c[l] = c[l] * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+            h[l] = torch.tanh(c[l]) * torch.sigmoid(o)
+            xin = h[l]
+        outs.append(torch.tanh(h[-1] @ p[s + '/fully_connected/W'] + p[s + '/fully_connected/b']))
+    return torch.stack(outs, dim=1)                                            # [B, 32, 2K]
+
+
+def final_model_forward(params, im, action_code, z, n_pts, cell_info=(1024, 1024)):
+    """FinalModel.build (models/final_model.py:49-122), inference-mode batch norm; z is injected (the reference draws it
+    unseeded, :71).  Returns pred_im_seq / mask / pred_im_crude / fut_pt_raw."""
+    net = Net(params, train_mode=False)
+    res = im.shape[1]
+    b = im.shape[0]
+    t = N_FUTURE_FRAMES
+    tiled_im = im.unsqueeze(1).expand(b, t, res, res, 3).reshape(b * t, res, res, 3)              # :57-59
+    emb = image_encoder(net, im)[-2]                                                              # :61-62
+    emb_t = emb.unsqueeze(1).expand(b, t, *emb.shape[1:]).reshape(b * t, *emb.shape[1:])          # :63-66
+    first_pt = pose_encoder(net, im, final_res=res)                                               # :68
+    pred_seq = vae_decoder(params, z, first_pt.reshape(b, n_pts * 2), action_code, cell_info, n_pts)   # :71-77
+    pred_seq = pred_seq.reshape(b, t, n_pts, 2)
+    heat = res // 4
+    cur_map = get_gaussian_maps(first_pt, [heat, heat])                                           # :79-84
+    cur_map_t = cur_map.unsqueeze(1).expand(b, t, *cur_map.shape[1:]).reshape(b * t, *cur_map.shape[1:])
+    pred_map = get_gaussian_maps(pred_seq.reshape(b * t, n_pts, 2), [heat, heat])                 # :88-92
+    joint = torch.cat([emb_t, cur_map_t, pred_map], dim=-1)                                       # :94
+    crude, mask = translator(net, joint, final_res=res)                                           # :95
+    final = tiled_im * mask + crude * (1 - mask)                                                  # :96
+    return dict(pred_im_seq=torch.clamp(final, -1, 1).reshape(b, t, res, res, 3),                  # :98-99
+                pred_im_crude=torch.clamp(crude, -1, 1).reshape(b, t, res, res, 3),
+                mask=mask.reshape(b, t, res, res, 1), fut_pt_raw=pred_seq, first_pt=first_pt)

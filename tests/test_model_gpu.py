@@ -233,3 +233,38 @@ def test_keypoint_model_inference_matches_oracle(tmp_path):
     make_pseudo_labels._save_output(str(tmp_path), out)
     saved = np.load(os.path.join(str(tmp_path), '0005.npy'))
     assert saved.shape == (6, k, 2) and saved.dtype == np.float32
+
+
+def test_final_model_rollout_matches_oracle():
+    """SURVEY 8f row 1 / BASELINE configs[4]: detector -> vae_decoder (LSTM x 32) -> translator on B*32 frames, inference BN."""
+    import kpx_amd
+    dev = torch.device('cuda:0')
+    res, k, b, cells, vdim = 32, 3, 2, (64, 64), 8
+    cfg = {'model': {'n_pts': k, 'cell_info': list(cells), 'vae_dim': vdim, 'n_action': 9}, 'paths': {'log_dir': '/tmp/kpx_final'}}
+    fm = kpx_amd.FinalModel(cfg, device=dev, image_size=res, frames_per_launch=32)
+    fm.build()
+    arrays = {**R.init_variables(k, res=res, seed=77), **R.init_stage2_decoder(k, cell_info=cells, vae_dim=vdim, seed=78)}
+    rs = np.random.RandomState(5)
+    for n in list(arrays):                          # non-trivial inference statistics and affine parameters
+        if n.endswith('moving_mean') or n.endswith('/beta'):
+            arrays[n] = (rs.randn(*arrays[n].shape) * 0.1).astype(np.float32)
+        elif n.endswith('moving_variance') or n.endswith('/gamma'):
+            arrays[n] = (rs.uniform(0.5, 1.5, arrays[n].shape)).astype(np.float32)
+        elif n.endswith('/bias') or n.endswith('/biases') or n.endswith('/b'):
+            arrays[n] = (rs.randn(*arrays[n].shape) * 0.05).astype(np.float32)
+    arrays = {n: a for n, a in arrays.items() if not n.startswith('img_discr')}
+    fm.store.load_numpy(arrays, strict=True)
+    im, _ = R.synthetic_pair(b, res=res, seed0=8, seed1=9)
+    act = np.eye(9, dtype=np.float32)[[2, 7]]
+    z = rs.randn(b, vdim).astype(np.float32)
+    out = fm.run(None, {'image': torch.from_numpy(im).to(dev), 'action_code': torch.from_numpy(act).to(dev)}, z=torch.from_numpy(z).to(dev))
+    with torch.no_grad():
+        want = R.final_model_forward({n: torch.from_numpy(a) for n, a in arrays.items()}, torch.from_numpy(im), torch.from_numpy(act),
+                                     torch.from_numpy(z), k, cell_info=cells)
+    assert tuple(out['pred_im_seq'].shape) == (b, 32, res, res, 3)
+    np.testing.assert_allclose(out['first_pt'].cpu().numpy(), want['first_pt'].numpy(), atol=2e-5)
+    np.testing.assert_allclose(out['fut_pt_raw'].cpu().numpy(), want['fut_pt_raw'].numpy(), atol=2e-5)
+    assert rel_l2(out['pred_im_seq'].cpu().numpy(), want['pred_im_seq'].numpy()) < 1e-4
+    assert rel_l2(out['pred_im_crude'].cpu().numpy(), want['pred_im_crude'].numpy()) < 1e-4
+    assert rel_l2(out['mask'].cpu().numpy(), want['mask'].numpy()) < 1e-4
+    assert float(out['pred_im_seq'].abs().max()) <= 1.0

@@ -7,7 +7,8 @@ from . import layers, model_utils, networks, ops, variables  # noqa: F401
 from .base_model import BaseModel  # noqa: F401
 from .detector_translator_model import DetectorTranslatorModel  # noqa: F401
 from .keypoint_model import KeypointModel  # noqa: F401
+from .final_model import FinalModel  # noqa: F401
 from .vgg import Vgg19, synthetic_vgg19_weights  # noqa: F401
 
-__all__ = ['BaseModel', 'DetectorTranslatorModel', 'KeypointModel', 'Vgg19', 'synthetic_vgg19_weights', 'layers', 'model_utils',
+__all__ = ['BaseModel', 'DetectorTranslatorModel', 'KeypointModel', 'FinalModel', 'Vgg19', 'synthetic_vgg19_weights', 'layers', 'model_utils',
            'networks', 'ops', 'variables']

@@ -61,6 +61,9 @@ SIGNATURES = {
     'kpx_sigmoid_xent_fwd_f32': (c_int, [P, c_size_t, c_float, c_size_t, c_float, P, P]),
     'kpx_sigmoid_xent_bwd_f32': (c_int, [P, c_size_t, c_float, c_size_t, c_float, P, c_float, P, P]),
     'kpx_adam_tf_flat_f32': (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),
+    'kpx_lstm_pointwise_f32': (c_int, [P, P, c_float, P, P, c_int, c_int, P]),
+    'kpx_tile_batch_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
+    'kpx_head_blend_tiled_fwd_f32': (c_int, [P, P, c_size_t, c_int, c_int, c_int, P, P, P, P]),
     'kpx_fill_f32': (c_int, [P, c_size_t, c_float, P]),
     'kpx_axpy_f32': (c_int, [P, P, c_size_t, c_float, P]),
 }

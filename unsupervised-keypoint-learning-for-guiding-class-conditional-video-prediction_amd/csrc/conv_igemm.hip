@@ -323,6 +323,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
                     float v = acc[i][n][r] + bv;
                     if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+                    else if (g.act == KPX_ACT_TANH) v = tanhf(v);
                     g.y[(size_t)pix * g.ldy + col] = v;
                 }
             }
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             float v = a[j] + (bias ? bias[c + j] : 0.f);
             if (act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
             else if (act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+            else if (act == KPX_ACT_TANH) v = tanhf(v);
             a[j] = v;
         }
         *reinterpret_cast<f32x4*>(y + pix * ldy + c) = a;
@@ -477,6 +479,7 @@ __global__ __launch_bounds__(256) void conv_small_cout_kernel(const ConvGeom g) 
             v += g.bias ? g.bias[o] : 0.f;
             if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
             else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+            else if (g.act == KPX_ACT_TANH) v = tanhf(v);
             g.y[(size_t)pix * g.ldy + o] = v;
         }
     }
@@ -513,7 +516,7 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
                                   float* y, int Ho, int Wo, int Cout, int ldy,
                                   int stride, int pad_t, int pad_l, int act, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !w || !y || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
-        KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || ldy < Cout || act < 0 || act > 2)
+        KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || ldy < Cout || act < 0 || act > 3)
         return KPX_EINVAL;
     ConvGeom g{};
     g.x = x; g.y = y; g.w = w; g.bias = bias;

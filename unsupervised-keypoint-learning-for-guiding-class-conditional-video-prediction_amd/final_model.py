@@ -1,0 +1,92 @@
+"""Full evaluation pipeline (reference: models/final_model.py) -- SURVEY 8f row 1 / BASELINE configs[4]:
+detector -> stage-2 vae_decoder (z ~ N(0,1), 32 LSTM steps) -> translator on B*32 frames, inference-mode batch norm.
+
+Only the tensors evaluate.py saves are produced; the colourised key-point visualisations (utils/model.py:13-46, unseeded
+``random``) are out of scope.  ``z`` can be injected for deterministic parity tests (the reference draws it unseeded, :71).
+"""
+import torch
+
+from . import model_utils, networks, ops, variables
+from .base_model import BaseModel
+from .variables import Sym
+
+N_FUTURE_FRAMES = 32          # reference :11
+IMAGE_SIZE = 128              # reference :12
+
+
+class FinalModel(BaseModel):
+    name = 'final'            # reference :21
+
+    def __init__(self, config, device='cuda', image_size=IMAGE_SIZE, frames_per_launch=256, seed=1234):
+        super(FinalModel, self).__init__(False)
+        model_config = config['model']
+        self.log_dir = config['paths']['log_dir']
+        self.n_points = model_config['n_pts']
+        self.cell_info = list(model_config['cell_info'])
+        self.vae_dim = model_config['vae_dim']
+        self.n_action = model_config.get('n_action', 9)
+        self.image_size = image_size
+        self.heat_size = image_size // 4
+        self.frames_per_launch = frames_per_launch      # translator slab size (B*32 frames are processed in slabs)
+        self.device = torch.device(device)
+        self.store = variables.VariableStore(device=self.device, seed=seed)
+
+    def build(self, inputs=None):
+        r, k, b = self.image_size, self.n_points, 2
+        with variables.as_default(self.store):
+            emb = networks.image_encoder(Sym(b, r, r, 3), False)
+            networks.pose_encoder(Sym(b, r, r, 3), k, False, final_res=r)
+            networks.vae_decoder(Sym(b, self.vae_dim), Sym(b, 2 * k), Sym(b, self.n_action), self.cell_info, self.vae_dim, k)
+            joint = Sym(b, self.heat_size, self.heat_size, (emb[-2].shape[-1] + 2 * k + 3) // 4 * 4)
+            networks.translator(joint, False, final_res=r, cin=emb[-2].shape[-1] + 2 * k)
+        self.store.materialise()
+
+    def run(self, sess, feed_dict, z=None):
+        """reference run (:124-125).  feed_dict: {'image': [B,H,W,3] in [-1,1], 'action_code': [B,n_action] one-hot,
+        optional 'real_im_seq', 'real_seq'}."""
+        im = feed_dict['image'].contiguous()
+        act = feed_dict['action_code'].contiguous()
+        b, r, k, t = im.shape[0], self.image_size, self.n_points, N_FUTURE_FRAMES
+        dev = im.device
+        with variables.as_default(self.store), torch.no_grad():
+            emb = networks.image_encoder(im, False)[-2]                                          # :61-62
+            first_pt = networks.pose_encoder(im, k, False, final_res=r)                          # :68
+            if z is None:
+                z = torch.randn((b, self.vae_dim), dtype=torch.float32, device=dev)              # :71
+            pred_seq = networks.vae_decoder(z, first_pt.reshape(b, 2 * k), act, self.cell_info, self.vae_dim, k)   # :72-77
+            pred_pts = pred_seq.reshape(b * t, k, 2)
+            # joint embedding [B*T, h, h, C+2K (+pad)]: tiled image embedding ‖ tiled current map ‖ per-frame predicted map
+            c = emb.shape[-1]
+            ld = (c + 2 * k + 3) // 4 * 4
+            hs = self.heat_size
+            finals, crudes, masks = [], [], []
+            fpl = max(t, (self.frames_per_launch // t) * t)          # whole samples per slab
+            first_tiled = ops.tile_batch(first_pt.reshape(b, 1, 2 * k), t).reshape(b * t, k, 2)   # :85-87 (points instead of maps)
+            for s in range(0, b * t, fpl):
+                e = min(b * t, s + fpl)
+                nb = (e - s) // t
+                joint = torch.empty((e - s, hs, hs, ld), dtype=torch.float32, device=dev)
+                if ld > c + 2 * k:
+                    ops.fill_raw_(joint, 0.0)
+                ops.tile_batch(emb[s // t:s // t + nb], t, out=joint, out_ld=ld, out_channel_offset=0)             # :63-66
+                for i, pts in enumerate((first_tiled[s:e], pred_pts[s:e])):                                        # :79-92
+                    ops.check(ops.lib.kpx_gaussian_maps_fwd_f32(pts.contiguous().data_ptr(), e - s, k, hs, hs, 14.3,
+                                                                joint.data_ptr() + 4 * (c + i * k), ld, ops._stream()),
+                              'kpx_gaussian_maps_fwd_f32')
+                raw4 = networks.translator(joint, False, final_res=r, cin=c + 2 * k)                                # :95
+                f_, c_, m_ = ops.head_blend_tiled(im[s // t:s // t + nb], raw4, t, clip=True)                       # :96-99
+                finals.append(f_); crudes.append(c_); masks.append(m_)
+            cat = lambda xs: xs[0] if len(xs) == 1 else torch.cat(xs, dim=0)
+            return {'im': im, 'real_im_seq': feed_dict.get('real_im_seq'),
+                    'pred_im_seq': cat(finals).reshape(b, t, r, r, 3), 'mask': cat(masks).reshape(b, t, r, r, 1),
+                    'pred_im_crude': cat(crudes).reshape(b, t, r, r, 3), 'fut_pt_raw': pred_seq.reshape(b, t, k, 2),
+                    'first_pt': first_pt}
+
+    def train_step(self, sess, feed_dict, step, batch_size, should_write_log=False, should_write_summary=False):
+        raise NotImplementedError          # reference :127-136
+
+    def test_step(self, sess, feed_dict, step, test_idx, batch_size):
+        raise NotImplementedError
+
+    def collect_test_results(self, results, step):
+        raise NotImplementedError

@@ -5,6 +5,8 @@
 kernels of libkpx_hip.so.  Extra keyword arguments (``act``, ``cin``, ``groups``...) expose fusions the TF graph did as
 separate ops (bias+activation epilogue, BN+ReLU, batched weight-sharing calls).
 """
+import torch
+
 from . import ops
 from .variables import Sym, default_store, is_sym
 
@@ -56,3 +58,61 @@ def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, 
     rounding noise for them, which its Adam turns into a +-lr random walk that batch norm again cancels in the forward."""
     x = conv(x, channels, kernel=kernel, stride=stride, scope=conv_scope, cin=cin, bias_grad=not (EXACT_ZERO_BIAS_GRAD and train_mode))
     return batch_norm(x, train_mode, scope=bn_scope, act=ACT_RELU, groups=groups, update_moving=update_moving)
+
+
+def fully_connected(x, num_outputs, scope='fully_connected', act=ACT_RELU):
+    """tf.contrib.layers.fully_connected (default activation ReLU; variables <scope>/{weights,biases})
+    (reference networks/__init__.py:120)."""
+    st = default_store()
+    with st.variable_scope(scope):
+        wn = st.get_variable('weights', (int(x.shape[-1]), int(num_outputs)), 'glorot2d')
+        bn = st.get_variable('biases', (int(num_outputs),), 'zeros')
+    if is_sym(x):
+        return Sym(x.shape[0], num_outputs)
+    return ops.dense(x, st[wn].detach(), st[bn].detach(), act=act)
+
+
+class _LstmStack:
+    """reference layers.lstm_model (layers.py:17-21): MultiRNNCell of LSTMCell(units, name='basic_lstm_cell') wrapped in
+    DropoutWrapper(keep_prob=1.0) = identity.  Variables multi_rnn_cell/cell_<i>/basic_lstm_cell/{kernel,bias}."""
+
+    def __init__(self, units):
+        self.units = [int(u) for u in units]
+
+    def zero_state(self, batch, device):
+        return [(torch.zeros((batch, u), dtype=torch.float32, device=device), torch.zeros((batch, u), dtype=torch.float32, device=device))
+                for u in self.units]
+
+    def declare(self, input_size):
+        st = default_store()
+        names, prev = [], int(input_size)
+        for i, u in enumerate(self.units):
+            with st.variable_scope('multi_rnn_cell'), st.variable_scope('cell_%d' % i), st.variable_scope('basic_lstm_cell'):
+                names.append((st.get_variable('kernel', (prev + u, 4 * u), 'glorot2d'), st.get_variable('bias', (4 * u,), 'zeros')))
+            prev = u
+        return names
+
+    def __call__(self, x, state):
+        st = default_store()
+        names = self.declare(x.shape[-1])
+        new_state = []
+        for (kn, bn), (c, h) in zip(names, state):
+            h2, c2 = ops.lstm_cell(x, h, c, st[kn].detach(), st[bn].detach())
+            new_state.append((c2, h2))
+            x = h2
+        return x, new_state
+
+
+def lstm_model(layers_):
+    return _LstmStack(layers_)
+
+
+def to_coord(input_, input_size, output_size, stddev=0.02, bias_start=0.0):
+    """reference layers.to_coord (layers.py:24-28): tanh(x W + b), variables fully_connected/{W,b}."""
+    st = default_store()
+    with st.variable_scope('fully_connected'):
+        wn = st.get_variable('W', (int(input_size), int(output_size)), 'normal002')
+        bn = st.get_variable('b', (int(output_size),), 'zeros')
+    if is_sym(input_):
+        return Sym(input_.shape[0], output_size)
+    return ops.dense(input_, st[wn].detach(), st[bn].detach(), act=ops.ACT_TANH)

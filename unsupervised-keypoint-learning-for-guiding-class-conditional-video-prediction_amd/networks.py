@@ -101,3 +101,33 @@ def img_discr(x):
             x = layers.conv(x, channel * 2, kernel=4, stride=2, pad=1, use_bias=True, scope='conv_' + str(i), act=ACT_LRELU)
             channel = channel * 2
         return layers.conv(x, channels=1, kernel=3, stride=1, pad=1, use_bias=False, scope='D_logit', act=ACT_NONE)
+
+
+def vae_decoder(x, f_pt, act_code, cell_info, vae_dim, n_pts, n_steps=32):
+    """reference vae_decoder (networks/__init__.py:116-129): z ‖ first key-points ‖ action code -> fc(32, relu) -> stacked
+    LSTM, the fc output as input at step 0 and zeros afterwards, to_coord(tanh) per step -> [B, 32, 2*n_pts]."""
+    st = default_store()
+    with st.variable_scope('vae_decoder'):
+        cell = layers.lstm_model(cell_info)
+        if is_sym(x):
+            inp = layers.fully_connected(Sym(x.shape[0], x.shape[1] + f_pt.shape[1] + act_code.shape[1]), 32)
+            cell.declare(32)
+            layers.to_coord(Sym(x.shape[0], cell_info[-1]), cell_info[-1], n_pts * 2)
+            return Sym(x.shape[0], n_steps, n_pts * 2)
+        import torch
+        b = x.shape[0]
+        cat = torch.empty((b, x.shape[1] + f_pt.shape[1] + act_code.shape[1]), dtype=torch.float32, device=x.device)
+        off = 0
+        for part in (x, f_pt, act_code):                                  # tf.concat([x, f_pt, act_code], -1) (:120)
+            part = part.contiguous()
+            ops.copy_channels_raw(part.data_ptr(), part.shape[1], cat.data_ptr() + 4 * off, cat.shape[1], b, part.shape[1])
+            off += part.shape[1]
+        input_ = layers.fully_connected(cat, 32)
+        empty_input = torch.zeros_like(input_)                            # :121
+        state = cell.zero_state(b, x.device)
+        outputs = torch.empty((b, n_steps, n_pts * 2), dtype=torch.float32, device=x.device)
+        for i in range(n_steps):                                          # :123-128
+            output, state = cell(input_ if i == 0 else empty_input, state)
+            o = layers.to_coord(output, cell_info[-1], n_pts * 2)
+            ops.copy_channels_raw(o.data_ptr(), n_pts * 2, outputs.data_ptr() + 4 * i * n_pts * 2, n_steps * n_pts * 2, b, n_pts * 2)
+        return outputs

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import lib, check
 
-ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 BN_EPS = 1e-5        # reference: models/networks/layers.py:14
 BN_DECAY = 0.999     # tf.contrib.layers.batch_norm default
 
@@ -551,3 +551,56 @@ def adam_tf_flat_(p, g, m, v, alpha, beta1, beta2, eps, gscale=1.0):
         _require_gpu(t)
     check(lib.kpx_adam_tf_flat_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                                    float(alpha), float(beta1), float(beta2), float(eps), float(gscale), _stream()), 'kpx_adam_tf_flat_f32')
+
+
+# ----------------------------------------------------------------------------------------------- rollout (forward only)
+def dense(x, w, b, act=ACT_NONE):
+    """act(x @ w + b) for x [B,In], w [In,Out]: a 1x1 convolution over a [B,1,1,In] tensor on the implicit-GEMM kernel
+    (tf.contrib.layers.fully_connected / LSTMCell matmul / to_coord, reference networks/__init__.py:120, layers.py:17-28)."""
+    _require_gpu(x)
+    x = x.contiguous()
+    bsz, n_in = x.shape
+    n_out = w.shape[1]
+    y = torch.empty((bsz, 1, 1, n_out), dtype=torch.float32, device=x.device)
+    conv_fwd_raw(x.view(bsz, 1, 1, n_in), n_in, n_in, w.contiguous().view(1, 1, n_in, n_out), b, y, n_out, 1, 0, 0, act)
+    return y.view(bsz, n_out)
+
+
+def lstm_cell(x, h, c, kernel, bias, forget_bias=1.0):
+    """One tf.nn.rnn_cell.LSTMCell step: returns (h', c')."""
+    bsz, units = h.shape
+    xin = torch.empty((bsz, x.shape[1] + units), dtype=torch.float32, device=x.device)
+    copy_channels_raw(x.contiguous().data_ptr(), x.shape[1], xin.data_ptr(), xin.shape[1], bsz, x.shape[1])
+    copy_channels_raw(h.contiguous().data_ptr(), units, xin.data_ptr() + 4 * x.shape[1], xin.shape[1], bsz, units)
+    gates = dense(xin, kernel, bias)
+    c2, h2 = torch.empty_like(c), torch.empty_like(h)
+    check(lib.kpx_lstm_pointwise_f32(gates.data_ptr(), c.contiguous().data_ptr(), float(forget_bias), c2.data_ptr(), h2.data_ptr(),
+                                     bsz, units, _stream()), 'kpx_lstm_pointwise_f32')
+    return h2, c2
+
+
+def tile_batch(x, t, out=None, out_ld=None, out_channel_offset=0):
+    """tf.tile over a new time axis + reshape: [B, ..., C] -> [B*T, ..., C] (optionally into a channel slice of ``out``)."""
+    _require_gpu(x)
+    x = x.contiguous()
+    bsz, c = x.shape[0], x.shape[-1]
+    pix = x.numel() // (bsz * c)
+    if out is None:
+        out = torch.empty((bsz * t,) + tuple(x.shape[1:]), dtype=torch.float32, device=x.device)
+        out_ld = c
+    check(lib.kpx_tile_batch_f32(x.data_ptr(), c, bsz, t, pix, c, out.data_ptr() + 4 * out_channel_offset, out_ld, _stream()),
+          'kpx_tile_batch_f32')
+    return out
+
+
+def head_blend_tiled(im, raw4, t, clip=True):
+    """final = tile(im,T)*mask + crude*(1-mask) with clip_by_value(-1,1) (reference final_model.py:95-99)."""
+    raw4 = raw4.contiguous()
+    n, h, w, _ = raw4.shape
+    dev = raw4.device
+    final = torch.empty((n, h, w, 3), dtype=torch.float32, device=dev)
+    crude = torch.empty((n, h, w, 3), dtype=torch.float32, device=dev)
+    mask = torch.empty((n, h, w, 1), dtype=torch.float32, device=dev)
+    check(lib.kpx_head_blend_tiled_fwd_f32(im.contiguous().data_ptr(), raw4.data_ptr(), n * h * w, h * w, t, 1 if clip else 0,
+                                           final.data_ptr(), crude.data_ptr(), mask.data_ptr(), _stream()), 'kpx_head_blend_tiled_fwd_f32')
+    return final, crude, mask

@@ -95,6 +95,11 @@ class VariableStore:
             kh, kw, ci, co = shape
             assert co == 4
             val = np.concatenate([self._xavier((kh, kw, ci, 3)), self._xavier((kh, kw, ci, 1))], axis=-1)
+        elif kind == 'glorot2d':                      # tf.get_variable default / contrib xavier for [in, out] matrices
+            lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+            val = self.rng.uniform(-lim, lim, size=shape).astype(np.float32)
+        elif kind == 'normal002':                     # tf.random_normal_initializer(stddev=0.02) (layers.py:26)
+            val = (self.rng.randn(*shape) * 0.02).astype(np.float32)
         elif kind in ('ones', 'moving_ones'):
             val = np.ones(shape, np.float32)
         else:
