@@ -1211,7 +1211,8 @@ static int wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW
     long tiles = (long)KH * KW * ((Cin + bm - 1) / bm) * ((Cout + bn - 1) / bn);
     if (wgrad_merge(Cin, Cin, KW)) tiles = (long)KH * ((Cout + bn - 1) / bn);
     const long P = (long)N * Ho * Wo;
-    long S = (1024 + tiles - 1) / tiles;
+    const long target = getenv("KPX_WGRAD_TARGET") ? atol(getenv("KPX_WGRAD_TARGET")) : (bm == 128 ? 2560 : 4096);   // measured optimum: several short rounds balance better than one long one
+    long S = (target + tiles - 1) / tiles;
     const long maxS_pix = P / 128 > 0 ? P / 128 : 1;
     if (S > maxS_pix) S = maxS_pix;
     const size_t slab_bytes = (size_t)KH * KW * Cin * Cout * 4;
