@@ -1212,8 +1212,8 @@ static int wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW
     if (wgrad_merge(Cin, Cin, KW)) tiles = (long)KH * ((Cout + bn - 1) / bn);
     const long P = (long)N * Ho * Wo;
     const long target = getenv("KPX_WGRAD_TARGET") ? atol(getenv("KPX_WGRAD_TARGET")) : (bm == 128 ? 2560 : 4096);   // measured optimum: several short rounds balance better than one long one
-    long S = (target + tiles - 1) / tiles;
-    const long maxS_pix = P / 128 > 0 ? P / 128 : 1;
+    long S = target / tiles;                            // floor: never split a layer that already has enough tiles
+    const long maxS_pix = P / 512 > 0 ? P / 512 : 1;   // >= 16 chunks of 32 pixels per split
     if (S > maxS_pix) S = maxS_pix;
     const size_t slab_bytes = (size_t)KH * KW * Cin * Cout * 4;
     const size_t cap = (size_t)256 << 20;
