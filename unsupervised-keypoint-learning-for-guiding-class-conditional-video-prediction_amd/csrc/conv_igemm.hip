@@ -15,6 +15,7 @@
 // {8u+4h+j}: a K permutation shared by A and B, so the product is unchanged.
 #include "kpx_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 // per stride-parity class of output pixels (dgrad of a strided conv); forward has exactly one class
 struct ConvClass { int Ha, Wa, oy0, ox0, Tr, Tq, iy0, ix0, wr0, wq0, M, mt; };
@@ -419,6 +420,12 @@ static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
             const double score = cs[i].eff * (double)nb / (double)(rounds * slots);
             if (score > best) { best = score; BM = cs[i].bm; BN = cs[i].bn; }
         }
+    }
+    if (const char* ov = getenv("KPX_TILE")) {            // debug / tuning override: "BM,BN" among the instantiated tiles
+        int obm = 0, obn = 0;
+        if (sscanf(ov, "%d,%d", &obm, &obn) == 2 && BN != 32 && (obm == 128 || obm == 64) && (obn == 128 || obn == 64) &&
+            (obn == 64 || g.Cout > 64))
+            { BM = obm; BN = obn; }
     }
     g.nt = (g.Cout + BN - 1) / BN;
     int mtmax = 0;
@@ -1320,7 +1327,8 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
         r.out = r.S > 1 ? (float*)workspace : dw;
         hipStream_t s = kpx_stream(stream);
         const dim3 grid((unsigned)(r.S * KH * KW * r.ct * r.kt));
-        if (bm == 128) hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<128, 128, 2, 4>), grid, dim3(512), 0, s, r);
+        if (bm == 128 && getenv("KPX_WGRAD_4W")) hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, r);
+        else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<128, 128, 2, 4>), grid, dim3(512), 0, s, r);
         else hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, r);
         int rc = kpx_launch_status();
         if (rc) return rc;
