@@ -130,6 +130,7 @@ class DetectorTranslatorModel(BaseModel):
         collective runs on RCCL's own stream and the returned handle is waited for just before the Adam update, so the
         178.9 MB discriminator exchange overlaps the VGG19 forward of the generator's perceptual loss."""
         bucket = self.store.buckets[which]
+        ops.join_side_stream(self.device)       # weight gradients are written on the side stream
         if self.world_size > 1:
             work = torch.distributed.all_reduce(bucket.grads, op=torch.distributed.ReduceOp.SUM, group=self.process_group,
                                                 async_op=async_op)

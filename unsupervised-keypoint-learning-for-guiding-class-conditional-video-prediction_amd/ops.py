@@ -51,13 +51,13 @@ def _nhwc(t):
 
 
 class _Scratch:
-    """Per-device scratch buffers; all kernels are stream-ordered so consecutive ops may share them."""
+    """Per-device, per-stream scratch buffers; kernels on one stream are ordered, so consecutive ops may share them."""
 
     def __init__(self):
         self._bufs = {}
 
     def get(self, key, nbytes, device):
-        k = (key, device)
+        k = (key, device, torch.cuda.current_stream(device).cuda_stream)
         b = self._bufs.get(k)
         if b is None or b.numel() < nbytes:
             b = torch.empty(int(max(nbytes, 1 << 16)), dtype=torch.uint8, device=device)
@@ -69,6 +69,30 @@ class _Scratch:
 
 
 scratch = _Scratch()
+
+# Weight gradients are off the backward critical path (only the optimiser consumes them), so they are launched on a second
+# HIP stream where they fill the ramp-up / tail gaps of the dgrad chain on the main stream.  join_side_stream() is called
+# before the gradient exchange / Adam update.  KPX_SIDE_WGRAD=0 disables it.
+import os as _os
+SIDE_WGRAD = _os.environ.get('KPX_SIDE_WGRAD', '1') != '0'
+_side_streams = {}
+_side_dirty = set()
+
+
+def _side_stream(device):
+    st = _side_streams.get(device)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[device] = st
+    return st
+
+
+def join_side_stream(device=None):
+    """Make the current stream wait for every weight-gradient kernel launched on the side stream."""
+    for dev in list(_side_dirty):
+        if device is None or dev == torch.device(device):
+            torch.cuda.current_stream(dev).wait_stream(_side_streams[dev])
+            _side_dirty.discard(dev)
 
 
 # ----------------------------------------------------------------------------------------------- raw launchers
@@ -182,14 +206,30 @@ class Conv2dFn(torch.autograd.Function):
             if cin < cx:
                 fill_raw_(dx, 0.0)
             conv_dgrad_raw(dy, cout, w, dx, cx, cin, stride, pad_t, pad_l)
-        if ctx.needs_input_grad[1]:
-            dw_buf = ctx.w_grad_out if ctx.w_grad_out is not None else torch.empty_like(w)
-            conv_wgrad_raw(x, ldx, cin, dy, cout, dw_buf, stride, pad_t, pad_l)
-            dw = None if ctx.w_grad_out is not None else dw_buf
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db_buf = ctx.b_grad_out if ctx.b_grad_out is not None else torch.empty(cout, dtype=torch.float32, device=x.device)
-            chan_sum_raw(dy, cout, dy.shape[0] * dy.shape[1] * dy.shape[2], cout, db_buf)
-            db = None if ctx.b_grad_out is not None else db_buf
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        # side stream only when the gradient goes straight into the flat bucket (nobody on the main stream reads it
+        # before join_side_stream())
+        side = SIDE_WGRAD and (want_w or want_b) and (not want_w or ctx.w_grad_out is not None) and (not want_b or ctx.b_grad_out is not None)
+        if side:
+            main = torch.cuda.current_stream(x.device)
+            st = _side_stream(x.device)
+            st.wait_stream(main)                         # dy (and x) are ready once the main stream reaches this point
+            dy.record_stream(st); x.record_stream(st)    # keep the allocator from recycling them under the side kernels
+            _side_dirty.add(x.device)
+            stream_ctx = torch.cuda.stream(st)
+        else:
+            import contextlib
+            stream_ctx = contextlib.nullcontext()
+        with stream_ctx:
+            if want_w:
+                dw_buf = ctx.w_grad_out if ctx.w_grad_out is not None else torch.empty_like(w)
+                conv_wgrad_raw(x, ldx, cin, dy, cout, dw_buf, stride, pad_t, pad_l)
+                dw = None if ctx.w_grad_out is not None else dw_buf
+            if want_b:
+                db_buf = ctx.b_grad_out if ctx.b_grad_out is not None else torch.empty(cout, dtype=torch.float32, device=x.device)
+                chan_sum_raw(dy, cout, dy.shape[0] * dy.shape[1] * dy.shape[2], cout, db_buf)
+                db = None if ctx.b_grad_out is not None else db_buf
         return dx, dw, db, None, None, None, None, None, None, None
 
 
