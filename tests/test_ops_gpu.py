@@ -290,3 +290,36 @@ def test_conv_fuzz_against_oracle(kpx, dev, n, h, w, cin, cout, k, s, pad, act):
     """Seeded random geometries (ragged channels, odd sizes, strides, explicit pads) through fwd / dgrad / wgrad."""
     # gradients here can be single numbers made of cancelling terms (e.g. a 1x1x1x1 kernel): 1e-4 instead of 1e-5
     test_conv_fwd_dgrad_wgrad(kpx, dev, n, h, w, cin, cout, k, s, pad, act, gtol=1e-4)
+
+
+def test_shared_variable_used_twice_accumulates_into_the_bucket(kpx, dev):
+    """Two ops using the same variable inside one backward (the reference's two pose_encoder calls, made unbatched) must ADD
+    their weight / BN gradients in the flat-bucket destination instead of overwriting each other."""
+    rs = np.random.RandomState(11)
+    x1 = rs.randn(2, 8, 8, 8).astype(np.float32); x2 = rs.randn(2, 8, 8, 8).astype(np.float32)
+    wt = (rs.randn(3, 3, 8, 8) * 0.2).astype(np.float32); b = rs.randn(8).astype(np.float32)
+    g = (rs.rand(8) + 0.5).astype(np.float32); be = rs.randn(8).astype(np.float32)
+    to = lambda a: torch.from_numpy(a).requires_grad_(True)
+    wo, bo, go, beo = to(wt), to(b), to(g), to(be)
+    total = 0
+    for x in (x1, x2):
+        y = R.conv(torch.from_numpy(x), wo, bo, 1)
+        y, _, _ = R.batch_norm_train(y, go, beo)
+        total = total + torch.relu(y).square().sum()
+    total.backward()
+    W, Bv, G, Be = (torch.from_numpy(a).to(dev).requires_grad_(True) for a in (wt, b, g, be))
+    bucket = {n: torch.full_like(t, 123.0).detach() for n, t in (('w', W), ('b', Bv), ('g', G), ('be', Be))}   # poisoned: must be overwritten
+    mm, mv = torch.zeros(8, device=dev), torch.ones(8, device=dev)
+    kpx.ops.begin_backward()
+    tot = 0
+    for x in (x1, x2):
+        y = kpx.ops.conv2d(torch.from_numpy(x).to(dev), W, Bv, stride=1, w_grad_out=bucket['w'], b_grad_out=bucket['b'])
+        y = kpx.ops.batch_norm(y, G, Be, mm, mv, train=True, act=1, g_grad_out=bucket['g'], b_grad_out=bucket['be'])
+        tot = tot + y.square().sum()
+    tot.backward()
+    kpx.ops.join_side_stream()
+    torch.cuda.synchronize()
+    assert rel_l2(t2n(bucket['w']), t2n(wo.grad)) < 1e-5
+    assert rel_l2(t2n(bucket['g']), t2n(go.grad)) < 1e-5
+    assert rel_l2(t2n(bucket['be']), t2n(beo.grad)) < 1e-5
+    np.testing.assert_allclose(t2n(bucket['b']), t2n(bo.grad), atol=1e-3)     # exactly zero in exact arithmetic (BN follows)

@@ -160,6 +160,7 @@ class DetectorTranslatorModel(BaseModel):
             final = fwd['final_output']
             # ---- D run (:93)
             d_losses = self._loss_D(final.detach(), future_im)
+            ops.begin_backward()
             torch.autograd.backward([d_losses], [self._e0])
             pending = self.exchange_gradients('D', async_op=True)          # overlaps the VGG forward below
             # ---- G run (:94): the perceptual forward does not involve the discriminator, so it runs first ...
@@ -167,6 +168,7 @@ class DetectorTranslatorModel(BaseModel):
             self._apply_adam('D', lr, pending=pending, exchanged=True)
             # ... and the adversarial term sees the UPDATED discriminator, exactly as the reference's second sess.run
             adv = self._loss_G_adv(final)
+            ops.begin_backward()
             torch.autograd.backward([recon, adv], [self._one, self._e0])
             self._apply_adam('G', lr)
         self.global_step += 1                                             # incremented by the G optimiser (:201-202)

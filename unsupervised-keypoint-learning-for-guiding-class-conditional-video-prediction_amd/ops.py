@@ -87,6 +87,28 @@ def _side_stream(device):
     return st
 
 
+# Gradients are written (not accumulated) into the flat bucket.  If one variable is used by several ops inside one backward
+# pass (e.g. the reference's two weight-sharing pose_encoder calls made as two calls instead of one batched call), the second
+# and later writers must ADD.  begin_backward() opens a new epoch; a destination already written in the current epoch is
+# accumulated into through a temporary + axpy.
+_grad_epoch = [0]
+_grad_written = {}
+
+
+def begin_backward():
+    _grad_epoch[0] += 1
+    if len(_grad_written) > 4096:
+        _grad_written.clear()
+
+
+def _claim_grad(dst):
+    """True if ``dst`` has not been written in this backward epoch yet (and mark it written)."""
+    key = (dst.data_ptr(), dst.numel())
+    first = _grad_written.get(key) != _grad_epoch[0]
+    _grad_written[key] = _grad_epoch[0]
+    return first
+
+
 def join_side_stream(device=None):
     """Make the current stream wait for every weight-gradient kernel launched on the side stream."""
     for dev in list(_side_dirty):
@@ -223,12 +245,18 @@ class Conv2dFn(torch.autograd.Function):
             stream_ctx = contextlib.nullcontext()
         with stream_ctx:
             if want_w:
-                dw_buf = ctx.w_grad_out if ctx.w_grad_out is not None else torch.empty_like(w)
+                direct = ctx.w_grad_out is not None and _claim_grad(ctx.w_grad_out)
+                dw_buf = ctx.w_grad_out if direct else torch.empty_like(w)
                 conv_wgrad_raw(x, ldx, cin, dy, cout, dw_buf, stride, pad_t, pad_l)
+                if ctx.w_grad_out is not None and not direct:
+                    axpy_raw_(ctx.w_grad_out, dw_buf)                 # second use of this variable in one backward
                 dw = None if ctx.w_grad_out is not None else dw_buf
             if want_b:
-                db_buf = ctx.b_grad_out if ctx.b_grad_out is not None else torch.empty(cout, dtype=torch.float32, device=x.device)
+                direct = ctx.b_grad_out is not None and _claim_grad(ctx.b_grad_out)
+                db_buf = ctx.b_grad_out if direct else torch.empty(cout, dtype=torch.float32, device=x.device)
                 chan_sum_raw(dy, cout, dy.shape[0] * dy.shape[1] * dy.shape[2], cout, db_buf)
+                if ctx.b_grad_out is not None and not direct:
+                    axpy_raw_(ctx.b_grad_out, db_buf)
                 db = None if ctx.b_grad_out is not None else db_buf
         return dx, dw, db, None, None, None, None, None, None, None
 
@@ -294,15 +322,19 @@ class BatchNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = ctx.g_grad_out if ctx.g_grad_out is not None else torch.empty(c, dtype=torch.float32, device=dev)
         db = ctx.b_grad_out if ctx.b_grad_out is not None else torch.empty(c, dtype=torch.float32, device=dev)
+        fresh = True
+        if ctx.g_grad_out is not None:
+            fresh = _claim_grad(ctx.g_grad_out)
+            _claim_grad(ctx.b_grad_out)
         sc = scratch.reduce(c, dev)
-        tmp = torch.empty((2, c), dtype=torch.float32, device=dev) if groups > 1 else None
+        tmp = torch.empty((2, c), dtype=torch.float32, device=dev) if (groups > 1 or not fresh) else None
         for g in range(groups):
             sl = slice(g * ng, (g + 1) * ng)
-            dgo, dbo = (dg, db) if g == 0 else (tmp[0], tmp[1])
+            dgo, dbo = (dg, db) if (g == 0 and fresh) else (tmp[0], tmp[1])
             check(lib.kpx_bn_bwd_f32(dy[sl].data_ptr(), c, x[sl].data_ptr(), c, pix, c, mean[g].data_ptr(), invstd[g].data_ptr(),
                                      gamma.data_ptr(), beta.data_ptr(), ctx.act, dx[sl].data_ptr(), c,
                                      dgo.data_ptr(), dbo.data_ptr(), sc.data_ptr(), _stream()), 'kpx_bn_bwd_f32')
-            if g > 0:
+            if g > 0 or not fresh:
                 axpy_raw_(dg, tmp[0])
                 axpy_raw_(db, tmp[1])
         return (dx, None if ctx.g_grad_out is not None else dg, None if ctx.b_grad_out is not None else db,
