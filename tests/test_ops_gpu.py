@@ -60,6 +60,9 @@ CONV_CASES = [
     (4, 128, 128, 3, 32, 7, 1, 0, 0),      # row-merged multi-tap wgrad (encoder conv_1 at full resolution)
     (8, 8, 8, 512, 512, 3, 1, 0, 1),       # split-K forward/dgrad (VGG conv5 shape), relu epilogue in the reduce
     (16, 10, 10, 256, 512, 4, 2, 1, 2),    # split-K with stride-2 parity classes (img_discr conv_4 geometry)
+    (2, 32, 48, 48, 96, 3, 1, 0, 2),       # fused Winograd F(2x2,3x3): non-square, 3 chunks of 16 channels, lrelu
+    (3, 16, 16, 64, 32, 3, 1, 0, 1),       # Winograd, one 16x16 block per image, relu
+    (2, 32, 32, 32, 48, 3, 1, 0, 0),       # Winograd dgrad only (Cout = 48 is not a multiple of 32 -> direct forward)
 ]
 
 
@@ -99,6 +102,12 @@ def test_conv_reads_and_writes_channel_slices(kpx, dev):
     want2 = R.conv(torch.from_numpy(full[..., 16:48].copy()), torch.from_numpy(w2), None, 1)
     got2 = kpx.ops.conv2d(sl, torch.from_numpy(w2).to(dev), None, stride=1)
     assert rel_l2(t2n(got2), t2n(want2)) < 1e-5
+    # Winograd-eligible geometry reading a channel slice of a wider buffer (translator conv_1_0-style joint buffer)
+    full3 = rs.randn(2, 16, 16, 96).astype(np.float32)
+    w3 = (rs.randn(3, 3, 64, 32) * 0.05).astype(np.float32)
+    want3 = R.conv(torch.from_numpy(full3[..., 16:80].copy()), torch.from_numpy(w3), None, 1)
+    got3 = kpx.ops.conv2d(torch.from_numpy(full3).to(dev)[..., 16:80], torch.from_numpy(w3).to(dev), None, stride=1)
+    assert rel_l2(t2n(got3), t2n(want3)) < 1e-5
 
 
 @pytest.mark.parametrize('groups', [1, 2])

@@ -507,15 +507,25 @@ static int dgrad_splitk_plan(int N, int Hi, int Wi, int Cin, int Cout, int KH, i
     return S;
 }
 
+// conv_wino.hip: fused Winograd F(2x2,3x3) for the stride-1 3x3 SAME layers
+extern "C" int kpx_wino_eligible(int H, int W, int K, int Nn, int ldin, const void* in_ptr);
+extern "C" int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int Cin, int Cout, int dgrad,
+                                const float* bias, int act, float* out, int Nn, int ldout, float* U_ws, hipStream_t s);
+static inline size_t wino_ws_bytes(int Cin, int Cout) { return (size_t)16 * Cin * Cout * 4; }
+
 extern "C" size_t kpx_conv2d_fwd_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
     if (Cin % 4 != 0) return 0;
     const int S = conv_splitk_plan((long)N * Ho * Wo, Cout, (long)KH * KW * ((Cin + 31) / 32));
-    return S > 1 ? (size_t)S * N * Ho * Wo * Cout * 4 : 0;
+    size_t b = S > 1 ? (size_t)S * N * Ho * Wo * Cout * 4 : 0;
+    if (KH == 3 && KW == 3 && b < wino_ws_bytes(Cin, Cout)) b = wino_ws_bytes(Cin, Cout);     // stride unknown here: upper bound
+    return b;
 }
 
 extern "C" size_t kpx_conv2d_dgrad_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride) {
     const int S = dgrad_splitk_plan(N, Hi, Wi, Cin, Cout, KH, KW, stride);
-    return S > 1 ? (size_t)S * N * Hi * Wi * Cin * 4 : 0;
+    size_t b = S > 1 ? (size_t)S * N * Hi * Wi * Cin * 4 : 0;
+    if (KH == 3 && KW == 3 && stride == 1 && b < wino_ws_bytes(Cin, Cout)) b = wino_ws_bytes(Cin, Cout);
+    return b;
 }
 
 extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
@@ -525,6 +535,9 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
     if (!x || !w || !y || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || ldy < Cout || act < 0 || act > 3)
         return KPX_EINVAL;
+    if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && act != KPX_ACT_TANH && aligned16(w) &&
+        workspace && workspace_bytes >= wino_ws_bytes(Cin, Cout) && kpx_wino_eligible(Hi, Wi, Cin, Cout, ldx, x))
+        return kpx_wino_conv3x3(x, N, Hi, Wi, Cin, ldx, w, Cin, Cout, 0, bias, act, y, Cout, ldy, (float*)workspace, kpx_stream(stream));
     ConvGeom g{};
     g.x = x; g.y = y; g.w = w; g.bias = bias;
     g.N = N; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.ldx = ldx;
@@ -552,6 +565,9 @@ extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int 
         KH <= 0 || KW <= 0 || stride <= 0 || lddy < Cout || lddx < Cin)
         return KPX_EINVAL;
     if (stride > 2) return KPX_EINVAL;             // at most 4 parity classes per launch (the path has strides 1 and 2)
+    if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi &&
+        workspace && workspace_bytes >= wino_ws_bytes(Cin, Cout) && kpx_wino_eligible(Hi, Wi, Cout, Cin, lddy, dy))
+        return kpx_wino_conv3x3(dy, N, Hi, Wi, Cout, lddy, w, Cin, Cout, 1, nullptr, KPX_ACT_NONE, dx, Cin, lddx, (float*)workspace, kpx_stream(stream));
     ConvGeom g{};
     g.x = dy; g.y = dx; g.w = w; g.bias = nullptr;
     g.N = N; g.Hi = Ho; g.Wi = Wo; g.Cin = Cout; g.ldx = lddy;       // "input" of the gather = dy
