@@ -82,11 +82,15 @@ def main():
             continue
         x = torch.randn(n, h, h, ld, device=dev)
         w = torch.randn(k, k, ci, co, device=dev) * 0.05
+        if os.environ.get('KPX_BENCH_ZERO'):
+            x.zero_(); w.zero_()
         b = torch.zeros(co, device=dev)
         pt, _, ho = ops.same_pad(h + 2 * pad, k, s)
         pad_t = pad + pt
         y = torch.empty(n, ho, ho, co, device=dev)
         dy = torch.randn(n, ho, ho, co, device=dev)
+        if os.environ.get('KPX_BENCH_ZERO'):
+            dy.zero_()
         dx = torch.empty(n, h, h, ld, device=dev)
         dw = torch.empty_like(w)
         flops = 2.0 * n * ho * ho * co * k * k * ci

@@ -4,11 +4,11 @@
 //
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A          d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
 //
-// One workgroup (8 wavefronts) owns 8x8 tiles = 16x16 output pixels of one image x 32 output channels and ALL 16 Winograd
+// One workgroup (8 wavefronts) owns 8x8 tiles = 16x16 output pixels of one image x 32 or 64 output channels and ALL 16 Winograd
 // points: the input and output transforms happen in LDS, so neither the transformed input (4x the input) nor the transformed
-// output ever touches HBM.  Per 16-channel chunk: the 18x18-pixel raw patch and the 16x16x32 slice of the pre-transformed
-// filters U are staged in LDS, every thread transforms half a tile (B^T d B) into V[point][tile][channel] (16-B slots
-// XOR-swizzled for conflict-free ds_read_b128), then wave w multiplies points 2w and 2w+1 (4 accumulators of 32x32).
+// output ever touches HBM.  Per 8-channel chunk: the 18x18-pixel raw patch and the slice of the pre-transformed filters U are
+// staged in LDS, every thread computes one row of B^T d B for one tile into V[point][tile][channel] (16-B halves XOR-swizzled
+// for conflict-free ds_read_b128), then wave w multiplies points 2w and 2w+1 (4 or 8 accumulators of 32x32).
 // After the K loop the accumulators go through LDS once more for A^T M A + bias + activation.
 // The same kernel serves dgrad with filters transformed from the flipped / transposed weights.
 #include "kpx_common.h"
@@ -55,149 +55,152 @@ __global__ __launch_bounds__(256) void wino_filter_transform_kernel(const float*
     }
 }
 
-#define WINO_RAW 5184      // 324 pixels x 16 channels
-#define WINO_U 8192        // 16 points x 16 channels x 32 couts
-#define WINO_V 16384       // 16 points x 64 tiles x 16 channels (re-used as M[16][32 tiles][32 couts] in the epilogue)
-#define WINO_LDS_BYTES ((WINO_RAW + WINO_U + WINO_V) * 4)
+// ---- v2 / v5: 8-channel chunks, one 16x16-pixel tile x (32*CT) output channels per workgroup of 8 wavefronts.
+//   CT = 1: 64 KB of LDS and <= 128 VGPRs so that TWO workgroups share a CU (their barrier / LDS latencies overlap).
+//   CT = 2: 64 output channels per workgroup: the transformed input V is shared by twice as many MFMAs (48 -> 32 KB of LDS operand
+//           traffic per 2048 MFMA cycles), 8 accumulators per wave (<= 256 VGPRs, one workgroup per CU).
+// Measured on MI355X (s_memtime stamps, PMC): in this kernel family the transform / staging work does NOT overlap the MFMA stream
+// (neither across wavefronts -- wave-specialised and anti-phase variants serialise completely -- nor as fillers between a wave's
+// own MFMAs), so time = MFMA time + other time and the lever is less "other" work per MFMA, i.e. the bigger tile.
+#define W8_RAW 2592        // 18 rows x 18 pixels x 8 channels; pixel order [0..7,16,8..15,17] within a row (see w8_pos)
+#define W8_V 8192          // 16 points x 64 tiles x 8 channels; 16-B half swizzled by (tile>>3)&1
+#define W8_U(CT) (4096 * (CT))   // 16 points x 8 channels x 32*CT couts
 
-__global__ __launch_bounds__(512) void conv_wino_kernel(const WinoGeom g) {
+// The 8 tiles of a tile row read patch pixels c, c+2, .., c+14 with one ds_read_b128: this order puts them on 8 distinct 32-B
+// bank groups for every column c.
+__device__ __forceinline__ int w8_pos(int p) { return p < 8 ? p : (p == 16 ? 8 : (p == 17 ? 17 : p + 1)); }
+__device__ __forceinline__ int w8_pix(int pos) { return pos < 8 ? pos : (pos == 8 ? 16 : (pos == 17 ? 17 : pos - 1)); }
+
+template <int CT>
+__global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const WinoGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* raw = smem;                     // [324][16]
-    float* Us = smem + WINO_RAW;           // [16][16][32]
-    float* Vs = smem + WINO_RAW + WINO_U;  // [16][64][16] swizzled ; epilogue: [16][32][32]
+    float* raw = smem;
+    float* Us = smem + W8_RAW;
+    float* Vs = smem + W8_RAW + W8_U(CT);
+    constexpr int NC = 32 * CT;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
     int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
-    const int nti = L % g.nt; L /= g.nt;
+    const int ntc = g.Cout / NC;
+    const int nti = L % ntc; L /= ntc;
     const int bx = L % g.tiles_x; L /= g.tiles_x;
     const int by = L % g.tiles_y;
     const int n = L / g.tiles_y;
-    const int oy0 = by * 16, ox0 = bx * 16, n0 = nti * 32;
+    const int oy0 = by * 16, ox0 = bx * 16, n0 = nti * NC;
 
-    // ---- fixed per-thread global-load units
-    const float* rp[3];                    // raw patch: unit u = t + 512*i < 1296 : pixel u>>2 (18x18), 16-B slot u&3
-    bool rok[3];
+    // raw patch units: u = t + 512*i < 648 : position u>>1 (18 rows x 18 positions), 16-B half u&1
+    const float* rp[2]; bool rok[2];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int u = t + 512 * i, px = u >> 2, py = px / 18, pxx = px - py * 18;
+    for (int i = 0; i < 2; ++i) {
+        const int u = t + 512 * i, q = u >> 1, py = q / 18, pxx = w8_pix(q - py * 18);
         const int iy = oy0 - 1 + py, ix = ox0 - 1 + pxx;
-        rok[i] = u < 1296 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-        rp[i] = g.x + ((size_t)(n * g.H + (rok[i] ? iy : 0)) * g.W + (rok[i] ? ix : 0)) * g.ldx + (u & 3) * 4;
+        rok[i] = u < 648 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        rp[i] = rok[i] ? g.x + ((size_t)(n * g.H + iy) * g.W + ix) * g.ldx + (u & 1) * 4 : wino_zero16;
     }
-    const float* up[4];                    // U slice: unit u = t + 512*i < 2048 : point u>>7, channel (u>>3)&15, cout slot u&7
+    // U slice units: u = t + 512*i < 1024*CT : [point][channel 8][NC/4 slots]
+    const float* up[2 * CT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int u = t + 512 * i;
-        up[i] = g.U + ((size_t)(u >> 7) * g.Cin + ((u >> 3) & 15)) * g.Cout + n0 + (u & 7) * 4;
+    for (int i = 0; i < 2 * CT; ++i) {
+        const int u = t + 512 * i, sl = u % (NC / 4), ch = (u / (NC / 4)) & 7, pt = u / (2 * NC);
+        up[i] = g.U + ((size_t)pt * g.Cin + ch) * g.Cout + n0 + sl * 4;
     }
-    // ---- fixed transform item: tile (8x8 grid), 16-B channel slot, half (rows 0-1 / 2-3 of B^T d B)
-    const int tslot = t & 3, thalf = (t >> 2) & 1, ttile = t >> 3;
+    // transform item: 16-B half, tile, row of V = B^T d B (uniform per wave pair)
+    const int tslot = t & 1, ttile = (t >> 1) & 63, vrow = t >> 7;
     const int tty = ttile >> 3, ttx = ttile & 7;
-    const int traw = ((2 * tty + thalf) * 18 + 2 * ttx) * 16 + tslot * 4;       // first patch row this item reads
-    // ---- fixed MFMA read addresses
-    int a_rd[2][2];                        // [tile group][u]
+    const int ra = vrow == 0 ? 0 : (vrow == 2 ? 2 : 1), rb = vrow == 0 ? 2 : (vrow == 1 ? 2 : (vrow == 2 ? 1 : 3));
+    const float sgn = vrow == 1 ? 1.f : -1.f;
+    int trd[4];
 #pragma unroll
-    for (int tg = 0; tg < 2; ++tg)
+    for (int c = 0; c < 4; ++c) trd[c] = (2 * tty + ra) * 144 + w8_pos(2 * ttx + c) * 8 + tslot * 4;
+    const int trb = (rb - ra) * 144;
+    const int vwr = (vrow * 4) * 512 + ttile * 8 + ((tslot ^ ((ttile >> 3) & 1)) << 2);
+    int a_rd[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int tile = tg * 32 + li;
-            a_rd[tg][u] = tile * 16 + ((((2 * u + lh)) ^ ((tile >> 2) & 3)) << 2);
-        }
+    for (int tg = 0; tg < 2; ++tg) { const int tile = tg * 32 + li; a_rd[tg] = tile * 8 + ((lh ^ ((tile >> 3) & 1)) << 2); }
     const int p0 = 2 * wave;
+    const int b_rd = (4 * lh) * NC + li;
 
-    f32x16 acc[2][2];                      // [point][tile group]
+    f32x16 acc[2][2][CT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
 
-    f32x4 rr[3], ru[4];
-    auto load_chunk = [&](int c0) {
+    f32x4 rr[2], ru[2 * CT];
+    const size_t ustep = (size_t)8 * g.Cout;
+    auto load_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) rr[i] = *reinterpret_cast<const f32x4*>(rok[i] ? rp[i] + c0 : wino_zero16);
+        for (int i = 0; i < 2; ++i) { rr[i] = *reinterpret_cast<const f32x4*>(rp[i]); if (rok[i]) rp[i] += 8; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ru[i] = *reinterpret_cast<const f32x4*>(up[i] + (size_t)c0 * g.Cout);
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) if (t + 512 * i < 1296) *reinterpret_cast<f32x4*>(&raw[(t + 512 * i) * 4]) = rr[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&Us[(t + 512 * i) * 4]) = ru[i];
+        for (int i = 0; i < 2 * CT; ++i) { ru[i] = *reinterpret_cast<const f32x4*>(up[i]); up[i] += ustep; }
     };
 
-    const int nchunks = g.Cin / 16;
-    load_chunk(0);
+    const int nchunks = g.Cin / 8;
+    load_chunk();
     for (int ch = 0; ch < nchunks; ++ch) {
-        store_chunk();
+        *reinterpret_cast<f32x4*>(&raw[t * 4]) = rr[0];
+        if (t < 136) *reinterpret_cast<f32x4*>(&raw[(t + 512) * 4]) = rr[1];
+#pragma unroll
+        for (int i = 0; i < 2 * CT; ++i) *reinterpret_cast<f32x4*>(&Us[(t + 512 * i) * 4]) = ru[i];
         __syncthreads();
-        // ---- input transform: this thread produces rows (2*thalf, 2*thalf+1) of V = B^T d B for its tile and 4 channels
         {
-            f32x4 d[3][4];
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) d[r][c] = *reinterpret_cast<const f32x4*>(&raw[traw + (r * 18 + c) * 16]);
-            f32x4 tr0[4], tr1[4];
+            f32x4 tr[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (thalf == 0) { tr0[c] = d[0][c] - d[2][c]; tr1[c] = d[1][c] + d[2][c]; }      // rows 0,1 from patch rows 0,1,2
-                else            { tr0[c] = d[1][c] - d[0][c]; tr1[c] = d[0][c] - d[2][c]; }      // rows 2,3 from patch rows 1,2,3
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&raw[trd[c]]);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(&raw[trd[c] + trb]);
+                tr[c] = a + sgn * b;
             }
-            const int vbase = ttile * 16 + ((tslot ^ ((ttile >> 2) & 3)) << 2);
-            const int prow = thalf * 2;
-#pragma unroll
-            for (int rrw = 0; rrw < 2; ++rrw) {
-                const f32x4* s = rrw ? tr1 : tr0;
-                const int p = (prow + rrw) * 4;
-                *reinterpret_cast<f32x4*>(&Vs[(p + 0) * 1024 + vbase]) = s[0] - s[2];
-                *reinterpret_cast<f32x4*>(&Vs[(p + 1) * 1024 + vbase]) = s[1] + s[2];
-                *reinterpret_cast<f32x4*>(&Vs[(p + 2) * 1024 + vbase]) = s[2] - s[1];
-                *reinterpret_cast<f32x4*>(&Vs[(p + 3) * 1024 + vbase]) = s[1] - s[3];
-            }
+            *reinterpret_cast<f32x4*>(&Vs[vwr]) = tr[0] - tr[2];
+            *reinterpret_cast<f32x4*>(&Vs[vwr + 512]) = tr[1] + tr[2];
+            *reinterpret_cast<f32x4*>(&Vs[vwr + 1024]) = tr[2] - tr[1];
+            *reinterpret_cast<f32x4*>(&Vs[vwr + 1536]) = tr[1] - tr[3];
         }
-        if (ch + 1 < nchunks) load_chunk((ch + 1) * 16);      // in flight during the MFMA phase
+        if (ch + 1 < nchunks) load_chunk();
         __syncthreads();
-        // ---- 16 batched GEMMs: wave w owns points 2w, 2w+1
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-            const float* Vp = Vs + (p0 + pt) * 1024;
-            const float* Up = Us + (p0 + pt) * 512;
+            const float* Vp = Vs + (p0 + pt) * 512;
+            const float* Up = Us + (p0 + pt) * 8 * NC + b_rd;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Vp[a_rd[0]]);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Vp[a_rd[1]]);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Vp[a_rd[0][u]]);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Vp[a_rd[1][u]]);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float b = Up[(4 * (2 * u + lh) + j) * 32 + li];
-                    acc[pt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b, acc[pt][0], 0, 0, 0);
-                    acc[pt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b, acc[pt][1], 0, 0, 0);
+                for (int ct = 0; ct < CT; ++ct) {
+                    const float b = Up[j * NC + ct * 32];
+                    acc[pt][0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b, acc[pt][0][ct], 0, 0, 0);
+                    acc[pt][1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b, acc[pt][1][ct], 0, 0, 0);
                 }
-            }
         }
         __syncthreads();
     }
 
-    // ---- output transform, one tile group (32 tiles = 4 tile rows) at a time through LDS: M[16][32][32]
+    // output transform through LDS, one (tile group, cout tile) quarter at a time: M[16][32 tiles][32 couts] = 64 KB
     const int oc = t & 31;
-    const float bv = g.bias ? g.bias[n0 + oc] : 0.f;
+    float* Ms = smem;
 #pragma unroll
-    for (int tg = 0; tg < 2; ++tg) {
-        if (tg) __syncthreads();
+    for (int q = 0; q < 2 * CT; ++q) {
+        const int tg = q & 1, ct = q >> 1;
+        if (q) __syncthreads();
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                Vs[((p0 + pt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[pt][tg][r];
+                Ms[((p0 + pt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[pt][tg][ct][r];
         __syncthreads();
+        const float bv = g.bias ? g.bias[n0 + ct * 32 + oc] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int tl = (t >> 5) + 16 * i;              // local tile 0..31 of this group
+            const int tl = (t >> 5) + 16 * i;
             float m[16];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) m[p] = Vs[(p * 32 + tl) * 32 + oc];
+            for (int p = 0; p < 16; ++p) m[p] = Ms[(p * 32 + tl) * 32 + oc];
             float s0[4], s1[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) { s0[c] = m[c] + m[4 + c] + m[8 + c]; s1[c] = m[4 + c] - m[8 + c] - m[12 + c]; }
@@ -212,18 +215,19 @@ __global__ __launch_bounds__(512) void conv_wino_kernel(const WinoGeom g) {
                     float v = yv[dy][dx] + bv;
                     if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
-                    g.y[((size_t)(n * g.H + oy0 + 2 * ty + dy) * g.W + ox0 + 2 * tx + dx) * g.ldy + n0 + oc] = v;
+                    g.y[((size_t)(n * g.H + oy0 + 2 * ty + dy) * g.W + ox0 + 2 * tx + dx) * g.ldy + n0 + ct * 32 + oc] = v;
                 }
         }
     }
 }
 
+static inline int w8_lds_bytes(int ct) { const int main = (W8_RAW + W8_U(ct) + W8_V) * 4; return main > 65536 ? main : 65536; }
 static bool wino_attr_set = false;
 
 // shape / alignment eligibility (stride-1 3x3 SAME only); K = channels of the gathered tensor, Nn = produced channels
 extern "C" int kpx_wino_eligible(int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
     if (getenv("KPX_NO_WINO")) return 0;
-    return (H % 16 == 0) && (W % 16 == 0) && (K % 16 == 0) && (Nn % 32 == 0) && K >= 32 && (ldin % 4 == 0) && (((uintptr_t)in_ptr) & 15) == 0;
+    return (H % 16 == 0) && (W % 16 == 0) && (K % 8 == 0) && (Nn % 32 == 0) && K >= 16 && (ldin % 4 == 0) && (((uintptr_t)in_ptr) & 15) == 0;
 }
 
 // forward: in = x (K = Cin), out = y (Nn = Cout);  dgrad: in = dy (K = Cout), out = dx (Nn = Cin), w always HWIO [3][3][Cin][Cout]
@@ -236,7 +240,9 @@ extern "C" int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int
     int rc = kpx_launch_status();
     if (rc) return rc;
     if (!wino_attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, w8_lds_bytes(1));
+        if (e != hipSuccess) return -(int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, w8_lds_bytes(2));
         if (e != hipSuccess) return -(int)e;
         wino_attr_set = true;
     }
@@ -245,6 +251,10 @@ extern "C" int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int
     g.N = N; g.H = H; g.W = W; g.Cin = K; g.ldx = ldin; g.Cout = Nn; g.ldy = ldout; g.act = act;
     g.tiles_y = H / 16; g.tiles_x = W / 16; g.nt = Nn / 32;
     const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x * g.nt);
-    hipLaunchKernelGGL(conv_wino_kernel, dim3(blocks), dim3(512), WINO_LDS_BYTES, s, g);
+    // 64 output channels per workgroup when that still fills the 256 CUs, else 32
+    static const int force_ct = getenv("KPX_WINO_CT") ? atoi(getenv("KPX_WINO_CT")) : 0;
+    const bool wide = force_ct ? force_ct == 2 : (blocks / 2 >= 256);
+    if (wide && Nn % 64 == 0) hipLaunchKernelGGL(conv_wino8_kernel<2>, dim3(blocks / 2), dim3(512), w8_lds_bytes(2), s, g);
+    else hipLaunchKernelGGL(conv_wino8_kernel<1>, dim3(blocks), dim3(512), w8_lds_bytes(1), s, g);
     return kpx_launch_status();
 }
