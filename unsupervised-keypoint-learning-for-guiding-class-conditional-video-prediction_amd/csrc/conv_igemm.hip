@@ -508,8 +508,8 @@ static int dgrad_splitk_plan(int N, int Hi, int Wi, int Cin, int Cout, int KH, i
 }
 
 // conv_wino.hip: fused Winograd F(2x2,3x3) for the stride-1 3x3 SAME layers
-extern "C" int kpx_wino_eligible(int H, int W, int K, int Nn, int ldin, const void* in_ptr);
-extern "C" int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int Cin, int Cout, int dgrad,
+extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int H, int W, int K, int Nn, int ldin, const void* in_ptr);
+extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int Cin, int Cout, int dgrad,
                                 const float* bias, int act, float* out, int Nn, int ldout, float* U_ws, hipStream_t s);
 static inline size_t wino_ws_bytes(int Cin, int Cout) { return (size_t)16 * Cin * Cout * 4; }
 

@@ -226,13 +226,13 @@ static inline int w8_lds_bytes(int ct) { const int main = (W8_RAW + W8_U(ct) + W
 static bool wino_attr_set = false;
 
 // shape / alignment eligibility (stride-1 3x3 SAME only); K = channels of the gathered tensor, Nn = produced channels
-extern "C" int kpx_wino_eligible(int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
+extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
     if (getenv("KPX_NO_WINO")) return 0;
     return (H % 16 == 0) && (W % 16 == 0) && (K % 8 == 0) && (Nn % 32 == 0) && K >= 16 && (ldin % 4 == 0) && (((uintptr_t)in_ptr) & 15) == 0;
 }
 
 // forward: in = x (K = Cin), out = y (Nn = Cout);  dgrad: in = dy (K = Cout), out = dx (Nn = Cin), w always HWIO [3][3][Cin][Cout]
-extern "C" int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int Cin, int Cout, int dgrad,
+extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int Cin, int Cout, int dgrad,
                                 const float* bias, int act, float* out, int Nn, int ldout, float* U_ws, hipStream_t s) {
     const size_t pairs = (size_t)K * Nn;
     size_t nb = (pairs + 255) / 256; if (nb > 1024) nb = 1024;
