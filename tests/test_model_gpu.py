@@ -77,7 +77,9 @@ def test_tiny_train_steps_match_oracle():
         # Gradients.  The step-0 state of this tiny case (B=2, 32x32, key-point softmax over near-uniform profiles) is
         # ill-conditioned: perturbing pose_encoder/encoder/conv_1's weights by 1e-7 (relative) in the ORACLE moves the
         # pose_encoder gradients by 1.5 % (measured), and a different fp32 summation order is such a perturbation.  So the
-        # per-variable bound is loose and the norm-weighted aggregate over all generator kernels is the tight one; the
+        # per-variable bound is loose and the norm-weighted aggregate over all generator kernels is the tight one (2 %: it measures
+        # 0.6 % with direct convolutions everywhere (KPX_NO_WINO=1) and 1.2 % with the fp32 Winograd kernels, whose ~1e-6 forward
+        # differences this ill-conditioned case amplifies like any other summation-order change); the
         # backward kernels themselves are checked to 1e-5 / 1e-4 one by one in test_ops_gpu.py.
         gnames = [n for n in want['grads_G'] if n.endswith('/kernel') and 'conv_6' not in n]
         num = den = 0.0
@@ -87,7 +89,7 @@ def test_tiny_train_steps_match_oracle():
             num += float(((g - w) ** 2).sum()); den += float((w ** 2).sum())
             if np.linalg.norm(w) > 1e-7:
                 assert rel_l2(g, w) < (5e-2 if step == 0 else 0.2), (step, n, rel_l2(g, w))
-        assert (num / den) ** 0.5 < (1e-2 if step == 0 else 0.1), (step, (num / den) ** 0.5)
+        assert (num / den) ** 0.5 < (2e-2 if step == 0 else 0.1), (step, (num / den) ** 0.5)
         # Re-synchronise the model to the oracle's state (parameters + Adam slots) so that the next step is compared from
         # an identical starting point: sign flips of noise-level gradients under Adam would otherwise compound.
         arrays = {n: p.numpy() for n, p in st.params.items()}

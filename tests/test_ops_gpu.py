@@ -62,7 +62,9 @@ CONV_CASES = [
     (16, 10, 10, 256, 512, 4, 2, 1, 2),    # split-K with stride-2 parity classes (img_discr conv_4 geometry)
     (2, 32, 48, 48, 96, 3, 1, 0, 2),       # fused Winograd F(2x2,3x3): non-square, 3 chunks of 16 channels, lrelu
     (3, 16, 16, 64, 32, 3, 1, 0, 1),       # Winograd, one 16x16 block per image, relu
-    (2, 32, 32, 32, 48, 3, 1, 0, 0),       # Winograd dgrad only (Cout = 48 is not a multiple of 32 -> direct forward)
+    (2, 32, 32, 32, 48, 3, 1, 0, 0),       # Winograd with the produced channels padded to 64 in U and masked on store
+    (2, 16, 16, 16, 16, 3, 1, 0, 1),       # Winograd, 16 -> 16 channels (pose conv_7_1 shape): two chunks, half-empty cout tile
+    (1, 32, 32, 24, 40, 3, 1, 0, 2),       # Winograd, K = 24 (3 chunks), Nn = 40
 ]
 
 
@@ -108,6 +110,14 @@ def test_conv_reads_and_writes_channel_slices(kpx, dev):
     want3 = R.conv(torch.from_numpy(full3[..., 16:80].copy()), torch.from_numpy(w3), None, 1)
     got3 = kpx.ops.conv2d(torch.from_numpy(full3).to(dev)[..., 16:80], torch.from_numpy(w3).to(dev), None, stride=1)
     assert rel_l2(t2n(got3), t2n(want3)) < 1e-5
+    # Winograd with a padded last channel chunk: 158 of 160 channels (translator conv_1_0); the two pad channels hold NaN and
+    # must not reach the result
+    full4 = rs.randn(2, 16, 16, 160).astype(np.float32)
+    w4 = (rs.randn(3, 3, 158, 32) * 0.05).astype(np.float32)
+    want4 = R.conv(torch.from_numpy(full4[..., :158].copy()), torch.from_numpy(w4), None, 1)
+    full4[..., 158:] = np.nan
+    got4 = kpx.ops.conv2d(torch.from_numpy(full4).to(dev), torch.from_numpy(w4).to(dev), None, stride=1, cin=158)
+    assert rel_l2(t2n(got4), t2n(want4)) < 1e-5
 
 
 @pytest.mark.parametrize('groups', [1, 2])

@@ -511,7 +511,10 @@ static int dgrad_splitk_plan(int N, int Hi, int Wi, int Cin, int Cout, int KH, i
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int H, int W, int K, int Nn, int ldin, const void* in_ptr);
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int Cin, int Cout, int dgrad,
                                 const float* bias, int act, float* out, int Nn, int ldout, float* U_ws, hipStream_t s);
-static inline size_t wino_ws_bytes(int Cin, int Cout) { return (size_t)16 * Cin * Cout * 4; }
+static inline size_t wino_ws_bytes(int Cin, int Cout) {          // U[16][K padded to 8][Nn padded to 32] for either direction
+    const size_t a = (size_t)((Cin + 7) & ~7) * ((Cout + 31) & ~31), b = (size_t)((Cout + 7) & ~7) * ((Cin + 31) & ~31);
+    return 16 * 4 * (a > b ? a : b);
+}
 
 extern "C" size_t kpx_conv2d_fwd_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
     if (Cin % 4 != 0) return 0;

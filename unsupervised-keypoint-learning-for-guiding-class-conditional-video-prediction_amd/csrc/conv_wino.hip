@@ -16,7 +16,8 @@
 
 struct WinoGeom {
     const float* x; float* y; const float* U; const float* bias;
-    int N, H, W, Cin, ldx, Cout, ldy, act;
+    int N, H, W, Cin, ldx, Cout, ldy, act;      // Cin / Cout: gathered / produced channels (real counts)
+    int Kp, Np;                                 // U is [16][Kp][Np]: Kp = Cin rounded up to 8, Np = Cout rounded up to 32 (zero padded)
     int tiles_y, tiles_x, nt;          // 16x16-pixel blocks per image, cout tiles of 32
 };
 
@@ -24,18 +25,19 @@ static __device__ __attribute__((aligned(16))) float wino_zero16[4] = {0.f, 0.f,
 
 // U[p][c][n] = sum_{r,q} G[i][r] g[r][q][c][n] G[j][q], p = 4*i + j.   dgrad: g'[r][q][c'][n'] = w[2-r][2-q][n'][c'].
 template <bool DGRAD>
-__global__ __launch_bounds__(256) void wino_filter_transform_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ U) {
-    // forward: K = Cin, Nn = Cout;  dgrad: K = Cout (channels of dy), Nn = Cin
+__global__ __launch_bounds__(256) void wino_filter_transform_kernel(const float* __restrict__ w, int Cin, int Cout, int Kp, int Np, float* __restrict__ U) {
+    // forward: K = Cin, Nn = Cout;  dgrad: K = Cout (channels of dy), Nn = Cin.  Rows >= K and columns >= Nn of U are zero.
     const int K = DGRAD ? Cout : Cin, Nn = DGRAD ? Cin : Cout;
-    const size_t total = (size_t)K * Nn;
+    const size_t total = (size_t)Kp * Np;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int c = (int)(idx / Nn), n = (int)(idx - (size_t)c * Nn);
+        const int c = (int)(idx / Np), n = (int)(idx - (size_t)c * Np);
+        const bool real = c < K && n < Nn;
         float g[3][3];
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                g[r][q] = DGRAD ? w[((size_t)((2 - r) * 3 + (2 - q)) * Cin + n) * Cout + c] : w[((size_t)(r * 3 + q) * Cin + c) * Cout + n];
+                g[r][q] = !real ? 0.f : (DGRAD ? w[((size_t)((2 - r) * 3 + (2 - q)) * Cin + n) * Cout + c] : w[((size_t)(r * 3 + q) * Cin + c) * Cout + n]);
         float t[4][3];                                   // G g
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -47,10 +49,10 @@ __global__ __launch_bounds__(256) void wino_filter_transform_kernel(const float*
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                    // (G g) G^T
             const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), u3 = t[i][2];
-            U[((size_t)(i * 4 + 0) * K + c) * Nn + n] = u0;
-            U[((size_t)(i * 4 + 1) * K + c) * Nn + n] = u1;
-            U[((size_t)(i * 4 + 2) * K + c) * Nn + n] = u2;
-            U[((size_t)(i * 4 + 3) * K + c) * Nn + n] = u3;
+            U[((size_t)(i * 4 + 0) * Kp + c) * Np + n] = u0;
+            U[((size_t)(i * 4 + 1) * Kp + c) * Np + n] = u1;
+            U[((size_t)(i * 4 + 2) * Kp + c) * Np + n] = u2;
+            U[((size_t)(i * 4 + 3) * Kp + c) * Np + n] = u3;
         }
     }
 }
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
     int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
-    const int ntc = g.Cout / NC;
+    const int ntc = g.Np / NC;
     const int nti = L % ntc; L /= ntc;
     const int bx = L % g.tiles_x; L /= g.tiles_x;
     const int by = L % g.tiles_y;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
 #pragma unroll
     for (int i = 0; i < 2 * CT; ++i) {
         const int u = t + 512 * i, sl = u % (NC / 4), ch = (u / (NC / 4)) & 7, pt = u / (2 * NC);
-        up[i] = g.U + ((size_t)pt * g.Cin + ch) * g.Cout + n0 + sl * 4;
+        up[i] = g.U + ((size_t)pt * g.Kp + ch) * g.Np + n0 + sl * 4;
     }
     // transform item: 16-B half, tile, row of V = B^T d B (uniform per wave pair)
     const int tslot = t & 1, ttile = (t >> 1) & 63, vrow = t >> 7;
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
                 for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
 
     f32x4 rr[2], ru[2 * CT];
-    const size_t ustep = (size_t)8 * g.Cout;
+    const size_t ustep = (size_t)8 * g.Np;
     auto load_chunk = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i) { rr[i] = *reinterpret_cast<const f32x4*>(rp[i]); if (rok[i]) rp[i] += 8; }
@@ -141,7 +143,8 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
         for (int i = 0; i < 2 * CT; ++i) { ru[i] = *reinterpret_cast<const f32x4*>(up[i]); up[i] += ustep; }
     };
 
-    const int nchunks = g.Cin / 8;
+    const int nchunks = g.Kp / 8;
+    const int ktail = g.Cin - (nchunks - 1) * 8 - tslot * 4;      // valid channels of this thread's 16-B half in the LAST chunk (<4: pad)
     load_chunk();
     for (int ch = 0; ch < nchunks; ++ch) {
         *reinterpret_cast<f32x4*>(&raw[t * 4]) = rr[0];
@@ -156,6 +159,12 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
                 const f32x4 a = *reinterpret_cast<const f32x4*>(&raw[trd[c]]);
                 const f32x4 b = *reinterpret_cast<const f32x4*>(&raw[trd[c] + trb]);
                 tr[c] = a + sgn * b;
+            }
+            if (ch == nchunks - 1 && ktail < 4) {        // channels >= Cin of a padded last chunk: whatever the buffer holds there must not reach V
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (j >= ktail) tr[c][j] = 0.f;
             }
             *reinterpret_cast<f32x4*>(&Vs[vwr]) = tr[0] - tr[2];
             *reinterpret_cast<f32x4*>(&Vs[vwr + 512]) = tr[1] + tr[2];
@@ -195,7 +204,8 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
             for (int r = 0; r < 16; ++r)
                 Ms[((p0 + pt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[pt][tg][ct][r];
         __syncthreads();
-        const float bv = g.bias ? g.bias[n0 + ct * 32 + oc] : 0.f;
+        const bool ocv = n0 + ct * 32 + oc < g.Cout;
+        const float bv = (g.bias && ocv) ? g.bias[n0 + ct * 32 + oc] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int tl = (t >> 5) + 16 * i;
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
                     float v = yv[dy][dx] + bv;
                     if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
-                    g.y[((size_t)(n * g.H + oy0 + 2 * ty + dy) * g.W + ox0 + 2 * tx + dx) * g.ldy + n0 + ct * 32 + oc] = v;
+                    if (ocv) g.y[((size_t)(n * g.H + oy0 + 2 * ty + dy) * g.W + ox0 + 2 * tx + dx) * g.ldy + n0 + ct * 32 + oc] = v;
                 }
         }
     }
@@ -228,16 +238,18 @@ static bool wino_attr_set = false;
 // shape / alignment eligibility (stride-1 3x3 SAME only); K = channels of the gathered tensor, Nn = produced channels
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
     if (getenv("KPX_NO_WINO")) return 0;
-    return (H % 16 == 0) && (W % 16 == 0) && (K % 8 == 0) && (Nn % 32 == 0) && K >= 16 && (ldin % 4 == 0) && (((uintptr_t)in_ptr) & 15) == 0;
+    // K is padded to a multiple of 8 (the pad channels must exist in the row: ldin >= Kp) and Nn to a multiple of 32
+    return (H % 16 == 0) && (W % 16 == 0) && K >= 16 && Nn >= 16 && ldin >= ((K + 7) & ~7) && (ldin % 4 == 0) && (((uintptr_t)in_ptr) & 15) == 0;
 }
 
 // forward: in = x (K = Cin), out = y (Nn = Cout);  dgrad: in = dy (K = Cout), out = dx (Nn = Cin), w always HWIO [3][3][Cin][Cout]
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int Cin, int Cout, int dgrad,
                                 const float* bias, int act, float* out, int Nn, int ldout, float* U_ws, hipStream_t s) {
-    const size_t pairs = (size_t)K * Nn;
+    const int Kp = (K + 7) & ~7, Np = (Nn + 31) & ~31;
+    const size_t pairs = (size_t)Kp * Np;
     size_t nb = (pairs + 255) / 256; if (nb > 1024) nb = 1024;
-    if (dgrad) hipLaunchKernelGGL(wino_filter_transform_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, U_ws);
-    else hipLaunchKernelGGL(wino_filter_transform_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, U_ws);
+    if (dgrad) hipLaunchKernelGGL(wino_filter_transform_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
+    else hipLaunchKernelGGL(wino_filter_transform_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
     int rc = kpx_launch_status();
     if (rc) return rc;
     if (!wino_attr_set) {
@@ -250,12 +262,13 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const floa
     WinoGeom g{};
     g.x = in; g.y = out; g.U = U_ws; g.bias = bias;
     g.N = N; g.H = H; g.W = W; g.Cin = K; g.ldx = ldin; g.Cout = Nn; g.ldy = ldout; g.act = act;
-    g.tiles_y = H / 16; g.tiles_x = W / 16; g.nt = Nn / 32;
+    g.Kp = Kp; g.Np = Np;
+    g.tiles_y = H / 16; g.tiles_x = W / 16; g.nt = Np / 32;
     const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x * g.nt);
     // 64 output channels per workgroup when that still fills the 256 CUs, else 32
     static const int force_ct = getenv("KPX_WINO_CT") ? atoi(getenv("KPX_WINO_CT")) : 0;
     const bool wide = force_ct ? force_ct == 2 : (blocks / 2 >= 256);
-    if (wide && Nn % 64 == 0) hipLaunchKernelGGL(conv_wino8_kernel<2>, dim3(blocks / 2), dim3(512), w8_lds_bytes(2), s, g);
+    if (wide && Np % 64 == 0) hipLaunchKernelGGL(conv_wino8_kernel<2>, dim3(blocks / 2), dim3(512), w8_lds_bytes(2), s, g);
     else hipLaunchKernelGGL(conv_wino8_kernel<1>, dim3(blocks), dim3(512), w8_lds_bytes(1), s, g);
     return kpx_launch_status();
 }
