@@ -508,7 +508,7 @@ static int dgrad_splitk_plan(int N, int Hi, int Wi, int Cin, int Cout, int KH, i
 }
 
 // conv_wino.hip: fused Winograd F(2x2,3x3) for the stride-1 3x3 SAME layers
-extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int H, int W, int K, int Nn, int ldin, const void* in_ptr);
+extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr);
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int Cin, int Cout, int dgrad,
                                 const float* bias, int act, float* out, int Nn, int ldout, float* U_ws, hipStream_t s);
 static inline size_t wino_ws_bytes(int Cin, int Cout) {          // U[16][K padded to 8][Nn padded to 32] for either direction
@@ -539,7 +539,7 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
         KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || ldy < Cout || act < 0 || act > 3)
         return KPX_EINVAL;
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && act != KPX_ACT_TANH && aligned16(w) &&
-        workspace && workspace_bytes >= wino_ws_bytes(Cin, Cout) && kpx_wino_eligible(Hi, Wi, Cin, Cout, ldx, x))
+        workspace && workspace_bytes >= wino_ws_bytes(Cin, Cout) && kpx_wino_eligible(N, Hi, Wi, Cin, Cout, ldx, x))
         return kpx_wino_conv3x3(x, N, Hi, Wi, Cin, ldx, w, Cin, Cout, 0, bias, act, y, Cout, ldy, (float*)workspace, kpx_stream(stream));
     ConvGeom g{};
     g.x = x; g.y = y; g.w = w; g.bias = bias;
@@ -569,7 +569,7 @@ extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int 
         return KPX_EINVAL;
     if (stride > 2) return KPX_EINVAL;             // at most 4 parity classes per launch (the path has strides 1 and 2)
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi &&
-        workspace && workspace_bytes >= wino_ws_bytes(Cin, Cout) && kpx_wino_eligible(Hi, Wi, Cout, Cin, lddy, dy))
+        workspace && workspace_bytes >= wino_ws_bytes(Cin, Cout) && kpx_wino_eligible(N, Hi, Wi, Cout, Cin, lddy, dy))
         return kpx_wino_conv3x3(dy, N, Hi, Wi, Cout, lddy, w, Cin, Cout, 1, nullptr, KPX_ACT_NONE, dx, Cin, lddx, (float*)workspace, kpx_stream(stream));
     ConvGeom g{};
     g.x = dy; g.y = dx; g.w = w; g.bias = nullptr;

@@ -17,6 +17,7 @@
 struct WinoGeom {
     const float* x; float* y; const float* U; const float* bias;
     int N, H, W, Cin, ldx, Cout, ldy, act;      // Cin / Cout: gathered / produced channels (real counts)
+    int pack;                                   // 1: H = W = 8, one workgroup = 4 consecutive images as a 2x2 mosaic
     int Kp, Np;                                 // U is [16][Kp][Np]: Kp = Cin rounded up to 8, Np = Cout rounded up to 32 (zero padded)
     int tiles_y, tiles_x, nt;          // 16x16-pixel blocks per image, cout tiles of 32
 };
@@ -64,7 +65,8 @@ __global__ __launch_bounds__(256) void wino_filter_transform_kernel(const float*
 // Measured on MI355X (s_memtime stamps, PMC): in this kernel family the transform / staging work does NOT overlap the MFMA stream
 // (neither across wavefronts -- wave-specialised and anti-phase variants serialise completely -- nor as fillers between a wave's
 // own MFMAs), so time = MFMA time + other time and the lever is less "other" work per MFMA, i.e. the bigger tile.
-#define W8_RAW 2880        // 18 rows x 20 positions (18 pixels + 2 pad) x 8 channels; pixel order [0..7,16,8..15,17] within a row (see w8_pos)
+#define W8_RAW 3200        // 20 rows x 20 positions x 8 channels.  Plain mode: 18 rows x 18 pixels of one image, pixel order [0..7,16,8..15,17]
+                           // within a row (see w8_pos).  Packed mode (8x8 images, VGG conv5): 2x2 images, each a 10x10 block with its own zero halo.
 #define W8_V 8192          // 16 points x 64 tiles x 8 channels; 16-B half swizzled by (tile>>3)&1
 #define W8_U(CT) (4096 * (CT))   // 16 points x 8 channels x 32*CT couts
 
@@ -89,17 +91,26 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
     const int nti = L % ntc; L /= ntc;
     const int bx = L % g.tiles_x; L /= g.tiles_x;
     const int by = L % g.tiles_y;
-    const int n = L / g.tiles_y;
+    const int n = g.pack ? 4 * L : L / g.tiles_y;       // packed: images n .. n+3
     const int oy0 = by * 16, ox0 = bx * 16, n0 = nti * NC;
 
-    // raw patch units: u = t + 512*i < 720 : position u>>1 (18 rows x 20 positions, the last 2 of a row are padding), 16-B half u&1
+    // raw patch units: u = t + 512*i < 720 (800 packed): position u>>1 (rows x 20 positions), 16-B half u&1
     const float* rp[2]; bool rok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int u = t + 512 * i, q = u >> 1, py = q / 20, ps = q - py * 20, pxx = w8_pix(ps);
-        const int iy = oy0 - 1 + py, ix = ox0 - 1 + pxx;
-        rok[i] = u < 720 && ps < 18 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-        rp[i] = rok[i] ? g.x + ((size_t)(n * g.H + iy) * g.W + ix) * g.ldx + (u & 1) * 4 : wino_zero16;
+        const int u = t + 512 * i, q = u >> 1, py = q / 20, ps = q - py * 20;
+        int iy, ix, ni = n;
+        bool ok;
+        if (g.pack) {            // row / column 10*s + 1 + l holds pixel l of sub-image s; 10*s and 10*s + 9 are its zero halo
+            const int sy = py / 10, sx = ps / 10;
+            iy = py - 10 * sy - 1; ix = ps - 10 * sx - 1; ni = n + 2 * sy + sx;
+            ok = u < 800 && (unsigned)iy < 8u && (unsigned)ix < 8u;
+        } else {
+            iy = oy0 - 1 + py; ix = ox0 - 1 + w8_pix(ps);
+            ok = u < 720 && ps < 18 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        }
+        rok[i] = ok;
+        rp[i] = ok ? g.x + ((size_t)(ni * g.H + iy) * g.W + ix) * g.ldx + (u & 1) * 4 : wino_zero16;
     }
     // U slice units: u = t + 512*i < 1024*CT : [point][channel 8][NC/4 slots]
     const float* up[2 * CT];
@@ -115,7 +126,9 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
     const float sgn = vrow == 1 ? 1.f : -1.f;
     int trd[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) trd[c] = (2 * tty + ra) * 160 + w8_pos(2 * ttx + c) * 8 + tslot * 4;
+    for (int c = 0; c < 4; ++c)
+        trd[c] = g.pack ? ((tty >> 2) * 10 + 2 * (tty & 3) + ra) * 160 + ((ttx >> 2) * 10 + 2 * (ttx & 3) + c) * 8 + tslot * 4
+                        : (2 * tty + ra) * 160 + w8_pos(2 * ttx + c) * 8 + tslot * 4;
     const int trb = (rb - ra) * 160;
     const int vwr = (vrow * 4) * 512 + ttile * 8 + ((tslot ^ ((ttile >> 3) & 1)) << 2);
     int a_rd[2];
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
     load_chunk();
     for (int ch = 0; ch < nchunks; ++ch) {
         *reinterpret_cast<f32x4*>(&raw[t * 4]) = rr[0];
-        if (t < 208) *reinterpret_cast<f32x4*>(&raw[(t + 512) * 4]) = rr[1];
+        if (t < 288) *reinterpret_cast<f32x4*>(&raw[(t + 512) * 4]) = rr[1];
 #pragma unroll
         for (int i = 0; i < 2 * CT; ++i) *reinterpret_cast<f32x4*>(&Us[(t + 512 * i) * 4]) = ru[i];
         __syncthreads();
@@ -219,6 +232,8 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
             yv[0][0] = s0[0] + s0[1] + s0[2]; yv[0][1] = s0[1] - s0[2] - s0[3];
             yv[1][0] = s1[0] + s1[1] + s1[2]; yv[1][1] = s1[1] - s1[2] - s1[3];
             const int tile = tg * 32 + tl, ty = tile >> 3, tx = tile & 7;
+            const int on = g.pack ? n + 2 * (ty >> 2) + (tx >> 2) : n;
+            const int oy = g.pack ? 2 * (ty & 3) : oy0 + 2 * ty, ox = g.pack ? 2 * (tx & 3) : ox0 + 2 * tx;
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -226,7 +241,7 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
                     float v = yv[dy][dx] + bv;
                     if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
-                    if (ocv) g.y[((size_t)(n * g.H + oy0 + 2 * ty + dy) * g.W + ox0 + 2 * tx + dx) * g.ldy + n0 + ct * 32 + oc] = v;
+                    if (ocv) g.y[((size_t)(on * g.H + oy + dy) * g.W + ox + dx) * g.ldy + n0 + ct * 32 + oc] = v;
                 }
         }
     }
@@ -236,10 +251,11 @@ static inline int w8_lds_bytes(int ct) { const int main = (W8_RAW + W8_U(ct) + W
 static bool wino_attr_set = false;
 
 // shape / alignment eligibility (stride-1 3x3 SAME only); K = channels of the gathered tensor, Nn = produced channels
-extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
+extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
     if (getenv("KPX_NO_WINO")) return 0;
     // K is padded to a multiple of 8 (the pad channels must exist in the row: ldin >= Kp) and Nn to a multiple of 32
-    return (H % 16 == 0) && (W % 16 == 0) && K >= 16 && Nn >= 16 && ldin >= ((K + 7) & ~7) && (ldin % 4 == 0) && (((uintptr_t)in_ptr) & 15) == 0;
+    const bool shape = (H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8 && N % 4 == 0);      // 8x8 images are packed four to a workgroup
+    return shape && K >= 16 && Nn >= 16 && ldin >= ((K + 7) & ~7) && (ldin % 4 == 0) && (((uintptr_t)in_ptr) & 15) == 0;
 }
 
 // forward: in = x (K = Cin), out = y (Nn = Cout);  dgrad: in = dy (K = Cout), out = dx (Nn = Cin), w always HWIO [3][3][Cin][Cout]
@@ -263,8 +279,9 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const floa
     g.x = in; g.y = out; g.U = U_ws; g.bias = bias;
     g.N = N; g.H = H; g.W = W; g.Cin = K; g.ldx = ldin; g.Cout = Nn; g.ldy = ldout; g.act = act;
     g.Kp = Kp; g.Np = Np;
-    g.tiles_y = H / 16; g.tiles_x = W / 16; g.nt = Np / 32;
-    const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x * g.nt);
+    g.pack = (H == 8 && W == 8) ? 1 : 0;
+    g.tiles_y = g.pack ? 1 : H / 16; g.tiles_x = g.pack ? 1 : W / 16; g.nt = Np / 32;
+    const unsigned blocks = (unsigned)((size_t)(g.pack ? N / 4 : N) * g.tiles_y * g.tiles_x * g.nt);
     // 64 output channels per workgroup when that still fills the 256 CUs, else 32
     static const int force_ct = getenv("KPX_WINO_CT") ? atoi(getenv("KPX_WINO_CT")) : 0;
     const bool wide = force_ct ? force_ct == 2 : (blocks / 2 >= 256);
