@@ -511,6 +511,10 @@ static int dgrad_splitk_plan(int N, int Hi, int Wi, int Cin, int Cout, int KH, i
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr);
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int Cin, int Cout, int dgrad,
                                 const float* bias, int act, float* out, int Nn, int ldout, float* U_ws, hipStream_t s);
+// conv_rgb.hip: LDS-resident first-layer kernel (Cin <= 4, stride 1)
+extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW,
+                                                                  const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
+                                                                  int pad_t, int pad_l, int act, hipStream_t s);
 static inline size_t wino_ws_bytes(int Cin, int Cout) {          // U[16][K padded to 8][Nn padded to 32] for either direction
     const size_t a = (size_t)((Cin + 7) & ~7) * ((Cout + 31) & ~31), b = (size_t)((Cout + 7) & ~7) * ((Cin + 31) & ~31);
     return 16 * 4 * (a > b ? a : b);
@@ -541,6 +545,10 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && act != KPX_ACT_TANH && aligned16(w) &&
         workspace && workspace_bytes >= wino_ws_bytes(Cin, Cout) && kpx_wino_eligible(N, Hi, Wi, Cin, Cout, ldx, x))
         return kpx_wino_conv3x3(x, N, Hi, Wi, Cin, ldx, w, Cin, Cout, 0, bias, act, y, Cout, ldy, (float*)workspace, kpx_stream(stream));
+    if (Cin <= 4 && ldx == Cin && stride == 1 && Cout <= 64 && Ho * Wo >= 256) {       // image-input layers: patch + filter resident in LDS
+        const int rc = kpx_conv_rgb_fwd(x, N, Hi, Wi, Cin, w, KH, KW, bias, y, Ho, Wo, Cout, ldy, pad_t, pad_l, act, kpx_stream(stream));
+        if (rc != -2) return rc;
+    }
     ConvGeom g{};
     g.x = x; g.y = y; g.w = w; g.bias = bias;
     g.N = N; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.ldx = ldx;

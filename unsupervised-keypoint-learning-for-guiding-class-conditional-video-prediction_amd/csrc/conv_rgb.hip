@@ -1,0 +1,118 @@
+// First-layer convolutions (image input, Cin <= 4, stride 1): the encoders' 7x7x3 -> 32 (reference models/networks/__init__.py:13)
+// and VGG19 conv1_1 3x3x3 -> 64 (models/networks/vgg.py:51).  The implicit-GEMM kernel has to gather these with scalar, unaligned
+// loads (a pixel is 12 bytes); here one workgroup stages the whole input patch of a 16x16 output tile (22x22x3 floats for 7x7) and
+// the complete filter in LDS once and runs the K = KH*KW*Cin contraction out of LDS with v_mfma_f32_32x32x2_f32:
+// the KW*Cin floats of a filter row are contiguous in NHWC, so k runs over (row, kk < KW*Cin) and the A operand of pixel (y, x) is
+// patch[(y + r) * PWC + x * Cin + kk].  4 wavefronts x 2 M-tiles of 32 pixels (two output rows) x Cout/32 N-tiles.
+#include "kpx_common.h"
+
+struct RgbGeom {
+    const float* x; const float* w; const float* bias; float* y;
+    int N, Hi, Wi, Cin, Ho, Wo, Cout, ldy;
+    int KH, KW, pad_t, pad_l, act;
+    int tiles_y, tiles_x;
+    int PH, PWC, KWC, KWCp;          // patch rows, floats per patch row (+ slack), floats per filter row, padded to even
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_rgb_kernel(const RgbGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* patch = smem;                                   // [PH][PWC] (+4 zero floats)
+    float* Ws = smem + ((g.PH * g.PWC + 4 + 3) & ~3);      // [KH][KWCp][32*NT]
+    constexpr int NC = 32 * NT;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+    int L = blockIdx.x;
+    const int bx = L % g.tiles_x; L /= g.tiles_x;
+    const int by = L % g.tiles_y;
+    const int n = L / g.tiles_y;
+    const int oy0 = by * 16, ox0 = bx * 16;
+
+    // ---- stage the patch (zero outside the image) and the filter (zero pad row when KW*Cin is odd)
+    const int iy0 = oy0 - g.pad_t, ixc0 = (ox0 - g.pad_l) * g.Cin, rowlen = g.Wi * g.Cin;
+    for (int i = t; i < g.PH * g.PWC + 4; i += 256) {
+        const int pr = i / g.PWC, pc = i - pr * g.PWC;
+        const int iy = iy0 + pr, ic = ixc0 + pc;
+        float v = 0.f;
+        if (pr < g.PH && (unsigned)iy < (unsigned)g.Hi && (unsigned)ic < (unsigned)rowlen) v = g.x[((size_t)n * g.Hi + iy) * rowlen + ic];
+        patch[i] = v;
+    }
+    for (int i = t; i < g.KH * g.KWCp * NC; i += 256) {
+        const int nn = i % NC, kk = (i / NC) % g.KWCp, r = i / (NC * g.KWCp);
+        Ws[i] = (kk < g.KWC && nn < g.Cout) ? g.w[((size_t)r * g.KWC + kk) * g.Cout + nn] : 0.f;
+    }
+    __syncthreads();
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // lane's pixel inside M-tile mt: row 2*mt + li/16, column li%16
+    const int a0 = (2 * (2 * wave) + (li >> 4)) * g.PWC + (li & 15) * g.Cin + lh;
+    const int a1 = a0 + 2 * g.PWC;
+    const int b0 = lh * NC + li;
+    const int ks = g.KWCp >> 1;
+    for (int r = 0; r < g.KH; ++r) {
+        const float* pa = patch + r * g.PWC;
+        const float* pb = Ws + r * g.KWCp * NC + b0;
+        for (int s = 0; s < ks; ++s) {
+            const float va0 = pa[a0 + 2 * s], va1 = pa[a1 + 2 * s];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float vb = pb[2 * s * NC + nt * 32];
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, vb, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, vb, acc[1][nt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = nt * 32 + li;
+            if (c >= g.Cout) continue;
+            const float bv = g.bias ? g.bias[c] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;           // pixel of the 32-pixel M-tile
+                const int oy = oy0 + 2 * (2 * wave + mt) + (m >> 4), ox = ox0 + (m & 15);
+                if (oy < g.Ho && ox < g.Wo) {
+                    float v = acc[mt][nt][r] + bv;
+                    if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+                    else if (g.act == KPX_ACT_TANH) v = tanhf(v);
+                    g.y[(((size_t)n * g.Ho + oy) * g.Wo + ox) * g.ldy + c] = v;
+                }
+            }
+        }
+}
+
+static bool rgb_attr_set = false;
+
+// stride-1 convolutions of a dense (ldx == Cin) image with Cin <= 4 and Cout <= 64; returns -2 when the shape is not handled
+extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW,
+                                                                  const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
+                                                                  int pad_t, int pad_l, int act, hipStream_t s) {
+    if (Cin > 4 || Cout > 64 || KH > 7 || KW > 7 || getenv("KPX_NO_RGB")) return -2;
+    RgbGeom g{};
+    g.x = x; g.w = w; g.bias = bias; g.y = y;
+    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
+    g.KH = KH; g.KW = KW; g.pad_t = pad_t; g.pad_l = pad_l; g.act = act;
+    g.tiles_y = (Ho + 15) / 16; g.tiles_x = (Wo + 15) / 16;
+    g.KWC = KW * Cin; g.KWCp = (g.KWC + 1) & ~1;
+    g.PH = 15 + KH; g.PWC = (15 + KW) * Cin + 1;          // +1: the padded k of the last pixel stays inside the row
+    const int nt = Cout <= 32 ? 1 : 2;
+    const size_t lds = ((size_t)((g.PH * g.PWC + 4 + 3) & ~3) + (size_t)KH * g.KWCp * 32 * nt) * 4;
+    if (!rgb_attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rgb_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        if (e != hipSuccess) return -(int)e;
+        rgb_attr_set = true;
+    }
+    if (lds > 98304) return -2;
+    const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x);
+    if (nt == 1) hipLaunchKernelGGL(conv_rgb_kernel<1>, dim3(blocks), dim3(256), lds, s, g);
+    else hipLaunchKernelGGL(conv_rgb_kernel<2>, dim3(blocks), dim3(256), lds, s, g);
+    return kpx_launch_status();
+}
