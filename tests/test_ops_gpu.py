@@ -65,6 +65,7 @@ CONV_CASES = [
     (2, 32, 32, 32, 48, 3, 1, 0, 0),       # Winograd with the produced channels padded to 64 in U and masked on store
     (2, 16, 16, 16, 16, 3, 1, 0, 1),       # Winograd, 16 -> 16 channels (pose conv_7_1 shape): two chunks, half-empty cout tile
     (1, 32, 32, 24, 40, 3, 1, 0, 2),       # Winograd, K = 24 (3 chunks), Nn = 40
+    (8, 32, 64, 64, 128, 3, 1, 0, 0),      # Winograd weight gradient (64-channel tiles, non-square image, 64 splits)
 ]
 
 

@@ -515,6 +515,9 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const floa
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW,
                                                                   const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
                                                                   int pad_t, int pad_l, int act, hipStream_t s);
+extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N, int H, int W, int Cin, int Cout);
+extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad3x3(const float* x, int N, int H, int W, int Cin, int ldx, const float* dy, int Cout, int lddy,
+                                                                   float* slabs, int S, hipStream_t s);
 static inline size_t wino_ws_bytes(int Cin, int Cout) {          // U[16][K padded to 8][Nn padded to 32] for either direction
     const size_t a = (size_t)((Cin + 7) & ~7) * ((Cout + 31) & ~31), b = (size_t)((Cout + 7) & ~7) * ((Cin + 31) & ~31);
     return 16 * 4 * (a > b ? a : b);
@@ -1259,6 +1262,11 @@ static int wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW
 extern "C" size_t kpx_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
     const int S = wgrad_splits(N, Ho, Wo, Cin, Cout, KH, KW);
     size_t need = S > 1 ? (size_t)S * KH * KW * Cin * Cout * 4 : 0;
+    if (KH == 3 && KW == 3) {                      // Winograd wgrad (stride / padding unknown here: upper bound)
+        const int Sw = kpx_wino_wgrad_splits(N, Ho, Wo, Cin, Cout);
+        const size_t nw = (size_t)Sw * 9 * Cin * Cout * 4;
+        if (Sw > 1 && nw > need) need = nw;
+    }
     int S2, cpb, CT;
     if (wgrad_rows_plan(N, Ho, Wo, Cin, Cout, KH, KW, &S2, &cpb, &CT)) {
         const size_t n2 = (size_t)S2 * KH * KW * Cin * Cout * 4;
@@ -1278,6 +1286,18 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     if (!x || !dy || !dw || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || lddy < Cout)
         return KPX_EINVAL;
+    if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && ldx % 4 == 0 && lddy % 4 == 0 &&
+        aligned16(x) && aligned16(dy)) {
+        const int Sw = kpx_wino_wgrad_splits(N, Hi, Wi, Cin, Cout);
+        const size_t slab = (size_t)9 * Cin * Cout;
+        if (Sw >= 1 && (Sw == 1 || (workspace && workspace_bytes >= (size_t)Sw * slab * 4))) {
+            hipStream_t s = kpx_stream(stream);
+            int rc = kpx_wino_wgrad3x3(x, N, Hi, Wi, Cin, ldx, dy, Cout, lddy, Sw > 1 ? (float*)workspace : dw, Sw, s);
+            if (rc) return rc;
+            if (Sw > 1) { launch_wgrad_reduce((const float*)workspace, dw, slab, Sw, s); rc = kpx_launch_status(); }
+            return rc;
+        }
+    }
     {
         int S2, cpb;
         if (stride == 1 && ldx == Cin && lddy % 4 == 0 && aligned16(dy) && wgrad_rows_merged_plan(N, Ho, Wo, Cin, Cout, KH, KW, &S2, &cpb)) {

@@ -289,3 +289,196 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const floa
     else hipLaunchKernelGGL(conv_wino8_kernel<1>, dim3(blocks), dim3(512), w8_lds_bytes(1), s, g);
     return kpx_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------ Winograd weight gradient
+// dU[p][c][n] = sum over 2x2-output tiles of V[p][tile][c] * dM[p][tile][n]   (V = B^T d B of the input patch, dM = A dY A^T of the
+// 2x2 output-gradient tile), then dg = G^T dU G: 16 multiplies per tile instead of 36, like the forward.  GEMM view per point:
+// M = Cin, N = Cout, K = tiles.  One workgroup (8 wavefronts) owns a 64 x 64 (c, n) block for all 16 points and a contiguous range
+// of tile chunks (split-K over the batch); wave w holds points 2w, 2w+1 as 2 x (2 x 2) accumulators of 32x32.  A chunk is 4 x 2
+// tiles = 8 x 4 output pixels: its 10 x 6 input patch and 8 x 4 dy pixels (64 channels each) are staged in LDS, transformed into
+// V[16][8][64] and D[16][8][64], and multiplied with ds_read_b32 operands (K = tile index).  The epilogue applies G^T . G and
+// writes a partial HWIO slab per split; the fixed-order wgrad_reduce_kernel sums the slabs (bitwise reproducible, no atomics).
+struct WinoWgradGeom {
+    const float* x; const float* dy; float* out;      // out: [S][9][Cin][Cout] partial slabs (or dw itself when S == 1)
+    int N, H, W, Cin, ldx, Cout, lddy;
+    int cit, cot, S, cps, total_chunks, chy, chx;     // 64-channel tiles, splits, chunks per split, chunks per image column / row
+    size_t slab;
+};
+
+#define WW_RAWX 3840       // 6 rows x 10 pixels x 64 channels
+#define WW_RAWD 2048       // 4 rows x 8 pixels x 64 channels
+#define WW_V 8192          // 16 points x 8 tiles x 64 channels
+#define WW_LDS_FLOATS (WW_RAWX + WW_RAWD + 2 * WW_V)      // 22272 floats = 87 KB; epilogue M[16][32][32] (64 KB) overlays the front
+
+__global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const WinoWgradGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* rawx = smem;
+    float* rawd = smem + WW_RAWX;
+    float* Vs = smem + WW_RAWX + WW_RAWD;
+    float* Ds = Vs + WW_V;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+    int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = L % g.S; L /= g.S;
+    const int cot = L % g.cot, cit = L / g.cot;
+    const int c0 = cit * 64, n0 = cot * 64;
+
+    // staging units (fixed per thread): x patch 60 pixels x 16 slots = 960 (t, t+512), dy 32 pixels x 16 slots = 512 (t)
+    int xpr[2], xpc[2]; bool xin[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int u = t + 512 * i, px = u >> 4; xin[i] = u < 960; xpr[i] = px / 10; xpc[i] = px - xpr[i] * 10; }
+    const int xsl = (t & 15) * 4;
+    const int dpr = (t >> 4) >> 3, dpc = (t >> 4) & 7;
+    // transform items: (tile 0..7, 16-B slot 0..15, row 0..3 of the 4x4 transformed tile); row is uniform per wave pair
+    const int tsl = (t & 15) * 4, ttile = (t >> 4) & 7, vrow = t >> 7;
+    const int tty = ttile >> 2, ttx = ttile & 3;
+    const int ra = vrow == 0 ? 0 : (vrow == 2 ? 2 : 1), rb = vrow == 0 ? 2 : (vrow == 1 ? 2 : (vrow == 2 ? 1 : 3));
+    const float sgn = vrow == 1 ? 1.f : -1.f;
+    const int xrd = ((2 * tty + ra) * 10 + 2 * ttx) * 64 + tsl, xrb = (rb - ra) * 640;
+    const int drd = ((2 * tty) * 8 + 2 * ttx) * 64 + tsl;
+    const float d0 = vrow == 3 ? 0.f : 1.f, d1 = vrow == 0 ? 0.f : (vrow == 1 ? 1.f : -1.f);      // row i of A: t = d0*dY[0] + d1*dY[1]
+    const int vwr = (vrow * 4) * 512 + ttile * 64 + tsl;
+    const int p0 = 2 * wave;
+
+    f32x16 acc[2][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+
+    const int ch_begin = split * g.cps;
+    int ch_end = ch_begin + g.cps; if (ch_end > g.total_chunks) ch_end = g.total_chunks;
+    f32x4 rx[2], rd;
+    auto load_chunk = [&](int ch) {
+        const int cx = ch % g.chx; int q = ch / g.chx;
+        const int cy = q % g.chy, n = q / g.chy;
+        const int y0 = cy * 4, x0 = cx * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = y0 - 1 + xpr[i], ix = x0 - 1 + xpc[i];
+            const bool ok = xin[i] && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+            rx[i] = *reinterpret_cast<const f32x4*>(ok ? g.x + ((size_t)(n * g.H + iy) * g.W + ix) * g.ldx + c0 + xsl : wino_zero16);
+        }
+        rd = *reinterpret_cast<const f32x4*>(g.dy + ((size_t)(n * g.H + y0 + dpr) * g.W + x0 + dpc) * g.lddy + n0 + xsl);
+    };
+    if (ch_begin < ch_end) load_chunk(ch_begin);
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+        *reinterpret_cast<f32x4*>(&rawx[t * 4]) = rx[0];
+        if (t < 448) *reinterpret_cast<f32x4*>(&rawx[(t + 512) * 4]) = rx[1];
+        *reinterpret_cast<f32x4*>(&rawd[t * 4]) = rd;
+        __syncthreads();
+        {
+            f32x4 tr[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&rawx[xrd + c * 64]);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(&rawx[xrd + c * 64 + xrb]);
+                tr[c] = a + sgn * b;
+            }
+            *reinterpret_cast<f32x4*>(&Vs[vwr]) = tr[0] - tr[2];
+            *reinterpret_cast<f32x4*>(&Vs[vwr + 512]) = tr[1] + tr[2];
+            *reinterpret_cast<f32x4*>(&Vs[vwr + 1024]) = tr[2] - tr[1];
+            *reinterpret_cast<f32x4*>(&Vs[vwr + 1536]) = tr[1] - tr[3];
+            const f32x4 y00 = *reinterpret_cast<const f32x4*>(&rawd[drd]), y01 = *reinterpret_cast<const f32x4*>(&rawd[drd + 64]);
+            const f32x4 y10 = *reinterpret_cast<const f32x4*>(&rawd[drd + 512]), y11 = *reinterpret_cast<const f32x4*>(&rawd[drd + 576]);
+            const f32x4 t0 = d0 * y00 + d1 * y10, t1 = d0 * y01 + d1 * y11;
+            *reinterpret_cast<f32x4*>(&Ds[vwr]) = t0;
+            *reinterpret_cast<f32x4*>(&Ds[vwr + 512]) = t0 + t1;
+            *reinterpret_cast<f32x4*>(&Ds[vwr + 1024]) = t0 - t1;
+            *reinterpret_cast<f32x4*>(&Ds[vwr + 1536]) = -t1;
+        }
+        if (ch + 1 < ch_end) load_chunk(ch + 1);
+        __syncthreads();
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const float* Vp = Vs + (p0 + pt) * 512 + lh * 64 + li;
+            const float* Dp = Ds + (p0 + pt) * 512 + lh * 64 + li;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float a0 = Vp[s * 128], a1 = Vp[s * 128 + 32];
+                const float b0 = Dp[s * 128], b1 = Dp[s * 128 + 32];
+                acc[pt][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[pt][0][0], 0, 0, 0);
+                acc[pt][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[pt][0][1], 0, 0, 0);
+                acc[pt][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[pt][1][0], 0, 0, 0);
+                acc[pt][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[pt][1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // dg = G^T dU G per (c, n), one 32 x 32 quarter at a time through LDS: M[16][32 c][32 n]
+    float* Ms = smem;
+    float* out = g.out + (size_t)split * g.slab;
+    const int oc = t & 31;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ci = q >> 1, co = q & 1;
+        if (q) __syncthreads();
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Ms[((p0 + pt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[pt][ci][co][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int cl = (t >> 5) + 16 * i;
+            float m[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) m[p] = Ms[(p * 32 + cl) * 32 + oc];
+            // rows of G^T: [1,.5,.5,0], [0,.5,-.5,0], [0,.5,.5,1]
+            float h[3][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h[0][j] = m[j] + 0.5f * (m[4 + j] + m[8 + j]);
+                h[1][j] = 0.5f * (m[4 + j] - m[8 + j]);
+                h[2][j] = 0.5f * (m[4 + j] + m[8 + j]) + m[12 + j];
+            }
+            float* o = out + (size_t)(c0 + ci * 32 + cl) * g.Cout + n0 + co * 32 + oc;
+            const size_t tap = (size_t)g.Cin * g.Cout;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                o[(r * 3 + 0) * tap] = h[r][0] + 0.5f * (h[r][1] + h[r][2]);
+                o[(r * 3 + 1) * tap] = 0.5f * (h[r][1] - h[r][2]);
+                o[(r * 3 + 2) * tap] = 0.5f * (h[r][1] + h[r][2]) + h[r][3];
+            }
+        }
+    }
+}
+
+// splits for the Winograd wgrad (0 = shape not handled): ~512 workgroups, >= 8 chunks per split, slabs <= 128 MB
+extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
+    if (getenv("KPX_NO_WINO") || getenv("KPX_NO_WINO_WGRAD")) return 0;
+    if (H % 4 || W % 8 || Cin % 64 || Cout % 64) return 0;
+    const long tc = (long)N * (H / 4) * (W / 8), tiles = (long)(Cin / 64) * (Cout / 64);
+    long S = (512 + tiles - 1) / tiles;
+    if (S > tc / 8) S = tc / 8;
+    const long cap = (128L << 20) / ((long)9 * Cin * Cout * 4);
+    if (S > cap) S = cap;
+    if (S < 1) S = 1;
+    if (tc < 64 || tiles * S < 128) return 0;             // too little work to fill the chip: the direct kernels do better
+    return (int)S;
+}
+
+extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad3x3(const float* x, int N, int H, int W, int Cin, int ldx, const float* dy, int Cout, int lddy,
+                                                                   float* slabs, int S, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS_FLOATS * 4);
+        if (e != hipSuccess) return -(int)e;
+        attr = true;
+    }
+    WinoWgradGeom g{};
+    g.x = x; g.dy = dy; g.out = slabs;
+    g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.ldx = ldx; g.Cout = Cout; g.lddy = lddy;
+    g.cit = Cin / 64; g.cot = Cout / 64; g.S = S;
+    g.chy = H / 4; g.chx = W / 8; g.total_chunks = N * g.chy * g.chx;
+    g.cps = (g.total_chunks + S - 1) / S;
+    g.slab = (size_t)9 * Cin * Cout;
+    hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3((unsigned)(g.cit * g.cot * S)), dim3(512), WW_LDS_FLOATS * 4, s, g);
+    return kpx_launch_status();
+}
