@@ -66,6 +66,8 @@ CONV_CASES = [
     (2, 16, 16, 16, 16, 3, 1, 0, 1),       # Winograd, 16 -> 16 channels (pose conv_7_1 shape): two chunks, half-empty cout tile
     (1, 32, 32, 24, 40, 3, 1, 0, 2),       # Winograd, K = 24 (3 chunks), Nn = 40
     (8, 32, 64, 64, 128, 3, 1, 0, 0),      # Winograd weight gradient (64-channel tiles, non-square image, 64 splits)
+    (16, 32, 32, 128, 16, 3, 1, 0, 0),     # Winograd weight gradient, 64 x 32 blocks with the 16 output channels masked (pose conv_7_0)
+    (16, 32, 32, 32, 160, 3, 1, 0, 1),     # Winograd weight gradient, 32 x 64 blocks, Cout = 160 overhangs the last block
 ]
 
 

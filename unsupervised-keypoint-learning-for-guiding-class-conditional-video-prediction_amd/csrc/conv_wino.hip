@@ -300,53 +300,57 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const floa
 // writes a partial HWIO slab per split; the fixed-order wgrad_reduce_kernel sums the slabs (bitwise reproducible, no atomics).
 struct WinoWgradGeom {
     const float* x; const float* dy; float* out;      // out: [S][9][Cin][Cout] partial slabs (or dw itself when S == 1)
-    int N, H, W, Cin, ldx, Cout, lddy;
-    int cit, cot, S, cps, total_chunks, chy, chx;     // 64-channel tiles, splits, chunks per split, chunks per image column / row
+    int N, H, W, Cin, ldx, Cout, lddy;                // Cin, Cout: real channel counts (multiples of 4); blocks may overhang them
+    int cit, cot, S, cps, total_chunks, chy, chx;     // channel blocks, splits, chunks per split, chunks per image column / row
     size_t slab;
 };
 
-#define WW_RAWX 3840       // 6 rows x 10 pixels x 64 channels
-#define WW_RAWD 2048       // 4 rows x 8 pixels x 64 channels
-#define WW_V 8192          // 16 points x 8 tiles x 64 channels
-#define WW_LDS_FLOATS (WW_RAWX + WW_RAWD + 2 * WW_V)      // 22272 floats = 87 KB; epilogue M[16][32][32] (64 KB) overlays the front
-
+// CIT x COT = 32-channel MFMA tiles per workgroup block: (2,2) = 64 x 64, (2,1) = 64 x 32 (few output channels), (1,2) = 32 x 64
+template <int CIT, int COT>
 __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const WinoWgradGeom g) {
+    constexpr int CI = 32 * CIT, CO = 32 * COT, SI = CI / 4, SO = CO / 4;     // channels and 16-B slots per pixel
+    constexpr int RAWX = 60 * CI, RAWD = 32 * CO, VF = 16 * 8 * CI, DF = 16 * 8 * CO;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* rawx = smem;
-    float* rawd = smem + WW_RAWX;
-    float* Vs = smem + WW_RAWX + WW_RAWD;
-    float* Ds = Vs + WW_V;
+    float* rawx = smem;                    // [6 rows][10 pixels][CI]
+    float* rawd = smem + RAWX;             // [4 rows][8 pixels][CO]
+    float* Vs = smem + RAWX + RAWD;        // [16 points][8 tiles][CI]
+    float* Ds = Vs + VF;                   // [16 points][8 tiles][CO]
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
     int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
     const int split = L % g.S; L /= g.S;
     const int cot = L % g.cot, cit = L / g.cot;
-    const int c0 = cit * 64, n0 = cot * 64;
+    const int c0 = cit * CI, n0 = cot * CO;
 
-    // staging units (fixed per thread): x patch 60 pixels x 16 slots = 960 (t, t+512), dy 32 pixels x 16 slots = 512 (t)
-    int xpr[2], xpc[2]; bool xin[2];
+    // staging units (fixed per thread): x patch 60 pixels x SI slots (<= 2 per thread), dy 32 pixels x SO slots (<= 1)
+    int xpr[2], xpc[2], xsl[2]; bool xin[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int u = t + 512 * i, px = u >> 4; xin[i] = u < 960; xpr[i] = px / 10; xpc[i] = px - xpr[i] * 10; }
-    const int xsl = (t & 15) * 4;
-    const int dpr = (t >> 4) >> 3, dpc = (t >> 4) & 7;
-    // transform items: (tile 0..7, 16-B slot 0..15, row 0..3 of the 4x4 transformed tile); row is uniform per wave pair
-    const int tsl = (t & 15) * 4, ttile = (t >> 4) & 7, vrow = t >> 7;
-    const int tty = ttile >> 2, ttx = ttile & 3;
+    for (int i = 0; i < 2; ++i) {
+        const int u = t + 512 * i, px = u / SI;
+        xsl[i] = (u - px * SI) * 4; xin[i] = u < 60 * SI && c0 + xsl[i] < g.Cin; xpr[i] = px / 10; xpc[i] = px - xpr[i] * 10;
+    }
+    const int dpx = t / SO, dsl = (t - dpx * SO) * 4, dpr = dpx >> 3, dpc = dpx & 7;
+    const bool din = t < 32 * SO && n0 + dsl < g.Cout;
+    // transform items: (16-B slot, tile 0..7, row 0..3 of the 4x4 transformed tile); the row is uniform per wavefront
+    const int vsl = (t % SI) * 4, vtile = (t / SI) & 7, vrow = t / (8 * SI);         // x side
+    const int esl = (t % SO) * 4, etile = (t / SO) & 7, erow = t / (8 * SO);         // dy side
+    const bool vact = t < 32 * SI, eact = t < 32 * SO;
     const int ra = vrow == 0 ? 0 : (vrow == 2 ? 2 : 1), rb = vrow == 0 ? 2 : (vrow == 1 ? 2 : (vrow == 2 ? 1 : 3));
     const float sgn = vrow == 1 ? 1.f : -1.f;
-    const int xrd = ((2 * tty + ra) * 10 + 2 * ttx) * 64 + tsl, xrb = (rb - ra) * 640;
-    const int drd = ((2 * tty) * 8 + 2 * ttx) * 64 + tsl;
-    const float d0 = vrow == 3 ? 0.f : 1.f, d1 = vrow == 0 ? 0.f : (vrow == 1 ? 1.f : -1.f);      // row i of A: t = d0*dY[0] + d1*dY[1]
-    const int vwr = (vrow * 4) * 512 + ttile * 64 + tsl;
+    const int xrd = ((2 * (vtile >> 2) + ra) * 10 + 2 * (vtile & 3)) * CI + vsl, xrb = (rb - ra) * 10 * CI;
+    const int vwr = (vrow * 4) * 8 * CI + vtile * CI + vsl;
+    const int drd = ((2 * (etile >> 2)) * 8 + 2 * (etile & 3)) * CO + esl;
+    const float d0 = erow == 3 ? 0.f : 1.f, d1 = erow == 0 ? 0.f : (erow == 1 ? 1.f : -1.f);      // row i of A: t = d0*dY[0] + d1*dY[1]
+    const int dwr = (erow * 4) * 8 * CO + etile * CO + esl;
     const int p0 = 2 * wave;
 
-    f32x16 acc[2][2][2];
+    f32x16 acc[2][CIT][COT];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < CIT; ++b)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < COT; ++c)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
 
@@ -359,52 +363,60 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const WinoWgrad
         const int y0 = cy * 4, x0 = cx * 8;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int iy = y0 - 1 + xpr[i], ix = x0 - 1 + xpc[i];
-            const bool ok = xin[i] && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-            rx[i] = *reinterpret_cast<const f32x4*>(ok ? g.x + ((size_t)(n * g.H + iy) * g.W + ix) * g.ldx + c0 + xsl : wino_zero16);
+            if (i * 512 < 60 * SI) {
+                const int iy = y0 - 1 + xpr[i], ix = x0 - 1 + xpc[i];
+                const bool ok = xin[i] && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                rx[i] = *reinterpret_cast<const f32x4*>(ok ? g.x + ((size_t)(n * g.H + iy) * g.W + ix) * g.ldx + c0 + xsl[i] : wino_zero16);
+            }
         }
-        rd = *reinterpret_cast<const f32x4*>(g.dy + ((size_t)(n * g.H + y0 + dpr) * g.W + x0 + dpc) * g.lddy + n0 + xsl);
+        rd = *reinterpret_cast<const f32x4*>(din ? g.dy + ((size_t)(n * g.H + y0 + dpr) * g.W + x0 + dpc) * g.lddy + n0 + dsl : wino_zero16);
     };
     if (ch_begin < ch_end) load_chunk(ch_begin);
     for (int ch = ch_begin; ch < ch_end; ++ch) {
-        *reinterpret_cast<f32x4*>(&rawx[t * 4]) = rx[0];
-        if (t < 448) *reinterpret_cast<f32x4*>(&rawx[(t + 512) * 4]) = rx[1];
-        *reinterpret_cast<f32x4*>(&rawd[t * 4]) = rd;
+        if (t < 60 * SI) *reinterpret_cast<f32x4*>(&rawx[t * 4]) = rx[0];
+        if (60 * SI > 512 && t + 512 < 60 * SI) *reinterpret_cast<f32x4*>(&rawx[(t + 512) * 4]) = rx[1];
+        if (t < 32 * SO) *reinterpret_cast<f32x4*>(&rawd[t * 4]) = rd;
         __syncthreads();
-        {
+        if (vact) {
             f32x4 tr[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(&rawx[xrd + c * 64]);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(&rawx[xrd + c * 64 + xrb]);
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&rawx[xrd + c * CI]);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(&rawx[xrd + c * CI + xrb]);
                 tr[c] = a + sgn * b;
             }
             *reinterpret_cast<f32x4*>(&Vs[vwr]) = tr[0] - tr[2];
-            *reinterpret_cast<f32x4*>(&Vs[vwr + 512]) = tr[1] + tr[2];
-            *reinterpret_cast<f32x4*>(&Vs[vwr + 1024]) = tr[2] - tr[1];
-            *reinterpret_cast<f32x4*>(&Vs[vwr + 1536]) = tr[1] - tr[3];
-            const f32x4 y00 = *reinterpret_cast<const f32x4*>(&rawd[drd]), y01 = *reinterpret_cast<const f32x4*>(&rawd[drd + 64]);
-            const f32x4 y10 = *reinterpret_cast<const f32x4*>(&rawd[drd + 512]), y11 = *reinterpret_cast<const f32x4*>(&rawd[drd + 576]);
+            *reinterpret_cast<f32x4*>(&Vs[vwr + 8 * CI]) = tr[1] + tr[2];
+            *reinterpret_cast<f32x4*>(&Vs[vwr + 16 * CI]) = tr[2] - tr[1];
+            *reinterpret_cast<f32x4*>(&Vs[vwr + 24 * CI]) = tr[1] - tr[3];
+        }
+        if (eact) {
+            const f32x4 y00 = *reinterpret_cast<const f32x4*>(&rawd[drd]), y01 = *reinterpret_cast<const f32x4*>(&rawd[drd + CO]);
+            const f32x4 y10 = *reinterpret_cast<const f32x4*>(&rawd[drd + 8 * CO]), y11 = *reinterpret_cast<const f32x4*>(&rawd[drd + 9 * CO]);
             const f32x4 t0 = d0 * y00 + d1 * y10, t1 = d0 * y01 + d1 * y11;
-            *reinterpret_cast<f32x4*>(&Ds[vwr]) = t0;
-            *reinterpret_cast<f32x4*>(&Ds[vwr + 512]) = t0 + t1;
-            *reinterpret_cast<f32x4*>(&Ds[vwr + 1024]) = t0 - t1;
-            *reinterpret_cast<f32x4*>(&Ds[vwr + 1536]) = -t1;
+            *reinterpret_cast<f32x4*>(&Ds[dwr]) = t0;
+            *reinterpret_cast<f32x4*>(&Ds[dwr + 8 * CO]) = t0 + t1;
+            *reinterpret_cast<f32x4*>(&Ds[dwr + 16 * CO]) = t0 - t1;
+            *reinterpret_cast<f32x4*>(&Ds[dwr + 24 * CO]) = -t1;
         }
         if (ch + 1 < ch_end) load_chunk(ch + 1);
         __syncthreads();
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-            const float* Vp = Vs + (p0 + pt) * 512 + lh * 64 + li;
-            const float* Dp = Ds + (p0 + pt) * 512 + lh * 64 + li;
+            const float* Vp = Vs + (p0 + pt) * 8 * CI + lh * CI + li;
+            const float* Dp = Ds + (p0 + pt) * 8 * CO + lh * CO + li;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float a0 = Vp[s * 128], a1 = Vp[s * 128 + 32];
-                const float b0 = Dp[s * 128], b1 = Dp[s * 128 + 32];
-                acc[pt][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[pt][0][0], 0, 0, 0);
-                acc[pt][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[pt][0][1], 0, 0, 0);
-                acc[pt][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[pt][1][0], 0, 0, 0);
-                acc[pt][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[pt][1][1], 0, 0, 0);
+                float a[CIT], b[COT];
+#pragma unroll
+                for (int i = 0; i < CIT; ++i) a[i] = Vp[s * 2 * CI + i * 32];
+#pragma unroll
+                for (int j = 0; j < COT; ++j) b[j] = Dp[s * 2 * CO + j * 32];
+#pragma unroll
+                for (int i = 0; i < CIT; ++i)
+#pragma unroll
+                    for (int j = 0; j < COT; ++j)
+                        acc[pt][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[pt][i][j], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -415,8 +427,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const WinoWgrad
     float* out = g.out + (size_t)split * g.slab;
     const int oc = t & 31;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ci = q >> 1, co = q & 1;
+    for (int q = 0; q < CIT * COT; ++q) {
+        const int ci = q / COT, co = q % COT;
         if (q) __syncthreads();
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt)
@@ -438,23 +450,31 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const WinoWgrad
                 h[1][j] = 0.5f * (m[4 + j] - m[8 + j]);
                 h[2][j] = 0.5f * (m[4 + j] + m[8 + j]) + m[12 + j];
             }
-            float* o = out + (size_t)(c0 + ci * 32 + cl) * g.Cout + n0 + co * 32 + oc;
-            const size_t tap = (size_t)g.Cin * g.Cout;
+            const int c = c0 + ci * 32 + cl, n = n0 + co * 32 + oc;
+            if (c < g.Cin && n < g.Cout) {
+                float* o = out + (size_t)c * g.Cout + n;
+                const size_t tap = (size_t)g.Cin * g.Cout;
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                o[(r * 3 + 0) * tap] = h[r][0] + 0.5f * (h[r][1] + h[r][2]);
-                o[(r * 3 + 1) * tap] = 0.5f * (h[r][1] - h[r][2]);
-                o[(r * 3 + 2) * tap] = 0.5f * (h[r][1] + h[r][2]) + h[r][3];
+                for (int r = 0; r < 3; ++r) {
+                    o[(r * 3 + 0) * tap] = h[r][0] + 0.5f * (h[r][1] + h[r][2]);
+                    o[(r * 3 + 1) * tap] = 0.5f * (h[r][1] - h[r][2]);
+                    o[(r * 3 + 2) * tap] = 0.5f * (h[r][1] + h[r][2]) + h[r][3];
+                }
             }
         }
     }
 }
 
+// block shape for a channel count: 64 when the count is a multiple of 64 or large, else 32
+static inline int ww_tile(int C) { return (C % 64 == 0 || C > 96) ? 2 : 1; }
+
 // splits for the Winograd wgrad (0 = shape not handled): ~512 workgroups, >= 8 chunks per split, slabs <= 128 MB
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
     if (getenv("KPX_NO_WINO") || getenv("KPX_NO_WINO_WGRAD")) return 0;
-    if (H % 4 || W % 8 || Cin % 64 || Cout % 64) return 0;
-    const long tc = (long)N * (H / 4) * (W / 8), tiles = (long)(Cin / 64) * (Cout / 64);
+    if (H % 4 || W % 8 || Cin % 4 || Cout % 4 || Cin < 32 || Cout < 16) return 0;
+    const int ti = ww_tile(Cin), to = ww_tile(Cout);
+    if (ti == 1 && to == 1) return 0;                     // 32 x 32 blocks: too few MFMAs per barrier, the direct kernels do better
+    const long tc = (long)N * (H / 4) * (W / 8), tiles = (long)((Cin + 32 * ti - 1) / (32 * ti)) * ((Cout + 32 * to - 1) / (32 * to));
     long S = (512 + tiles - 1) / tiles;
     if (S > tc / 8) S = tc / 8;
     const long cap = (128L << 20) / ((long)9 * Cin * Cout * 4);
@@ -467,18 +487,27 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad3x3(const float* x, int N, int H, int W, int Cin, int ldx, const float* dy, int Cout, int lddy,
                                                                    float* slabs, int S, hipStream_t s) {
     static bool attr = false;
+    const int lds22 = (60 * 64 + 32 * 64 + 2 * 16 * 8 * 64) * 4, lds21 = (60 * 64 + 32 * 32 + 16 * 8 * 64 + 16 * 8 * 32) * 4,
+              lds12 = (60 * 32 + 32 * 64 + 16 * 8 * 32 + 16 * 8 * 64) * 4;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WW_LDS_FLOATS * 4);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds22);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds21 > 65536 ? lds21 : 65536);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds12 > 65536 ? lds12 : 65536);
         if (e != hipSuccess) return -(int)e;
         attr = true;
     }
+    const int ti = ww_tile(Cin), to = ww_tile(Cout);
     WinoWgradGeom g{};
     g.x = x; g.dy = dy; g.out = slabs;
     g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.ldx = ldx; g.Cout = Cout; g.lddy = lddy;
-    g.cit = Cin / 64; g.cot = Cout / 64; g.S = S;
+    g.cit = (Cin + 32 * ti - 1) / (32 * ti); g.cot = (Cout + 32 * to - 1) / (32 * to); g.S = S;
     g.chy = H / 4; g.chx = W / 8; g.total_chunks = N * g.chy * g.chx;
     g.cps = (g.total_chunks + S - 1) / S;
     g.slab = (size_t)9 * Cin * Cout;
-    hipLaunchKernelGGL(conv_wino_wgrad_kernel, dim3((unsigned)(g.cit * g.cot * S)), dim3(512), WW_LDS_FLOATS * 4, s, g);
+    const dim3 grid((unsigned)(g.cit * g.cot * S));
+    // the epilogue's M[16][32][32] (64 KB) overlays the main-loop buffers: at least 64 KB
+    if (ti == 2 && to == 2) hipLaunchKernelGGL((conv_wino_wgrad_kernel<2, 2>), grid, dim3(512), lds22, s, g);
+    else if (ti == 2) hipLaunchKernelGGL((conv_wino_wgrad_kernel<2, 1>), grid, dim3(512), lds21 > 65536 ? lds21 : 65536, s, g);
+    else hipLaunchKernelGGL((conv_wino_wgrad_kernel<1, 2>), grid, dim3(512), lds12 > 65536 ? lds12 : 65536, s, g);
     return kpx_launch_status();
 }
