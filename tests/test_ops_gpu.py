@@ -123,6 +123,21 @@ def test_conv_reads_and_writes_channel_slices(kpx, dev):
     assert rel_l2(t2n(got4), t2n(want4)) < 1e-5
 
 
+def test_wgrad_of_a_158_channel_slice_ignores_the_pad_channels(kpx, dev):
+    """Winograd wgrad with Cin = 158 read from a 160-channel buffer (translator conv_1_0): the two pad channels hold NaN."""
+    rs = np.random.RandomState(5)
+    full = rs.randn(8, 32, 32, 160).astype(np.float32)
+    wt = (rs.randn(3, 3, 158, 64) * 0.05).astype(np.float32)
+    gy = rs.randn(8, 32, 32, 64).astype(np.float32)
+    xo = torch.from_numpy(full[..., :158].copy()); wo = torch.from_numpy(wt).requires_grad_(True)
+    R.conv(xo, wo, None, 1).backward(torch.from_numpy(gy))
+    full[..., 158:] = np.nan
+    wg = torch.from_numpy(wt).to(dev).requires_grad_(True)
+    y = kpx.ops.conv2d(torch.from_numpy(full).to(dev), wg, None, stride=1, cin=158)
+    y.backward(torch.from_numpy(gy).to(dev))
+    assert rel_l2(t2n(wg.grad), t2n(wo.grad)) < 1e-5
+
+
 @pytest.mark.parametrize('groups', [1, 2])
 def test_batch_norm_train_fwd_bwd_and_moving(kpx, dev, groups):
     rs = np.random.RandomState(groups)

@@ -1287,7 +1287,7 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
         KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || lddy < Cout)
         return KPX_EINVAL;
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && ldx % 4 == 0 && lddy % 4 == 0 &&
-        aligned16(x) && aligned16(dy)) {
+        ldx >= ((Cin + 3) & ~3) && aligned16(x) && aligned16(dy)) {
         const int Sw = kpx_wino_wgrad_splits(N, Hi, Wi, Cin, Cout);
         const size_t slab = (size_t)9 * Cin * Cout;
         if (Sw >= 1 && (Sw == 1 || (workspace && workspace_bytes >= (size_t)Sw * slab * 4))) {

@@ -300,7 +300,7 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const floa
 // writes a partial HWIO slab per split; the fixed-order wgrad_reduce_kernel sums the slabs (bitwise reproducible, no atomics).
 struct WinoWgradGeom {
     const float* x; const float* dy; float* out;      // out: [S][9][Cin][Cout] partial slabs (or dw itself when S == 1)
-    int N, H, W, Cin, ldx, Cout, lddy;                // Cin, Cout: real channel counts (multiples of 4); blocks may overhang them
+    int N, H, W, Cin, ldx, Cout, lddy;                // Cin, Cout: real channel counts (Cout a multiple of 4); blocks may overhang them
     int cit, cot, S, cps, total_chunks, chy, chx;     // channel blocks, splits, chunks per split, chunks per image column / row
     size_t slab;
 };
@@ -323,11 +323,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const WinoWgrad
     const int c0 = cit * CI, n0 = cot * CO;
 
     // staging units (fixed per thread): x patch 60 pixels x SI slots (<= 2 per thread), dy 32 pixels x SO slots (<= 1)
-    int xpr[2], xpc[2], xsl[2]; bool xin[2];
+    int xpr[2], xpc[2], xsl[2], xtail[2]; bool xin[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int u = t + 512 * i, px = u / SI;
         xsl[i] = (u - px * SI) * 4; xin[i] = u < 60 * SI && c0 + xsl[i] < g.Cin; xpr[i] = px / 10; xpc[i] = px - xpr[i] * 10;
+        xtail[i] = g.Cin - (c0 + xsl[i]);        // valid channels of this 16-B unit (>= 4: all)
     }
     const int dpx = t / SO, dsl = (t - dpx * SO) * 4, dpr = dpx >> 3, dpc = dpx & 7;
     const bool din = t < 32 * SO && n0 + dsl < g.Cout;
@@ -373,6 +374,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const WinoWgrad
     };
     if (ch_begin < ch_end) load_chunk(ch_begin);
     for (int ch = ch_begin; ch < ch_end; ++ch) {
+        if (g.Cin & 3) {                     // a 16-B unit straddling Cin: the row's pad channels must not count (masked here, at the
+#pragma unroll                              // consumer, so that the prefetch above stays asynchronous)
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 1; j < 4; ++j) if (j >= xtail[i]) rx[i][j] = 0.f;
+        }
         if (t < 60 * SI) *reinterpret_cast<f32x4*>(&rawx[t * 4]) = rx[0];
         if (60 * SI > 512 && t + 512 < 60 * SI) *reinterpret_cast<f32x4*>(&rawx[(t + 512) * 4]) = rx[1];
         if (t < 32 * SO) *reinterpret_cast<f32x4*>(&rawd[t * 4]) = rd;
@@ -471,7 +478,7 @@ static inline int ww_tile(int C) { return (C % 64 == 0 || C > 96) ? 2 : 1; }
 // splits for the Winograd wgrad (0 = shape not handled): ~512 workgroups, >= 8 chunks per split, slabs <= 128 MB
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
     if (getenv("KPX_NO_WINO") || getenv("KPX_NO_WINO_WGRAD")) return 0;
-    if (H % 4 || W % 8 || Cin % 4 || Cout % 4 || Cin < 32 || Cout < 16) return 0;
+    if (H % 4 || W % 8 || Cout % 4 || Cin < 32 || Cout < 16) return 0;         // (a Cin that is not a multiple of 4 needs ldx >= Cin rounded up, checked by the caller)
     const int ti = ww_tile(Cin), to = ww_tile(Cout);
     if (ti == 1 && to == 1) return 0;                     // 32 x 32 blocks: too few MFMAs per barrier, the direct kernels do better
     const long tc = (long)N * (H / 4) * (W / 8), tiles = (long)((Cin + 32 * ti - 1) / (32 * ti)) * ((Cout + 32 * to - 1) / (32 * to));
