@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const RgbGeom g) {
         }
 }
 
-static bool rgb_attr_set = false;
+static unsigned long long rgb_attr_mask = 0;
 
 // stride-1 convolutions of a dense (ldx == Cin) image with Cin <= 4 and Cout <= 64; returns -2 when the shape is not handled
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW,
@@ -105,10 +105,10 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const floa
     g.PH = 15 + KH; g.PWC = (15 + KW) * Cin + 1;          // +1: the padded k of the last pixel stays inside the row
     const int nt = Cout <= 32 ? 1 : 2;
     const size_t lds = ((size_t)((g.PH * g.PWC + 4 + 3) & ~3) + (size_t)KH * g.KWCp * 32 * nt) * 4;
-    if (!rgb_attr_set) {
+    if (kpx_first_use_on_device(&rgb_attr_mask)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rgb_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rgb_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
         if (e != hipSuccess) return -(int)e;
-        rgb_attr_set = true;
     }
     if (lds > 98304) return -2;
     const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x);

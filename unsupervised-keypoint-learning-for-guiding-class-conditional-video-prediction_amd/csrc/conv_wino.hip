@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
 }
 
 static inline int w8_lds_bytes(int ct) { const int main = (W8_RAW + W8_U(ct) + W8_V) * 4; return main > 65536 ? main : 65536; }
-static bool wino_attr_set = false;
+static unsigned long long wino_attr_mask = 0;
 
 // shape / alignment eligibility (stride-1 3x3 SAME only); K = channels of the gathered tensor, Nn = produced channels
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
@@ -268,12 +268,11 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const floa
     else hipLaunchKernelGGL(wino_filter_transform_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
     int rc = kpx_launch_status();
     if (rc) return rc;
-    if (!wino_attr_set) {
+    if (kpx_first_use_on_device(&wino_attr_mask)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, w8_lds_bytes(1));
         if (e != hipSuccess) return -(int)e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, w8_lds_bytes(2));
         if (e != hipSuccess) return -(int)e;
-        wino_attr_set = true;
     }
     WinoGeom g{};
     g.x = in; g.y = out; g.U = U_ws; g.bias = bias;
@@ -493,15 +492,14 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N
 
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad3x3(const float* x, int N, int H, int W, int Cin, int ldx, const float* dy, int Cout, int lddy,
                                                                    float* slabs, int S, hipStream_t s) {
-    static bool attr = false;
+    static unsigned long long attr_mask = 0;
     const int lds22 = (60 * 64 + 32 * 64 + 2 * 16 * 8 * 64) * 4, lds21 = (60 * 64 + 32 * 32 + 16 * 8 * 64 + 16 * 8 * 32) * 4,
               lds12 = (60 * 32 + 32 * 64 + 16 * 8 * 32 + 16 * 8 * 64) * 4;
-    if (!attr) {
+    if (kpx_first_use_on_device(&attr_mask)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds22);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds21 > 65536 ? lds21 : 65536);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds12 > 65536 ? lds12 : 65536);
         if (e != hipSuccess) return -(int)e;
-        attr = true;
     }
     const int ti = ww_tile(Cin), to = ww_tile(Cout);
     WinoWgradGeom g{};

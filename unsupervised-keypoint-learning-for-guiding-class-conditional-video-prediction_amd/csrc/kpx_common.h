@@ -39,3 +39,12 @@ __device__ __forceinline__ float kpx_wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Large-LDS kernels need hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per device; `mask` is a per-kernel-family bitmask.
+static inline bool kpx_first_use_on_device(unsigned long long* mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    if ((*mask >> dev) & 1ULL) return false;
+    *mask |= 1ULL << dev;
+    return true;
+}
