@@ -77,6 +77,8 @@ import os as _os
 SIDE_WGRAD = _os.environ.get('KPX_SIDE_WGRAD', '1') != '0'
 _side_streams = {}
 _side_dirty = set()
+_side_keep = []          # tensors read by kernels on the side stream: kept alive until join_side_stream() (cheaper than
+                         # Tensor.record_stream, whose pending events the caching allocator polls on every allocation)
 
 
 def _side_stream(device):
@@ -115,6 +117,8 @@ def join_side_stream(device=None):
         if device is None or dev == torch.device(device):
             torch.cuda.current_stream(dev).wait_stream(_side_streams[dev])
             _side_dirty.discard(dev)
+    if not _side_dirty:
+        _side_keep.clear()       # the current stream is now ordered after every side kernel: the blocks may be recycled
 
 
 # ----------------------------------------------------------------------------------------------- raw launchers
@@ -237,7 +241,7 @@ class Conv2dFn(torch.autograd.Function):
             main = torch.cuda.current_stream(x.device)
             st = _side_stream(x.device)
             st.wait_stream(main)                         # dy (and x) are ready once the main stream reaches this point
-            dy.record_stream(st); x.record_stream(st)    # keep the allocator from recycling them under the side kernels
+            _side_keep.append((dy, x))                   # keep the allocator from recycling them under the side kernels
             _side_dirty.add(x.device)
             stream_ctx = torch.cuda.stream(st)
         else:
