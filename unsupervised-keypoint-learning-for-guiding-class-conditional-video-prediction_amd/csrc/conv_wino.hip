@@ -474,14 +474,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const WinoWgrad
 // block shape for a channel count: 64 when the count is a multiple of 64 or large, else 32
 static inline int ww_tile(int C) { return (C % 64 == 0 || C > 96) ? 2 : 1; }
 
-// splits for the Winograd wgrad (0 = shape not handled): ~512 workgroups, >= 8 chunks per split, slabs <= 128 MB
+// splits for the Winograd wgrad (0 = shape not handled): ~256 workgroups (one per CU; measured best of 128..1024), >= 8 chunks per split, slabs <= 128 MB
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
     if (getenv("KPX_NO_WINO") || getenv("KPX_NO_WINO_WGRAD")) return 0;
     if (H % 4 || W % 8 || Cout % 4 || Cin < 32 || Cout < 16) return 0;         // (a Cin that is not a multiple of 4 needs ldx >= Cin rounded up, checked by the caller)
     const int ti = ww_tile(Cin), to = ww_tile(Cout);
     if (ti == 1 && to == 1) return 0;                     // 32 x 32 blocks: too few MFMAs per barrier, the direct kernels do better
     const long tc = (long)N * (H / 4) * (W / 8), tiles = (long)((Cin + 32 * ti - 1) / (32 * ti)) * ((Cout + 32 * to - 1) / (32 * to));
-    long S = (512 + tiles - 1) / tiles;
+    static const long target = getenv("KPX_WW_TARGET") ? atol(getenv("KPX_WW_TARGET")) : 256;
+    long S = (target + tiles - 1) / tiles;
     if (S > tc / 8) S = tc / 8;
     const long cap = (128L << 20) / ((long)9 * Cin * Cout * 4);
     if (S > cap) S = cap;
