@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void wino_filter_transform_kernel(const float*
     }
 }
 
-// ---- v2 / v5: 8-channel chunks, one 16x16-pixel tile x (32*CT) output channels per workgroup of 8 wavefronts.
+// ---- forward / dgrad kernel: 8-channel chunks, one 16x16-pixel tile x (32*CT) output channels per workgroup of 8 wavefronts.
 //   CT = 1: 64 KB of LDS and <= 128 VGPRs so that TWO workgroups share a CU (their barrier / LDS latencies overlap).
 //   CT = 2: 64 output channels per workgroup: the transformed input V is shared by twice as many MFMAs (48 -> 32 KB of LDS operand
 //           traffic per 2048 MFMA cycles), 8 accumulators per wave (<= 256 VGPRs, one workgroup per CU).
