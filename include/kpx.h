@@ -161,6 +161,11 @@ int kpx_head_blend_tiled_fwd_f32(const float* im, const float* raw4, size_t P, i
 int kpx_fill_f32(float* p, size_t n, float value, void* stream);
 int kpx_axpy_f32(float* y, const float* x, size_t n, float a, void* stream);   /* y += a*x (gradient accumulation) */
 
+/* Input pipeline (next row): uint8 frames -> float32 in [-1,1] on the device, with the reference's arithmetic
+ * dst = float32(src / 255.0) * 2 - 1  (data/image_pair_dataloader.py:163-164 float64 division, tf.data float32 cast,
+ * map_fn :64-69 in float32).  Lets the loader ship uint8 over PCIe (a quarter of the bytes). */
+int kpx_u8_to_unit_f32(const unsigned char* src, size_t n, float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

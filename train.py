@@ -5,8 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --mode ... (data parallel)
 
 Only the stage-1 ``detector_translator`` mode is built (BASELINE.json hot path); ``motion_generator`` is out of scope and
-raises.  The JPEG input pipeline of the reference (data/image_pair_dataloader.py) is out of scope too: ``--synthetic``
-feeds Penn-shaped random pairs with the same output contract (float32 NHWC in [-1,1], keys image / future_image).
+raises.  Without ``--synthetic`` the frames come from ``paths.data_dir`` through kpx_amd.data.ImagePairDataLoader (the
+reference's data/image_pair_dataloader.py + tf.data pipeline: threaded PIL augmentation, uint8 batches in pinned memory, async
+copy + on-device conversion); ``--synthetic`` feeds Penn-shaped random pairs with the same output contract (float32 NHWC in
+[-1,1], keys image / future_image).
 """
 import logging
 import os
@@ -67,25 +69,41 @@ def main(argv=None):
     model = _get_model_by_mode(args.mode, config, 0, device=dev, vgg=vgg)
     print('model initialized')
     model.build(None)
-    if not args.synthetic:
-        raise Exception('the Penn Action JPEG pipeline (data/image_pair_dataloader.py) is out of scope; run with --synthetic')
-
     batch_size = train_config['batch_size']          # per process, like the reference's single-device batch
+    train_it = test_it = None
+    if not args.synthetic:                           # reference train.py:125-135, 60-70: is_train -> random_order + randomness
+        data_dir = paths_config['data_dir']
+        if not os.path.exists(os.path.join(str(data_dir), 'train_set.txt')):
+            raise Exception('no train_set.txt under paths.data_dir = %s (pass --synthetic for benchmarking)' % data_dir)
+        import random
+        import numpy as np
+        random.seed(1000 + rank); np.random.seed(1000 + rank)          # different sample streams per data-parallel rank
+        train_it = iter(kpx_amd.ImagePairDataLoader(data_dir, 'train', random_order=True, randomness=True)
+                        .batches(batch_size, dev, repeat=True, shuffle=True))
+        if os.path.exists(os.path.join(str(data_dir), 'test_set.txt')):
+            test_loader = kpx_amd.ImagePairDataLoader(data_dir, 'test', random_order=False, randomness=False)
+            test_it = lambda: iter(test_loader.batches(batch_size, dev, repeat=False, shuffle=False))
     n_steps = args.steps if args.steps is not None else train_config['n_steps']
     model.initialize_loggers(paths_config['log_dir'], None)
     print('training start')
     for step in range(model.global_step, n_steps):   # reference train.py:84-113
         should_write_log = step % train_config['log_interval'] == 0
-        pair = synthetic_pair(batch_size, res=model.image_size, seed0=2 * (step * world + rank), seed1=2 * (step * world + rank) + 1)
-        feed_dict = {k: torch.from_numpy(v).to(dev) for k, v in pair.items()}
+        if train_it is not None:
+            feed_dict = next(train_it)
+        else:
+            pair = synthetic_pair(batch_size, res=model.image_size, seed0=2 * (step * world + rank), seed1=2 * (step * world + rank) + 1)
+            feed_dict = {k: torch.from_numpy(v).to(dev) for k, v in pair.items()}
         model.train_step(None, feed_dict, step, batch_size, should_write_log=should_write_log and rank == 0,
                          should_write_summary=False)
         if step % train_config['checkpoint_interval'] == 0 and rank == 0:
             model.save_checkpoint(None, step)
         if step % train_config['test_interval'] == 0 and rank == 0:
-            tp = synthetic_pair(batch_size, res=model.image_size, seed0=10 ** 6, seed1=10 ** 6 + 1)
-            result = model.test_step(None, {k: torch.from_numpy(v).to(dev) for k, v in tp.items()}, step, 0, batch_size)
-            model.collect_test_results([result], step)
+            if test_it is not None:                  # reference train.py:97-110: one pass over the test subset
+                results = [model.test_step(None, fd, step, i, fd['image'].shape[0]) for i, fd in enumerate(test_it())]
+            else:
+                tp = synthetic_pair(batch_size, res=model.image_size, seed0=10 ** 6, seed1=10 ** 6 + 1)
+                results = [model.test_step(None, {k: torch.from_numpy(v).to(dev) for k, v in tp.items()}, step, 0, batch_size)]
+            model.collect_test_results(results, step)
     if world > 1:
         torch.distributed.destroy_process_group()
 

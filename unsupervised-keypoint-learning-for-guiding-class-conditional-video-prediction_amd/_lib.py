@@ -66,6 +66,7 @@ SIGNATURES = {
     'kpx_head_blend_tiled_fwd_f32': (c_int, [P, P, c_size_t, c_int, c_int, c_int, P, P, P, P]),
     'kpx_fill_f32': (c_int, [P, c_size_t, c_float, P]),
     'kpx_axpy_f32': (c_int, [P, P, c_size_t, c_float, P]),
+    'kpx_u8_to_unit_f32': (c_int, [P, c_size_t, P, P]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

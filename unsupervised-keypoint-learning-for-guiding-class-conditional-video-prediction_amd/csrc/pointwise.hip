@@ -26,6 +26,19 @@ extern "C" int kpx_fill_f32(float* p, size_t n, float value, void* stream) {
     return kpx_launch_status();
 }
 
+__global__ __launch_bounds__(256) void u8_to_unit_kernel(const unsigned char* __restrict__ src, size_t n, float* __restrict__ dst) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = (float)((double)src[i] / 255.0);          // numpy's float64 division, then tf.data's float32 cast
+        dst[i] = __fsub_rn(__fmul_rn(v, 2.0f), 1.0f);              // map_fn in float32 (no fma contraction)
+    }
+}
+extern "C" int kpx_u8_to_unit_f32(const unsigned char* src, size_t n, float* dst, void* stream) {
+    if (!src || !dst) return KPX_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(u8_to_unit_kernel, dim3(grid_for(n)), dim3(256), 0, kpx_stream(stream), src, n, dst);
+    return kpx_launch_status();
+}
+
 __global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, size_t n, float a) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = fmaf(a, x[i], y[i]);
 }
