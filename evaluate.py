@@ -64,10 +64,30 @@ def main(argv=None):
     model.build(None)
     model.restore(None, args.checkpoint_stage1)                      # reference :76-77: two partial restores by name
     model.restore(None, args.checkpoint_stage2)
-    if not args.synthetic:
-        raise Exception('the Penn Action sequence loader (data/sequence_dataloader.py) is out of scope; run with --synthetic N')
     n_action = config['model']['n_action']
     sample_idx, frames, t0 = 0, 0, time.time()
+    if not args.synthetic:                       # reference :43-51, :84-130: the test subset through the sequence loader
+        loader = kpx_amd.data.SequenceDataLoader(config['paths']['data_dir'], 'test', n_points=config['model']['n_pts'], n_action=n_action,
+                                                 random_order=False, randomness=False, with_image_seq=True)
+        for batch in loader.batches(args.batch, dev, repeat=False, num_preprocess_threads=12):
+            outputs = model.run(None, {'image': batch['image'], 'action_code': batch['action_code']})
+            bsz = batch['image'].shape[0]
+            frames += bsz * 32
+            if not args.no_save:
+                o = {k: v.cpu().numpy() for k, v in outputs.items() if isinstance(v, torch.Tensor)}
+                real = batch['real_im_seq'].cpu().numpy()
+                for batch_idx in range(bsz):
+                    d = osp.join(args.save_dir, '%04d' % sample_idx)
+                    os.makedirs(d, exist_ok=True)
+                    _save_img(osp.join(d, 'input_im.png'), o['im'][batch_idx], rescale=True)
+                    _save_img_sequence(osp.join(d, 'real_seq'), real[batch_idx], rescale=True)
+                    _save_img_sequence(osp.join(d, 'pred_seq'), o['pred_im_seq'][batch_idx], rescale=True)
+                    _save_img_sequence(osp.join(d, 'mask'), o['mask'][batch_idx], rescale=False)
+                    _save_img_sequence(osp.join(d, 'crude'), o['pred_im_crude'][batch_idx], rescale=True)
+                    sample_idx += 1
+        torch.cuda.synchronize()
+        print('iteration through test set finished: %d predicted frames, %.1f frames/sec' % (frames, frames / (time.time() - t0)))
+        return
     for start in range(0, args.synthetic, args.batch):
         bsz = min(args.batch, args.synthetic - start)
         rs = np.random.RandomState(start)

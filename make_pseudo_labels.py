@@ -33,7 +33,7 @@ def main(argv=None):
     parser = ArgumentParser()
     parser.add_argument('--config', type=str, required=True, help='path of the configuration file')
     parser.add_argument('--checkpoint', type=str, required=True, help='path of the pretrained keypoints detector')
-    parser.add_argument('--synthetic', type=int, default=0, help='number of synthetic videos (the JPEG loader is out of scope)')
+    parser.add_argument('--synthetic', type=int, default=0, help='number of synthetic videos instead of paths.data_dir')
     parser.add_argument('--frames', type=int, default=MAX_FRAMES)
     args = parser.parse_args(argv)
     config = load_config(args.config)
@@ -48,9 +48,18 @@ def main(argv=None):
     model.build(None)
     restored = model.restore(None, args.checkpoint)
     print('restored %d arrays' % len(restored))
-    if not args.synthetic:
-        raise Exception('the Penn Action JPEG loader (data/keypoint_dataloader.py) is out of scope; run with --synthetic V')
     t0, frames = time.time(), 0
+    if not args.synthetic:                       # reference :36-37, :79-95: every video of the train and the test subset
+        data_dir = config['paths']['data_dir']
+        for subset in ('train', 'test'):
+            for v in kpx_amd.data.KeypointDataLoader(data_dir, subset).videos(dev):
+                outputs = model.run(None, {'image': v['image'][None], 'idx': np.array([v['idx']]), 'len': np.array([v['len']])})
+                _save_output(keypoints_root_dir, outputs)
+                frames += v['len']
+            print('iteration through %s set finished' % subset)
+        torch.cuda.synchronize()
+        print('%d frames, %.1f frames/sec' % (frames, frames / (time.time() - t0)))
+        return
     for v in range(args.synthetic):
         rs = np.random.RandomState(v)
         n = int(rs.randint(args.frames // 4, args.frames + 1))

@@ -3,12 +3,16 @@
 
     python -B tests/golden/make_input_golden.py
 
-Pins the image-pair input pipeline against the REFERENCE's own loader, executed unmodified
-(/root/reference/data/image_pair_dataloader.py + utils/data.py) on a small synthetic Penn-Action-shaped dataset:
+Pins the input pipelines against the REFERENCE's own loaders, executed unmodified
+(/root/reference/data/{image_pair,keypoint,sequence}_dataloader.py + utils/data.py) on a small synthetic
+Penn-Action-shaped dataset:
 
-* the dataset: three "videos" (landscape 176x132, portrait 120x168, square 150x150) of 11-14 JPEG frames drawn by this
-  script (a smooth random background with a moving disc); the encoded JPEG bytes are stored in the fixture so the test
-  can rebuild the directory tree;
+* the dataset: three "videos" frames/0001..3 (landscape 144x108 x 40 frames, portrait 96x136 x 70, square 120x120 x 20 -- i.e.
+  frame gaps 1, 2 and the "short video" branch of the sequence loader) drawn by this script (a smooth random background with a
+  moving disc) plus random float32 pseudo_labels/*.npy key points; the encoded bytes are stored in the fixture so the test can
+  rebuild the directory tree;
+* KeypointDataLoader: SHA-256 of every video's centre-cropped frames, length and id; SequenceDataLoader: 12 augmented samples
+  with the future-frame sequence and 3 sequential ones (key-point arrays in full, images as SHA-256);
 * the expected samples: ``ImagePairDataLoader.sample_generator()`` of the reference after ``random.seed(S)`` /
   ``np.random.seed(S)`` -- 30 samples with random_order=True, randomness=True (rotation, random crop, flip, the ten
   filters) and the 3 sequential samples with both switched off.  Stored as the uint8 image (the reference yields
@@ -35,7 +39,8 @@ REF = '/root/reference'
 SEED = 20190611
 sys.dont_write_bytecode = True
 
-VIDEOS = (('0001', 176, 132, 12, 3), ('0002', 120, 168, 14, 7), ('0003', 150, 150, 11, 0))     # name, w, h, frames, action id
+VIDEOS = (('frames/0001', 144, 108, 40, 3), ('frames/0002', 96, 136, 70, 7), ('frames/0003', 120, 120, 20, 0))     # name, w, h, frames, action id
+N_POINTS, N_ACTION = 5, 9
 
 
 def make_dataset(root):
@@ -44,6 +49,13 @@ def make_dataset(root):
     rs = np.random.RandomState(7)
     for name, w, h, n, act in VIDEOS:
         os.makedirs(os.path.join(root, name), exist_ok=True)
+        os.makedirs(os.path.join(root, 'pseudo_labels'), exist_ok=True)
+        kp = (rs.rand(n, N_POINTS, 2) * 1.6 - 0.8).astype(np.float32)         # what make_pseudo_labels.py writes: [frames, K, 2] float32
+        buf = io.BytesIO(); np.save(buf, kp)
+        rel = name.replace('frames', 'pseudo_labels') + '.npy'
+        files[rel] = buf.getvalue()
+        with open(os.path.join(root, rel), 'wb') as f:
+            f.write(files[rel])
         low = rs.rand(h // 12 + 2, w // 12 + 2, 3)
         bg = np.asarray(Image.fromarray((low * 255).astype(np.uint8)).resize((w, h), Image.BILINEAR)).astype(np.float32)
         yy, xx = np.mgrid[0:h, 0:w]
@@ -53,7 +65,7 @@ def make_dataset(root):
             img = bg.copy()
             img[disc] = (250, 40 + 10 * i, 30)
             buf = io.BytesIO()
-            Image.fromarray(img.astype(np.uint8)).save(buf, format='JPEG', quality=90)
+            Image.fromarray(img.astype(np.uint8)).save(buf, format='JPEG', quality=85)
             rel = '%s/%06d.jpg' % (name, i + 1)
             files[rel] = buf.getvalue()
             with open(os.path.join(root, rel), 'wb') as f:
@@ -64,16 +76,16 @@ def make_dataset(root):
     return files, listing
 
 
-def reference_loader_class():
+def reference_loader_classes():
     tf = types.ModuleType('tensorflow')
-    tf.float32 = 'float32'
+    tf.float32, tf.int16 = 'float32', 'int16'
     sys.modules['tensorflow'] = tf
     sys.path.insert(0, REF)
     try:
-        from data.image_pair_dataloader import ImagePairDataLoader
+        from data import ImagePairDataLoader, KeypointDataLoader, SequenceDataLoader
     finally:
         sys.path.remove(REF)
-    return ImagePairDataLoader
+    return ImagePairDataLoader, KeypointDataLoader, SequenceDataLoader
 
 
 def signature(u8):
@@ -97,24 +109,57 @@ def collect(loader, n_samples):
 
 
 def main():
-    ref_cls = reference_loader_class()
+    ref_cls, ref_kp_cls, ref_seq_cls = reference_loader_classes()
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    extra = {}
     with tempfile.TemporaryDirectory() as root:
         files, listing = make_dataset(root)
         random.seed(SEED); np.random.seed(SEED)
         rand = collect(ref_cls(root, 'train', random_order=True, randomness=True), 30)
         random.seed(SEED); np.random.seed(SEED)
         seq = collect(ref_cls(root, 'train', random_order=False, randomness=False), 3)
+        # whole-video loader (data/keypoint_dataloader.py): SHA-256 of the real frames as uint8, the padding is checked to be zeros
+        kp_sha, kp_len, kp_idx = [], [], []
+        for s in ref_kp_cls(root, 'train').sample_generator():
+            x, n = s['image'], s['len']
+            assert x.shape == (663, 128, 128, 3) and x.dtype == np.float64 and not x[n:].any()
+            u8 = np.rint(x[:n] * 255.0).astype(np.uint8)
+            assert np.array_equal(u8 / 255.0, x[:n])
+            kp_sha.append(sha(u8)); kp_len.append(n); kp_idx.append(s['idx'])
+        extra.update(kp_sha256=np.array(kp_sha), kp_len=np.array(kp_len), kp_idx=np.array(kp_idx))
+        # sequence loader (data/sequence_dataloader.py): 12 random augmented samples with the future frames, 3 plain sequential ones
+        for tag, kw, n_s in (('sq_rand', dict(with_image_seq=True, random_order=True, randomness=True), 12),
+                             ('sq_seq', dict(with_image_seq=False, random_order=False, randomness=False), 3)):
+            random.seed(SEED + 1); np.random.seed(SEED + 1)
+            loader = ref_seq_cls(root, 'train', N_POINTS, N_ACTION, **kw)
+            got = []
+            while len(got) < n_s:
+                for s in loader.sample_generator():
+                    got.append(s)
+                    if len(got) == n_s:
+                        break
+            for key in ('keypoints', 'real_seq', 'action_code'):
+                extra['%s_%s' % (tag, key)] = np.stack([g[key] for g in got])
+            ims = [np.rint(g['image'] * 255.0).astype(np.uint8) for g in got]
+            assert all(np.array_equal(u / 255.0, g['image']) for u, g in zip(ims, got))
+            extra['%s_image_sha256' % tag] = np.array([sha(u) for u in ims])
+            if kw['with_image_seq']:
+                sq = [np.rint(g['real_im_seq'] * 255.0).astype(np.uint8) for g in got]
+                assert all(np.array_equal(u / 255.0, g['real_im_seq']) and u.shape == (32, 128, 128, 3) for u, g in zip(sq, got))
+                extra['%s_im_seq_sha256' % tag] = np.array([sha(u) for u in sq])
     out = {'seed': np.int64(SEED), 'listing': np.frombuffer(listing.encode(), dtype=np.uint8),
            'file_names': np.array(sorted(files)),
            'rand_sha256': np.array([hashlib.sha256(a.tobytes()).hexdigest() for a in rand]),
            'rand_sig': np.stack([np.stack([signature(f) for f in a]) for a in rand]),
            'rand_full_idx': np.array([0, 7, 18, 29]), 'rand_full': rand[[0, 7, 18, 29]],
            'seq_sha256': np.array([hashlib.sha256(a.tobytes()).hexdigest() for a in seq]), 'seq_full': seq}
+    out.update(extra)
+    out['n_points'], out['n_action'] = np.int64(N_POINTS), np.int64(N_ACTION)
     for k, name in enumerate(sorted(files)):
         out['file_%03d' % k] = np.frombuffer(files[name], dtype=np.uint8)
     path = os.path.join(HERE, 'image_pair_ref.npz')
     np.savez_compressed(path, **out)
-    print('wrote', path, os.path.getsize(path) // 1024, 'KiB;', len(files), 'jpeg frames,', len(rand), '+', len(seq), 'samples')
+    print('wrote', path, os.path.getsize(path) // 1024, 'KiB;', len(files), 'files,', len(rand), '+', len(seq), 'pair samples')
 
 
 if __name__ == '__main__':

@@ -64,3 +64,39 @@ def test_train_py_runs_on_the_jpeg_pipeline(kpx, tmp_path):
     import train
     train.main(['--mode', 'detector_translator', '--config', str(cfg_path), '--synthetic-vgg', '--steps', '2'])
     assert (tmp_path / 'results' / 'detector_translator' / 'model.ckpt-0.npz').exists()
+
+
+def _fixture_dataset(root):
+    golden = np.load(os.path.join(HERE, 'golden', 'image_pair_ref.npz'))
+    for k, rel in enumerate(str(n) for n in golden['file_names']):
+        p = root / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(golden['file_%03d' % k].tobytes())
+    for subset in ('train', 'test'):
+        (root / (subset + '_set.txt')).write_bytes(golden['listing'].tobytes())
+    return golden
+
+
+def test_pseudo_label_and_evaluate_scripts_run_on_jpeg_data(kpx, tmp_path):
+    """make_pseudo_labels.py (KeypointDataLoader) then evaluate.py (SequenceDataLoader with the future frames) on the fixture videos."""
+    import yaml
+    data = tmp_path / 'penn'
+    golden = _fixture_dataset(data)
+    k = int(golden['n_points'])
+    cfg = {'paths': {'data_dir': str(data), 'vggnet': str(tmp_path / 'none.npy'), 'log_dir': str(tmp_path / 'results')},
+           'training': {'n_steps': 1, 'summary_interval': 500, 'test_interval': 500, 'checkpoint_interval': 1000, 'log_interval': 1,
+                        'batch_size': 2, 'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}},
+           'model': {'n_pts': k, 'n_action': int(golden['n_action']), 'cell_info': [32, 32], 'vae_dim': 8}}
+    cfg_path = tmp_path / 'cfg.yaml'
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    dev = torch.device('cuda', 0)
+    fm = kpx.FinalModel(cfg, device=dev); fm.build(None); fm.initialize_loggers(str(tmp_path / 'ckpt'))
+    ckpt = fm.save_checkpoint(None, 0)
+    import make_pseudo_labels, evaluate
+    make_pseudo_labels.main(['--config', str(cfg_path), '--checkpoint', ckpt])
+    for vid, n in zip(golden['kp_idx'], golden['kp_len']):
+        pts = np.load(str(data / 'pseudo_labels' / ('%04d.npy' % int(vid))))
+        assert pts.shape == (int(n), k, 2) and np.isfinite(pts).all() and np.abs(pts).max() <= 1.0
+    evaluate.main(['--config', str(cfg_path), '--checkpoint_stage1', ckpt, '--checkpoint_stage2', ckpt, '--save_dir', str(tmp_path / 'eval'), '--batch', '2'])
+    assert sorted(os.listdir(str(tmp_path / 'eval'))) == ['0000', '0001', '0002']
+    assert len(os.listdir(str(tmp_path / 'eval' / '0000' / 'pred_seq'))) == 32 and len(os.listdir(str(tmp_path / 'eval' / '0000' / 'real_seq'))) == 32

@@ -9,7 +9,8 @@ from .detector_translator_model import DetectorTranslatorModel  # noqa: F401
 from .keypoint_model import KeypointModel  # noqa: F401
 from .final_model import FinalModel  # noqa: F401
 from .vgg import Vgg19, synthetic_vgg19_weights  # noqa: F401
-from .data import ImagePairDataLoader  # noqa: F401
+from . import data  # noqa: F401
+from .data import ImagePairDataLoader, KeypointDataLoader, SequenceDataLoader  # noqa: F401
 
-__all__ = ['BaseModel', 'DetectorTranslatorModel', 'KeypointModel', 'FinalModel', 'Vgg19', 'synthetic_vgg19_weights', 'ImagePairDataLoader', 'layers', 'model_utils',
+__all__ = ['BaseModel', 'DetectorTranslatorModel', 'KeypointModel', 'FinalModel', 'Vgg19', 'synthetic_vgg19_weights', 'ImagePairDataLoader', 'KeypointDataLoader', 'SequenceDataLoader', 'data', 'layers', 'model_utils',
            'networks', 'ops', 'variables']

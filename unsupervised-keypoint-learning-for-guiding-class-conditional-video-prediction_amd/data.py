@@ -254,3 +254,247 @@ class _DeviceBatcher(object):
         while len(self._inflight) < self.depth and self._submit():      # keep the decode pool busy during the step
             pass
         return {'image': both[0], 'future_image': both[1]}
+
+
+# ------------------------------------------------------------------------------------------------ whole-video and sequence loaders
+MIN_IMAGE_SEQ_LEN = 663      # data/keypoint_dataloader.py:13
+N_SEQUENCE_LEN = 33          # data/sequence_dataloader.py:14
+
+
+def center_crop_box(w, h, target_size=IMAGE_SIZE):
+    """utils/data.py:40-60: crop box (in the resized frame) and resize ratio for a centred target x target window."""
+    half = target_size // 2
+    if w > h:
+        ratio = h / float(target_size)
+        ox = int(w / ratio) / 2.0
+        return (ox - half, 0, ox + half, target_size), ratio
+    ratio = w / float(target_size)
+    oy = int(h / ratio) / 2.0
+    return (0, oy - half, target_size, oy + half), ratio
+
+
+def rotate_keypoints(keypoints, angle, ox=0, oy=0):
+    """utils/data.py:63-72 (rotation by -angle degrees about (ox, oy), same operation order -> same rounding)."""
+    import math
+    c, s = math.cos(math.radians(-angle)), math.sin(math.radians(-angle))
+    qx = ox + c * (keypoints[..., 0] - ox) - s * (keypoints[..., 1] - oy)
+    qy = oy + s * (keypoints[..., 0] - ox) + c * (keypoints[..., 1] - oy)
+    return np.concatenate([np.expand_dims(qx, -1), np.expand_dims(qy, -1)], axis=-1)
+
+
+def _to_device_unit(u8, device):
+    """uint8 host array -> float32 [-1,1] tensor on ``device`` (pinned copy + kpx_u8_to_unit_f32 on a GPU)."""
+    import torch
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return torch.from_numpy(_u8_to_unit_numpy(u8))
+    from ._lib import lib, check
+    host = torch.from_numpy(np.ascontiguousarray(u8)).pin_memory()
+    dev_u8 = host.to(device, non_blocking=True)
+    out = torch.empty(host.shape, dtype=torch.float32, device=device)
+    check(lib.kpx_u8_to_unit_f32(dev_u8.data_ptr(), dev_u8.numel(), out.data_ptr(), torch.cuda.current_stream(device).cuda_stream), 'kpx_u8_to_unit_f32')
+    return out
+
+
+class _ListedVideos(object):
+    def __init__(self, data_dir, subset):
+        self._data_dir = data_dir
+        with open(osp.join(data_dir, subset + '_set.txt'), 'r') as f:
+            self._images = f.read().splitlines()
+        self._total = len(self._images)
+        print(subset + 'set : ', self._total)
+
+    def length(self):
+        return self._total
+
+    def _frame(self, video, idx):
+        return Image.open(osp.join(self._data_dir, video, '{:06d}'.format(idx + 1) + '.jpg'))
+
+    def _n_frames(self, video):
+        return len(os.listdir(osp.join(self._data_dir, video)))
+
+
+class KeypointDataLoader(_ListedVideos):
+    """data/keypoint_dataloader.py:16-86: every frame of a video, centre-cropped to 128x128, zero-padded to 663 frames."""
+
+    def __init__(self, data_dir, subset, threads=8):
+        super(KeypointDataLoader, self).__init__(data_dir, subset)
+        self._threads = threads
+
+    def get_sample_shape(self):
+        return {'image': [MIN_IMAGE_SEQ_LEN, IMAGE_SIZE, IMAGE_SIZE, 3], 'len': None, 'idx': None}
+
+    def get_sample_dtype(self):
+        import torch
+        return {'image': torch.float32, 'len': torch.int16, 'idx': torch.int16}
+
+    def map_fn(self, inputs):
+        return {'image': inputs['image'] * 2.0 - 1.0, 'len': inputs['len'], 'idx': inputs['idx']}
+
+    def render_video(self, idx):
+        """-> (uint8 [len,128,128,3], len, video id)"""
+        video = self._images[idx].split()[0]
+        n = self._n_frames(video)
+        with self._frame(video, 0) as first:
+            w, h = first.size
+        box, ratio = center_crop_box(w, h)
+        size = [int(w / ratio), int(h / ratio)]
+
+        def one(i):
+            return np.asarray(self._frame(video, i).resize(size).crop(box))
+        with ThreadPoolExecutor(max_workers=self._threads) as pool:
+            frames = list(pool.map(one, range(n)))
+        return np.stack(frames), n, int(video.split('/')[-1])
+
+    def sample_generator(self):
+        for idx in range(self._total):
+            frames, n, vid = self.render_video(idx)
+            seq = frames
+            if n < MIN_IMAGE_SEQ_LEN:
+                seq = np.concatenate([frames, np.zeros([MIN_IMAGE_SEQ_LEN - n, IMAGE_SIZE, IMAGE_SIZE, 3])], axis=0)
+            yield {'image': seq / 255.0, 'idx': vid, 'len': n}
+
+    def videos(self, device):
+        """Device-side iterator: {'image': float32 [663,128,128,3] in [-1,1] (pad frames = -1 like the reference), 'len', 'idx'}."""
+        for idx in range(self._total):
+            frames, n, vid = self.render_video(idx)
+            if n < MIN_IMAGE_SEQ_LEN:
+                frames = np.concatenate([frames, np.zeros([MIN_IMAGE_SEQ_LEN - n, IMAGE_SIZE, IMAGE_SIZE, 3], dtype=np.uint8)], axis=0)
+            yield {'image': _to_device_unit(frames, device), 'len': n, 'idx': vid}
+
+
+SeqPlan = namedtuple('SeqPlan', 'index video n_files im_idx angle flip scale')
+
+
+class SequenceDataLoader(_ListedVideos):
+    """data/sequence_dataloader.py:17-198: start frame + 32 future key-point sets (+ optionally the future frames) of a video."""
+
+    def __init__(self, data_dir, subset, n_points, n_action, with_image_seq=False, random_order=True, randomness=False,
+                 rng=None, np_rng=None):
+        super(SequenceDataLoader, self).__init__(data_dir, subset)
+        self.n_points, self.n_action = n_points, n_action
+        self._with_image_seq, self._random_order, self._randomness = with_image_seq, random_order, randomness
+        self._rng = rng if rng is not None else _random
+        self._np_rng = np_rng if np_rng is not None else np.random
+
+    def get_sample_shape(self):
+        d = {'image': [IMAGE_SIZE, IMAGE_SIZE, 3], 'keypoints': [self.n_points, 2],
+             'real_seq': [N_SEQUENCE_LEN - 1, self.n_points, 2], 'action_code': [self.n_action]}
+        if self._with_image_seq:
+            d['real_im_seq'] = [N_SEQUENCE_LEN - 1, IMAGE_SIZE, IMAGE_SIZE, 3]
+        return d
+
+    def get_sample_dtype(self):
+        import torch
+        return {k: torch.float32 for k in self.get_sample_shape()}
+
+    def map_fn(self, inputs):
+        out = {'image': inputs['image'] * 2.0 - 1.0, 'keypoints': inputs['keypoints'], 'real_seq': inputs['real_seq'],
+               'action_code': inputs['action_code']}
+        if self._with_image_seq:
+            out['real_im_seq'] = inputs['real_im_seq'] * 2.0 - 1.0
+        return out
+
+    def plans(self):
+        if self._random_order:
+            for _ in range(self._total):
+                yield self.plan(int(self._np_rng.randint(len(self._images))))
+        else:
+            for idx in range(self._total):
+                yield self.plan(idx)
+
+    def plan(self, idx):
+        """All random draws of one sample, in the reference's order (:112-118 start frame, :140 rotation, :177 flip, :186 scale)."""
+        video = self._images[idx].split()[0]
+        n = self._n_frames(video)
+        gap = int(n / N_SEQUENCE_LEN)
+        im_idx, angle, flip, scale = 0, None, None, None
+        if self._randomness:
+            rng = self._rng
+            im_idx = rng.randint(0, n - N_SEQUENCE_LEN * gap) if gap >= 1 else rng.randint(0, n - ((N_SEQUENCE_LEN - 1) // 2 + 1))
+            angle = rng.randrange(-15, 16)
+            flip = rng.randint(0, 1)
+            scale = rng.randint(70, 120) / 100.0
+        return SeqPlan(idx, video, n, im_idx, angle, flip, scale)
+
+    def render(self, plan):
+        """-> dict with uint8 'image' (and 'real_im_seq'), float 'keypoints' / 'real_seq' / 'action_code' (before the /255)."""
+        video, n, im_idx = plan.video, plan.n_files, plan.im_idx
+        action_idx = self._images[plan.index].split()[1]
+        keypoints = np.load(osp.join(self._data_dir, video.replace('frames', 'pseudo_labels') + '.npy'))
+        gap = int(n / N_SEQUENCE_LEN)
+        image = self._frame(video, im_idx)
+        if gap >= 1:
+            real_seq = keypoints[[im_idx + gap * i for i in range(N_SEQUENCE_LEN)], :, :]
+        else:                                    # short video: every second entry is the mean of its neighbours (:126-136)
+            n_seq = (N_SEQUENCE_LEN - 1) // 2 + 1
+            real_seq = np.zeros([N_SEQUENCE_LEN, self.n_points, 2])
+            half = keypoints[im_idx:im_idx + n_seq, :, :]
+            for i in range(n_seq - 1):
+                real_seq[i * 2] = half[i]
+                real_seq[i * 2 + 1] = (half[i] + half[i + 1]) / 2.0
+            real_seq[-1] = half[-1]
+        if self._randomness:
+            image = image.rotate(plan.angle)
+            real_seq = rotate_keypoints(real_seq, plan.angle)
+        w, h = image.size
+        box, ratio = center_crop_box(w, h)
+        size = [int(w / ratio), int(h / ratio)]
+        image = image.resize(size).crop(box)
+        out = {}
+        if self._with_image_seq:                 # the future frames start at frame gap (not im_idx + gap) and are never rotated / flipped (:152-171)
+            n_future, twice = N_SEQUENCE_LEN - 1, False
+            if gap < 1:
+                gap, twice, n_future = 1, True, (N_SEQUENCE_LEN - 1) // 2
+            seq = []
+            for i in range(1, n_future + 1):
+                cur = np.asarray(self._frame(video, i * gap).resize(size).crop(box))
+                seq.append(cur)
+                if twice:
+                    seq.append(cur)
+            out['real_im_seq'] = np.stack(seq)
+        if self._randomness and plan.flip:
+            image = image.transpose(Image.FLIP_LEFT_RIGHT)
+            real_seq[:, :, 0] *= -1
+        label = np.zeros(self.n_action)
+        label[int(action_idx)] = 1
+        if self._randomness:
+            real_seq *= plan.scale
+        out.update({'image': np.asarray(image), 'keypoints': real_seq[0, ::], 'real_seq': real_seq[1:, ::], 'action_code': label})
+        return out
+
+    def sample_generator(self):
+        for plan in self.plans():
+            s = self.render(plan)
+            s['image'] = s['image'] / 255.0
+            if self._with_image_seq:
+                s['real_im_seq'] = s['real_im_seq'] / 255.0
+            yield s
+
+    def batches(self, batch_size, device, repeat=False, num_preprocess_threads=8):
+        """get_dataset(batch_size, ...) + map_fn: float32 tensors on ``device``; images in [-1,1] (converted on the GPU)."""
+        import torch
+        pool = ThreadPoolExecutor(max_workers=max(1, num_preprocess_threads))
+        try:
+            while True:
+                chunk = []
+                for plan in self.plans():
+                    chunk.append(plan)
+                    if len(chunk) == batch_size:
+                        yield self._collate(list(pool.map(self.render, chunk)), device)
+                        chunk = []
+                if chunk:
+                    yield self._collate(list(pool.map(self.render, chunk)), device)
+                if not repeat:
+                    break
+        finally:
+            pool.shutdown(wait=False)
+
+    def _collate(self, samples, device):
+        import torch
+        out = {'image': _to_device_unit(np.stack([s['image'] for s in samples]), device)}
+        for k in ('keypoints', 'real_seq', 'action_code'):
+            out[k] = torch.from_numpy(np.stack([s[k] for s in samples]).astype(np.float32)).to(device)
+        if self._with_image_seq:
+            out['real_im_seq'] = _to_device_unit(np.stack([s['real_im_seq'] for s in samples]), device)
+        return out
