@@ -55,7 +55,7 @@ def main(argv=None):
     args = parser.parse_args(argv)
     config = load_config(args.config)
     for p in (args.checkpoint_stage1, args.checkpoint_stage2):       # reference :34-38
-        if not osp.exists(p):
+        if not (osp.exists(p) or osp.exists(p + '.index')):                 # .npz file or TensorFlow bundle prefix
             raise Exception('checkpoint not found at %s' % p)
     import kpx_amd
     dev = torch.device('cuda', 0)

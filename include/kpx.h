@@ -166,6 +166,10 @@ int kpx_axpy_f32(float* y, const float* x, size_t n, float a, void* stream);   /
  * map_fn :64-69 in float32).  Lets the loader ship uint8 over PCIe (a quarter of the bytes). */
 int kpx_u8_to_unit_f32(const unsigned char* src, size_t n, float* dst, void* stream);
 
+/* Host utility (no device access): CRC-32C of n bytes continuing from `crc` (0 to start) -- the checksum of TensorFlow V2
+ * checkpoint bundles (next row; models/base_model.py:74-91 saves / restores through tf.train.Saver). */
+unsigned int kpx_crc32c_host(unsigned int crc, const void* data, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,7 +39,7 @@ def main(argv=None):
     config = load_config(args.config)
     keypoints_root_dir = osp.join(config['paths']['data_dir'], 'pseudo_labels')
     os.makedirs(keypoints_root_dir, exist_ok=True)
-    if not osp.exists(args.checkpoint):
+    if not (osp.exists(args.checkpoint) or osp.exists(args.checkpoint + '.index')):      # .npz file or TensorFlow bundle prefix
         raise Exception('checkpoint not found at %s' % args.checkpoint)          # reference :31-32
     import kpx_amd
     dev = torch.device('cuda', 0)

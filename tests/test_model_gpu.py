@@ -143,6 +143,17 @@ def test_checkpoint_roundtrip_uses_reference_names(tmp_path):
     a2 = m2.checkpoint_arrays()
     for k_, v in arrays.items():
         assert np.array_equal(np.asarray(v), np.asarray(a2[k_])), k_
+    # the same state as a TensorFlow V2 bundle (what tf.train.Saver writes: .index + .data-00000-of-00001 + `checkpoint`)
+    prefix = model.save_checkpoint(None, 1, fmt='tf')
+    assert os.path.exists(prefix + '.index') and os.path.exists(prefix + '.data-00000-of-00001') and os.path.exists(os.path.join(os.path.dirname(prefix), 'checkpoint'))
+    from kpx_amd import tf_bundle
+    listed = tf_bundle.list_bundle(prefix)
+    assert sorted(listed) == sorted(arrays) and listed['translator/conv_6_0/conv2d/kernel'] == (np.float32, (3, 3, 64, 3))
+    m3 = make_model(32, 3, 2, dev)
+    m3.restore(None, prefix)
+    a3 = m3.checkpoint_arrays()
+    for k_, v in arrays.items():
+        assert np.array_equal(np.asarray(v), np.asarray(a3[k_])), k_
 
 
 def _dp_gpu_worker(rank, world, port, q):

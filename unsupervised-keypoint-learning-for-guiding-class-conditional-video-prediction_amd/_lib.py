@@ -67,6 +67,7 @@ SIGNATURES = {
     'kpx_fill_f32': (c_int, [P, c_size_t, c_float, P]),
     'kpx_axpy_f32': (c_int, [P, P, c_size_t, c_float, P]),
     'kpx_u8_to_unit_f32': (c_int, [P, c_size_t, P, P]),
+    'kpx_crc32c_host': (ctypes.c_uint, [ctypes.c_uint, P, c_size_t]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -46,16 +46,27 @@ class BaseModel(ABC):
         """Everything tf.train.Saver(tf.global_variables()) would hold (reference :74)."""
         return self.store.export_numpy(include_slots=self.is_training)
 
-    def save_checkpoint(self, sess, step):
-        """reference :77-81 -> <log_dir>/<name>/model.ckpt-<step>(.npz)."""
-        checkpoint_path = osp.join(self.log_dir, self.__class__.name, 'model.ckpt-%d.npz' % step)
-        np.savez(checkpoint_path, **{k.replace('/', '|'): v for k, v in self.checkpoint_arrays().items()})
-        return checkpoint_path
+    def save_checkpoint(self, sess, step, fmt=None):
+        """reference :77-81 -> <log_dir>/<name>/model.ckpt-<step>.  ``fmt`` (or $KPX_CKPT_FORMAT): 'npz' (default, one file) or
+        'tf' = a TensorFlow V2 bundle (.index + .data-00000-of-00001 + ``checkpoint``) that tf.train.Saver can restore."""
+        fmt = fmt or os.environ.get('KPX_CKPT_FORMAT', 'npz')
+        prefix = osp.join(self.log_dir, self.__class__.name, 'model.ckpt-%d' % step)
+        if fmt == 'tf':
+            from . import tf_bundle
+            tf_bundle.write_bundle(prefix, self.checkpoint_arrays())
+            return prefix
+        np.savez(prefix + '.npz', **{k.replace('/', '|'): v for k, v in self.checkpoint_arrays().items()})
+        return prefix + '.npz'
 
     def restore(self, sess, checkpoint_path):
-        """reference :83-91: restore the intersection of checkpoint variables and model variables, by name."""
-        data = np.load(checkpoint_path)
-        arrays = {k.replace('|', '/'): data[k] for k in data.files}
+        """reference :83-91: restore the intersection of checkpoint variables and model variables, by name.  Accepts the .npz
+        container or the prefix of a TensorFlow V2 bundle (e.g. the published stage-1 / stage-2 checkpoints)."""
+        from . import tf_bundle
+        if tf_bundle.is_bundle(checkpoint_path):
+            arrays = tf_bundle.read_bundle(checkpoint_path)
+        else:
+            data = np.load(checkpoint_path)
+            arrays = {k.replace('|', '/'): data[k] for k in data.files}
         self.store.load_numpy(arrays, strict=False)
         self._restore_extra(arrays)
         return sorted(arrays)

@@ -3,6 +3,7 @@
 //   xent : detector_translator_model.py:249-254,265-267  reduce_mean(sigmoid_cross_entropy_with_logits)
 //   Adam : detector_translator_model.py:198-202  tf.train.AdamOptimizer(lr, 0.5, 0.999) -> ApplyAdam arithmetic
 #include "kpx_common.h"
+#include <string.h>
 
 __global__ __launch_bounds__(256) void l1_pair_partial_kernel(const float* __restrict__ f, size_t half, double* __restrict__ part) {
     double s = 0.0;
@@ -136,3 +137,35 @@ extern "C" int kpx_adam_tf_flat_f32(float* p, const float* g, float* m, float* v
 }
 
 extern "C" int kpx_abi_version(void) { return KPX_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------ host utility
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slice-by-8: the checksum TensorFlow's V2 checkpoint bundles carry for
+// every tensor and table block (tensor_bundle.cc / lib/io/format.cc); used by the bundle reader / writer (tf_bundle.py).
+// Pure host code: no device pointer is touched.
+static uint32_t kpx_crc_tab[8][256];
+static bool kpx_crc_ready = false;
+static void kpx_crc_init() {
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+        kpx_crc_tab[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+        for (int t = 1; t < 8; ++t) kpx_crc_tab[t][i] = (kpx_crc_tab[t - 1][i] >> 8) ^ kpx_crc_tab[0][kpx_crc_tab[t - 1][i] & 0xff];
+    kpx_crc_ready = true;
+}
+extern "C" unsigned int kpx_crc32c_host(unsigned int crc, const void* data, size_t n) {
+    if (!kpx_crc_ready) kpx_crc_init();
+    const unsigned char* p = (const unsigned char*)data;
+    uint32_t c = ~crc;
+    while (n && ((uintptr_t)p & 7)) { c = kpx_crc_tab[0][(c ^ *p++) & 0xff] ^ (c >> 8); --n; }
+    while (n >= 8) {
+        uint64_t v; memcpy(&v, p, 8);
+        v ^= c;
+        c = kpx_crc_tab[7][v & 0xff] ^ kpx_crc_tab[6][(v >> 8) & 0xff] ^ kpx_crc_tab[5][(v >> 16) & 0xff] ^ kpx_crc_tab[4][(v >> 24) & 0xff] ^
+            kpx_crc_tab[3][(v >> 32) & 0xff] ^ kpx_crc_tab[2][(v >> 40) & 0xff] ^ kpx_crc_tab[1][(v >> 48) & 0xff] ^ kpx_crc_tab[0][(v >> 56) & 0xff];
+        p += 8; n -= 8;
+    }
+    while (n--) c = kpx_crc_tab[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+    return ~c;
+}
