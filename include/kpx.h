@@ -64,8 +64,8 @@ int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx
                          float* dw_hwio, int KH, int KW, int stride, int pad_t, int pad_l,
                          void* workspace, size_t workspace_bytes, void* stream);
 
-/* dz = dy * act'(y) (y = the activated conv output; dz may alias dy): relu / leaky_relu(0.01) backward
- * (tf.nn.relu vgg.py:54, tf.nn.leaky_relu networks/__init__.py:145,148). */
+/* dz = dy * act'(y) (y = the activated conv output; dz may alias dy): relu / leaky_relu(0.01) / tanh backward
+ * (tf.nn.relu vgg.py:54, tf.nn.leaky_relu networks/__init__.py:145,148, tf.tanh layers.py:28 in stage-2 training). */
 int kpx_act_bwd_f32(const float* dy, const float* y, float* dz, size_t n, int act, void* stream);
 
 /* ---- per-channel reductions over P pixels: sum[c] = sum_p x[p,c] (double accumulation).
@@ -160,6 +160,17 @@ int kpx_head_blend_tiled_fwd_f32(const float* im, const float* raw4, size_t P, i
 /* ---- utilities */
 int kpx_fill_f32(float* p, size_t n, float value, void* stream);
 int kpx_axpy_f32(float* y, const float* x, size_t n, float a, void* stream);   /* y += a*x (gradient accumulation) */
+
+/* Stage-2 training (next row, SURVEY 8f-4 last item: models/motion_generator_model.py).
+ * LSTMCell backward of one step (layers.py:17-21): gates [B,4U] pre-activations (i,j,f,o), c_prev [B,U] (NULL = zeros),
+ * dh [B,U], dc_in [B,U] (NULL = zeros) -> dgates [B,4U], dc_prev [B,U]. */
+int kpx_lstm_pointwise_bwd_f32(const float* gates, const float* c_prev, const float* dh, const float* dc_in, float forget_bias,
+                               float* dgates, float* dc_prev, int B, int U, void* stream);
+/* z = mu + stddev*eps and the KL term of motion_generator_model.py:146,291-293 on logit = [mu | stddev] [B,2V]; backward from dz
+ * (NULL = zeros) and the KL gradient gkl_dev[0] * gkl_host. */
+int kpx_vae_sample_kl_fwd_f32(const float* logit, const float* eps, float* z, float* kl_out, int B, int V, void* stream);
+int kpx_vae_sample_kl_bwd_f32(const float* logit, const float* eps, const float* dz, const float* gkl_dev, float gkl_host,
+                              float* dlogit, int B, int V, void* stream);
 
 /* Input pipeline (next row): uint8 frames -> float32 in [-1,1] on the device, with the reference's arithmetic
  * dst = float32(src / 255.0) * 2 - 1  (data/image_pair_dataloader.py:163-164 float64 division, tf.data float32 cast,

@@ -603,3 +603,127 @@ def final_model_forward(params, im, action_code, z, n_pts, cell_info=(1024, 1024
     return dict(pred_im_seq=torch.clamp(final, -1, 1).reshape(b, t, res, res, 3),                  # :98-99
                 pred_im_crude=torch.clamp(crude, -1, 1).reshape(b, t, res, res, 3),
                 mask=mask.reshape(b, t, res, res, 1), fut_pt_raw=pred_seq, first_pt=first_pt)
+
+
+# --------------------------------------------------------------------------- stage-2 training: MotionGeneratorModel (last item)
+def _lstm_vars(out, scope, in_size, cell_info):
+    prev = in_size
+    for i, units in enumerate(cell_info):                                      # layers.lstm_model (layers.py:17-21)
+        out[scope + '/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel' % i] = (prev + units, 4 * units)
+        out[scope + '/multi_rnn_cell/cell_%d/basic_lstm_cell/bias' % i] = (4 * units,)
+        prev = units
+
+
+def motion_generator_manifest(n_pts, n_action=9, cell_info=(1024, 1024), vae_dim=64, discr_cells=(1024, 1024)):
+    """Trainable variables of models/motion_generator_model.py: vae_encoder (:105-114 of networks/__init__.py; dynamic_rnn names
+    its cell variables under 'rnn/'), vae_decoder (:116-129) and seq_discr (:132-138)."""
+    out = OrderedDict()
+    _lstm_vars(out, 'vae_encoder/rnn', 2 * n_pts, cell_info)
+    out['vae_encoder/fully_connected/weights'] = (cell_info[-1] + 2 * n_pts + n_action, 2 * vae_dim)
+    out['vae_encoder/fully_connected/biases'] = (2 * vae_dim,)
+    out.update(stage2_decoder_manifest(n_pts, n_action, cell_info, vae_dim))
+    _lstm_vars(out, 'seq_discr/rnn', 2 * n_pts, discr_cells)
+    out['seq_discr/fully_connected/weights'] = (discr_cells[-1], 1)
+    out['seq_discr/fully_connected/biases'] = (1,)
+    return out
+
+
+def init_motion_generator(n_pts, n_action=9, cell_info=(1024, 1024), vae_dim=64, discr_cells=(1024, 1024), seed=777):
+    rs = np.random.RandomState(seed)
+    out = OrderedDict()
+    for name, shape in motion_generator_manifest(n_pts, n_action, cell_info, vae_dim, discr_cells).items():
+        if name.endswith('/W'):
+            out[name] = (rs.randn(*shape) * 0.02).astype(np.float32)
+        elif len(shape) == 2:
+            lim = math.sqrt(6.0 / (shape[0] + shape[1]))
+            out[name] = rs.uniform(-lim, lim, size=shape).astype(np.float32)
+        else:
+            out[name] = np.zeros(shape, np.float32)
+    return out
+
+
+def _dynamic_rnn(p, scope, x, cell_info):
+    """tf.nn.dynamic_rnn over a MultiRNNCell of LSTMCells with zero initial state: x [B,T,In] -> top-layer outputs [B,T,U]."""
+    b, t, _ = x.shape
+    c = [torch.zeros(b, u) for u in cell_info]
+    h = [torch.zeros(b, u) for u in cell_info]
+    outs = []
+    for step in range(t):
+        xin = x[:, step]
+        for l, u in enumerate(cell_info):
+            g = torch.cat([xin, h[l]], dim=-1) @ p[scope + '/multi_rnn_cell/cell_%d/basic_lstm_cell/kernel' % l] + \
+                p[scope + '/multi_rnn_cell/cell_%d/basic_lstm_cell/bias' % l]
+            i, j, f, o = torch.split(g, u, dim=-1)
+            c[l] = c[l] * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+            h[l] = torch.tanh(c[l]) * torch.sigmoid(o)
+            xin = h[l]
+        outs.append(h[-1])
+    return torch.stack(outs, dim=1)
+
+
+def vae_encoder(p, x, f_pt, act_code, cell_info, vae_dim):
+    """networks.vae_encoder (:105-114): LSTM over the real sequence, last output ++ first point ++ action -> fully_connected
+    (tf.contrib default activation: ReLU, so mu and stddev are non-negative) -> (mu, stddev)."""
+    out = _dynamic_rnn(p, 'vae_encoder/rnn', x, cell_info)
+    logit = F.relu(torch.cat([out[:, -1, :], f_pt, act_code], dim=-1) @ p['vae_encoder/fully_connected/weights'] +
+                   p['vae_encoder/fully_connected/biases'])
+    return logit[:, :vae_dim], logit[:, vae_dim:]
+
+
+def seq_discr(p, x, discr_cells=(1024, 1024)):
+    """networks.seq_discr (:132-138): 2-layer LSTM, fully_connected(outputs, 1) (ReLU again), logit of the last step [B,1]."""
+    out = _dynamic_rnn(p, 'seq_discr/rnn', x, discr_cells)
+    logit = F.relu(out @ p['seq_discr/fully_connected/weights'] + p['seq_discr/fully_connected/biases'])
+    return logit[:, -1, :]
+
+
+def motion_generator_losses(p, keypoints, real_seq, action_code, eps, n_pts, cell_info=(1024, 1024), vae_dim=64, discr_cells=(1024, 1024)):
+    """MotionGeneratorModel._define_forward_pass (training branch, :137-150) + _compute_loss_D / _compute_loss_G (:257-308);
+    ``eps`` is the N(0,1) draw of tf.random_normal (:146), injected."""
+    b = keypoints.shape[0]
+    first_pt = keypoints.reshape(b, n_pts * 2)
+    real = real_seq.reshape(b, N_FUTURE_FRAMES, n_pts * 2)
+    mu, stddev = vae_encoder(p, real, first_pt, action_code, cell_info, vae_dim)
+    z = mu + stddev * eps
+    pred = vae_decoder(p, z, first_pt, action_code, cell_info, n_pts)
+    real_, fake_ = seq_discr(p, real, discr_cells), seq_discr(p, pred, discr_cells)
+    loss_d_real = sigmoid_xent(real_, 1.0).mean()
+    loss_d_fake = sigmoid_xent(fake_, 0.0).mean()
+    recon = (1000 * torch.abs(pred - real)).mean()
+    kl = (0.5 * torch.sum(mu * mu + stddev * stddev - torch.log(1e-8 + stddev * stddev) - 1, dim=1)).mean()
+    adv = sigmoid_xent(fake_, 1.0).mean()
+    return dict(loss_D=loss_d_real + loss_d_fake, loss_D_real=loss_d_real, loss_D_fake=loss_d_fake,
+                loss_G=kl + recon + adv, loss_G_recon=recon, loss_G_kl=kl, loss_G_adv=adv, pred_seq=pred, mu=mu, stddev=stddev)
+
+
+class MotionTrainState:
+    def __init__(self, params, n_pts, n_action=9, cell_info=(1024, 1024), vae_dim=64, discr_cells=(1024, 1024), lr_cfg=None):
+        self.params = OrderedDict((k, torch.as_tensor(np.asarray(v)).clone()) for k, v in params.items())
+        self.cfg = dict(n_pts=n_pts, cell_info=tuple(cell_info), vae_dim=vae_dim, discr_cells=tuple(discr_cells))
+        self.d_names = [n for n in self.params if 'discr' in n]                # :176-178
+        self.g_names = [n for n in self.params if 'discr' not in n]
+        self.opt_D = AdamTF(self.d_names, self.params)
+        self.opt_G = AdamTF(self.g_names, self.params)
+        self.global_step = 0
+        self.lr_cfg = lr_cfg or {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}
+
+
+def motion_train_step(state, keypoints, real_seq, action_code, eps_D, eps_G):
+    """MotionGeneratorModel.train_step (:80-104): D-run then G-run, each a full forward (with its own random_normal draw)."""
+    p = state.params
+    kp, rs, ac = (torch.as_tensor(a) for a in (keypoints, real_seq, action_code))
+    lr = exponential_decay(state.lr_cfg['start_val'], state.global_step, state.lr_cfg['step'], state.lr_cfg['decay'])
+    for n in state.d_names + state.g_names:
+        p[n].requires_grad_(True)
+    out_d = motion_generator_losses(p, kp, rs, ac, torch.as_tensor(eps_D), **state.cfg)
+    g_d = _grads(out_d['loss_D'], p, state.d_names)
+    state.opt_D.step(p, g_d, lr)
+    out_g = motion_generator_losses(p, kp, rs, ac, torch.as_tensor(eps_G), **state.cfg)
+    g_g = _grads(out_g['loss_G'], p, state.g_names)
+    state.opt_G.step(p, g_g, lr)
+    state.global_step += 1
+    for n in state.d_names + state.g_names:
+        p[n].requires_grad_(False)
+    f = lambda t: float(t.detach())
+    return dict(loss_D=f(out_d['loss_D']), loss_G=f(out_g['loss_G']), loss_G_recon=f(out_g['loss_G_recon']), loss_G_kl=f(out_g['loss_G_kl']),
+                loss_G_adv=f(out_g['loss_G_adv']), lr=float(lr), grads_D=g_d, grads_G=g_g, pred_seq=out_g['pred_seq'].detach())

@@ -100,3 +100,22 @@ def test_pseudo_label_and_evaluate_scripts_run_on_jpeg_data(kpx, tmp_path):
     evaluate.main(['--config', str(cfg_path), '--checkpoint_stage1', ckpt, '--checkpoint_stage2', ckpt, '--save_dir', str(tmp_path / 'eval'), '--batch', '2'])
     assert sorted(os.listdir(str(tmp_path / 'eval'))) == ['0000', '0001', '0002']
     assert len(os.listdir(str(tmp_path / 'eval' / '0000' / 'pred_seq'))) == 32 and len(os.listdir(str(tmp_path / 'eval' / '0000' / 'real_seq'))) == 32
+
+
+def test_train_py_motion_generator_on_sequence_loader(kpx, tmp_path):
+    """train.py --mode motion_generator on the fixture videos + pseudo labels (SequenceDataLoader batches), tiny cells."""
+    import yaml
+    data = tmp_path / 'penn'
+    golden = _fixture_dataset(data)
+    cfg = {'paths': {'data_dir': str(data), 'vggnet': None, 'log_dir': str(tmp_path / 'results')},
+           'training': {'n_steps': 3, 'summary_interval': 500, 'test_interval': 2, 'checkpoint_interval': 2, 'log_interval': 1,
+                        'batch_size': 2, 'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}},
+           'model': {'n_pts': int(golden['n_points']), 'n_action': int(golden['n_action']), 'cell_info': [32, 32], 'vae_dim': 8}}
+    cfg_path = tmp_path / 'cfg.yaml'
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    import train
+    train.main(['--mode', 'motion_generator', '--config', str(cfg_path), '--steps', '3'])
+    ck = tmp_path / 'results' / 'motion_generator' / 'model.ckpt-2.npz'
+    assert ck.exists()
+    names = set(k.replace('|', '/') for k in np.load(str(ck)).files)
+    assert 'seq_discr/rnn/multi_rnn_cell/cell_1/basic_lstm_cell/kernel/Adam' in names and 'vae_encoder/fully_connected/weights' in names

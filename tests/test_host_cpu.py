@@ -64,8 +64,10 @@ def test_lr_schedule_and_config_surface():
     assert set(cfg['training']) == {'n_steps', 'summary_interval', 'test_interval', 'checkpoint_interval', 'log_interval', 'batch_size', 'lr'}
     assert cfg['model']['n_pts'] == 40 and cfg['training']['batch_size'] == 16 and cfg['training']['lr'] == {'start_val': 0.0001, 'step': 20000, 'decay': 0.95}
     import train
-    with pytest.raises(Exception, match='unknown model|motion_generator'):
-        train._get_model_by_mode('motion_generator', cfg, 0)
+    with pytest.raises(Exception, match='unknown model'):            # reference train.py:117-123
+        train._get_model_by_mode('no_such_mode', cfg, 0)
+    mg = train._get_model_by_mode('motion_generator', cfg, 0, device='cpu')          # stage 2 (constructed only: no kernels run on CPU)
+    assert mg.name == 'motion_generator' and mg.cell_info == [1024, 1024] and mg.vae_dim == 64
 
 
 def test_synthetic_pairs_follow_the_loader_contract():

@@ -4,8 +4,8 @@
     python train.py --mode detector_translator --config configs/penn.yaml [--synthetic] [--steps N]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py --mode ... (data parallel)
 
-Only the stage-1 ``detector_translator`` mode is built (BASELINE.json hot path); ``motion_generator`` is out of scope and
-raises.  Without ``--synthetic`` the frames come from ``paths.data_dir`` through kpx_amd.data.ImagePairDataLoader (the
+Both modes are built: ``detector_translator`` (stage 1, the BASELINE.json hot path) and ``motion_generator`` (stage 2, the
+sequence VAE-GAN over the pseudo labels written by make_pseudo_labels.py).  Without ``--synthetic`` the frames come from ``paths.data_dir`` through kpx_amd.data.ImagePairDataLoader (the
 reference's data/image_pair_dataloader.py + tf.data pipeline: threaded PIL augmentation, uint8 batches in pinned memory, async
 copy + on-device conversion); ``--synthetic`` feeds Penn-shaped random pairs with the same output contract (float32 NHWC in
 [-1,1], keys image / future_image).
@@ -35,8 +35,51 @@ def _get_model_by_mode(mode, config, global_step, **kw):
         from kpx_amd import DetectorTranslatorModel
         return DetectorTranslatorModel(config, global_step, is_training=True, **kw)
     if mode == 'motion_generator':
-        raise Exception('mode motion_generator (stage 2) is outside the MI355X hot-path build; see DESIGN.md')
+        from kpx_amd import MotionGeneratorModel
+        kw.pop('vgg', None)
+        return MotionGeneratorModel(config, global_step, is_training=True, **kw)
     raise Exception('unknown model %s' % mode)
+
+
+def _train_motion_generator(args, config, dev, rank, world):
+    """reference train.py:136-147 (SequenceDataLoader, is_train -> random_order + randomness) + the common loop (:84-113)."""
+    import numpy as np
+    import kpx_amd
+    paths_config, train_config, model_config = config['paths'], config['training'], config['model']
+    model = _get_model_by_mode('motion_generator', config, 0, device=dev)
+    print('model initialized')
+    model.build(None)
+    batch_size = train_config['batch_size']
+    n_steps = args.steps if args.steps is not None else train_config['n_steps']
+    k, a = model_config['n_pts'], model_config['n_action']
+    train_it = test_batches = None
+    if not args.synthetic:
+        import random
+        random.seed(1000 + rank); np.random.seed(1000 + rank)
+        mk = lambda subset, train: kpx_amd.SequenceDataLoader(paths_config['data_dir'], subset, n_points=k, n_action=a,
+                                                              random_order=train, randomness=train)
+        train_it = mk('train', True).batches(batch_size, dev, repeat=True)
+        if os.path.exists(os.path.join(str(paths_config['data_dir']), 'test_set.txt')):
+            test_loader = mk('test', False)
+            test_batches = lambda: test_loader.batches(batch_size, dev, repeat=False)
+
+    def synthetic(seed):
+        rs = np.random.RandomState(seed)
+        d = {'keypoints': rs.rand(batch_size, k, 2) * 1.6 - 0.8, 'real_seq': rs.rand(batch_size, 32, k, 2) * 1.6 - 0.8,
+             'action_code': np.eye(a)[rs.randint(0, a, size=batch_size)]}
+        return {n: torch.from_numpy(v.astype(np.float32)).to(dev) for n, v in d.items()}
+    model.initialize_loggers(paths_config['log_dir'], None)
+    print('training start')
+    for step in range(model.global_step, n_steps):
+        feed = next(train_it) if train_it is not None else synthetic(step * world + rank)
+        model.train_step(None, feed, step, batch_size, should_write_log=step % train_config['log_interval'] == 0 and rank == 0)
+        if step % train_config['checkpoint_interval'] == 0 and rank == 0:
+            model.save_checkpoint(None, step)
+        if step % train_config['test_interval'] == 0 and rank == 0:
+            feeds = test_batches() if test_batches is not None else [synthetic(10 ** 6)]
+            model.collect_test_results([model.test_step(None, f, step, i, f['keypoints'].shape[0]) for i, f in enumerate(feeds)], step)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def main(argv=None):
@@ -62,6 +105,8 @@ def main(argv=None):
     import kpx_amd
     from kpx_amd.synthetic import synthetic_pair
     vgg = None
+    if args.mode == 'motion_generator':
+        return _train_motion_generator(args, config, dev, rank, world)
     if args.synthetic_vgg or not os.path.exists(str(paths_config.get('vggnet'))):
         if not args.synthetic_vgg:
             raise Exception('file of pretrained vgg19 does not exist at: %s (pass --synthetic-vgg for benchmarking)' % paths_config.get('vggnet'))

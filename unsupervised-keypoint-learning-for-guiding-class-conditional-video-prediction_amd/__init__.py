@@ -8,9 +8,10 @@ from .base_model import BaseModel  # noqa: F401
 from .detector_translator_model import DetectorTranslatorModel  # noqa: F401
 from .keypoint_model import KeypointModel  # noqa: F401
 from .final_model import FinalModel  # noqa: F401
+from .motion_generator_model import MotionGeneratorModel  # noqa: F401
 from .vgg import Vgg19, synthetic_vgg19_weights  # noqa: F401
 from . import data  # noqa: F401
 from .data import ImagePairDataLoader, KeypointDataLoader, SequenceDataLoader  # noqa: F401
 
-__all__ = ['BaseModel', 'DetectorTranslatorModel', 'KeypointModel', 'FinalModel', 'Vgg19', 'synthetic_vgg19_weights', 'ImagePairDataLoader', 'KeypointDataLoader', 'SequenceDataLoader', 'data', 'layers', 'model_utils',
+__all__ = ['BaseModel', 'DetectorTranslatorModel', 'KeypointModel', 'FinalModel', 'MotionGeneratorModel', 'Vgg19', 'synthetic_vgg19_weights', 'ImagePairDataLoader', 'KeypointDataLoader', 'SequenceDataLoader', 'data', 'layers', 'model_utils',
            'networks', 'ops', 'variables']

@@ -66,6 +66,9 @@ SIGNATURES = {
     'kpx_head_blend_tiled_fwd_f32': (c_int, [P, P, c_size_t, c_int, c_int, c_int, P, P, P, P]),
     'kpx_fill_f32': (c_int, [P, c_size_t, c_float, P]),
     'kpx_axpy_f32': (c_int, [P, P, c_size_t, c_float, P]),
+    'kpx_lstm_pointwise_bwd_f32': (c_int, [P, P, P, P, c_float, P, P, c_int, c_int, P]),
+    'kpx_vae_sample_kl_fwd_f32': (c_int, [P, P, P, P, c_int, c_int, P]),
+    'kpx_vae_sample_kl_bwd_f32': (c_int, [P, P, P, P, c_float, P, c_int, c_int, P]),
     'kpx_u8_to_unit_f32': (c_int, [P, c_size_t, P, P]),
     'kpx_crc32c_host': (ctypes.c_uint, [ctypes.c_uint, P, c_size_t]),
 }

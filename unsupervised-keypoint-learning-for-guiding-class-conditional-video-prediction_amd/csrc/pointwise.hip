@@ -77,14 +77,14 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* dy, const flo
         f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
         const f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) g[j] = v[j] > 0.f ? g[j] : g[j] * neg;
+        for (int j = 0; j < 4; ++j) g[j] = act == KPX_ACT_TANH ? g[j] * (1.0f - v[j] * v[j]) : (v[j] > 0.f ? g[j] : g[j] * neg);
         reinterpret_cast<f32x4*>(dz)[i] = g;
     }
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        dz[i] = y[i] > 0.f ? dy[i] : dy[i] * neg;
+        dz[i] = act == KPX_ACT_TANH ? dy[i] * (1.0f - y[i] * y[i]) : (y[i] > 0.f ? dy[i] : dy[i] * neg);
 }
 extern "C" int kpx_act_bwd_f32(const float* dy, const float* y, float* dz, size_t n, int act, void* stream) {
-    if (!dy || !y || !dz || act < 0 || act > 2 || (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dz) & 15)) return KPX_EINVAL;
+    if (!dy || !y || !dz || act < 0 || act > 3 || (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dz) & 15)) return KPX_EINVAL;
     if (n == 0) return 0;
     if (act == KPX_ACT_NONE && dz == dy) return 0;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, kpx_stream(stream), dy, y, dz, n, act);

@@ -88,3 +88,77 @@ extern "C" int kpx_head_blend_tiled_fwd_f32(const float* im, const float* raw4, 
     hipLaunchKernelGGL(head_blend_tiled_kernel, dim3((unsigned)nb), dim3(256), 0, kpx_stream(stream), im, raw4, P, HW, T, clip, final_out, crude_out, mask_out);
     return kpx_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------ stage-2 training (motion generator)
+// Backward of one LSTMCell step (models/networks/layers.py:17-21; forward above).  Everything is recomputed from the saved gate
+// pre-activations and c_prev:  dh' and dc' (from the next step) -> dgates [B,4U] (i,j,f,o order) and dc_prev.
+__global__ __launch_bounds__(256) void lstm_pointwise_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev,
+                                                                 const float* __restrict__ dh, const float* __restrict__ dc_in, float forget_bias,
+                                                                 float* __restrict__ dgates, float* __restrict__ dc_prev, int B, int U) {
+    const int total = B * U;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int b = idx / U, u = idx - b * U;
+        const float* gr = gates + (size_t)b * 4 * U;
+        const float i = gr[u], j = gr[U + u], f = gr[2 * U + u], o = gr[3 * U + u];
+        const float si = 1.0f / (1.0f + expf(-i)), sf = 1.0f / (1.0f + expf(-(f + forget_bias))), so = 1.0f / (1.0f + expf(-o));
+        const float tj = tanhf(j), cp = c_prev ? c_prev[idx] : 0.f;
+        const float c = cp * sf + si * tj, tc = tanhf(c);
+        const float dhv = dh[idx];
+        const float dct = (dc_in ? dc_in[idx] : 0.f) + dhv * so * (1.0f - tc * tc);
+        float* dg = dgates + (size_t)b * 4 * U;
+        dg[u] = dct * tj * si * (1.0f - si);
+        dg[U + u] = dct * si * (1.0f - tj * tj);
+        dg[2 * U + u] = dct * cp * sf * (1.0f - sf);
+        dg[3 * U + u] = dhv * tc * so * (1.0f - so);
+        dc_prev[idx] = dct * sf;
+    }
+}
+extern "C" int kpx_lstm_pointwise_bwd_f32(const float* gates, const float* c_prev, const float* dh, const float* dc_in, float forget_bias,
+                                          float* dgates, float* dc_prev, int B, int U, void* stream) {
+    if (!gates || !dh || !dgates || !dc_prev || B <= 0 || U <= 0) return KPX_EINVAL;
+    int nb = (B * U + 255) / 256; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3(nb), dim3(256), 0, kpx_stream(stream), gates, c_prev, dh, dc_in, forget_bias, dgates, dc_prev, B, U);
+    return kpx_launch_status();
+}
+
+// Reparameterisation + KL term of the sequence VAE (models/motion_generator_model.py:146, :291-293) on logit = [mu | stddev] [B,2V]:
+//   z = mu + stddev * eps ;  kl = mean_b( 0.5 * sum_v( mu^2 + s^2 - log(1e-8 + s^2) - 1 ) )
+__global__ __launch_bounds__(256) void vae_sample_kl_fwd_kernel(const float* __restrict__ logit, const float* __restrict__ eps, float* __restrict__ z,
+                                                                float* __restrict__ kl, int B, int V) {
+    double s = 0.0;
+    for (int idx = threadIdx.x; idx < B * V; idx += 256) {
+        const int b = idx / V, v = idx - b * V;
+        const float mu = logit[(size_t)b * 2 * V + v], sd = logit[(size_t)b * 2 * V + V + v];
+        z[idx] = fmaf(sd, eps[idx], mu);
+        s += (double)(mu * mu + sd * sd - logf(1e-8f + sd * sd) - 1.0f);
+    }
+    s = kpx_wave_sum_d(s);
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *kl = (float)(0.5 * (sm[0] + sm[1] + sm[2] + sm[3]) / (double)B);
+}
+extern "C" int kpx_vae_sample_kl_fwd_f32(const float* logit, const float* eps, float* z, float* kl_out, int B, int V, void* stream) {
+    if (!logit || !eps || !z || !kl_out || B <= 0 || V <= 0) return KPX_EINVAL;
+    hipLaunchKernelGGL(vae_sample_kl_fwd_kernel, dim3(1), dim3(256), 0, kpx_stream(stream), logit, eps, z, kl_out, B, V);
+    return kpx_launch_status();
+}
+// dlogit from dz [B,V] and the scalar gradient of the KL term (device scalar times host scale)
+__global__ __launch_bounds__(256) void vae_sample_kl_bwd_kernel(const float* __restrict__ logit, const float* __restrict__ eps, const float* __restrict__ dz,
+                                                                const float* gkl_dev, float gkl_host, float* __restrict__ dlogit, int B, int V) {
+    const float gk = gkl_host * (gkl_dev ? *gkl_dev : 1.0f) / (float)B;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * V; idx += gridDim.x * 256) {
+        const int b = idx / V, v = idx - b * V;
+        const float mu = logit[(size_t)b * 2 * V + v], sd = logit[(size_t)b * 2 * V + V + v];
+        const float dzv = dz ? dz[idx] : 0.f;
+        dlogit[(size_t)b * 2 * V + v] = dzv + gk * mu;
+        dlogit[(size_t)b * 2 * V + V + v] = dzv * eps[idx] + gk * (sd - sd / (1e-8f + sd * sd));
+    }
+}
+extern "C" int kpx_vae_sample_kl_bwd_f32(const float* logit, const float* eps, const float* dz, const float* gkl_dev, float gkl_host,
+                                         float* dlogit, int B, int V, void* stream) {
+    if (!logit || !eps || !dlogit || B <= 0 || V <= 0) return KPX_EINVAL;
+    int nb = (B * V + 255) / 256; if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(vae_sample_kl_bwd_kernel, dim3(nb), dim3(256), 0, kpx_stream(stream), logit, eps, dz, gkl_dev, gkl_host, dlogit, B, V);
+    return kpx_launch_status();
+}

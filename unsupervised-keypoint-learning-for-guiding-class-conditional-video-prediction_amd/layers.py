@@ -60,15 +60,18 @@ def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, 
     return batch_norm(x, train_mode, scope=bn_scope, act=ACT_RELU, groups=groups, update_moving=update_moving)
 
 
-def fully_connected(x, num_outputs, scope='fully_connected', act=ACT_RELU):
+def fully_connected(x, num_outputs, scope='fully_connected', act=ACT_RELU, trainable=False):
     """tf.contrib.layers.fully_connected (default activation ReLU; variables <scope>/{weights,biases})
-    (reference networks/__init__.py:120)."""
+    (reference networks/__init__.py:112,120,137).  ``trainable``: differentiable path writing gradients into the flat bucket."""
     st = default_store()
     with st.variable_scope(scope):
         wn = st.get_variable('weights', (int(x.shape[-1]), int(num_outputs)), 'glorot2d')
         bn = st.get_variable('biases', (int(num_outputs),), 'zeros')
     if is_sym(x):
         return Sym(x.shape[0], num_outputs)
+    if trainable:
+        (w_, wg), (b_, bg) = st.param(wn), st.param(bn)
+        return ops.dense_train(x, w_, b_, act=act, w_grad_out=wg, b_grad_out=bg)
     return ops.dense(x, st[wn].detach(), st[bn].detach(), act=act)
 
 
@@ -92,6 +95,18 @@ class _LstmStack:
             prev = u
         return names
 
+    def sequence(self, x_seq, scope_prefix=None):
+        """Differentiable run over a whole sequence x_seq [T,B,In] with zero initial state -> top layer outputs [T,B,U]
+        (tf.nn.dynamic_rnn, or the unrolled cell calls of vae_decoder); gradients go to the flat bucket."""
+        st = default_store()
+        names = self.declare(x_seq.shape[-1])
+        if is_sym(x_seq):
+            return Sym(x_seq.shape[0], x_seq.shape[1], self.units[-1])
+        for kn, bn in names:
+            (k_, kg), (b_, bg) = st.param(kn), st.param(bn)
+            x_seq = ops.lstm_layer(x_seq, k_, b_, w_grad_out=kg, b_grad_out=bg)
+        return x_seq
+
     def __call__(self, x, state):
         st = default_store()
         names = self.declare(x.shape[-1])
@@ -107,7 +122,7 @@ def lstm_model(layers_):
     return _LstmStack(layers_)
 
 
-def to_coord(input_, input_size, output_size, stddev=0.02, bias_start=0.0):
+def to_coord(input_, input_size, output_size, stddev=0.02, bias_start=0.0, trainable=False):
     """reference layers.to_coord (layers.py:24-28): tanh(x W + b), variables fully_connected/{W,b}."""
     st = default_store()
     with st.variable_scope('fully_connected'):
@@ -115,4 +130,7 @@ def to_coord(input_, input_size, output_size, stddev=0.02, bias_start=0.0):
         bn = st.get_variable('b', (int(output_size),), 'zeros')
     if is_sym(input_):
         return Sym(input_.shape[0], output_size)
+    if trainable:
+        (w_, wg), (b_, bg) = st.param(wn), st.param(bn)
+        return ops.dense_train(input_, w_, b_, act=ops.ACT_TANH, w_grad_out=wg, b_grad_out=bg)
     return ops.dense(input_, st[wn].detach(), st[bn].detach(), act=ops.ACT_TANH)

@@ -131,3 +131,55 @@ def vae_decoder(x, f_pt, act_code, cell_info, vae_dim, n_pts, n_steps=32):
             o = layers.to_coord(output, cell_info[-1], n_pts * 2)
             ops.copy_channels_raw(o.data_ptr(), n_pts * 2, outputs.data_ptr() + 4 * i * n_pts * 2, n_steps * n_pts * 2, b, n_pts * 2)
         return outputs
+
+
+# ------------------------------------------------------------------------------------------------ stage-2 training graphs
+def _cat_features(parts):
+    """tf.concat(parts, -1) for [B, n] tensors (torch glue: tiny, differentiable)."""
+    import torch
+    return torch.cat([p_ for p_ in parts], dim=-1)
+
+
+def vae_encoder(x, f_pt, act_code, cell_info, vae_dim):
+    """reference vae_encoder (networks/__init__.py:105-114): dynamic_rnn over x [B,32,2K], last output ++ first point ++ action
+    code -> fully_connected(2*vae_dim) with the contrib default ReLU -> logit = [mu | stddev]  [B, 2*vae_dim]."""
+    st = default_store()
+    with st.variable_scope('vae_encoder'):
+        cell = layers.lstm_model(cell_info)
+        if is_sym(x):
+            with st.variable_scope('rnn'):
+                cell.declare(x.shape[-1])
+            return layers.fully_connected(Sym(x.shape[0], cell_info[-1] + f_pt.shape[1] + act_code.shape[1]), vae_dim * 2)
+        with st.variable_scope('rnn'):                                    # dynamic_rnn's variable scope
+            out = cell.sequence(x.transpose(0, 1).contiguous())            # [T,B,U]
+        return layers.fully_connected(_cat_features([out[-1], f_pt, act_code]), vae_dim * 2, trainable=True)
+
+
+def vae_decoder_train(z, f_pt, act_code, cell_info, vae_dim, n_pts, n_steps=32):
+    """Differentiable vae_decoder (same variables as ``vae_decoder``): the LSTM input is the fc output at step 0 and zeros
+    afterwards (:121-128), so the stack runs as whole-sequence layers and to_coord is one GEMM over all T*B rows."""
+    import torch
+    st = default_store()
+    with st.variable_scope('vae_decoder'):
+        cell = layers.lstm_model(cell_info)
+        inp = layers.fully_connected(_cat_features([z, f_pt, act_code]), 32, trainable=True)               # [B,32]
+        x_seq = torch.cat([inp.unsqueeze(0), torch.zeros((n_steps - 1,) + tuple(inp.shape), dtype=inp.dtype, device=inp.device)], dim=0)
+        out = cell.sequence(x_seq)                                                                         # [T,B,U]
+        t, b, u = out.shape
+        coords = layers.to_coord(out.reshape(t * b, u), cell_info[-1], n_pts * 2, trainable=True)           # [T*B, 2K]
+        return coords.reshape(t, b, n_pts * 2).transpose(0, 1)                                             # [B,T,2K]
+
+
+def seq_discr(x, discr_cells=(1024, 1024)):
+    """reference seq_discr (networks/__init__.py:132-138): 2-layer LSTM(1024), fully_connected(outputs, 1) (ReLU), logit of the
+    last step [B,1].  Only the last step's fc output is used, so only that row block is computed."""
+    st = default_store()
+    with st.variable_scope('seq_discr'):
+        cell = layers.lstm_model(list(discr_cells))
+        if is_sym(x):
+            with st.variable_scope('rnn'):
+                cell.declare(x.shape[-1])
+            return layers.fully_connected(Sym(x.shape[0], discr_cells[-1]), 1)
+        with st.variable_scope('rnn'):
+            out = cell.sequence(x.transpose(0, 1).contiguous())
+        return layers.fully_connected(out[-1], 1, trainable=True)

@@ -680,3 +680,153 @@ def head_blend_tiled(im, raw4, t, clip=True):
     check(lib.kpx_head_blend_tiled_fwd_f32(im.contiguous().data_ptr(), raw4.data_ptr(), n * h * w, h * w, t, 1 if clip else 0,
                                            final.data_ptr(), crude.data_ptr(), mask.data_ptr(), _stream()), 'kpx_head_blend_tiled_fwd_f32')
     return final, crude, mask
+
+
+# ----------------------------------------------------------------------------------------------- stage-2 training (motion generator)
+def dense_train(x, w, b, act=ACT_NONE, w_grad_out=None, b_grad_out=None):
+    """Differentiable ``dense``: a 1x1 convolution over [B,1,1,In] (forward / dgrad / wgrad on the conv kernels)."""
+    bsz, n_in = x.shape
+    n_out = w.shape[1]
+    y = conv2d(x.reshape(bsz, 1, 1, n_in), w.view(1, 1, n_in, n_out), b, stride=1, pad=0, act=act,
+               w_grad_out=w_grad_out.view(1, 1, n_in, n_out) if w_grad_out is not None else None, b_grad_out=b_grad_out)
+    return y.reshape(bsz, n_out)
+
+
+class LstmLayerFn(torch.autograd.Function):
+    """One LSTMCell layer over a whole sequence with zero initial state (tf.nn.dynamic_rnn / the unrolled cell calls of
+    reference networks/__init__.py:105-138): x [T,B,In] -> h [T,B,U].  Forward: per step [x_t, h_{t-1}] @ kernel + bias on the
+    conv kernel, then kpx_lstm_pointwise_f32.  Backward: per step kpx_lstm_pointwise_bwd_f32 and the dgrad GEMM (the recurrence
+    needs dh_{t-1}); the weight gradient is ONE GEMM over all T*B rows, the bias gradient one channel sum."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, bias, w_grad_out, b_grad_out):
+        _require_gpu(x)
+        x = x.contiguous()
+        t, bsz, n_in = x.shape
+        units = kernel.shape[1] // 4
+        dev = x.device
+        xin = torch.empty((t, bsz, n_in + units), dtype=torch.float32, device=dev)
+        gates = torch.empty((t, bsz, 4 * units), dtype=torch.float32, device=dev)
+        cs = torch.empty((t, bsz, units), dtype=torch.float32, device=dev)
+        hs = torch.empty((t, bsz, units), dtype=torch.float32, device=dev)
+        zero = torch.zeros((bsz, units), dtype=torch.float32, device=dev)
+        w4 = kernel.view(1, 1, n_in + units, 4 * units)
+        for s in range(t):
+            h_prev, c_prev = (hs[s - 1], cs[s - 1]) if s else (zero, zero)
+            copy_channels_raw(x[s].data_ptr(), n_in, xin[s].data_ptr(), n_in + units, bsz, n_in)
+            copy_channels_raw(h_prev.data_ptr(), units, xin[s].data_ptr() + 4 * n_in, n_in + units, bsz, units)
+            conv_fwd_raw(xin[s].view(bsz, 1, 1, n_in + units), n_in + units, n_in + units, w4, bias, gates[s].view(bsz, 1, 1, 4 * units),
+                         4 * units, 1, 0, 0, ACT_NONE)
+            check(lib.kpx_lstm_pointwise_f32(gates[s].data_ptr(), c_prev.data_ptr(), 1.0, cs[s].data_ptr(), hs[s].data_ptr(), bsz, units, _stream()),
+                  'kpx_lstm_pointwise_f32')
+        ctx.save_for_backward(xin, gates, cs, kernel)
+        ctx.w_grad_out, ctx.b_grad_out, ctx.n_in = w_grad_out, b_grad_out, n_in
+        return hs
+
+    @staticmethod
+    def backward(ctx, dhs):
+        xin, gates, cs, kernel = ctx.saved_tensors
+        t, bsz, width = xin.shape
+        n_in, units = ctx.n_in, gates.shape[2] // 4
+        dev = xin.device
+        dhs = dhs.contiguous()
+        dgates = torch.empty_like(gates)
+        dx = torch.empty((t, bsz, n_in), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dxin = torch.empty((bsz, width), dtype=torch.float32, device=dev)
+        dh = torch.empty((bsz, units), dtype=torch.float32, device=dev)
+        dc = [torch.zeros((bsz, units), dtype=torch.float32, device=dev), torch.empty((bsz, units), dtype=torch.float32, device=dev)]
+        w4 = kernel.view(1, 1, width, 4 * units)
+        for s in range(t - 1, -1, -1):
+            if s == t - 1:
+                dh_s = dhs[s]
+            else:                                   # dh_s = dhs[s] + (dxin of step s+1)[:, n_in:]
+                copy_channels_raw(dxin.data_ptr() + 4 * n_in, width, dh.data_ptr(), units, bsz, units)
+                axpy_raw_(dh, dhs[s])
+                dh_s = dh
+            check(lib.kpx_lstm_pointwise_bwd_f32(gates[s].data_ptr(), cs[s - 1].data_ptr() if s else None, dh_s.data_ptr(), dc[0].data_ptr(), 1.0,
+                                                 dgates[s].data_ptr(), dc[1].data_ptr(), bsz, units, _stream()), 'kpx_lstm_pointwise_bwd_f32')
+            dc.reverse()
+            if s or dx is not None:
+                conv_dgrad_raw(dgates[s].view(bsz, 1, 1, 4 * units), 4 * units, w4, dxin.view(bsz, 1, 1, width), width, width, 1, 0, 0)
+                if dx is not None:
+                    copy_channels_raw(dxin.data_ptr(), width, dx[s].data_ptr(), n_in, bsz, n_in)
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            direct = ctx.w_grad_out is not None and _claim_grad(ctx.w_grad_out)
+            dw_buf = ctx.w_grad_out if direct else torch.empty_like(kernel)
+            conv_wgrad_raw(xin.view(t * bsz, 1, 1, width), width, width, dgates.view(t * bsz, 1, 1, 4 * units), 4 * units,
+                           dw_buf.view(1, 1, width, 4 * units), 1, 0, 0)
+            if ctx.w_grad_out is not None and not direct:
+                axpy_raw_(ctx.w_grad_out, dw_buf)
+            dw = None if ctx.w_grad_out is not None else dw_buf
+        if ctx.needs_input_grad[2]:
+            direct = ctx.b_grad_out is not None and _claim_grad(ctx.b_grad_out)
+            db_buf = ctx.b_grad_out if direct else torch.empty(4 * units, dtype=torch.float32, device=dev)
+            chan_sum_raw(dgates, 4 * units, t * bsz, 4 * units, db_buf)
+            if ctx.b_grad_out is not None and not direct:
+                axpy_raw_(ctx.b_grad_out, db_buf)
+            db = None if ctx.b_grad_out is not None else db_buf
+        return dx, dw, db, None, None
+
+
+def lstm_layer(x_seq, kernel, bias, w_grad_out=None, b_grad_out=None):
+    return LstmLayerFn.apply(x_seq, kernel, bias, w_grad_out, b_grad_out)
+
+
+class VaeSampleKlFn(torch.autograd.Function):
+    """logit [B,2V] = [mu | stddev], eps [B,V] -> (z [B,V], kl [1])  (reference motion_generator_model.py:146, :291-293)."""
+
+    @staticmethod
+    def forward(ctx, logit, eps):
+        _require_gpu(logit)
+        logit, eps = logit.contiguous(), eps.contiguous()
+        bsz, v = eps.shape
+        z = torch.empty((bsz, v), dtype=torch.float32, device=logit.device)
+        kl = torch.empty(1, dtype=torch.float32, device=logit.device)
+        check(lib.kpx_vae_sample_kl_fwd_f32(logit.data_ptr(), eps.data_ptr(), z.data_ptr(), kl.data_ptr(), bsz, v, _stream()), 'kpx_vae_sample_kl_fwd_f32')
+        ctx.save_for_backward(logit, eps)
+        return z, kl
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        logit, eps = ctx.saved_tensors
+        bsz, v = eps.shape
+        dlogit = torch.empty_like(logit)
+        dz = dz.contiguous() if dz is not None else None
+        dkl = dkl.contiguous() if dkl is not None else None
+        check(lib.kpx_vae_sample_kl_bwd_f32(logit.data_ptr(), eps.data_ptr(), dz.data_ptr() if dz is not None else None,
+                                            dkl.data_ptr() if dkl is not None else None, 1.0 if dkl is not None else 0.0,
+                                            dlogit.data_ptr(), bsz, v, _stream()), 'kpx_vae_sample_kl_bwd_f32')
+        return dlogit, None
+
+
+def vae_sample_kl(logit, eps):
+    return VaeSampleKlFn.apply(logit, eps)
+
+
+class L1MeanFn(torch.autograd.Function):
+    """scale * mean(|target - pred|), differentiated wrt pred (reference motion_generator_model.py:288-289, scale = 1000)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, scale):
+        _require_gpu(pred)
+        both = torch.cat([target.reshape(-1), pred.reshape(-1)]).contiguous()          # kpx_l1_pair works on [a | b] halves
+        half = pred.numel()
+        out = torch.empty(1, dtype=torch.float32, device=pred.device)
+        sc = scratch.get('l1', 8192, pred.device)
+        check(lib.kpx_l1_pair_fwd_f32(both.data_ptr(), half, out.data_ptr(), sc.data_ptr(), _stream()), 'kpx_l1_pair_fwd_f32')
+        ctx.save_for_backward(both)
+        ctx.shape, ctx.scale = pred.shape, float(scale)
+        return out * float(scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        (both,) = ctx.saved_tensors
+        half = both.numel() // 2
+        dpred = torch.empty(half, dtype=torch.float32, device=both.device)
+        check(lib.kpx_l1_pair_bwd_f32(both.data_ptr(), half, g.contiguous().data_ptr(), ctx.scale / half, dpred.data_ptr(), _stream()), 'kpx_l1_pair_bwd_f32')
+        return dpred.view(ctx.shape), None, None
+
+
+def l1_mean(pred, target, scale=1.0):
+    return L1MeanFn.apply(pred, target, scale)

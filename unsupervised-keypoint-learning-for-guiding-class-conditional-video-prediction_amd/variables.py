@@ -120,13 +120,13 @@ class VariableStore:
         """Allocate the buckets on the device and turn every variable into a view of them."""
         for name, (shape, kind) in self.specs.items():
             if self.is_trainable(kind):
-                self.buckets['D' if 'img_discr' in name else 'G'].add(name, shape)   # reference :191-192
+                self.buckets['D' if 'discr' in name else 'G'].add(name, shape)   # reference :191-192 ('discr' in var.name: img_discr, seq_discr)
         for b in self.buckets.values():
             b.allocate(self.device)
         for name, (shape, kind) in self.specs.items():
             val = torch.from_numpy(self.init_values[name])
             if self.is_trainable(kind):
-                b = self.buckets['D' if 'img_discr' in name else 'G']
+                b = self.buckets['D' if 'discr' in name else 'G']
                 v = b.view(b.params, name)
                 v.copy_(val)
                 v.requires_grad_(True)
