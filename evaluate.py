@@ -5,8 +5,9 @@
                        [--synthetic N] [--no-save]
 
 One source image -> 32 predicted frames per sample (FinalModel).  PNG writer semantics as the reference (:137-156).  The
-Penn Action sequence loader (data/sequence_dataloader.py) is out of scope: ``--synthetic N`` feeds N random images with
-random one-hot action codes.  Checkpoints are the ``.npz`` containers written by this repo (TF variable names).
+test subset of ``paths.data_dir`` is read through kpx_amd.data.SequenceDataLoader (the reference's data/sequence_dataloader.py);
+``--synthetic N`` feeds N random images with random one-hot action codes instead.  Checkpoints: the ``.npz`` containers written
+by this repo or TensorFlow V2 bundle prefixes (TF variable names either way).
 """
 import os
 import sys

@@ -3,9 +3,10 @@
 
     python make_pseudo_labels.py --config configs/penn.yaml --checkpoint results/detector_translator/model.ckpt-N.npz [--synthetic V]
 
-For every video writes ``<data_dir>/pseudo_labels/NNNN.npy`` = float32 [len, K, 2] key-points (reference :98-101).  The Penn
-Action JPEG loader (data/keypoint_dataloader.py) is out of scope; ``--synthetic V`` feeds V random videos padded to 663 frames
-with the loader's output contract ({'image': [1,663,128,128,3] in [-1,1], 'idx', 'len'}).
+For every video writes ``<data_dir>/pseudo_labels/NNNN.npy`` = float32 [len, K, 2] key-points (reference :98-101).  Videos come
+from the train and test subsets of ``paths.data_dir`` through kpx_amd.data.KeypointDataLoader (the reference's
+data/keypoint_dataloader.py); ``--synthetic V`` feeds V random videos padded to 663 frames with the loader's output contract
+({'image': [1,663,128,128,3] in [-1,1], 'idx', 'len'}) instead.
 """
 import os
 import sys
