@@ -166,6 +166,19 @@ int kpx_axpy_f32(float* y, const float* x, size_t n, float a, void* stream);   /
  * dh [B,U], dc_in [B,U] (NULL = zeros) -> dgates [B,4U], dc_prev [B,U]. */
 int kpx_lstm_pointwise_bwd_f32(const float* gates, const float* c_prev, const float* dh, const float* dc_in, float forget_bias,
                                float* dgates, float* dc_prev, int B, int U, void* stream);
+/* Whole-sequence LSTM layer with zero initial state (dynamic_rnn / unrolled cells, networks/__init__.py:105-138); the time loop
+ * runs inside the library.  x [T,B,In], kernel [In+U,4U], bias [4U]; xin [T,B,In+U], gates [T,B,4U], cs, hs [T,B,U] are written
+ * (and are what the backward needs); zeros_bu = B*U zero floats; workspace as for kpx_conv2d_fwd_f32 / _dgrad_f32 of a
+ * [B,1,1,In+U] x [1,1,In+U,4U] convolution.  Backward: dhs [T,B,U] -> dgates [T,B,4U] and (if non-NULL) dx [T,B,In];
+ * scratch dxin [B,In+U], dh [B,U], dc0 [B,U] (zero-filled by the caller), dc1 [B,U].  The weight gradient is then ONE
+ * kpx_conv2d_wgrad_f32 over xin / dgates viewed as [T*B,1,1,.], the bias gradient one kpx_chan_sum_f32 of dgates. */
+int kpx_lstm_layer_fwd_f32(const float* x, int T, int B, int In, const float* kernel, const float* bias, int U,
+                           float* xin, float* gates, float* cs, float* hs, const float* zeros_bu,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int kpx_lstm_layer_bwd_f32(const float* dhs, int T, int B, int In, const float* kernel, int U,
+                           const float* gates, const float* cs, float* dgates, float* dx,
+                           float* dxin, float* dh, float* dc0, float* dc1,
+                           void* workspace, size_t workspace_bytes, void* stream);
 /* z = mu + stddev*eps and the KL term of motion_generator_model.py:146,291-293 on logit = [mu | stddev] [B,2V]; backward from dz
  * (NULL = zeros) and the KL gradient gkl_dev[0] * gkl_host. */
 int kpx_vae_sample_kl_fwd_f32(const float* logit, const float* eps, float* z, float* kl_out, int B, int V, void* stream);

@@ -67,6 +67,8 @@ SIGNATURES = {
     'kpx_fill_f32': (c_int, [P, c_size_t, c_float, P]),
     'kpx_axpy_f32': (c_int, [P, P, c_size_t, c_float, P]),
     'kpx_lstm_pointwise_bwd_f32': (c_int, [P, P, P, P, c_float, P, P, c_int, c_int, P]),
+    'kpx_lstm_layer_fwd_f32': (c_int, [P, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P, c_size_t, P]),
+    'kpx_lstm_layer_bwd_f32': (c_int, [P, c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P, c_size_t, P]),
     'kpx_vae_sample_kl_fwd_f32': (c_int, [P, P, P, P, c_int, c_int, P]),
     'kpx_vae_sample_kl_bwd_f32': (c_int, [P, P, P, P, c_float, P, c_int, c_int, P]),
     'kpx_u8_to_unit_f32': (c_int, [P, c_size_t, P, P]),

@@ -162,3 +162,56 @@ extern "C" int kpx_vae_sample_kl_bwd_f32(const float* logit, const float* eps, c
     hipLaunchKernelGGL(vae_sample_kl_bwd_kernel, dim3(nb), dim3(256), 0, kpx_stream(stream), logit, eps, dz, gkl_dev, gkl_host, dlogit, B, V);
     return kpx_launch_status();
 }
+
+// Whole-sequence LSTM layer (tf.nn.dynamic_rnn / the unrolled cell calls of networks/__init__.py:105-138), zero initial state.
+// The time loop lives here, not in the host language: per step two channel copies ([x_t, h_{t-1}] -> xin_t), the gate GEMM on
+// the conv kernel (a 1x1 "convolution" over [B,1,1,In+U]) and the gate math -- 4 launches per step issued back to back from C.
+//   x [T,B,In] ; kernel [In+U, 4U] ; bias [4U] ; saved for the backward: xin [T,B,In+U], gates [T,B,4U], cs [T,B,U] ; out hs [T,B,U]
+extern "C" int kpx_lstm_layer_fwd_f32(const float* x, int T, int B, int In, const float* kernel, const float* bias, int U,
+                                      float* xin, float* gates, float* cs, float* hs, const float* zeros_bu,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !kernel || !bias || !xin || !gates || !cs || !hs || !zeros_bu || T <= 0 || B <= 0 || In <= 0 || U <= 0) return KPX_EINVAL;
+    const int W = In + U;
+    for (int s = 0; s < T; ++s) {
+        const float* h_prev = s ? hs + (size_t)(s - 1) * B * U : zeros_bu;
+        const float* c_prev = s ? cs + (size_t)(s - 1) * B * U : zeros_bu;
+        float* xs = xin + (size_t)s * B * W;
+        float* gs = gates + (size_t)s * B * 4 * U;
+        int rc = kpx_copy_channels_f32(x + (size_t)s * B * In, In, xs, W, (size_t)B, In, stream);
+        if (!rc) rc = kpx_copy_channels_f32(h_prev, U, xs + In, W, (size_t)B, U, stream);
+        if (!rc) rc = kpx_conv2d_fwd_f32(xs, B, 1, 1, W, W, kernel, 1, 1, bias, gs, 1, 1, 4 * U, 4 * U, 1, 0, 0, KPX_ACT_NONE, workspace, workspace_bytes, stream);
+        if (!rc) rc = kpx_lstm_pointwise_f32(gs, c_prev, 1.0f, cs + (size_t)s * B * U, hs + (size_t)s * B * U, B, U, stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Backward through time of the layer above: dhs [T,B,U] -> dgates [T,B,4U] (for the single batched weight-gradient GEMM the caller
+// runs afterwards) and, when dx != NULL, dx [T,B,In].  Scratch: dxin [B,In+U], dh [B,U], dc0 / dc1 [B,U] (dc0 must be zero-filled).
+extern "C" int kpx_lstm_layer_bwd_f32(const float* dhs, int T, int B, int In, const float* kernel, int U,
+                                      const float* gates, const float* cs, float* dgates, float* dx,
+                                      float* dxin, float* dh, float* dc0, float* dc1,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dhs || !kernel || !gates || !cs || !dgates || !dxin || !dh || !dc0 || !dc1 || T <= 0 || B <= 0 || In <= 0 || U <= 0) return KPX_EINVAL;
+    const int W = In + U;
+    float* dc_in = dc0; float* dc_out = dc1;
+    for (int s = T - 1; s >= 0; --s) {
+        const float* dh_s = dhs + (size_t)s * B * U;
+        int rc = 0;
+        if (s != T - 1) {                              // dh_s = dhs[s] + (dxin of step s+1)[:, In:]
+            rc = kpx_copy_channels_f32(dxin + In, W, dh, U, (size_t)B, U, stream);
+            if (!rc) rc = kpx_axpy_f32(dh, dh_s, (size_t)B * U, 1.0f, stream);
+            dh_s = dh;
+        }
+        float* dg = dgates + (size_t)s * B * 4 * U;
+        if (!rc) rc = kpx_lstm_pointwise_bwd_f32(gates + (size_t)s * B * 4 * U, s ? cs + (size_t)(s - 1) * B * U : nullptr, dh_s, dc_in, 1.0f,
+                                                 dg, dc_out, B, U, stream);
+        float* tmp = dc_in; dc_in = dc_out; dc_out = tmp;
+        if (!rc && (s || dx)) {
+            rc = kpx_conv2d_dgrad_f32(dg, B, 1, 1, 4 * U, 4 * U, kernel, 1, 1, dxin, 1, 1, W, W, 1, 0, 0, workspace, workspace_bytes, stream);
+            if (!rc && dx) rc = kpx_copy_channels_f32(dxin, W, dx + (size_t)s * B * In, In, (size_t)B, In, stream);
+        }
+        if (rc) return rc;
+    }
+    return 0;
+}

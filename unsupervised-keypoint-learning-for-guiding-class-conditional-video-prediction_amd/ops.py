@@ -694,9 +694,10 @@ def dense_train(x, w, b, act=ACT_NONE, w_grad_out=None, b_grad_out=None):
 
 class LstmLayerFn(torch.autograd.Function):
     """One LSTMCell layer over a whole sequence with zero initial state (tf.nn.dynamic_rnn / the unrolled cell calls of
-    reference networks/__init__.py:105-138): x [T,B,In] -> h [T,B,U].  Forward: per step [x_t, h_{t-1}] @ kernel + bias on the
-    conv kernel, then kpx_lstm_pointwise_f32.  Backward: per step kpx_lstm_pointwise_bwd_f32 and the dgrad GEMM (the recurrence
-    needs dh_{t-1}); the weight gradient is ONE GEMM over all T*B rows, the bias gradient one channel sum."""
+    reference networks/__init__.py:105-138): x [T,B,In] -> h [T,B,U].  The time loops run inside the library
+    (kpx_lstm_layer_fwd_f32 / _bwd_f32): per step [x_t, h_{t-1}] @ kernel + bias on the conv kernel + the gate math, backwards the
+    gate-math backward + the dgrad GEMM (the recurrence needs dh_{t-1}); the weight gradient is ONE GEMM over all T*B rows, the
+    bias gradient one channel sum."""
 
     @staticmethod
     def forward(ctx, x, kernel, bias, w_grad_out, b_grad_out):
@@ -710,15 +711,12 @@ class LstmLayerFn(torch.autograd.Function):
         cs = torch.empty((t, bsz, units), dtype=torch.float32, device=dev)
         hs = torch.empty((t, bsz, units), dtype=torch.float32, device=dev)
         zero = torch.zeros((bsz, units), dtype=torch.float32, device=dev)
-        w4 = kernel.view(1, 1, n_in + units, 4 * units)
-        for s in range(t):
-            h_prev, c_prev = (hs[s - 1], cs[s - 1]) if s else (zero, zero)
-            copy_channels_raw(x[s].data_ptr(), n_in, xin[s].data_ptr(), n_in + units, bsz, n_in)
-            copy_channels_raw(h_prev.data_ptr(), units, xin[s].data_ptr() + 4 * n_in, n_in + units, bsz, units)
-            conv_fwd_raw(xin[s].view(bsz, 1, 1, n_in + units), n_in + units, n_in + units, w4, bias, gates[s].view(bsz, 1, 1, 4 * units),
-                         4 * units, 1, 0, 0, ACT_NONE)
-            check(lib.kpx_lstm_pointwise_f32(gates[s].data_ptr(), c_prev.data_ptr(), 1.0, cs[s].data_ptr(), hs[s].data_ptr(), bsz, units, _stream()),
-                  'kpx_lstm_pointwise_f32')
+        width = n_in + units
+        nbytes = lib.kpx_conv2d_fwd_workspace_bytes(bsz, 1, 1, width, 4 * units, 1, 1)
+        ws = scratch.get('splitk', nbytes, dev) if nbytes else None
+        check(lib.kpx_lstm_layer_fwd_f32(x.data_ptr(), t, bsz, n_in, kernel.data_ptr(), bias.data_ptr(), units, xin.data_ptr(), gates.data_ptr(),
+                                         cs.data_ptr(), hs.data_ptr(), zero.data_ptr(), ws.data_ptr() if ws is not None else None, nbytes, _stream()),
+              'kpx_lstm_layer_fwd_f32')
         ctx.save_for_backward(xin, gates, cs, kernel)
         ctx.w_grad_out, ctx.b_grad_out, ctx.n_in = w_grad_out, b_grad_out, n_in
         return hs
@@ -734,22 +732,13 @@ class LstmLayerFn(torch.autograd.Function):
         dx = torch.empty((t, bsz, n_in), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         dxin = torch.empty((bsz, width), dtype=torch.float32, device=dev)
         dh = torch.empty((bsz, units), dtype=torch.float32, device=dev)
-        dc = [torch.zeros((bsz, units), dtype=torch.float32, device=dev), torch.empty((bsz, units), dtype=torch.float32, device=dev)]
-        w4 = kernel.view(1, 1, width, 4 * units)
-        for s in range(t - 1, -1, -1):
-            if s == t - 1:
-                dh_s = dhs[s]
-            else:                                   # dh_s = dhs[s] + (dxin of step s+1)[:, n_in:]
-                copy_channels_raw(dxin.data_ptr() + 4 * n_in, width, dh.data_ptr(), units, bsz, units)
-                axpy_raw_(dh, dhs[s])
-                dh_s = dh
-            check(lib.kpx_lstm_pointwise_bwd_f32(gates[s].data_ptr(), cs[s - 1].data_ptr() if s else None, dh_s.data_ptr(), dc[0].data_ptr(), 1.0,
-                                                 dgates[s].data_ptr(), dc[1].data_ptr(), bsz, units, _stream()), 'kpx_lstm_pointwise_bwd_f32')
-            dc.reverse()
-            if s or dx is not None:
-                conv_dgrad_raw(dgates[s].view(bsz, 1, 1, 4 * units), 4 * units, w4, dxin.view(bsz, 1, 1, width), width, width, 1, 0, 0)
-                if dx is not None:
-                    copy_channels_raw(dxin.data_ptr(), width, dx[s].data_ptr(), n_in, bsz, n_in)
+        dc0 = torch.zeros((bsz, units), dtype=torch.float32, device=dev)
+        dc1 = torch.empty((bsz, units), dtype=torch.float32, device=dev)
+        nbytes = lib.kpx_conv2d_dgrad_workspace_bytes(bsz, 1, 1, width, 4 * units, 1, 1, 1)
+        ws = scratch.get('splitk', nbytes, dev) if nbytes else None
+        check(lib.kpx_lstm_layer_bwd_f32(dhs.data_ptr(), t, bsz, n_in, kernel.data_ptr(), units, gates.data_ptr(), cs.data_ptr(), dgates.data_ptr(),
+                                         dx.data_ptr() if dx is not None else None, dxin.data_ptr(), dh.data_ptr(), dc0.data_ptr(), dc1.data_ptr(),
+                                         ws.data_ptr() if ws is not None else None, nbytes, _stream()), 'kpx_lstm_layer_bwd_f32')
         dw = db = None
         if ctx.needs_input_grad[1]:
             direct = ctx.w_grad_out is not None and _claim_grad(ctx.w_grad_out)
