@@ -7,6 +7,11 @@ import ctypes
 import os
 from ctypes import c_double, c_float, c_int, c_size_t, c_void_p
 
+import torch  # noqa: F401  -- MUST precede the CDLL below: PyTorch-ROCm ships its own libamdhip64; if libkpx_hip.so were loaded
+#                first it would pull in the system ROCm runtime and the process would end up with two HIP runtimes (tensors
+#                allocated by one are unknown to the other: launches fail with hipErrorNoDevice).  Loaded after torch, the
+#                library's libamdhip64 dependency resolves to the runtime that is already in the process.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libkpx_hip.so')
 
