@@ -68,6 +68,7 @@ CONV_CASES = [
     (8, 32, 64, 64, 128, 3, 1, 0, 0),      # Winograd weight gradient (64-channel tiles, non-square image, 64 splits)
     (16, 32, 32, 128, 16, 3, 1, 0, 0),     # Winograd weight gradient, 64 x 32 blocks with the 16 output channels masked (pose conv_7_0)
     (16, 32, 32, 32, 160, 3, 1, 0, 1),     # Winograd weight gradient, 32 x 64 blocks, Cout = 160 overhangs the last block
+    (8, 64, 64, 64, 4, 3, 1, 0, 0),        # translator head shape: Winograd with 4 produced channels (fwd), 4 gathered channels (dgrad), wgrad 64 x 32 block
 ]
 
 

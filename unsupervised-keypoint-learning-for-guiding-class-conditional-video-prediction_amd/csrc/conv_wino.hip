@@ -109,6 +109,7 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
             iy = oy0 - 1 + py; ix = ox0 - 1 + w8_pix(ps);
             ok = u < 720 && ps < 18 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
         }
+        if (g.Cin <= 4 && (u & 1)) ok = false;          // a 4-channel input (ldx may be 4): the upper half of the single 8-channel chunk is padding
         rok[i] = ok;
         rp[i] = ok ? g.x + ((size_t)(ni * g.H + iy) * g.W + ix) * g.ldx + (u & 1) * 4 : wino_zero16;
     }
@@ -255,7 +256,9 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int N, in
     if (getenv("KPX_NO_WINO")) return 0;
     // K is padded to a multiple of 8 (the pad channels must exist in the row: ldin >= Kp) and Nn to a multiple of 32
     const bool shape = (H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8 && N % 4 == 0);      // 8x8 images are packed four to a workgroup
-    return shape && K >= 16 && Nn >= 16 && ldin >= ((K + 7) & ~7) && (ldin % 4 == 0) && (((uintptr_t)in_ptr) & 15) == 0;
+    static const int kmin = getenv("KPX_WINO_KMIN") ? atoi(getenv("KPX_WINO_KMIN")) : 4, nmin = getenv("KPX_WINO_NMIN") ? atoi(getenv("KPX_WINO_NMIN")) : 4;
+    const bool kfit = ldin >= ((K + 7) & ~7) || K == 4;          // K = 4: only the lower 16-B half of the chunk is ever loaded
+    return shape && K >= kmin && Nn >= nmin && (K >= 16 || K == 4 || K == 8) && kfit && (ldin % 4 == 0) && (((uintptr_t)in_ptr) & 15) == 0;
 }
 
 // forward: in = x (K = Cin), out = y (Nn = Cout);  dgrad: in = dy (K = Cout), out = dx (Nn = Cin), w always HWIO [3][3][Cin][Cout]
@@ -477,7 +480,8 @@ static inline int ww_tile(int C) { return (C % 64 == 0 || C > 96) ? 2 : 1; }
 // splits for the Winograd wgrad (0 = shape not handled): ~256 workgroups (one per CU; measured best of 128..1024), >= 8 chunks per split, slabs <= 128 MB
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
     if (getenv("KPX_NO_WINO") || getenv("KPX_NO_WINO_WGRAD")) return 0;
-    if (H % 4 || W % 8 || Cout % 4 || Cin < 32 || Cout < 16) return 0;         // (a Cin that is not a multiple of 4 needs ldx >= Cin rounded up, checked by the caller)
+    static const int comin = getenv("KPX_WW_COMIN") ? atoi(getenv("KPX_WW_COMIN")) : 4;
+    if (H % 4 || W % 8 || Cout % 4 || Cin < 32 || Cout < comin) return 0;         // (a Cin that is not a multiple of 4 needs ldx >= Cin rounded up, checked by the caller)
     const int ti = ww_tile(Cin), to = ww_tile(Cout);
     if (ti == 1 && to == 1) return 0;                     // 32 x 32 blocks: too few MFMAs per barrier, the direct kernels do better
     const long tc = (long)N * (H / 4) * (W / 8), tiles = (long)((Cin + 32 * ti - 1) / (32 * ti)) * ((Cout + 32 * to - 1) / (32 * to));
