@@ -193,18 +193,25 @@ extern "C" size_t kpx_chan_reduce_scratch_bytes(int C) {
     return (size_t)KPX_RED_BLOCKS * 2 * c * sizeof(double) + ((2 * c * sizeof(float) + 15) & ~(size_t)15);
 }
 
-// Finalize kernels: one wavefront per channel; lanes stride over the (up to 1024) block partials, then a shuffle tree.
+// 256 threads per channel: the (up to 1024) block partials are summed in a fixed order -- thread t takes partials t, t+256, ..;
+// shuffle tree per wavefront, then the four wave sums in LDS order -- so the result does not depend on timing.  (One wavefront per
+// channel took 7-10 us of dependent-load latency per launch, 120 launches per step.)
 __device__ __forceinline__ void kpx_sum_partials(const double* part, int nb, int C, int c, double& s, double& q) {
-    s = 0.0; q = 0.0;
-    for (int b = threadIdx.x; b < nb; b += 64) {
-        s += part[((size_t)b * 2) * C + c];
-        q += part[((size_t)b * 2 + 1) * C + c];
+    double a0 = 0.0, a1 = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) {
+        a0 += part[((size_t)b * 2) * C + c];
+        a1 += part[((size_t)b * 2 + 1) * C + c];
     }
-    s = kpx_wave_sum_d(s);
-    q = kpx_wave_sum_d(q);
+    a0 = kpx_wave_sum_d(a0);
+    a1 = kpx_wave_sum_d(a1);
+    __shared__ double sm[2][4];
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a0; sm[1][threadIdx.x >> 6] = a1; }
+    __syncthreads();
+    s = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
+    q = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
 }
 
-__global__ __launch_bounds__(64) void chan_sum_finalize_kernel(const double* part, int nb, int C, float* out) {
+__global__ __launch_bounds__(256) void chan_sum_finalize_kernel(const double* part, int nb, int C, float* out) {
     const int c = blockIdx.x;
     double s, q;
     kpx_sum_partials(part, nb, C, c, s, q);
@@ -215,12 +222,12 @@ extern "C" int kpx_chan_sum_f32(const float* x, size_t P, int C, int ldx, float*
     RedArgs a{}; a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.part = (double*)scratch;
     int nb; int rc = launch_chan_reduce(0, a, &nb, kpx_stream(stream));
     if (rc) return rc;
-    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(C), dim3(64), 0, kpx_stream(stream), (const double*)scratch, nb, C, sum_out);
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(C), dim3(256), 0, kpx_stream(stream), (const double*)scratch, nb, C, sum_out);
     return kpx_launch_status();
 }
 
 // ------------------------------------------------------------------------------------------ batch norm
-__global__ __launch_bounds__(64) void bn_stats_finalize_kernel(const double* part, int nb, int C, double count, float eps,
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* part, int nb, int C, double count, float eps,
                                                                float* mean, float* invstd, float* var_biased,
                                                                float* mm, float* mv, float decay) {
     const int c = blockIdx.x;
@@ -248,7 +255,7 @@ extern "C" int kpx_bn_stats_f32(const float* x, size_t P, int C, int ldx, float 
     RedArgs a{}; a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.part = (double*)scratch;
     int nb; int rc = launch_chan_reduce(1, a, &nb, kpx_stream(stream));
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(64), 0, kpx_stream(stream), (const double*)scratch, nb, C,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(C), dim3(256), 0, kpx_stream(stream), (const double*)scratch, nb, C,
                        (double)P, eps, mean, invstd, var_biased, moving_mean, moving_var, decay);
     return kpx_launch_status();
 }
@@ -301,7 +308,7 @@ extern "C" int kpx_bn_apply_f32(const float* x, size_t P, int C, int ldx, const 
     return kpx_launch_status();
 }
 
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* part, int nb, int C, float* dgamma, float* dbeta, float* sums) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* part, int nb, int C, float* dgamma, float* dbeta, float* sums) {
     const int c = blockIdx.x;
     double s, q;
     kpx_sum_partials(part, nb, C, c, s, q);
@@ -353,7 +360,7 @@ extern "C" int kpx_bn_bwd_f32(const float* dy, int lddy, const float* x, int ldx
     if (rc) return rc;
     // the per-channel sums are parked (as floats) behind the partials in the scratch buffer
     float* sums = reinterpret_cast<float*>((double*)scratch + (size_t)KPX_RED_BLOCKS * 2 * C);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, s, (const double*)scratch, nb, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)scratch, nb, C, dgamma, dbeta, sums);
     rc = kpx_launch_status();
     if (rc) return rc;
     const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) &&
