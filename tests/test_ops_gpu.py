@@ -78,18 +78,27 @@ def test_conv_fwd_dgrad_wgrad(kpx, dev, n, h, w, cin, cout, k, s, pad, act, gtol
     x = rs.randn(n, h, w, cin).astype(np.float32)
     wt = (rs.randn(k, k, cin, cout) / np.sqrt(k * k * cin)).astype(np.float32)
     b = rs.randn(cout).astype(np.float32)
-    # oracle (+ autograd)
-    xo = torch.from_numpy(x).requires_grad_(True); wo = torch.from_numpy(wt).requires_grad_(True); bo = torch.from_numpy(b).requires_grad_(True)
-    yo = R.conv(xo, wo, bo, s, pad)
-    if act == 1: yo = torch.relu(yo)
-    if act == 2: yo = torch.nn.functional.leaky_relu(yo, 0.01)
-    gy = rs.randn(*yo.shape).astype(np.float32)
-    yo.backward(torch.from_numpy(gy))
-    # HIP
+    # HIP forward first: the activation's backward mask (y > 0) is taken from ITS output for the oracle's backward too -- an
+    # element whose pre-activation is ~1e-7 from zero may land on the other side in two correct fp32 implementations, and one
+    # such flip alone moves a gradient's rel-L2 by ~1e-3 (seen with the Winograd forward, whose error is ~4e-7 instead of ~1e-7)
     xg = torch.from_numpy(x).to(dev).requires_grad_(True); wg = torch.from_numpy(wt).to(dev).requires_grad_(True); bg = torch.from_numpy(b).to(dev).requires_grad_(True)
     yg = kpx.ops.conv2d(xg, wg, bg, stride=s, pad=pad, act=act)
+    # oracle (+ autograd)
+    xo = torch.from_numpy(x).requires_grad_(True); wo = torch.from_numpy(wt).requires_grad_(True); bo = torch.from_numpy(b).requires_grad_(True)
+    zo = R.conv(xo, wo, bo, s, pad)
+    yo = zo
+    if act == 1: yo = torch.relu(zo)
+    if act == 2: yo = torch.nn.functional.leaky_relu(zo, 0.01)
     assert tuple(yg.shape) == tuple(yo.shape)
     assert rel_l2(t2n(yg), t2n(yo)) < 1e-5
+    gy = rs.randn(*yo.shape).astype(np.float32)
+    if act:
+        pos = yg.detach().cpu() > 0
+        flips = int((pos != (zo.detach() > 0)).sum())
+        assert flips <= 2 + 1e-5 * pos.numel(), flips                       # the two masks differ only on a handful of ~0 elements
+        zo.backward(torch.from_numpy(gy) * torch.where(pos, torch.tensor(1.0), torch.tensor(0.0 if act == 1 else 0.01)))
+    else:
+        zo.backward(torch.from_numpy(gy))
     yg.backward(torch.from_numpy(gy).to(dev))
     assert rel_l2(t2n(xg.grad), t2n(xo.grad)) < gtol
     assert rel_l2(t2n(wg.grad), t2n(wo.grad)) < gtol
@@ -321,6 +330,28 @@ def _fuzz_cases():
     cases += [(2, 64, 64, 36, 20, 3, 1, 0, 0), (3, 32, 96, 64, 64, 3, 1, 0, 1), (2, 64, 32, 128, 128, 3, 2, 0, 0),
               (32, 8, 8, 256, 192, 3, 1, 0, 2), (9, 12, 12, 320, 256, 4, 2, 1, 1), (1, 128, 128, 48, 8, 3, 1, 0, 0)]
     return cases
+
+
+def _wino_fuzz_cases():
+    """3x3 stride-1 SAME geometries around the Winograd eligibility rules (tile multiples, padded channel counts, 8x8 packing,
+    weight-gradient block shapes and split counts)."""
+    rs = np.random.RandomState(77)
+    cases = []
+    for _ in range(22):
+        h = int(rs.choice([16, 32, 48, 64])); w = int(rs.choice([16, 32, 48, 64, 80]))
+        n = int(rs.choice([1, 2, 3, 4, 8]))
+        if rs.rand() < 0.2:
+            h = w = 8; n = int(rs.choice([4, 8, 12]))
+        cin = int(rs.choice([4, 8, 16, 24, 40, 64, 72, 96, 128, 160]))
+        cout = int(rs.choice([4, 8, 16, 24, 32, 48, 64, 96, 128, 160]))
+        cases.append((n, h, w, cin, cout, 3, 1, 0, int(rs.choice([0, 1, 2]))))
+    cases += [(16, 32, 32, 64, 64, 3, 1, 0, 0), (4, 64, 64, 192, 64, 3, 1, 0, 1), (8, 32, 64, 96, 36, 3, 1, 0, 0)]     # wgrad splits / block shapes
+    return cases
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,k,s,pad,act', _wino_fuzz_cases())
+def test_winograd_fuzz_against_oracle(kpx, dev, n, h, w, cin, cout, k, s, pad, act):
+    test_conv_fwd_dgrad_wgrad(kpx, dev, n, h, w, cin, cout, k, s, pad, act, gtol=2e-5)
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout,k,s,pad,act', _fuzz_cases())
