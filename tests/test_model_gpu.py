@@ -315,3 +315,44 @@ def test_configs0_train_step_128_k15_b4_matches_oracle():
         # 0.6-0.9 % at this size (measured: image_encoder 0.65 %, pose_encoder 0.93 %, translator 0.56 %).  Two fp32
         # implementations with different summation orders therefore agree to ~1 %, not 1e-4; bound = 3 %.
         assert (num / den) ** 0.5 < 3e-2, (which, (num / den) ** 0.5)
+
+
+def test_test_step_leaves_moving_statistics_untouched_and_default_device_joins_side_stream():
+    """reference test_step (:119-141) runs only [loss_D, loss_G]: the BN UPDATE_OPS ride on train_op_G (:199-202), so an
+    evaluation pass must not change any moving_mean / moving_variance.  The model is built with device='cuda' (no index,
+    the constructor default), which must still join the weight-gradient side stream before Adam."""
+    import kpx_amd
+    from kpx_amd import ops
+    res, k, b = 32, 3, 2
+    cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': b},
+           'model': {'n_pts': k}, 'paths': {'log_dir': '/tmp/kpx_test', 'vggnet': None}}
+    vgg = kpx_amd.Vgg19(weights=kpx_amd.synthetic_vgg19_weights(seed=19, width_div=8), device='cuda')
+    model = kpx_amd.DetectorTranslatorModel(cfg, device='cuda', vgg=vgg, image_size=res)
+    model.build()
+    assert model.device == torch.device('cuda', torch.cuda.current_device())
+    dev = model.device
+    im, fut = R.synthetic_pair(b, res=res, seed0=3, seed1=4)
+    feed = {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}
+    model.train_step(None, feed, 0, b)
+    assert not ops._side_dirty and not ops._side_keep          # joined (and released) before the Adam updates
+    before = {n: a.copy() for n, a in model.store.export_numpy().items()}
+    moving = [n for n in before if n.endswith('/moving_mean') or n.endswith('/moving_variance')]
+    assert len(moving) == 2 * (8 + 8 + 14 + 10)
+    assert any(np.abs(before[n]).max() > 0 for n in moving if n.endswith('moving_mean'))      # the train step did move them
+    im2, fut2 = R.synthetic_pair(b, res=res, seed0=5, seed1=6)
+    feed2 = {'image': torch.from_numpy(im2).to(dev), 'future_image': torch.from_numpy(fut2).to(dev)}
+    loss_d, loss_g, _, n = model.test_step(None, feed2, 1, 0, b)
+    after = model.store.export_numpy()
+    for name in before:                                            # nothing at all changes in an evaluation pass
+        assert np.array_equal(before[name], after[name]), name
+    assert n == b and model.global_step == 1
+    # the losses are the reference's batch-statistics forward (SURVEY N4) on the current weights
+    params = {n_: torch.from_numpy(np.asarray(a)) for n_, a in before.items()}
+    net = R.Net(params, train_mode=True)
+    vggw = {k_: (torch.from_numpy(w), torch.from_numpy(bb)) for k_, (w, bb) in R.synthetic_vgg(seed=19, width_div=8).items()}
+    with torch.no_grad():
+        fwd = R.forward_pass(net, torch.from_numpy(im2), torch.from_numpy(fut2), with_vis_maps=False)
+        want_d = float(R.loss_D(net, fwd['final_output'], torch.from_numpy(fut2))[0])
+        want_g = float(R.loss_G(net, vggw, fwd['final_output'], torch.from_numpy(fut2))[0])
+    assert abs(loss_d - want_d) <= 1e-4 * max(1.0, abs(want_d)), (loss_d, want_d)
+    assert abs(loss_g - want_g) <= 1e-4 * max(1.0, abs(want_g)), (loss_g, want_g)

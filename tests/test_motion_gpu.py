@@ -64,6 +64,7 @@ def test_checkpoint_names_and_sampling():
                  'vae_decoder/multi_rnn_cell/cell_1/basic_lstm_cell/bias', 'vae_decoder/fully_connected/W', 'seq_discr/rnn/multi_rnn_cell/cell_0/basic_lstm_cell/kernel',
                  'seq_discr/fully_connected/biases', 'seq_discr/fully_connected/weights/Adam', 'vae_decoder/fully_connected/b/Adam_1', 'global_step', 'beta2_power_1'):
         assert name in arrays, name
+    assert np.asarray(arrays['global_step']).dtype == np.int32      # tf.Variable(0) (reference train.py:30) is DT_INT32
     kp = torch.rand(4, K, 2, device=dev) * 1.6 - 0.8
     ac = torch.eye(A, device=dev)[:4].contiguous()
     z = torch.randn(4, VAE, device=dev)

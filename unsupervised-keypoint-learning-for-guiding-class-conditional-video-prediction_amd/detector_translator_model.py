@@ -36,7 +36,7 @@ class DetectorTranslatorModel(BaseModel):
         self.vgg19_path = paths_config.get('vggnet')
         self.image_size = image_size            # literal 128 in the reference loaders (image_pair_dataloader.py:13)
         self.heat_size = image_size // 4        # literal [32, 32] (:168-169)
-        self.device = torch.device(device)
+        self.device = ops.normalize_device(device)
         self.global_step = int(global_step or 0)
         self.process_group = process_group
         self.world_size = torch.distributed.get_world_size(process_group) if (
@@ -70,11 +70,11 @@ class DetectorTranslatorModel(BaseModel):
         train = self.is_training
         sym = variables.is_sym(im)
         b = im.shape[0]
-        embeddings = networks.image_encoder(im, train)                                     # :165
+        embeddings = networks.image_encoder(im, train, update_moving=update_moving)        # :165
         # :166-167 -- the two weight-sharing pose_encoder calls as one batched launch, BN statistics per call
         both = Sym(2 * b, *im.shape[1:]) if sym else ops.concat_batch(im, future_im)
         pts, logits = networks.pose_encoder(both, self.n_points, train, final_res=self.image_size, bn_groups=2,
-                                            return_logits=True)
+                                            return_logits=True, update_moving=update_moving)
         if sym:
             joint = Sym(b, self.heat_size, self.heat_size, (embeddings[-2].shape[-1] + 2 * self.n_points + 3) // 4 * 4)
             cur_pt = fut_pt = None
@@ -82,7 +82,8 @@ class DetectorTranslatorModel(BaseModel):
             cur_pt, fut_pt = pts[:b], pts[b:]
             joint = ops.joint_embedding(embeddings[-2], cur_pt, fut_pt)                    # :168-170
         raw4 = networks.translator(joint, train, final_res=self.image_size,
-                                   cin=embeddings[-2].shape[-1] + 2 * self.n_points)       # :173
+                                   cin=embeddings[-2].shape[-1] + 2 * self.n_points,
+                                   update_moving=update_moving)                            # :173
         if sym:
             return None
         final_output, crude_output, mask = ops.head_blend(im, raw4)                        # :174

@@ -28,7 +28,7 @@ class FinalModel(BaseModel):
         self.image_size = image_size
         self.heat_size = image_size // 4
         self.frames_per_launch = frames_per_launch      # translator slab size (B*32 frames are processed in slabs)
-        self.device = torch.device(device)
+        self.device = ops.normalize_device(device)
         self.store = variables.VariableStore(device=self.device, seed=seed)
 
     def build(self, inputs=None):

@@ -6,7 +6,7 @@ the input / config.  Frames are processed in slabs so a 663-frame video (9.7 GB 
 """
 import torch
 
-from . import networks, variables
+from . import networks, ops, variables
 from .base_model import BaseModel
 from .variables import Sym
 
@@ -20,7 +20,7 @@ class KeypointModel(BaseModel):
         self.log_dir = config['paths']['log_dir']
         self.image_size = image_size
         self.frames_per_launch = frames_per_launch
-        self.device = torch.device(device)
+        self.device = ops.normalize_device(device)
         self.store = variables.VariableStore(device=self.device, seed=seed)
 
     def build(self, inputs=None):

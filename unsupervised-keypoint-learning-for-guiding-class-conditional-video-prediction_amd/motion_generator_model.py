@@ -37,7 +37,7 @@ class MotionGeneratorModel(BaseModel):
         self.cell_info = list(model_config['cell_info'])
         self.vae_dim = model_config['vae_dim']
         self.discr_cells = tuple(discr_cells)          # literal [1024, 1024] in the reference (networks/__init__.py:134)
-        self.device = torch.device(device)
+        self.device = ops.normalize_device(device)
         self.global_step = int(global_step or 0)
         self.process_group = process_group
         self.world_size = torch.distributed.get_world_size(process_group) if (
@@ -168,7 +168,7 @@ class MotionGeneratorModel(BaseModel):
 
     def checkpoint_arrays(self):
         arrays = self.store.export_numpy(include_slots=self.is_training)
-        arrays['global_step'] = np.int64(self.global_step)
+        arrays['global_step'] = np.int32(self.global_step)   # tf.Variable(0) in train.py:30 is int32
         if self.is_training:
             arrays.update({'beta1_power': self.beta_power['D'][0], 'beta2_power': self.beta_power['D'][1],
                            'beta1_power_1': self.beta_power['G'][0], 'beta2_power_1': self.beta_power['G'][1]})

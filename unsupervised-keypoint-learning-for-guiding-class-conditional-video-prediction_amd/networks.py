@@ -18,46 +18,46 @@ def _upsample_concat(x, skip):
     return ops.upsample2x_concat(x, skip)
 
 
-def encoder(x, train_mode, filters=32, bn_groups=1, skip_last_block=False):
+def encoder(x, train_mode, filters=32, bn_groups=1, skip_last_block=False, update_moving=True):
     """reference encoder (networks/__init__.py:7-26).  Returns the 4 block features."""
     st = default_store()
     with st.variable_scope('encoder'):
         feats = []
-        x = layers.conv_bn_relu(x, filters, 7, 1, train_mode, 'conv_1', 'b_norm_1', bn_groups)
-        x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_2', 'b_norm_2', bn_groups)
+        x = layers.conv_bn_relu(x, filters, 7, 1, train_mode, 'conv_1', 'b_norm_1', bn_groups, update_moving=update_moving)
+        x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_2', 'b_norm_2', bn_groups, update_moving=update_moving)
         feats.append(x)
         for i in range(3):
             filters *= 2
-            x = layers.conv_bn_relu(x, filters, 3, 2, train_mode, 'conv_%d' % (i * 2 + 3), 'b_norm_%d' % (i * 2 + 3), bn_groups)
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d' % (i * 2 + 4), 'b_norm_%d' % (i * 2 + 4), bn_groups)
+            x = layers.conv_bn_relu(x, filters, 3, 2, train_mode, 'conv_%d' % (i * 2 + 3), 'b_norm_%d' % (i * 2 + 3), bn_groups, update_moving=update_moving)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d' % (i * 2 + 4), 'b_norm_%d' % (i * 2 + 4), bn_groups, update_moving=update_moving)
             feats.append(x)
         return feats
 
 
-def image_encoder(x, train_mode):
+def image_encoder(x, train_mode, update_moving=True):
     """reference image_encoder (:29-33): [x] + the 4 encoder blocks."""
     st = default_store()
     with st.variable_scope('image_encoder'):
-        return [x] + encoder(x, train_mode)
+        return [x] + encoder(x, train_mode, update_moving=update_moving)
 
 
-def pose_encoder(x, n_pts, train_mode, final_res=128, filters=128, bn_groups=1, return_logits=False):
+def pose_encoder(x, n_pts, train_mode, final_res=128, filters=128, bn_groups=1, return_logits=False, update_moving=True):
     """reference pose_encoder (:36-72): encoder + U-Net decoder + 1x1 head -> separable-softmax key-points [B,K,2]."""
     st = default_store()
     with st.variable_scope('pose_encoder'):
-        block_features = encoder(x, train_mode, bn_groups=bn_groups)
+        block_features = encoder(x, train_mode, bn_groups=bn_groups, update_moving=update_moving)
         x = block_features[-1]
         size = x.shape[1]
         conv_id = 1
         for i in range(4):
             # i > 0: x is already the [up-sampled ‖ skip] concat buffer written by the previous stage (:44)
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % conv_id, 'b_norm_%d_0' % conv_id, bn_groups)
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id, bn_groups)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % conv_id, 'b_norm_%d_0' % conv_id, bn_groups, update_moving=update_moving)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id, bn_groups, update_moving=update_moving)
             if size == final_res:
                 x = layers.conv(x, n_pts, kernel=1, stride=1)        # default scope 'conv_0' (:54)
                 break
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1), bn_groups)
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % (conv_id + 1), 'b_norm_%d_1' % (conv_id + 1), bn_groups)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1), bn_groups, update_moving=update_moving)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % (conv_id + 1), 'b_norm_%d_1' % (conv_id + 1), bn_groups, update_moving=update_moving)
             x = _upsample_concat(x, block_features[-1 * (i + 2)])     # resize (:63) + next stage's concat (:44)
             size = 2 * size
             conv_id += 2
@@ -67,7 +67,7 @@ def pose_encoder(x, n_pts, train_mode, final_res=128, filters=128, bn_groups=1, 
         return (gauss_mu, x) if return_logits else gauss_mu
 
 
-def translator(x, train_mode, final_res=128, filters=256, cin=None):
+def translator(x, train_mode, final_res=128, filters=256, cin=None, update_moving=True):
     """reference translator (:75-102).  Returns the fused 4-channel head output raw4 = crude(3) ‖ mask-logit(1);
     sigmoid + blend happen in ops.head_blend."""
     st = default_store()
@@ -75,14 +75,14 @@ def translator(x, train_mode, final_res=128, filters=256, cin=None):
         size = x.shape[1]
         conv_id = 1
         while size <= final_res:
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % conv_id, 'b_norm_%d_0' % conv_id, cin=cin)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % conv_id, 'b_norm_%d_0' % conv_id, cin=cin, update_moving=update_moving)
             cin = None
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id, update_moving=update_moving)
             if size == final_res:
                 # conv_N_0 (crude, 3 ch, :87) and conv_N_1 (mask, 1 ch, :88) as one 4-channel conv
                 return layers.conv(x, 4, kernel=3, stride=1, scope='conv_%d_0+1' % (conv_id + 1), head31=True)
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1))
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % (conv_id + 1), 'b_norm_%d_1' % (conv_id + 1))
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1), update_moving=update_moving)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % (conv_id + 1), 'b_norm_%d_1' % (conv_id + 1), update_moving=update_moving)
             x = _upsample_concat(x, None)                              # :98
             size = 2 * size
             conv_id += 2

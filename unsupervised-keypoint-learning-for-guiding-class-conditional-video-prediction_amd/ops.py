@@ -111,10 +111,21 @@ def _claim_grad(dst):
     return first
 
 
+def normalize_device(device):
+    """torch.device with an explicit index: 'cuda' (index None) becomes the current device, so that it compares equal to the
+    ``tensor.device`` values the ops record (torch.device('cuda') != torch.device('cuda:0'))."""
+    dev = torch.device(device)
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    return dev
+
+
 def join_side_stream(device=None):
     """Make the current stream wait for every weight-gradient kernel launched on the side stream."""
+    if device is not None:
+        device = normalize_device(device)
     for dev in list(_side_dirty):
-        if device is None or dev == torch.device(device):
+        if device is None or dev == device:
             torch.cuda.current_stream(dev).wait_stream(_side_streams[dev])
             _side_dirty.discard(dev)
     if not _side_dirty:
