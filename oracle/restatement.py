@@ -5,8 +5,9 @@ reference function, each citing the reference file:line it follows.  Gradients c
 torch autograd over this forward restatement, which makes them an independent check of the
 hand-written HIP backward kernels.
 
-PARITY UNPINNED (see oracle/__init__.py): the [TF-sem] rules of SURVEY.md Appendix C are
-encoded here as executable assumptions about tensorflow-gpu==1.12.0.
+Wiring pinned / op numerics UNPINNED (see oracle/__init__.py): the graph structure is checked against the reference's
+own files (tests/test_reference_graph.py); the [TF-sem] rules of SURVEY.md Appendix C are encoded here as executable
+assumptions about tensorflow-gpu==1.12.0.
 """
 import math
 from collections import OrderedDict

@@ -356,3 +356,81 @@ def test_test_step_leaves_moving_statistics_untouched_and_default_device_joins_s
         want_g = float(R.loss_G(net, vggw, fwd['final_output'], torch.from_numpy(fut2))[0])
     assert abs(loss_d - want_d) <= 1e-4 * max(1.0, abs(want_d)), (loss_d, want_d)
     assert abs(loss_g - want_g) <= 1e-4 * max(1.0, abs(want_g)), (loss_g, want_g)
+
+
+def test_against_the_reference_graph_fixture(golden_dir):
+    """The HIP path against tests/golden/networks_ref.npz = what the REFERENCE's own graph files (models/networks/*.py,
+    utils/model.py, models/detector_translator_model.py, run unmodified under tests/golden/tf_standin.py) produced at 128x128, K=3,
+    batch 2: the variable registry, a forward at the initial weights, two train steps fed like the reference's session (a NEW
+    batch for the G-run) and one test_step.  Wiring is pinned by the reference's files; op numerics remain [TF-sem]."""
+    import kpx_amd
+    ref = np.load(os.path.join(golden_dir, 'networks_ref.npz'))
+    res, k, b, _, vgg_seed, vgg_div, seed = (int(v) for v in ref['case'])
+    dev = torch.device('cuda:0')
+    cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': b},
+           'model': {'n_pts': k}, 'paths': {'log_dir': '/tmp/kpx_test', 'vggnet': None}}
+    vgg = kpx_amd.Vgg19(weights=kpx_amd.synthetic_vgg19_weights(seed=vgg_seed, width_div=vgg_div), device=dev)
+    model = kpx_amd.DetectorTranslatorModel(cfg, device=dev, vgg=vgg, image_size=res, seed=seed)
+    model.build()
+
+    def feed(i, suffix=''):
+        im, fut = R.synthetic_pair(b, res=res, seed0=100 + 2 * i, seed1=101 + 2 * i)
+        return {'image' + suffix: torch.from_numpy(im).to(dev), 'future_image' + suffix: torch.from_numpy(fut).to(dev)}
+
+    def dg(a):
+        a = np.asarray(a, np.float64).ravel()
+        return np.sqrt((a * a).sum())
+    # registry: checkpoint names and shapes = the reference's tf.global_variables() (incl. Adam slots, beta powers, int32 global_step)
+    arrays = model.checkpoint_arrays()
+    want_shapes = {str(n): tuple(int(s) for s in str(sh).split(',') if s) for n, sh in zip(ref['var_names'], ref['var_shapes'])}
+    assert set(arrays) == set(want_shapes)
+    for n, sh in want_shapes.items():
+        assert tuple(np.asarray(arrays[n]).shape) == sh, n
+    assert np.asarray(arrays['global_step']).dtype == np.int32
+    for i, n in enumerate(str(s) for s in ref['model_var_names']):          # same initial draws in the same creation order
+        assert abs(dg(arrays[n]) - ref['init_digest'][i][0]) <= 1e-12 * max(1.0, ref['init_digest'][i][0]), n
+    # forward at the initial weights on batch 0
+    f0 = feed(0)
+    got = model.forward(f0['image'], f0['future_image'], with_vis_maps=True)
+    np.testing.assert_allclose(got['current_points'].cpu().numpy(), ref['fwd_current_points'], atol=1e-5)
+    np.testing.assert_allclose(got['future_points'].cpu().numpy(), ref['fwd_future_points'], atol=1e-5)
+    for key in ('final_output', 'crude_output', 'mask', 'current_keypoints_map', 'future_keypoints_map'):
+        a = got[key].cpu().numpy()
+        assert a.shape == tuple(ref['fwd_%s_shape' % key])
+        assert rel_l2(a[:, ::2, ::2, :], ref['fwd_%s_sub2' % key]) < 1e-4, key
+        assert abs(dg(a) - ref['fwd_%s_digest' % key][0]) <= 1e-4 * ref['fwd_%s_digest' % key][0], key
+    ld, lg, _, _ = model.test_step(None, f0, 0, 1, b)
+    assert abs(ld - float(ref['fwd_loss_D'])) <= 1e-4 * max(1.0, abs(float(ref['fwd_loss_D'])))
+    assert abs(lg - float(ref['fwd_loss_G'])) <= 1e-4 * max(1.0, abs(float(ref['fwd_loss_G'])))
+    # the reference's train_step twice: D-run on batch 2n+1, G-run on batch 2n+2 (a new batch per sess.run)
+    state_names = [str(n) for n in ref['state_names']]
+    for step in range(2):
+        model.train_step(None, {**feed(1 + 2 * step), **feed(2 + 2 * step, '_G')}, step, b)
+        vals = model.loss_values()
+        tol = 1e-4 if step == 0 else 1e-3       # step 1 starts from weights whose noise-gradient elements stepped +-lr differently
+        for key in ('loss_D', 'loss_G'):
+            want = float(ref['step%d_%s' % (step, key)])
+            assert abs(vals[key] - want) <= tol * max(1.0, abs(want)), (step, key, vals[key], want)
+        # generator gradients of this step are still in the flat bucket: norm-weighted aggregate of the kernel-gradient norms
+        want = ref['step%d_grad_G_digest' % step]
+        num = den = 0.0
+        for i, n in enumerate(str(s) for s in ref['G_var_list']):
+            if not n.endswith('/kernel'):
+                continue
+            num += (dg(model.store.grad(n).cpu().numpy()) - want[i][0]) ** 2
+            den += want[i][0] ** 2
+        assert (num / den) ** 0.5 < 2e-2, (step, (num / den) ** 0.5)
+        arrays = model.checkpoint_arrays()
+        assert int(arrays['global_step']) == int(ref['step%d_global_step' % step])
+        want = ref['step%d_state_digest' % step]
+        for i, n in enumerate(state_names):
+            base = n.replace('/Adam_1', '').replace('/Adam', '')
+            if '/Adam' in n or (base.endswith('/bias') and not base.startswith('img_discr') and 'translator/conv_6' not in base):
+                continue                          # slots follow the gradient tolerance; pre-BN biases hold +-lr noise (or exact 0 here)
+            if n.startswith('beta'):
+                assert abs(float(arrays[n]) - want[i][0]) < 1e-7, n
+                continue
+            assert abs(dg(arrays[n]) - want[i][0]) <= 2e-5 * (step + 1) * max(want[i][0], 1.0) + 1e-7, (step, n, dg(arrays[n]), want[i][0])
+    ld, lg, _, _ = model.test_step(None, feed(5), 2, 1, b)
+    assert abs(ld - float(ref['test_loss_D'])) <= 1e-3 * max(1.0, abs(float(ref['test_loss_D'])))
+    assert abs(lg - float(ref['test_loss_G'])) <= 1e-3 * max(1.0, abs(float(ref['test_loss_G'])))

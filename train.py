@@ -89,6 +89,9 @@ def main(argv=None):
     parser.add_argument('--synthetic', action='store_true', help='synthetic Penn-shaped pairs instead of the JPEG pipeline')
     parser.add_argument('--synthetic-vgg', action='store_true', help='He-normal VGG19 weights when paths.vggnet is absent')
     parser.add_argument('--steps', type=int, default=None, help='override training.n_steps')
+    parser.add_argument('--batch-per-run', action='store_true',
+                        help="feed a NEW batch to the G update like the reference's two sess.run (train.py:46-50); default: one batch per "
+                             'step with a shared generator forward')
     args = parser.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format='%(message)s')
 
@@ -135,9 +138,15 @@ def main(argv=None):
         should_write_log = step % train_config['log_interval'] == 0
         if train_it is not None:
             feed_dict = next(train_it)
+            if args.batch_per_run:                   # the reference's input node serves a new batch to each of the two sess.run (:46-50)
+                feed_dict = dict(feed_dict, **{k + '_G': v for k, v in next(train_it).items() if k in ('image', 'future_image')})
         else:
             pair = synthetic_pair(batch_size, res=model.image_size, seed0=2 * (step * world + rank), seed1=2 * (step * world + rank) + 1)
             feed_dict = {k: torch.from_numpy(v).to(dev) for k, v in pair.items()}
+            if args.batch_per_run:
+                s2 = 10 ** 7 + 2 * (step * world + rank)
+                pair = synthetic_pair(batch_size, res=model.image_size, seed0=s2, seed1=s2 + 1)
+                feed_dict.update({k + '_G': torch.from_numpy(v).to(dev) for k, v in pair.items()})
         model.train_step(None, feed_dict, step, batch_size, should_write_log=should_write_log and rank == 0,
                          should_write_summary=False)
         if step % train_config['checkpoint_interval'] == 0 and rank == 0:

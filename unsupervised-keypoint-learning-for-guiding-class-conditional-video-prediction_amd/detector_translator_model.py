@@ -152,19 +152,33 @@ class DetectorTranslatorModel(BaseModel):
 
     # ------------------------------------------------------------------------------------------------ steps
     def train_step(self, sess, feed_dict, step, batch_size, should_write_log=False, should_write_summary=False):
-        """reference train_step (:79-117).  feed_dict = {'image': [B,H,W,3], 'future_image': [B,H,W,3]} in [-1,1]."""
+        """reference train_step (:79-117).  feed_dict = {'image': [B,H,W,3], 'future_image': [B,H,W,3]} in [-1,1].
+
+        With only those two keys the D-run and the G-run see the same batch and share one generator forward (the benchmark
+        convention).  The reference's input node hands a NEW batch to each sess.run (train.py:46-50):
+        pass that second batch as 'image_G' / 'future_image_G' and the G-run recomputes the forward on it, exactly like the
+        reference's second sess.run (BN moving statistics then come from the G-run's batch only, :199-202)."""
         im, future_im = feed_dict['image'], feed_dict['future_image']
+        separate = 'image_G' in feed_dict
         start_time = time.time()
         lr = self.current_lr()
         with variables.as_default(self.store):
-            fwd = self._define_forward_pass(im, future_im)
-            final = fwd['final_output']
             # ---- D run (:93)
-            d_losses = self._loss_D(final.detach(), future_im)
+            if separate:
+                with torch.no_grad():
+                    final_d = self._define_forward_pass(im, future_im, update_moving=False)['final_output']
+            else:
+                fwd = self._define_forward_pass(im, future_im)
+                final_d = fwd['final_output'].detach()
+            d_losses = self._loss_D(final_d, future_im)
             ops.begin_backward()
             torch.autograd.backward([d_losses], [self._e0])
             pending = self.exchange_gradients('D', async_op=True)          # overlaps the VGG forward below
             # ---- G run (:94): the perceptual forward does not involve the discriminator, so it runs first ...
+            if separate:
+                im, future_im = feed_dict['image_G'], feed_dict['future_image_G']
+                fwd = self._define_forward_pass(im, future_im)
+            final = fwd['final_output']
             recon = self._loss_G_recon(final, future_im)
             self._apply_adam('D', lr, pending=pending, exchanged=True)
             # ... and the adversarial term sees the UPDATED discriminator, exactly as the reference's second sess.run
