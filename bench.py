@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the detector_translator train step (BASELINE.json metric) on N MI355X of one node.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps 10 --warmup 3            (N > 1: starts one child process per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = the reference's D-run + G-run (models/detector_translator_model.py:79-117) on one synthetic batch of
@@ -64,23 +64,31 @@ def _time_conv_3_1(dev):
 
 
 def _pmc_traffic(name):
-    try:            # HBM bytes per launch from the committed rocprofv3 PMC passes of this same kernel / shape
-        return int(json.load(open(os.path.join(ROOT, 'profiles', name)))['traffic_bytes_per_launch'])
+    """HBM bytes per launch from a committed rocprofv3 PMC summary of this same kernel / shape (profiles/<name>); the
+    counters cannot be collected inside a normal bench run, so the JSON line names the file they come from."""
+    try:
+        return int(json.load(open(os.path.join(ROOT, 'profiles', name)))['traffic_bytes_per_launch']), 'profiles/' + name
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
+
+
+WINO_PMC, DIRECT_PMC, RENDER_PMC = 'r02_wino_pmc.json', 'r01_conv_pmc.json', 'r02_render_pmc.json'
 
 
 def roofline_conv(dev):
     """Dominant kernel: the fused Winograd F(2x2,3x3) conv (fp32 MFMA) on the translator's 3x3 128->128 layer at 64x64
-    (conv_3_1 / 4_0 / 4_1, SURVEY Appendix A: 603 979 776 MAC per image), batch 32.  One C-ABI call = filter transform (tiny)
-    + conv_wino8_kernel<2>.  `achieved` is ALGORITHMIC (direct-convolution) FLOP/s, so it can exceed the MFMA peak: the kernel
-    executes 2.25x fewer MACs; `mfma_frac` is the executed-MFMA share of the peak."""
+    (conv_3_1 / 4_0 / 4_1, SURVEY Appendix A: 603 979 776 MAC per image), batch 32.  `achieved` / `frac` count the MFMA FLOPs the
+    kernel EXECUTES (algorithmic / 2.25: 16 instead of 36 multiplies per 2x2 output tile) against the fp32 MFMA peak;
+    `algorithmic_tflops` / `algorithmic_frac` count direct-convolution FLOPs and may exceed 1."""
     ms, flops = _time_conv_3_1(dev)
-    ach = flops / (ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'kernel': 'conv_wino8_kernel<2> (+ filter transform) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
+    alg = flops / (ms * 1e-3) / 1e12
+    ach = alg / 2.25
+    traffic, src = _pmc_traffic(WINO_PMC)
+    return {'bound': 'mfma', 'kernel': 'conv_wino kernel fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), one C-ABI call',
             'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4),
-            'traffic': _pmc_traffic('r01_wino_pmc.json'), 'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops,
-            'mfma_flops_per_launch': flops / 2.25, 'mfma_frac': round(ach / 2.25 / 157.3, 4)}
+            'traffic': traffic, 'traffic_source': src, 'avg_launch_ms': round(ms, 4),
+            'flops_per_launch_executed': flops / 2.25, 'flops_per_launch_algorithmic': flops,
+            'algorithmic_tflops': round(alg, 2), 'algorithmic_frac': round(alg / 157.3, 4)}
 
 
 def roofline_conv_direct(dev):
@@ -91,27 +99,34 @@ def roofline_conv_direct(dev):
     finally:
         del os.environ['KPX_NO_WINO']
     ach = flops / (ms * 1e-3) / 1e12
+    traffic, src = _pmc_traffic(DIRECT_PMC)
     return {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,128,2,4> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1, KPX_NO_WINO=1)',
             'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4),
-            'traffic': _pmc_traffic('r01_conv_pmc.json'), 'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops}
+            'traffic': traffic, 'traffic_source': src, 'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops}
 
 
 def roofline_render(dev):
     """HBM-bound kernel the north star singles out: Gaussian heat-map render at [128,128,K=15], batch 32:
-    algorithmic bytes = B*H*W*K*4 written (+ K*8 read) per launch (983 040 B per image)."""
+    algorithmic bytes = B*H*W*K*4 written (+ K*8 read) per launch (983 040 B per image).  The launches rotate over
+    nine 62.9 MB outputs (566 MB > the 256 MB Infinity Cache) so that every launch's stores have to reach HBM."""
     from kpx_amd import ops
     from kpx_amd._lib import lib, check
     b = 2 * BATCH                      # current + future key-point maps of one batch of 32 pairs
     mu = (torch.rand(b, K_PTS, 2, device=dev) * 2 - 1).contiguous()
-    out = torch.empty(b, RES, RES, K_PTS, device=dev)
+    outs = [torch.empty(b, RES, RES, K_PTS, device=dev) for _ in range(9)]
+    it = [0]
 
     def run():
+        out = outs[it[0] % len(outs)]
+        it[0] += 1
         check(lib.kpx_gaussian_maps_fwd_f32(mu.data_ptr(), b, K_PTS, RES, RES, 14.3, out.data_ptr(), K_PTS, ops._stream()), 'gauss')
-    ms = time_kernel(run, iters=200, warm=20)
+    ms = time_kernel(run, iters=198, warm=18)
     nbytes = b * (RES * RES * K_PTS * 4 + K_PTS * 8)
     ach = nbytes / (ms * 1e-3) / 1e9
-    return {'bound': 'hbm', 'kernel': 'gauss_fwd_flat_kernel [64,128,128,15] (current+future maps of 32 pairs)', 'achieved': round(ach, 1), 'peak': 8000.0,
-            'unit': 'GB/s', 'frac': round(ach / 8000.0, 4), 'traffic': None, 'avg_launch_ms': round(ms, 5), 'bytes_per_launch': nbytes}
+    traffic, src = _pmc_traffic(RENDER_PMC)
+    return {'bound': 'hbm', 'kernel': 'gauss_fwd kernel [64,128,128,15] (current+future maps of 32 pairs), 9 rotating outputs', 'achieved': round(ach, 1),
+            'peak': 8000.0, 'unit': 'GB/s', 'frac': round(ach / 8000.0, 4), 'traffic': traffic, 'traffic_source': src,
+            'avg_launch_ms': round(ms, 5), 'bytes_per_launch': nbytes}
 
 
 def host_cores():
@@ -149,6 +164,40 @@ def cpu_baseline():
             'sec_per_step': round(med, 3)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start one child per GPU (fresh processes: this parent never initialises
+    the GPU and never exec()s), rank 0 prints the JSON line on the inherited stdout; non-zero if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    for q in pending:                # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -159,22 +208,29 @@ def main():
     ap.add_argument('--roofline-only', action='store_true', help='only the two kernel microbenchmarks (used for the rocprofv3 cross-check)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args.gpus))             # nothing in this process has touched the GPU yet
+    launched = 'WORLD_SIZE' in os.environ            # under torch.distributed.run (or self_launch): always build the process group
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
-                         '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
-    local_rank %= max(1, torch.cuda.device_count())     # (several ranks may share one GPU only in the gloo self-test below)
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    backend = os.environ.get('KPX_DIST_BACKEND', 'nccl')              # nccl = RCCL over xGMI; gloo only to self-test on one GPU
+    n_dev = max(1, torch.cuda.device_count())
+    if backend == 'nccl' and world > n_dev:
+        raise SystemExit('--gpus %d needs %d GPUs, %d visible (RCCL wants one GPU per rank; KPX_DIST_BACKEND=gloo shares GPUs for self-tests)'
+                         % (world, world, n_dev))
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    if launched:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        backend = os.environ.get('KPX_DIST_BACKEND', 'nccl')          # nccl = RCCL over xGMI; gloo only to self-test on one GPU
         if backend == 'nccl':
             torch.distributed.init_process_group('nccl', device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
+        assert torch.distributed.get_world_size() == world
 
     import kpx_amd
     from kpx_amd.synthetic import synthetic_pair
@@ -191,7 +247,7 @@ def main():
     feed = {k: torch.from_numpy(v).to(dev) for k, v in pair.items()}
 
     def sync():
-        if world > 1:
+        if launched:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -207,10 +263,16 @@ def main():
     t_enq = time.perf_counter() - t0          # host time to enqueue K steps (the GPU runs behind it)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    enq = [t_enq / args.steps * 1e3]
+    n_ranks_seen = 1
+    if launched:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        n_ranks_seen = torch.distributed.get_world_size()
+        e = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        torch.distributed.all_gather(e, torch.tensor(enq, dtype=torch.float64, device=dev))
+        enq = [float(x.item()) for x in e]
     losses = model.loss_values()
     assert np.isfinite(losses['loss_D']) and np.isfinite(losses['loss_G']), losses
 
@@ -229,7 +291,8 @@ def main():
                           'algorithmic_gmac_per_pair': round(gmac, 2)},
                'step_tflops': round(2 * gmac * 1e9 * value / 1e12, 2),
                'step_mfma_frac_of_f32_peak': round(2 * gmac * 1e9 * value / world / 157.3e12, 4),
-               'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3),
+               'n_ranks_seen': n_ranks_seen, 'dist_backend': backend if launched else None,
+               'host_enqueue_ms_per_step': round(max(enq), 3), 'host_enqueue_ms_per_step_by_rank': [round(x, 3) for x in enq],
                'loss_D': round(losses['loss_D'], 5), 'loss_G': round(losses['loss_G'], 5)}
         if world == 1:
             out['roofline'] = roofline_conv(dev)
@@ -238,7 +301,7 @@ def main():
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if launched:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -69,6 +69,10 @@ CONV_CASES = [
     (16, 32, 32, 128, 16, 3, 1, 0, 0),     # Winograd weight gradient, 64 x 32 blocks with the 16 output channels masked (pose conv_7_0)
     (16, 32, 32, 32, 160, 3, 1, 0, 1),     # Winograd weight gradient, 32 x 64 blocks, Cout = 160 overhangs the last block
     (8, 64, 64, 64, 4, 3, 1, 0, 0),        # translator head shape: Winograd with 4 produced channels (fwd), 4 gathered channels (dgrad), wgrad 64 x 32 block
+    (32, 64, 64, 128, 128, 3, 1, 0, 1),    # THE bench / roofline shape (translator conv_3_1 at B=32): 64-cout Winograd workgroups, 16 chunks, fwd + dgrad
+    (64, 32, 32, 24, 64, 3, 1, 0, 2),      # 64-cout Winograd workgroups with a 3-chunk K loop (only the un-pipelined tail iterations run)
+    (128, 8, 8, 64, 512, 3, 1, 0, 0),      # 64-cout Winograd workgroups on packed 8x8 images (VGG conv5 at a large batch)
+    (8, 64, 64, 64, 40, 3, 1, 0, 0),       # 32-cout Winograd workgroups (Np = 64 but too few blocks), couts 40..63 masked, 8-chunk pipelined loop
 ]
 
 

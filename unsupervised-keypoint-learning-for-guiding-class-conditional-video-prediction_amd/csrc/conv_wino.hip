@@ -13,6 +13,7 @@
 // The same kernel serves dgrad with filters transformed from the flipped / transposed weights.
 #include "kpx_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct WinoGeom {
     const float* x; float* y; const float* U; const float* bias;
@@ -20,6 +21,7 @@ struct WinoGeom {
     int pack;                                   // 1: H = W = 8, one workgroup = 4 consecutive images as a 2x2 mosaic
     int Kp, Np;                                 // U is [16][Kp][Np]: Kp = Cin rounded up to 8, Np = Cout rounded up to 32 (zero padded)
     int tiles_y, tiles_x, nt;          // 16x16-pixel blocks per image, cout tiles of 32
+    int stagger;                       // v2: wavefronts 4-7 run the MFMA half of a chunk first
 };
 
 static __device__ __attribute__((aligned(16))) float wino_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -54,6 +56,48 @@ __global__ __launch_bounds__(256) void wino_filter_transform_kernel(const float*
             U[((size_t)(i * 4 + 1) * Kp + c) * Np + n] = u1;
             U[((size_t)(i * 4 + 2) * Kp + c) * Np + n] = u2;
             U[((size_t)(i * 4 + 3) * Kp + c) * Np + n] = u3;
+        }
+    }
+}
+
+
+// Fragment layout for the v2 kernel: Uf[p][kc = Kp/8][nb = Np/32][lh 2][li 32][j 4] = U[p][c = 8 kc + 4 lh + j][n = 32 nb + li], i.e. the
+// B operand of v_mfma_f32_32x32x2_f32 for (point p, 8-channel chunk kc, 32-cout block nb) is ONE coalesced 16-B load per lane (1 KB per
+// wavefront), element j feeding the MFMA of k-pair j.  The filter never passes through LDS.
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void wino_filter_transform_frag_kernel(const float* __restrict__ w, int Cin, int Cout, int Kp, int Np, float* __restrict__ Uf) {
+    const int K = DGRAD ? Cout : Cin, Nn = DGRAD ? Cin : Cout;
+    const int KC = Kp >> 3, NB = Np >> 5;
+    const size_t total = (size_t)Kp * Np;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        // idx enumerates the fragment order (kc, nb, lh, li, j) so that the 16 stores of a wavefront are 16 contiguous 256-B runs
+        const int j = (int)(idx & 3), li = (int)((idx >> 2) & 31), lh = (int)((idx >> 7) & 1);
+        const size_t blk = idx >> 8;
+        const int nb = (int)(blk % NB), kc = (int)(blk / NB);
+        const int c = 8 * kc + 4 * lh + j, n = 32 * nb + li;
+        const bool real = c < K && n < Nn;
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                g[r][q] = !real ? 0.f : (DGRAD ? w[((size_t)((2 - r) * 3 + (2 - q)) * Cin + n) * Cout + c] : w[((size_t)(r * 3 + q) * Cin + c) * Cout + n]);
+        float t[4][3];                                   // G g
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            t[0][q] = g[0][q];
+            t[1][q] = 0.5f * (g[0][q] + g[1][q] + g[2][q]);
+            t[2][q] = 0.5f * (g[0][q] - g[1][q] + g[2][q]);
+            t[3][q] = g[2][q];
+        }
+        const size_t pstride = (size_t)KC * NB * 256;
+        float* o = Uf + blk * 256 + (idx & 255);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                    // (G g) G^T
+            o[(size_t)(i * 4 + 0) * pstride] = t[i][0];
+            o[(size_t)(i * 4 + 1) * pstride] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+            o[(size_t)(i * 4 + 2) * pstride] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+            o[(size_t)(i * 4 + 3) * pstride] = t[i][2];
         }
     }
 }
@@ -248,6 +292,264 @@ __global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const 
     }
 }
 
+
+// ---- v2 forward / dgrad kernel ----------------------------------------------------------------------------------------------------
+// Same tile (16x16 output pixels x 32*MODE output channels x all 16 Winograd points per workgroup of 8 wavefronts) and the same
+// conflict-free raw / V images as above, restructured so that the matrix pipe is the only thing on the critical path:
+//   * the transformed filters never pass through LDS: each lane loads its B fragments straight from the fragment-ordered Uf
+//     (one 16-B load per point and chunk, L2-resident);
+//   * raw and V are double buffered: while chunk k is multiplied, chunk k+1 is transformed and chunk k+2 is staged, by the same
+//     wavefronts, as independent instruction streams inside one basic block -- ONE barrier per 8-channel chunk instead of three;
+//   * wavefront w owns Winograd row a = w & 3 (points 4a .. 4a+3) of one 32-cout half (MODE 2) / one 32-tile half (MODE 1), so the
+//     sum over the point columns of A^T M A happens in registers and the single-pass LDS epilogue moves half the accumulator bytes.
+#define W2_RAW 3200
+#define W2_V 8192
+#define W2_MAIN (2 * W2_RAW + 2 * W2_V)
+
+#ifdef KPX_WINO_STAMP      // diagnostic build only (profiles/wino_stamps.sh): s_memtime stamps of wavefronts 0 and 4 of the first 64 workgroups
+__device__ unsigned long long* wino_dbg = nullptr;
+extern "C" int kpx_debug_wino_stamps(unsigned long long* buf) { return -(int)hipMemcpyToSymbol(HIP_SYMBOL(wino_dbg), &buf, sizeof(buf)); }
+#define W2_STAMP(slot) do { if (dbg) dbg[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W2_STAMP(slot) do { } while (0)
+#endif
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NC = 32 * MODE, NTG = MODE;
+    float* const rawb = smem;
+    float* const Vb = smem + 2 * W2_RAW;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wa = wave & 3, hsel = wave >> 2;
+    int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    const int ntc = g.Np / NC;
+    const int nti = L % ntc; L /= ntc;
+    const int bx = L % g.tiles_x; L /= g.tiles_x;
+    const int by = L % g.tiles_y;
+    const int n = g.pack ? 4 * L : L / g.tiles_y;       // packed: images n .. n+3
+    const int oy0 = by * 16, ox0 = bx * 16, n0 = nti * NC;
+
+    // raw patch units: u = t + 512*i < 720 (800 packed): position u>>1 (rows x 20 positions), 16-B half u&1
+    const float* rp[2]; bool rok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = t + 512 * i, q = u >> 1, py = q / 20, ps = q - py * 20;
+        int iy, ix, ni = n;
+        bool ok;
+        if (g.pack) {
+            const int sy = py / 10, sx = ps / 10;
+            iy = py - 10 * sy - 1; ix = ps - 10 * sx - 1; ni = n + 2 * sy + sx;
+            ok = u < 800 && (unsigned)iy < 8u && (unsigned)ix < 8u;
+        } else {
+            iy = oy0 - 1 + py; ix = ox0 - 1 + w8_pix(ps);
+            ok = u < 720 && ps < 18 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        }
+        if (g.Cin <= 4 && (u & 1)) ok = false;
+        rok[i] = ok;
+        rp[i] = ok ? g.x + ((size_t)(ni * g.H + iy) * g.W + ix) * g.ldx + (u & 1) * 4 : wino_zero16;
+    }
+    // B fragments: points 4*wa + b, 32-cout block nb of this wavefront
+    const int KC = g.Kp >> 3, NB = g.Np >> 5;
+    const int nb = MODE == 2 ? nti * 2 + hsel : nti;
+    const size_t ub_pstride = (size_t)KC * NB * 256, ub_step = (size_t)NB * 256;
+    const float* ubp = g.U + ((size_t)(4 * wa) * KC * NB + nb) * 256 + lane * 4;
+    // transform item: 16-B half, tile, row of V = B^T d B
+    const int tslot = t & 1, ttile = (t >> 1) & 63, vrow = t >> 7;
+    const int tty = ttile >> 3, ttx = ttile & 7;
+    const int ra = vrow == 0 ? 0 : (vrow == 2 ? 2 : 1), rb = vrow == 0 ? 2 : (vrow == 1 ? 2 : (vrow == 2 ? 1 : 3));
+    const float sgn = vrow == 1 ? 1.f : -1.f;
+    int trd[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        trd[c] = g.pack ? ((tty >> 2) * 10 + 2 * (tty & 3) + ra) * 160 + ((ttx >> 2) * 10 + 2 * (ttx & 3) + c) * 8 + tslot * 4
+                        : (2 * tty + ra) * 160 + w8_pos(2 * ttx + c) * 8 + tslot * 4;
+    const int trb = (rb - ra) * 160;
+    const int vwr = (vrow * 4) * 512 + ttile * 8 + ((tslot ^ ((ttile >> 3) & 1)) << 2);
+    int a_rd[NTG];
+#pragma unroll
+    for (int i = 0; i < NTG; ++i) {
+        const int tile = (MODE == 2 ? i : hsel) * 32 + li;
+        a_rd[i] = (4 * wa) * 512 + tile * 8 + ((lh ^ ((tile >> 3) & 1)) << 2);
+    }
+
+    f32x16 acc[4][NTG];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < NTG; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][i][r] = 0.f;
+
+    const int nchunks = g.Kp / 8;
+    const int ktail = g.Cin - (nchunks - 1) * 8 - tslot * 4;      // valid channels of this thread's 16-B half in the LAST chunk (<4: pad)
+    f32x4 rr[2], ub[4];
+    auto load_raw = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { rr[i] = *reinterpret_cast<const f32x4*>(rp[i]); if (rok[i]) rp[i] += 8; }
+    };
+    // second staging unit of threads >= 288 does not exist (720 / 800 units): they re-store their first unit (same address, same
+    // value) so that the chunk body stays ONE basic block the scheduler can interleave with the MFMAs
+    const int st2 = t < 288 ? (t + 512) * 4 : t * 4;
+    auto stage = [&](float* rawW) {
+        *reinterpret_cast<f32x4*>(&rawW[t * 4]) = rr[0];
+        *reinterpret_cast<f32x4*>(&rawW[st2]) = t < 288 ? rr[1] : rr[0];
+    };
+    auto transform = [&](const float* rawR, float* Vw, bool mask_tail) {
+        f32x4 tr[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&rawR[trd[c]]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&rawR[trd[c] + trb]);
+            tr[c] = a + sgn * b;
+        }
+        if (mask_tail) {                                 // channels >= Cin of a padded last chunk must not reach V
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (j >= ktail) tr[c][j] = 0.f;
+        }
+        *reinterpret_cast<f32x4*>(&Vw[vwr]) = tr[0] - tr[2];
+        *reinterpret_cast<f32x4*>(&Vw[vwr + 512]) = tr[1] + tr[2];
+        *reinterpret_cast<f32x4*>(&Vw[vwr + 1024]) = tr[2] - tr[1];
+        *reinterpret_cast<f32x4*>(&Vw[vwr + 1536]) = tr[1] - tr[3];
+    };
+    // the B fragment of point b is refreshed in place (next chunk) right after its last MFMA of this chunk: 16 registers, and a
+    // full chunk of MFMA time to cover the L2 latency
+    auto mfma = [&](const float* Vr, bool refill) {
+        f32x4 av[2][NTG];                                  // A fragments of point b+1 are read under the MFMAs of point b
+#pragma unroll
+        for (int i = 0; i < NTG; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(&Vr[a_rd[i]]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b < 3) {
+#pragma unroll
+                for (int i = 0; i < NTG; ++i) av[(b + 1) & 1][i] = *reinterpret_cast<const f32x4*>(&Vr[a_rd[i] + (b + 1) * 512]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < NTG; ++i)
+                    acc[b][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][i][j], ub[b][j], acc[b][i], 0, 0, 0);
+            if (refill) ub[b] = *reinterpret_cast<const f32x4*>(ubp + (size_t)b * ub_pstride);
+        }
+        ubp += ub_step;
+    };
+    const bool late = g.stagger && __builtin_amdgcn_readfirstlane(t) >= 256;      // wave-uniform by construction
+#ifdef KPX_WINO_STAMP
+    unsigned long long* dbg = (wino_dbg && lane == 0 && (wave & 3) == 0 && blockIdx.x < 64) ? wino_dbg + ((size_t)blockIdx.x * 2 + (wave >> 2)) * 256 : nullptr;
+    if (dbg) { dbg[0] = __builtin_amdgcn_s_memtime(); dbg[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    // one chunk: multiply chunk k while chunk k+1 is transformed and chunk k+2 staged.  FULL: k + 3 < nchunks (no conditions)
+    auto body = [&](int k, auto full_tag, auto parity_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr int PAR = decltype(parity_tag)::value;       // 0 / 1: k & 1 known at compile time (LDS offsets become immediates); 2: runtime
+        const int cur = PAR == 2 ? (k & 1) : PAR;
+        float* const rawC = rawb + cur * W2_RAW;
+        float* const rawN = rawb + (cur ^ 1) * W2_RAW;
+        float* const Vc = Vb + cur * W2_V;
+        float* const Vn = Vb + (cur ^ 1) * W2_V;
+        W2_STAMP(8 + 4 * k);
+        __syncthreads();                                 // V[cur] (chunk k) and raw[cur^1] (chunk k+1) are complete
+        W2_STAMP(9 + 4 * k);
+        // The two wavefronts of a SIMD (w, w+4) run the halves of the chunk in opposite order: while one transforms / stages, the
+        // other owns the matrix pipe, and the late transformer works under its partner's last MFMAs (MI355X: stagger by wave >= 4).
+        if (late) mfma(Vc, FULL || k + 1 < nchunks);
+        if (late) W2_STAMP(10 + 4 * k);
+        if (FULL || k + 1 < nchunks) transform(rawN, Vn, !FULL && k + 1 == nchunks - 1 && ktail < 4);
+        if (FULL || k + 2 < nchunks) stage(rawC);        // chunk k+2 (raw[cur] was consumed by the transform of iteration k-1)
+        if (FULL || k + 3 < nchunks) load_raw();         // chunk k+3
+        if (!late) W2_STAMP(10 + 4 * k);
+        if (!late) mfma(Vc, FULL || k + 1 < nchunks);
+        W2_STAMP(11 + 4 * k);
+    };
+
+    // prologue: chunk 0 staged + transformed, chunk 1 staged, chunk 2 in flight
+    load_raw();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) ub[b] = *reinterpret_cast<const f32x4*>(ubp + (size_t)b * ub_pstride);
+    ubp += ub_step;
+    stage(rawb);
+    if (nchunks > 1) load_raw();
+    __syncthreads();
+    transform(rawb, Vb, nchunks == 1 && ktail < 4);
+    if (nchunks > 1) stage(rawb + W2_RAW);
+    if (nchunks > 2) load_raw();
+    int k = 0;
+    for (; k + 4 < nchunks; k += 2) {
+        body(k, std::true_type{}, std::integral_constant<int, 0>{});
+        body(k + 1, std::true_type{}, std::integral_constant<int, 1>{});
+    }
+    for (; k < nchunks; ++k) body(k, std::false_type{}, std::integral_constant<int, 2>{});
+
+    // epilogue, one pass: the sum over the point columns b of A^T M A in registers (P[a][j] = sum_b M[a][b] A[b][j]),
+    // P[4 a][2 j][64 tiles][NC couts] through LDS, then Y[i][j] = sum_a A[a][i] P[a][j] + bias + activation, 16-B stores.
+#ifdef KPX_WINO_STAMP
+    if (dbg) { dbg[2] = __builtin_amdgcn_s_memtime(); }
+#endif
+    __syncthreads();
+    float* const P = smem;
+#pragma unroll
+    for (int i = 0; i < NTG; ++i) {
+        const int tg = MODE == 2 ? i : hsel;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0 = acc[0][i][r], m1 = acc[1][i][r], m2 = acc[2][i][r], m3 = acc[3][i][r];
+            const int tile = tg * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int col = (MODE == 2 ? hsel * 32 : 0) + li;
+            P[((wa * 2 + 0) * 64 + tile) * NC + col] = m0 + m1 + m2;
+            P[((wa * 2 + 1) * 64 + tile) * NC + col] = m1 - m2 - m3;
+        }
+    }
+    __syncthreads();
+    const bool vec_ok = (g.ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.y) & 15) == 0);
+#pragma unroll
+    for (int it = 0; it < MODE; ++it) {
+        const int idx = t + 512 * it;
+        const int tile = idx / (NC / 4), cq = idx - tile * (NC / 4);
+        f32x4 pv[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pv[a][j] = *reinterpret_cast<const f32x4*>(&P[((a * 2 + j) * 64 + tile) * NC + cq * 4]);
+        const int c0 = n0 + cq * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c0 + e < g.Cout) bv[e] = g.bias[c0 + e];
+        }
+        const int ty = tile >> 3, tx = tile & 7;
+        const int on = g.pack ? n + 2 * (ty >> 2) + (tx >> 2) : n;
+        const int oy = g.pack ? 2 * (ty & 3) : oy0 + 2 * ty, ox = g.pack ? 2 * (tx & 3) : ox0 + 2 * tx;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                f32x4 v = (dy == 0 ? pv[0][dx] + pv[1][dx] + pv[2][dx] : pv[1][dx] - pv[2][dx] - pv[3][dx]) + bv;
+                if (g.act == KPX_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                } else if (g.act == KPX_ACT_LRELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+                }
+                float* o = g.y + ((size_t)(on * g.H + oy + dy) * g.W + ox + dx) * g.ldy + c0;
+                if (vec_ok && c0 + 3 < g.Cout) *reinterpret_cast<f32x4*>(o) = v;
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (c0 + e < g.Cout) o[e] = v[e];
+                }
+            }
+    }
+#ifdef KPX_WINO_STAMP
+    if (dbg) { dbg[3] = __builtin_amdgcn_s_memtime(); dbg[4] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+}
+
+static inline int w2_lds_bytes(int mode) { const int main = W2_MAIN * 4, epi = 4 * 2 * 64 * 32 * mode * 4; return main > epi ? main : epi; }
+
 static inline int w8_lds_bytes(int ct) { const int main = (W8_RAW + W8_U(ct) + W8_V) * 4; return main > 65536 ? main : 65536; }
 static unsigned long long wino_attr_mask = 0;
 
@@ -267,14 +569,21 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const floa
     const int Kp = (K + 7) & ~7, Np = (Nn + 31) & ~31;
     const size_t pairs = (size_t)Kp * Np;
     size_t nb = (pairs + 255) / 256; if (nb > 1024) nb = 1024;
-    if (dgrad) hipLaunchKernelGGL(wino_filter_transform_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
-    else hipLaunchKernelGGL(wino_filter_transform_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
+    static const int version = getenv("KPX_WINO_V") ? atoi(getenv("KPX_WINO_V")) : 2;
+    if (version == 2) {
+        if (dgrad) hipLaunchKernelGGL(wino_filter_transform_frag_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
+        else hipLaunchKernelGGL(wino_filter_transform_frag_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
+    } else {
+        if (dgrad) hipLaunchKernelGGL(wino_filter_transform_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
+        else hipLaunchKernelGGL(wino_filter_transform_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
+    }
     int rc = kpx_launch_status();
     if (rc) return rc;
     if (kpx_first_use_on_device(&wino_attr_mask)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, w8_lds_bytes(1));
-        if (e != hipSuccess) return -(int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, w8_lds_bytes(2));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, w8_lds_bytes(2));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_v2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, w2_lds_bytes(1));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_v2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, w2_lds_bytes(2));
         if (e != hipSuccess) return -(int)e;
     }
     WinoGeom g{};
@@ -286,9 +595,16 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const floa
     const unsigned blocks = (unsigned)((size_t)(g.pack ? N / 4 : N) * g.tiles_y * g.tiles_x * g.nt);
     // 64 output channels per workgroup when that still fills the 256 CUs, else 32
     static const int force_ct = getenv("KPX_WINO_CT") ? atoi(getenv("KPX_WINO_CT")) : 0;
-    const bool wide = force_ct ? force_ct == 2 : (blocks / 2 >= 256);
-    if (wide && Np % 64 == 0) hipLaunchKernelGGL(conv_wino8_kernel<2>, dim3(blocks / 2), dim3(512), w8_lds_bytes(2), s, g);
-    else hipLaunchKernelGGL(conv_wino8_kernel<1>, dim3(blocks), dim3(512), w8_lds_bytes(1), s, g);
+    const bool wide = (force_ct ? force_ct == 2 : (blocks / 2 >= 256)) && Np % 64 == 0;
+    static const int stagger = getenv("KPX_WINO_STAGGER") ? atoi(getenv("KPX_WINO_STAGGER")) : 1;
+    g.stagger = stagger;
+    if (version == 2) {
+        if (wide) hipLaunchKernelGGL(conv_wino_v2_kernel<2>, dim3(blocks / 2), dim3(512), w2_lds_bytes(2), s, g);
+        else hipLaunchKernelGGL(conv_wino_v2_kernel<1>, dim3(blocks), dim3(512), w2_lds_bytes(1), s, g);
+    } else {
+        if (wide) hipLaunchKernelGGL(conv_wino8_kernel<2>, dim3(blocks / 2), dim3(512), w8_lds_bytes(2), s, g);
+        else hipLaunchKernelGGL(conv_wino8_kernel<1>, dim3(blocks), dim3(512), w8_lds_bytes(1), s, g);
+    }
     return kpx_launch_status();
 }
 

@@ -10,6 +10,7 @@
 // linspace follows tf.linspace in fp32 (start + step*i, two roundings) via __fmul_rn/__fadd_rn so that hipcc's
 // default fp-contraction cannot fuse it.
 #include "kpx_common.h"
+#include <stdlib.h>
 
 #define KP_RS 8   // rows per stripe in stage 1
 
@@ -157,48 +158,85 @@ extern "C" int kpx_keypoint_head_bwd_f32(const float* dmu, const float* mu, cons
 }
 
 // ------------------------------------------------------------------------------------------ Gaussian maps
+// ONE definition of a heat-map element for every renderer and for the backward: the reference's rounding sequence
+// square(y - mu_y) + square(x - mu_x), times float32(inv_std**2), negate, exp (utils/model.py:56-59); exp is the hardware
+// exp2 path (__expf: |err| <= ~2 ulp of a result in [0,1], inside the 2e-6 absolute budget).  Because both renderers call
+// this function, a map element has the same bits whether it is rendered contiguously or into a channel slice.
 __device__ __forceinline__ float kpx_gauss(float yv, float xv, float my, float mx, float inv2) {
     const float dy = __fsub_rn(yv, my), dx = __fsub_rn(xv, mx);
     const float dist = __fmul_rn(__fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dx, dx)), inv2);
-    return expf(-dist);
+    return __expf(-dist);
 }
 
-// contiguous output (ldy == K): one workgroup per (image, row-group); the W*K floats of a row are written as float4 with
-// 32-bit index arithmetic only (one multiply-shift division per float4), exp via expf.  Pure write stream.
+// contiguous output (ldy == K): pure write stream.  The H*W*K floats of one image are covered as float4 by blockIdx.x
+// slices of `per_block` float4 (a multiple of 256: every wave writes 1 KB contiguous per store instruction, no partial
+// iterations); index arithmetic is 32-bit with multiply-shift divisions; streaming (non-temporal) stores.
 __global__ __launch_bounds__(256) void gauss_fwd_flat_kernel(const float* __restrict__ mu, int K, int H, int W, float inv2,
-                                                             float* __restrict__ out, int rows_per_block) {
+                                                             float* __restrict__ out, int per_block) {
     const int b = blockIdx.y;
-    const int WK = W * K;
-    const int h0 = blockIdx.x * rows_per_block;
-    __shared__ float smx[256], smy[256], sxs[512];
+    __shared__ float smx[256], smy[256], sxs[512], sys[512];
     for (int i = threadIdx.x; i < K; i += 256) { smx[i] = mu[((size_t)b * K + i) * 2]; smy[i] = mu[((size_t)b * K + i) * 2 + 1]; }
     for (int i = threadIdx.x; i < W; i += 256) sxs[i] = kpx_linspace(i, W);
+    for (int i = threadIdx.x; i < H; i += 256) sys[i] = kpx_linspace(i, H);
     __syncthreads();
-    const float invK = 1.0f / (float)K;
-    float* ob = out + (size_t)b * H * WK;
-    const int n4 = WK >> 2;                                   // WK % 4 == 0 is checked by the launcher
-    for (int hh = 0; hh < rows_per_block; ++hh) {
-        const int h = h0 + hh;
-        if (h >= H) break;
-        const float yv = kpx_linspace(h, H);
-        float* orow = ob + (size_t)h * WK;
-        for (int i = threadIdx.x; i < n4; i += 256) {
-            const int f = i * 4;
-            int w = (int)(((float)f + 0.5f) * invK);          // exact for f < 2^22
-            int k = f - w * K;
-            if (k < 0) { --w; k += K; } else if (k >= K) { ++w; k -= K; }
+    const float invK = 1.0f / (float)K, invW = 1.0f / (float)W;
+    const int n4 = (H * W * K) >> 2;                          // (H*W*K) % 4 == 0 is checked by the launcher
+    f32x4* ob = reinterpret_cast<f32x4*>(out + (size_t)b * H * W * K);
+    const int i0 = blockIdx.x * per_block;
+    const int i1 = min(i0 + per_block, n4);
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const int f = i * 4;
+        int pix = (int)(((float)f + 0.5f) * invK);            // exact after the +-1 fix-up for f < 2^23
+        int k = f - pix * K;
+        if (k < 0) { --pix; k += K; } else if (k >= K) { ++pix; k -= K; }
+        int h = (int)(((float)pix + 0.5f) * invW);
+        int w = pix - h * W;
+        if (w < 0) { --h; w += W; } else if (w >= W) { ++h; w -= W; }
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[j] = kpx_gauss(sys[h], sxs[w], smy[k], smx[k], inv2);
+            if (++k == K) { k = 0; if (++w == W) { w = 0; ++h; } }
+        }
+        __builtin_nontemporal_store(r, ob + i);
+    }
+}
+// contiguous output, K >= 4, no LDS and no barrier: the workgroup has T = K*m threads, so a thread's float4 index advances by a
+// multiple of K floats per iteration and its four channels k0..k0+3 (mod K) never change -- their (mu_x, mu_y) live in registers,
+// loaded once.  blockIdx.x covers `iters` consecutive T-float4 slabs of image blockIdx.y; streaming (non-temporal) 16-B stores.
+__global__ __launch_bounds__(512) void gauss_fwd_reg_kernel(const float* __restrict__ mu, int K, int H, int W, float inv2,
+                                                            float* __restrict__ out, int iters) {
+    const int b = blockIdx.y, T = blockDim.x;
+    const int n4 = (H * W * K) >> 2;
+    int i = blockIdx.x * iters * T + threadIdx.x;
+    const int f = i * 4;
+    int pix = f / K;
+    const int k0 = f - pix * K;
+    int h = pix / W, w = pix - h * W;
+    float mx[4], my[4]; int carry[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int kk = k0 + j;
+        carry[j] = kk >= K;
+        if (carry[j]) kk -= K;
+        mx[j] = mu[((size_t)b * K + kk) * 2]; my[j] = mu[((size_t)b * K + kk) * 2 + 1];
+    }
+    const int step_pix = (4 * T) / K;
+    f32x4* ob = reinterpret_cast<f32x4*>(out + (size_t)b * H * W * K);
+    for (int it = 0; it < iters; ++it) {
+        if (i < n4) {
             f32x4 r;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                // same rounding sequence as kpx_gauss up to the exponent; exp via the hardware exp2 (|err| <= ~2 ulp of
-                // the result here, far inside the 2e-6 absolute budget on values in [0,1])
-                const float dy = __fsub_rn(yv, smy[k]), dx = __fsub_rn(sxs[w], smx[k]);
-                const float dist = __fmul_rn(__fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dx, dx)), inv2);
-                r[j] = __expf(-dist);
-                if (++k == K) { k = 0; ++w; }
+                int wj = w + carry[j], hj = h;
+                if (wj >= W) { wj -= W; ++hj; }
+                r[j] = kpx_gauss(kpx_linspace(hj, H), kpx_linspace(wj, W), my[j], mx[j], inv2);
             }
-            reinterpret_cast<f32x4*>(orow)[i] = r;
+            __builtin_nontemporal_store(r, ob + i);
         }
+        i += T;
+        w += step_pix;
+        while (w >= W) { w -= W; ++h; }
     }
 }
 // strided output (channel slice of a wider concat buffer)
@@ -220,10 +258,24 @@ extern "C" int kpx_gaussian_maps_fwd_f32(const float* mu, int B, int K, int H, i
     const float inv2 = (float)(inv_std * inv_std);      // python: inv_std ** 2 in float64, then cast (utils/model.py:58)
     const size_t total = (size_t)B * H * W * K;
     hipStream_t s = kpx_stream(stream);
-    if (ldy == K && (((uintptr_t)maps) & 15) == 0 && (W * K) % 4 == 0 && K <= 256 && W <= 512) {
-        int rpb = 1;
-        while ((long)B * ((H + rpb - 1) / rpb) > 4096 && rpb < H) rpb *= 2;      // ~2-4k workgroups
-        hipLaunchKernelGGL(gauss_fwd_flat_kernel, dim3((unsigned)((H + rpb - 1) / rpb), (unsigned)B), dim3(256), 0, s, mu, K, H, W, inv2, maps, rpb);
+    const bool flat = ldy == K && (((uintptr_t)maps) & 15) == 0 && ((size_t)H * W * K) % 4 == 0 && (size_t)H * W * K < (1u << 23);
+    if (flat && K >= 4 && K <= 512) {
+        int m = 1, best = 0;                                  // T = K*m threads: fullest last wavefront among T in [128, 512]
+        for (int mm = 1; K * mm <= 512; ++mm) {
+            const int T = K * mm, fill = T * 1000 / (((T + 63) / 64) * 64) + (T >= 192 ? 1000 : 0);
+            if (fill >= best) { best = fill; m = mm; }
+        }
+        const int T = K * m, n4 = (int)(((size_t)H * W * K) >> 2);
+        static const int target = getenv("KPX_GAUSS_BLOCKS") ? atoi(getenv("KPX_GAUSS_BLOCKS")) : 2048;
+        int G = target / B; if (G < 1) G = 1;
+        int iters = (n4 + T * G - 1) / (T * G); if (iters < 1) iters = 1;
+        G = (n4 + T * iters - 1) / (T * iters);
+        hipLaunchKernelGGL(gauss_fwd_reg_kernel, dim3((unsigned)G, (unsigned)B), dim3((unsigned)T), 0, s, mu, K, H, W, inv2, maps, iters);
+    } else if (flat && K <= 256 && W <= 512 && H <= 512) {
+        const int n4 = (int)(((size_t)H * W * K) >> 2);
+        int per_block = 1024;                                 // 4 float4 per thread; fewer when that would leave CUs idle
+        while (per_block > 256 && (long)B * ((n4 + per_block - 1) / per_block) < 2048) per_block >>= 1;
+        hipLaunchKernelGGL(gauss_fwd_flat_kernel, dim3((unsigned)((n4 + per_block - 1) / per_block), (unsigned)B), dim3(256), 0, s, mu, K, H, W, inv2, maps, per_block);
     } else {
         size_t nb = (total + 255) / 256; if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(gauss_fwd_strided_kernel, dim3((unsigned)nb), dim3(256), 0, s, mu, B, K, H, W, inv2, maps, ldy);

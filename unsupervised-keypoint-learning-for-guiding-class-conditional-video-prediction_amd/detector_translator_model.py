@@ -39,8 +39,9 @@ class DetectorTranslatorModel(BaseModel):
         self.device = ops.normalize_device(device)
         self.global_step = int(global_step or 0)
         self.process_group = process_group
-        self.world_size = torch.distributed.get_world_size(process_group) if (
-            torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        # a process group (even of one rank, e.g. `torch.distributed.run --nproc-per-node 1`) means: exchange through it
+        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.world_size = torch.distributed.get_world_size(process_group) if self.distributed else 1
         self.store = variables.VariableStore(device=self.device, seed=seed)
         self.vgg = vgg
         # Adam state (two optimisers, reference :198 and :201): fp32 beta powers like TF's beta{1,2}_power variables
@@ -132,7 +133,7 @@ class DetectorTranslatorModel(BaseModel):
         178.9 MB discriminator exchange overlaps the VGG19 forward of the generator's perceptual loss."""
         bucket = self.store.buckets[which]
         ops.join_side_stream(self.device)       # weight gradients are written on the side stream
-        if self.world_size > 1:
+        if self.distributed:
             work = torch.distributed.all_reduce(bucket.grads, op=torch.distributed.ReduceOp.SUM, group=self.process_group,
                                                 async_op=async_op)
             return work if async_op else None
