@@ -49,7 +49,10 @@ def conv(x, kernel, bias, stride, pad=0):
     pt, pb, _ = same_pad(h + 2 * pad, kh, stride)
     pl, pr, _ = same_pad(w + 2 * pad, kw, stride)
     xp = F.pad(x.permute(0, 3, 1, 2), (pad + pl, pad + pr, pad + pt, pad + pb))
-    y = F.conv2d(xp, kernel.permute(3, 2, 0, 1), bias, stride)
+    wk = kernel.permute(3, 2, 0, 1)
+    if wk.dtype == torch.float64:
+        wk = wk.contiguous()                 # the float64 CPU path (slow_conv2d) wants a contiguous weight gradient
+    y = F.conv2d(xp, wk, bias, stride)
     return y.permute(0, 2, 3, 1)
 
 
@@ -457,9 +460,12 @@ def synthetic_pair(batch, res=128, seed0=0, seed1=1):
 class TrainState:
     """Everything tf.train.Saver would hold for stage 1, as torch-CPU tensors."""
 
-    def __init__(self, variables, vgg, lr_cfg=(1e-4, 20000, 0.95)):
-        self.params = OrderedDict((k, torch.from_numpy(np.array(v, copy=True))) for k, v in variables.items())
-        self.vgg = {k: (torch.from_numpy(w), torch.from_numpy(b)) for k, (w, b) in vgg.items()}
+    def __init__(self, variables, vgg, lr_cfg=(1e-4, 20000, 0.95), dtype=torch.float32):
+        """``dtype=torch.float64`` runs the same restatement in double precision: the arbiter the tests use to tell an fp32
+        implementation's rounding noise (amplified by the discontinuous L1 / ReLU / max-pool gradient) from a wiring error."""
+        self.dtype = dtype
+        self.params = OrderedDict((k, torch.from_numpy(np.array(v, copy=True)).to(dtype)) for k, v in variables.items())
+        self.vgg = {k: (torch.from_numpy(np.asarray(w)).to(dtype), torch.from_numpy(np.asarray(b)).to(dtype)) for k, (w, b) in vgg.items()}
         train_names = [k for k in self.params if not ('moving_' in k)]
         self.d_names = [k for k in train_names if 'img_discr' in k]          # :191-192
         self.g_names = [k for k in train_names if 'img_discr' not in k]
@@ -485,8 +491,9 @@ def train_step(state, im, future_im, same_batch=True, im_G=None, future_im_G=Non
     are updated by the G-run only (UPDATE_OPS gate, :199-202).  Returns a dict of scalars/tensors.
     """
     p = state.params
-    im = torch.as_tensor(im)
-    future_im = torch.as_tensor(future_im)
+    dtype = getattr(state, 'dtype', torch.float32)
+    im = torch.as_tensor(im).to(dtype)
+    future_im = torch.as_tensor(future_im).to(dtype)
     lr = state.lr()
     for n in state.d_names + state.g_names:
         p[n].requires_grad_(True)
@@ -500,7 +507,7 @@ def train_step(state, im, future_im, same_batch=True, im_G=None, future_im_G=Non
 
     # ---- G run (:94): (re)forward with the updated D, G loss, Adam on G vars, BN moving update
     if not same_batch:
-        im, future_im = torch.as_tensor(im_G), torch.as_tensor(future_im_G)
+        im, future_im = torch.as_tensor(im_G).to(dtype), torch.as_tensor(future_im_G).to(dtype)
     net = Net(p, train_mode=True)
     fwd = forward_pass(net, im, future_im, with_vis_maps=False)
     l_g, l_recon, l_adv = loss_G(net, state.vgg, fwd['final_output'], future_im)

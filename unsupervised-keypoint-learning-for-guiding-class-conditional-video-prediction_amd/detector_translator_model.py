@@ -97,8 +97,10 @@ class DetectorTranslatorModel(BaseModel):
         return out
 
     def forward(self, im, future_im, with_vis_maps=True):
+        """Fetch the model outputs only: like a sess.run of the output tensors, this runs no UPDATE_OPS (they ride on train_op_G,
+        reference :199-202), so the BN moving statistics stay untouched."""
         with variables.as_default(self.store), torch.no_grad():
-            return self._define_forward_pass(im, future_im, with_vis_maps=with_vis_maps)
+            return self._define_forward_pass(im, future_im, with_vis_maps=with_vis_maps, update_moving=False)
 
     # ------------------------------------------------------------------------------------------------ losses
     def _loss_D(self, future_im_pred, future_im):
