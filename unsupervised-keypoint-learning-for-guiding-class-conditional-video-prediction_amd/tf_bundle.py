@@ -13,9 +13,12 @@ can restore checkpoints written here.  Formats restated from their public defini
   variable name mapping to a ``BundleEntryProto`` (dtype, shape, shard_id, offset, size, masked CRC-32C of the bytes);
 * masked CRC: ``((crc >> 15) | (crc << 17)) + 0xa282ead8`` (lib/hash/crc32c.h).
 
-PARITY UNPINNED: neither TensorFlow nor a TensorFlow-written checkpoint exists in this environment, so the only checks are
-the published CRC-32C test vectors, hand-assembled protobuf / table fragments and write -> read round trips
-(tests/test_tf_bundle.py).  The reader verifies every checksum it meets, so a real bundle that parses here parsed correctly.
+PARITY UNPINNED against TensorFlow itself: neither TensorFlow nor a TensorFlow-written checkpoint exists in this environment.
+What is checked (tests/test_tf_bundle.py): the published CRC-32C test vectors; the protobuf layer against google.protobuf; and a
+complete bundle assembled byte by byte from the public format definitions by an independent second implementation
+(tests/golden/make_bundle_golden.py: its own bit-wise CRC-32C, google.protobuf messages, its own table builder), which ``read_bundle``
+must parse and ``write_bundle`` must reproduce bit for bit.  The reader verifies every checksum it meets and refuses compressed
+blocks loudly, so a real bundle that parses here parsed correctly.
 """
 import os
 import struct
@@ -182,18 +185,45 @@ def _read_block(buf, offset, size):
     return content
 
 
+def _short_separator(start, limit):
+    """leveldb BytewiseComparator::FindShortestSeparator: a short key k with start <= k < limit."""
+    n = min(len(start), len(limit))
+    i = 0
+    while i < n and start[i] == limit[i]:
+        i += 1
+    if i < n and start[i] < 0xff and start[i] + 1 < limit[i]:
+        return start[:i] + bytes([start[i] + 1])
+    return start
+
+
+def _short_successor(key):
+    """leveldb BytewiseComparator::FindShortSuccessor: the first byte that is not 0xff incremented, the rest dropped."""
+    for i, b in enumerate(key):
+        if b != 0xff:
+            return key[:i] + bytes([b + 1])
+    return key
+
+
 def write_table(path, items):
-    """items: sorted list of (key bytes, value bytes)"""
+    """items: sorted list of (key bytes, value bytes).  Follows TableBuilder (core/lib/io/table_builder.cc = LevelDB's): a data block is
+    flushed once its encoded size (entries + restart array + count) reaches BLOCK_SIZE; the index key of a block is the shortest
+    separator between its last key and the next block's first key, the short successor of the last key for the final block."""
     with open(path, 'wb') as f:
-        index, block, size = [], [], 0
+        index, block, pending = [], [], None            # pending = (last key of the flushed block, its handle)
         for k, v in items:
-            block.append((k, v)); size += len(k) + len(v) + 3
-            if size >= BLOCK_SIZE:
-                h = _emit_block(f, _build_block(block, RESTART_INTERVAL)); index.append((block[-1][0], _varint(h[0]) + _varint(h[1])))
-                block, size = [], 0
-        if block or not index:
+            if pending is not None:
+                index.append((_short_separator(pending[0], k), pending[1]))
+                pending = None
+            block.append((k, v))
+            if len(_build_block(block, RESTART_INTERVAL)) >= BLOCK_SIZE:
+                h = _emit_block(f, _build_block(block, RESTART_INTERVAL))
+                pending = (block[-1][0], _varint(h[0]) + _varint(h[1]))
+                block = []
+        if block:
             h = _emit_block(f, _build_block(block, RESTART_INTERVAL))
-            index.append((block[-1][0] if block else b'', _varint(h[0]) + _varint(h[1])))
+            pending = (block[-1][0], _varint(h[0]) + _varint(h[1]))
+        if pending is not None:
+            index.append((_short_successor(pending[0]), pending[1]))
         meta = _emit_block(f, _build_block([], RESTART_INTERVAL))
         idx = _emit_block(f, _build_block(index, 1))
         footer = _varint(meta[0]) + _varint(meta[1]) + _varint(idx[0]) + _varint(idx[1])
