@@ -105,6 +105,22 @@ def roofline_conv_direct(dev):
             'traffic': traffic, 'traffic_source': src, 'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops}
 
 
+def roofline_conv_bf16(dev):
+    """The bf16-MFMA direct 3x3 kernel (BASELINE configs[2]) on the same layer: fp32 tensors in HBM, so the bound is HBM traffic
+    (x read + y written = 134.2 MB algorithmic) rather than the 2.5 PFLOP/s bf16 matrix peak; both fractions are reported."""
+    from kpx_amd import ops
+    ops.set_compute_dtype('bf16')
+    try:
+        ms, flops = _time_conv_3_1(dev)
+    finally:
+        ops.set_compute_dtype('f32')
+    nbytes = 2 * BATCH * 64 * 64 * 128 * 4 + 9 * 128 * 128 * 4
+    return {'bound': 'hbm', 'kernel': 'conv3x3_bf16_kernel<2> (+ weight prepare) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
+            'achieved': round(nbytes / (ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(nbytes / (ms * 1e-3) / 8e12, 4),
+            'traffic': None, 'avg_launch_ms': round(ms, 4), 'bytes_per_launch': nbytes,
+            'mfma_tflops_bf16': round(flops / (ms * 1e-3) / 1e12, 1), 'mfma_frac_of_bf16_peak': round(flops / (ms * 1e-3) / 2.5e15, 4)}
+
+
 def roofline_render(dev):
     """HBM-bound kernel the north star singles out: Gaussian heat-map render at [128,128,K=15], batch 32:
     algorithmic bytes = B*H*W*K*4 written (+ K*8 read) per launch (983 040 B per image).  The launches rotate over
@@ -204,6 +220,10 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH, help='image pairs per GPU')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
+                    help="f32: the headline / parity configuration (BASELINE configs[1]).  bf16: BASELINE configs[2]'s arithmetic -- forward and "
+                         'data gradient of the 3x3 stride-1 layers on the bf16 matrix pipe (fp32 tensors, accumulate, master weights, BN '
+                         'statistics, weight gradients); a SEPARATE configuration, never the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--roofline-only', action='store_true', help='only the two kernel microbenchmarks (used for the rocprofv3 cross-check)')
     args = ap.parse_args()
@@ -233,10 +253,13 @@ def main():
         assert torch.distributed.get_world_size() == world
 
     import kpx_amd
+    from kpx_amd import ops as kops
     from kpx_amd.synthetic import synthetic_pair
+    kops.set_compute_dtype(args.dtype)
     if args.roofline_only:
+        kops.set_compute_dtype('f32')
         print(json.dumps({'roofline': roofline_conv(dev), 'roofline_direct_conv': roofline_conv_direct(dev),
-                          'roofline_hbm_render': roofline_render(dev)}), flush=True)
+                          'roofline_hbm_render': roofline_render(dev), 'roofline_bf16_conv': roofline_conv_bf16(dev)}), flush=True)
         return
     cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': args.batch},
            'model': {'n_pts': K_PTS}, 'paths': {'log_dir': '/tmp/kpx_bench', 'vggnet': None}}
@@ -283,8 +306,10 @@ def main():
         out = {'metric': 'detector_translator train frames/sec @128x128 K=15', 'value': round(value, 2),
                'unit': 'image pairs/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f32', 'data': 'synthetic',
-               'config': {'workload': 'Penn 128x128 K=15 detector_translator fp32, batch=%d per GPU (BASELINE configs[1])' % args.batch,
+               'dtype': 'f32' if args.dtype == 'f32' else 'bf16 operands on the 3x3 stride-1 fwd/dgrad convs (fp32 storage, accumulate, wgrad, BN, Adam)',
+               'data': 'synthetic',
+               'config': {'workload': 'Penn 128x128 K=15 detector_translator %s, batch=%d per GPU (BASELINE configs[%d])'
+                                      % ('fp32' if args.dtype == 'f32' else 'bf16 + VGG19 perceptual loss', args.batch, 1 if args.dtype == 'f32' else 2),
                           'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
                           'step': 'D update + G update on one batch (generator forward shared, SURVEY 8d restructured step), '
                                   'VGG19 perceptual loss with synthetic He-normal weights, two fused Adam updates',
@@ -295,6 +320,9 @@ def main():
                'host_enqueue_ms_per_step': round(max(enq), 3), 'host_enqueue_ms_per_step_by_rank': [round(x, 3) for x in enq],
                'loss_D': round(losses['loss_D'], 5), 'loss_G': round(losses['loss_G'], 5)}
         if world == 1:
+            kops.set_compute_dtype('f32')
+            if args.dtype == 'bf16':
+                out['roofline_bf16_conv'] = roofline_conv_bf16(dev)
             out['roofline'] = roofline_conv(dev)
             out['roofline_direct_conv'] = roofline_conv_direct(dev)
             out['roofline_hbm_render'] = roofline_render(dev)

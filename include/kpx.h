@@ -47,6 +47,21 @@ int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
                        int stride, int pad_t, int pad_l, int act,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- bf16-MFMA variant of the 3x3 stride-1 SAME convolution (BASELINE configs[2]: "bf16"; same reference call sites as above:
+ *      models/networks/layers.py:6-9 for kernel=3, stride=1; models/networks/vgg.py:51-54).  Tensors stay float32 in HBM (fp32
+ *      master weights, fp32 bias / BN statistics); operands are rounded to bf16 on the way into the matrix pipe
+ *      (v_mfma_f32_32x32x16_bf16), accumulation is fp32.  Two steps:
+ *        kpx_conv3x3_bf16_prepare_f32: HWIO fp32 filter -> fragment-ordered bf16 copy `wf` (size kpx_conv3x3_bf16_weights_bytes);
+ *            dgrad != 0 prepares the flipped / transposed filter of the data gradient;
+ *        kpx_conv3x3_bf16_f32: out[N,H,W,Nn] = act(conv3x3_same(in[N,H,W,K], wf) + bias).  Forward: in = x, K = Cin, Nn = Cout;
+ *            data gradient: in = dy, K = Cout, Nn = Cin, wf prepared with dgrad = 1, bias NULL.
+ *      H and W must be multiples of 16, ldin a multiple of 4, `in` 16-byte aligned (kpx_conv3x3_bf16_eligible tells). */
+size_t kpx_conv3x3_bf16_weights_bytes(int Cin, int Cout);
+int kpx_conv3x3_bf16_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in);
+int kpx_conv3x3_bf16_prepare_f32(const float* w_hwio, int Cin, int Cout, int dgrad, void* wf, void* stream);
+int kpx_conv3x3_bf16_f32(const float* in, int N, int H, int W, int K, int ldin, const void* wf, const float* bias,
+                         float* out, int Nn, int ldout, int act, void* stream);
+
 /* dx = d(loss)/dx given dy (gradient of the conv output BEFORE activation).  Writes every element of dx.
  * stride <= 2.  `workspace`: optional split-K scratch, see kpx_conv2d_fwd_f32. */
 size_t kpx_conv2d_dgrad_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride);

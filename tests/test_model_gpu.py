@@ -514,3 +514,42 @@ def test_configs4_rollout_128_lstm1024_matches_oracle():
     np.testing.assert_allclose(out['fut_pt_raw'].cpu().numpy(), want['fut_pt_raw'].numpy(), atol=5e-5)       # 32 LSTM steps of 1024 units
     assert rel_l2(out['pred_im_seq'].cpu().numpy(), want['pred_im_seq'].numpy()) < 1e-4
     assert rel_l2(out['mask'].cpu().numpy(), want['mask'].numpy()) < 1e-4
+
+
+def test_bf16_mode_forward_and_train_step_tolerance():
+    """BASELINE configs[2] arithmetic (bf16 operands on the 3x3 stride-1 convs, fp32 everything else) against the fp32 oracle at
+    128x128, K=15, B=2: the tolerance of THIS mode (stated, not the fp32 parity bar): key-points abs 2e-2 of the [-1,1] range,
+    frame rel-L2 1e-1 (ten stacked bf16 conv + batch-norm layers), losses 2e-2 relative.  Measured on MI355X: key-points 1e-3, frame
+    5.4e-2, losses 5e-4, cosine of the generator gradient with the fp32 oracle's ~0.6 -- on these synthetic inputs (noise images,
+    random VGG19) the loss gradient is chaotic: a 1e-7 perturbation already moves it by 1 % (float64-arbiter tests), so bf16's 4e-3
+    saturates it; only the direction is checked."""
+    from kpx_amd import ops
+    dev = torch.device('cuda:0')
+    res, k, b = 128, 15, 2
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    im, fut = R.synthetic_pair(b, res=res)
+    st = R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=4))
+    want = R.train_step(st, im, fut)
+    ops.set_compute_dtype('bf16')
+    try:
+        model = make_model(res, k, b, dev, width_div=4)
+        model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, 0, b)
+        got = model.loss_values()
+        fwd = model.last['fwd']
+        kp_err = float(np.abs(fwd['current_points'].cpu().numpy() - want['current_points'].numpy()).max())
+        fr_err = rel_l2(fwd['final_output'].cpu().numpy(), want['final_output'].numpy())
+        gnames = [n for n in want['grads_G'] if n.endswith('/kernel') and 'conv_6' not in n]
+        dot = gg = ww = 0.0
+        for n in gnames:
+            g = model.store.grad(n).cpu().numpy().astype(np.float64); w = want['grads_G'][n].numpy().astype(np.float64)
+            dot += float((g * w).sum()); gg += float((g * g).sum()); ww += float((w * w).sum())
+        g_cos = dot / (gg * ww) ** 0.5
+    finally:
+        ops.set_compute_dtype('f32')
+    print('bf16 mode vs fp32 oracle: key-points max abs %.2e, frame rel-L2 %.2e, generator-gradient cosine %.3f, losses %s vs %s'
+          % (kp_err, fr_err, g_cos, {k_: round(v, 5) for k_, v in got.items()}, {k_: round(want[k_], 5) for k_ in got if k_ in want}))
+    assert kp_err < 2e-2 and fr_err < 1e-1
+    for key in ('loss_D', 'loss_G_recon', 'loss_G_adv'):
+        assert abs(got[key] - want[key]) <= 2e-2 * max(1.0, abs(want[key])), (key, got[key], want[key])
+    assert g_cos > 0.3                      # direction check only (see the docstring)
+    assert fr_err > 1e-5                    # the bf16 kernels really ran

@@ -40,6 +40,10 @@ SIGNATURES = {
     'kpx_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_wgrad_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int,
                                      P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'kpx_conv3x3_bf16_weights_bytes': (c_size_t, [c_int, c_int]),
+    'kpx_conv3x3_bf16_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'kpx_conv3x3_bf16_prepare_f32': (c_int, [P, c_int, c_int, c_int, P, P]),
+    'kpx_conv3x3_bf16_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
     'kpx_act_bwd_f32': (c_int, [P, P, P, c_size_t, c_int, P]),
     'kpx_chan_reduce_scratch_bytes': (c_size_t, [c_int]),
     'kpx_chan_sum_f32': (c_int, [P, c_size_t, c_int, c_int, P, P, P]),

@@ -8,6 +8,8 @@ Weight / bias / gamma / beta gradients are written by the kernels straight into 
 flat gradient bucket (``*_grad_out``), so the RCCL all-reduce and the fused Adam step run on one contiguous buffer
 without a gather pass.
 """
+import os as _os
+
 import torch
 
 from . import _lib
@@ -73,7 +75,6 @@ scratch = _Scratch()
 # Weight gradients are off the backward critical path (only the optimiser consumes them), so they are launched on a second
 # HIP stream where they fill the ramp-up / tail gaps of the dgrad chain on the main stream.  join_side_stream() is called
 # before the gradient exchange / Adam update.  KPX_SIDE_WGRAD=0 disables it.
-import os as _os
 SIDE_WGRAD = _os.environ.get('KPX_SIDE_WGRAD', '1') != '0'
 _side_streams = {}
 _side_dirty = set()
@@ -132,10 +133,43 @@ def join_side_stream(device=None):
         _side_keep.clear()       # the current stream is now ordered after every side kernel: the blocks may be recycled
 
 
+# ----------------------------------------------------------------------------------------------- compute dtype
+# 'f32' (default, the parity configuration) or 'bf16' (BASELINE configs[2]): in bf16 mode the forward and the data gradient of
+# every eligible 3x3 stride-1 SAME layer run on the bf16 matrix pipe (fp32 tensors, fp32 accumulate, fp32 master weights, fp32
+# batch-norm statistics); everything else -- and the weight gradients -- stays on the fp32 kernels.
+_compute_dtype = [_os.environ.get('KPX_DTYPE', 'f32')]
+
+
+def set_compute_dtype(name):
+    if name not in ('f32', 'bf16'):
+        raise ValueError("compute dtype must be 'f32' or 'bf16'")
+    _compute_dtype[0] = name
+
+
+def compute_dtype():
+    return _compute_dtype[0]
+
+
+def _bf16_conv(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad):
+    """3x3 stride-1 SAME convolution on the bf16 matrix pipe; returns False when the shape is not eligible."""
+    n, h, wd = inp.shape[0], inp.shape[1], inp.shape[2]
+    if not lib.kpx_conv3x3_bf16_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr()):
+        return False
+    cin, cout = w.shape[2], w.shape[3]
+    wf = scratch.get('bf16w', lib.kpx_conv3x3_bf16_weights_bytes(cin, cout), inp.device)
+    check(lib.kpx_conv3x3_bf16_prepare_f32(w.data_ptr(), cin, cout, 1 if dgrad else 0, wf.data_ptr(), _stream()), 'kpx_conv3x3_bf16_prepare_f32')
+    check(lib.kpx_conv3x3_bf16_f32(inp.data_ptr(), n, h, wd, k, ld_in, wf.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                   out.data_ptr(), nn, ld_out, act, _stream()), 'kpx_conv3x3_bf16_f32')
+    return True
+
+
 # ----------------------------------------------------------------------------------------------- raw launchers
 def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act):
     n, hi, wi = x.shape[0], x.shape[1], x.shape[2]
     kh, kw, _, cout = w.shape
+    if (_compute_dtype[0] == 'bf16' and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cin >= 8
+            and y.shape[1] == hi and y.shape[2] == wi and _bf16_conv(x, ldx, cin, w, bias, y, ldy, cout, act, False)):
+        return
     nbytes = lib.kpx_conv2d_fwd_workspace_bytes(n, y.shape[1], y.shape[2], cin, cout, kh, kw)
     ws = scratch.get('splitk', nbytes, x.device) if nbytes else None
     check(lib.kpx_conv2d_fwd_f32(x.data_ptr(), n, hi, wi, cin, ldx, w.data_ptr(), kh, kw,
@@ -148,6 +182,9 @@ def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act):
 def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l):
     n, ho, wo = dy.shape[0], dy.shape[1], dy.shape[2]
     kh, kw, _, cout = w.shape
+    if (_compute_dtype[0] == 'bf16' and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cout >= 8
+            and dx.shape[1] == ho and dx.shape[2] == wo and _bf16_conv(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True)):
+        return
     nbytes = lib.kpx_conv2d_dgrad_workspace_bytes(n, dx.shape[1], dx.shape[2], cin, cout, kh, kw, stride)
     ws = scratch.get('splitk', nbytes, dy.device) if nbytes else None
     check(lib.kpx_conv2d_dgrad_f32(dy.data_ptr(), n, ho, wo, cout, lddy, w.data_ptr(), kh, kw,
