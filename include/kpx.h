@@ -14,7 +14,9 @@
  *     buffer (this is how tf.concat(axis=-1) is realised without a copy);
  *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *   - return 0 on success, KPX_EINVAL (-1) for a bad argument, or -(hipError_t) if the launch failed;
- *     nothing throws across the ABI; re-entrant, callable from any host thread.
+ *     nothing throws across the ABI; re-entrant, callable from any host thread.  The only process state is a per-device
+ *     "large-LDS attribute already set" bit per kernel family (std::atomic, idempotent) and tuning switches read once from the
+ *     environment (KPX_*, function-local statics: thread-safe initialisation).
  */
 #ifndef KPX_H
 #define KPX_H
@@ -46,6 +48,23 @@ int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
                        float* y, int Ho, int Wo, int Cout, int ldy,
                        int stride, int pad_t, int pad_l, int act,
                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- fused Winograd F(2x2,3x3) path of the 3x3 stride-1 SAME convolution with PRE-TRANSFORMED filters (fp32 MFMA; same reference
+ *      call sites as kpx_conv2d_fwd_f32 for kernel=3, stride=1).  kpx_conv2d_fwd_f32 / _dgrad_f32 take this path by themselves when a
+ *      workspace is given (transforming the filter on every call); a caller that keeps U = G g G^T between calls -- constant filters
+ *      (VGG19, vgg.py:57-61), or once per optimiser update for trainable ones -- uses these entry points directly:
+ *        kpx_wino_u_bytes: size of U for a [3][3][Cin][Cout] filter (either direction);
+ *        kpx_wino_filter_transform_f32: one filter; dgrad != 0 transforms the flipped / transposed filter of the data gradient;
+ *        kpx_wino_filter_transform_batch_f32: n filters in ONE launch, `descs` = DEVICE array of KpxWinoDesc;
+ *        kpx_conv3x3_wino_f32: out[N,H,W,Nn] = act(conv3x3_same(in[N,H,W,K]) + bias) with U for (K gathered, Nn produced) channels.
+ *      Shapes: H, W multiples of 16 (or 8x8 images with N a multiple of 4), see kpx_conv3x3_wino_eligible. */
+typedef struct KpxWinoDesc { const float* w; float* u; int cin, cout, dgrad, reserved; } KpxWinoDesc;
+size_t kpx_wino_u_bytes(int Cin, int Cout);
+int kpx_wino_filter_transform_f32(const float* w_hwio, int Cin, int Cout, int dgrad, float* u, void* stream);
+int kpx_wino_filter_transform_batch_f32(const void* descs, int n, void* stream);
+int kpx_conv3x3_wino_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in);
+int kpx_conv3x3_wino_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u, const float* bias,
+                         float* out, int Nn, int ldout, int act, void* stream);
 
 /* ---- bf16-MFMA variant of the 3x3 stride-1 SAME convolution (BASELINE configs[2]: "bf16"; same reference call sites as above:
  *      models/networks/layers.py:6-9 for kernel=3, stride=1; models/networks/vgg.py:51-54).  Tensors stay float32 in HBM (fp32

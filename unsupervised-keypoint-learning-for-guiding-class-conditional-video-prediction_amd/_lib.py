@@ -40,6 +40,11 @@ SIGNATURES = {
     'kpx_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_wgrad_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int,
                                      P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'kpx_wino_u_bytes': (c_size_t, [c_int, c_int]),
+    'kpx_wino_filter_transform_f32': (c_int, [P, c_int, c_int, c_int, P, P]),
+    'kpx_wino_filter_transform_batch_f32': (c_int, [P, c_int, P]),
+    'kpx_conv3x3_wino_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'kpx_conv3x3_wino_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
     'kpx_conv3x3_bf16_weights_bytes': (c_size_t, [c_int, c_int]),
     'kpx_conv3x3_bf16_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'kpx_conv3x3_bf16_prepare_f32': (c_int, [P, c_int, c_int, c_int, P, P]),

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16Geom g) 
     }
 }
 
-static unsigned long long bf16_attr_mask = 0;
+static std::atomic<unsigned long long> bf16_attr_mask{0};
 static inline int bf16_lds_bytes(int nbw) { return 2 * B16_RAWB + 2 * 9 * nbw * 1024; }
 
 extern "C" size_t kpx_conv3x3_bf16_weights_bytes(int Cin, int Cout) {

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const RgbGeom g) {
         }
 }
 
-static unsigned long long rgb_attr_mask = 0;
+static std::atomic<unsigned long long> rgb_attr_mask{0};
 
 // stride-1 convolutions of a dense (ldx == Cin) image with Cin <= 4 and Cout <= 64; returns -2 when the shape is not handled
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW,

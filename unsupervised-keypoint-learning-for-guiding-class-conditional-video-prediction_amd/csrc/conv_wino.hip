@@ -6,14 +6,16 @@
 //
 // One workgroup (8 wavefronts) owns 8x8 tiles = 16x16 output pixels of one image x 32 or 64 output channels and ALL 16 Winograd
 // points: the input and output transforms happen in LDS, so neither the transformed input (4x the input) nor the transformed
-// output ever touches HBM.  Per 8-channel chunk: the 18x18-pixel raw patch and the slice of the pre-transformed filters U are
-// staged in LDS, every thread computes one row of B^T d B for one tile into V[point][tile][channel] (16-B halves XOR-swizzled
-// for conflict-free ds_read_b128), then wave w multiplies points 2w and 2w+1 (4 or 8 accumulators of 32x32).
-// After the K loop the accumulators go through LDS once more for A^T M A + bias + activation.
-// The same kernel serves dgrad with filters transformed from the flipped / transposed weights.
+// output ever touches HBM.  Per 8-channel chunk the 18x18-pixel raw patch is staged in LDS, every thread computes one row of
+// B^T d B for one tile into V[point][tile][channel] (16-B halves XOR-swizzled for conflict-free ds_read_b128), and the wavefronts
+// multiply V with filter fragments they load straight from the pre-transformed, fragment-ordered U (see conv_wino_v2_kernel).
+// The same kernel serves dgrad with filters transformed from the flipped / transposed weights.  The filter transform is its own
+// entry point (kpx_wino_filter_transform[_batch]_f32): constant filters (VGG19) are transformed once, trainable ones once per
+// optimiser update in ONE launch, instead of once per convolution call.
 #include "kpx_common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <atomic>
 
 struct WinoGeom {
     const float* x; float* y; const float* U; const float* bias;
@@ -27,40 +29,6 @@ struct WinoGeom {
 static __device__ __attribute__((aligned(16))) float wino_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 // U[p][c][n] = sum_{r,q} G[i][r] g[r][q][c][n] G[j][q], p = 4*i + j.   dgrad: g'[r][q][c'][n'] = w[2-r][2-q][n'][c'].
-template <bool DGRAD>
-__global__ __launch_bounds__(256) void wino_filter_transform_kernel(const float* __restrict__ w, int Cin, int Cout, int Kp, int Np, float* __restrict__ U) {
-    // forward: K = Cin, Nn = Cout;  dgrad: K = Cout (channels of dy), Nn = Cin.  Rows >= K and columns >= Nn of U are zero.
-    const int K = DGRAD ? Cout : Cin, Nn = DGRAD ? Cin : Cout;
-    const size_t total = (size_t)Kp * Np;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int c = (int)(idx / Np), n = (int)(idx - (size_t)c * Np);
-        const bool real = c < K && n < Nn;
-        float g[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                g[r][q] = !real ? 0.f : (DGRAD ? w[((size_t)((2 - r) * 3 + (2 - q)) * Cin + n) * Cout + c] : w[((size_t)(r * 3 + q) * Cin + c) * Cout + n]);
-        float t[4][3];                                   // G g
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            t[0][q] = g[0][q];
-            t[1][q] = 0.5f * (g[0][q] + g[1][q] + g[2][q]);
-            t[2][q] = 0.5f * (g[0][q] - g[1][q] + g[2][q]);
-            t[3][q] = g[2][q];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                    // (G g) G^T
-            const float u0 = t[i][0], u1 = 0.5f * (t[i][0] + t[i][1] + t[i][2]), u2 = 0.5f * (t[i][0] - t[i][1] + t[i][2]), u3 = t[i][2];
-            U[((size_t)(i * 4 + 0) * Kp + c) * Np + n] = u0;
-            U[((size_t)(i * 4 + 1) * Kp + c) * Np + n] = u1;
-            U[((size_t)(i * 4 + 2) * Kp + c) * Np + n] = u2;
-            U[((size_t)(i * 4 + 3) * Kp + c) * Np + n] = u3;
-        }
-    }
-}
-
-
 // Fragment layout for the v2 kernel: Uf[p][kc = Kp/8][nb = Np/32][lh 2][li 32][j 4] = U[p][c = 8 kc + 4 lh + j][n = 32 nb + li], i.e. the
 // B operand of v_mfma_f32_32x32x2_f32 for (point p, 8-channel chunk kc, 32-cout block nb) is ONE coalesced 16-B load per lane (1 KB per
 // wavefront), element j feeding the MFMA of k-pair j.  The filter never passes through LDS.
@@ -102,196 +70,11 @@ __global__ __launch_bounds__(256) void wino_filter_transform_frag_kernel(const f
     }
 }
 
-// ---- forward / dgrad kernel: 8-channel chunks, one 16x16-pixel tile x (32*CT) output channels per workgroup of 8 wavefronts.
-//   CT = 1: 64 KB of LDS and <= 128 VGPRs so that TWO workgroups share a CU (their barrier / LDS latencies overlap).
-//   CT = 2: 64 output channels per workgroup: the transformed input V is shared by twice as many MFMAs (48 -> 32 KB of LDS operand
-//           traffic per 2048 MFMA cycles), 8 accumulators per wave (<= 256 VGPRs, one workgroup per CU).
-// Measured on MI355X (s_memtime stamps, PMC): in this kernel family the transform / staging work does NOT overlap the MFMA stream
-// (neither across wavefronts -- wave-specialised and anti-phase variants serialise completely -- nor as fillers between a wave's
-// own MFMAs), so time = MFMA time + other time and the lever is less "other" work per MFMA, i.e. the bigger tile.
-#define W8_RAW 3200        // 20 rows x 20 positions x 8 channels.  Plain mode: 18 rows x 18 pixels of one image, pixel order [0..7,16,8..15,17]
-                           // within a row (see w8_pos).  Packed mode (8x8 images, VGG conv5): 2x2 images, each a 10x10 block with its own zero halo.
-#define W8_V 8192          // 16 points x 64 tiles x 8 channels; 16-B half swizzled by (tile>>3)&1
-#define W8_U(CT) (4096 * (CT))   // 16 points x 8 channels x 32*CT couts
-
 // One ds_read_b128 of the transform serves lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (MI355X LDS), i.e. tiles
 // {0,1,6,7} of one tile row + {2,3,4,5} of the next: with this pixel order and a row stride of 160 floats (two rows = 0 mod 64
 // banks) those 16 lanes hit 16 distinct 16-B bank groups for every patch column c.
 __device__ __forceinline__ int w8_pos(int p) { return p < 8 ? p : (p == 16 ? 8 : (p == 17 ? 17 : p + 1)); }
 __device__ __forceinline__ int w8_pix(int pos) { return pos < 8 ? pos : (pos == 8 ? 16 : (pos == 17 ? 17 : pos - 1)); }
-
-template <int CT>
-__global__ __launch_bounds__(512, CT == 1 ? 4 : 2) void conv_wino8_kernel(const WinoGeom g) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* raw = smem;
-    float* Us = smem + W8_RAW;
-    float* Vs = smem + W8_RAW + W8_U(CT);
-    constexpr int NC = 32 * CT;
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int li = lane & 31, lh = lane >> 5;
-    int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
-    const int ntc = g.Np / NC;
-    const int nti = L % ntc; L /= ntc;
-    const int bx = L % g.tiles_x; L /= g.tiles_x;
-    const int by = L % g.tiles_y;
-    const int n = g.pack ? 4 * L : L / g.tiles_y;       // packed: images n .. n+3
-    const int oy0 = by * 16, ox0 = bx * 16, n0 = nti * NC;
-
-    // raw patch units: u = t + 512*i < 720 (800 packed): position u>>1 (rows x 20 positions), 16-B half u&1
-    const float* rp[2]; bool rok[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int u = t + 512 * i, q = u >> 1, py = q / 20, ps = q - py * 20;
-        int iy, ix, ni = n;
-        bool ok;
-        if (g.pack) {            // row / column 10*s + 1 + l holds pixel l of sub-image s; 10*s and 10*s + 9 are its zero halo
-            const int sy = py / 10, sx = ps / 10;
-            iy = py - 10 * sy - 1; ix = ps - 10 * sx - 1; ni = n + 2 * sy + sx;
-            ok = u < 800 && (unsigned)iy < 8u && (unsigned)ix < 8u;
-        } else {
-            iy = oy0 - 1 + py; ix = ox0 - 1 + w8_pix(ps);
-            ok = u < 720 && ps < 18 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-        }
-        if (g.Cin <= 4 && (u & 1)) ok = false;          // a 4-channel input (ldx may be 4): the upper half of the single 8-channel chunk is padding
-        rok[i] = ok;
-        rp[i] = ok ? g.x + ((size_t)(ni * g.H + iy) * g.W + ix) * g.ldx + (u & 1) * 4 : wino_zero16;
-    }
-    // U slice units: u = t + 512*i < 1024*CT : [point][channel 8][NC/4 slots]
-    const float* up[2 * CT];
-#pragma unroll
-    for (int i = 0; i < 2 * CT; ++i) {
-        const int u = t + 512 * i, sl = u % (NC / 4), ch = (u / (NC / 4)) & 7, pt = u / (2 * NC);
-        up[i] = g.U + ((size_t)pt * g.Kp + ch) * g.Np + n0 + sl * 4;
-    }
-    // transform item: 16-B half, tile, row of V = B^T d B (uniform per wave pair)
-    const int tslot = t & 1, ttile = (t >> 1) & 63, vrow = t >> 7;
-    const int tty = ttile >> 3, ttx = ttile & 7;
-    const int ra = vrow == 0 ? 0 : (vrow == 2 ? 2 : 1), rb = vrow == 0 ? 2 : (vrow == 1 ? 2 : (vrow == 2 ? 1 : 3));
-    const float sgn = vrow == 1 ? 1.f : -1.f;
-    int trd[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        trd[c] = g.pack ? ((tty >> 2) * 10 + 2 * (tty & 3) + ra) * 160 + ((ttx >> 2) * 10 + 2 * (ttx & 3) + c) * 8 + tslot * 4
-                        : (2 * tty + ra) * 160 + w8_pos(2 * ttx + c) * 8 + tslot * 4;
-    const int trb = (rb - ra) * 160;
-    const int vwr = (vrow * 4) * 512 + ttile * 8 + ((tslot ^ ((ttile >> 3) & 1)) << 2);
-    int a_rd[2];
-#pragma unroll
-    for (int tg = 0; tg < 2; ++tg) { const int tile = tg * 32 + li; a_rd[tg] = tile * 8 + ((lh ^ ((tile >> 3) & 1)) << 2); }
-    const int p0 = 2 * wave;
-    const int b_rd = (4 * lh) * NC + li;
-
-    f32x16 acc[2][2][CT];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int c = 0; c < CT; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
-
-    f32x4 rr[2], ru[2 * CT];
-    const size_t ustep = (size_t)8 * g.Np;
-    auto load_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { rr[i] = *reinterpret_cast<const f32x4*>(rp[i]); if (rok[i]) rp[i] += 8; }
-#pragma unroll
-        for (int i = 0; i < 2 * CT; ++i) { ru[i] = *reinterpret_cast<const f32x4*>(up[i]); up[i] += ustep; }
-    };
-
-    const int nchunks = g.Kp / 8;
-    const int ktail = g.Cin - (nchunks - 1) * 8 - tslot * 4;      // valid channels of this thread's 16-B half in the LAST chunk (<4: pad)
-    load_chunk();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        *reinterpret_cast<f32x4*>(&raw[t * 4]) = rr[0];
-        if (t < 288) *reinterpret_cast<f32x4*>(&raw[(t + 512) * 4]) = rr[1];
-#pragma unroll
-        for (int i = 0; i < 2 * CT; ++i) *reinterpret_cast<f32x4*>(&Us[(t + 512 * i) * 4]) = ru[i];
-        __syncthreads();
-        {
-            f32x4 tr[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(&raw[trd[c]]);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(&raw[trd[c] + trb]);
-                tr[c] = a + sgn * b;
-            }
-            if (ch == nchunks - 1 && ktail < 4) {        // channels >= Cin of a padded last chunk: whatever the buffer holds there must not reach V
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (j >= ktail) tr[c][j] = 0.f;
-            }
-            *reinterpret_cast<f32x4*>(&Vs[vwr]) = tr[0] - tr[2];
-            *reinterpret_cast<f32x4*>(&Vs[vwr + 512]) = tr[1] + tr[2];
-            *reinterpret_cast<f32x4*>(&Vs[vwr + 1024]) = tr[2] - tr[1];
-            *reinterpret_cast<f32x4*>(&Vs[vwr + 1536]) = tr[1] - tr[3];
-        }
-        if (ch + 1 < nchunks) load_chunk();
-        __syncthreads();
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt) {
-            const float* Vp = Vs + (p0 + pt) * 512;
-            const float* Up = Us + (p0 + pt) * 8 * NC + b_rd;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(&Vp[a_rd[0]]);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&Vp[a_rd[1]]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const float b = Up[j * NC + ct * 32];
-                    acc[pt][0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b, acc[pt][0][ct], 0, 0, 0);
-                    acc[pt][1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b, acc[pt][1][ct], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-    }
-
-    // output transform through LDS, one (tile group, cout tile) quarter at a time: M[16][32 tiles][32 couts] = 64 KB
-    const int oc = t & 31;
-    float* Ms = smem;
-#pragma unroll
-    for (int q = 0; q < 2 * CT; ++q) {
-        const int tg = q & 1, ct = q >> 1;
-        if (q) __syncthreads();
-#pragma unroll
-        for (int pt = 0; pt < 2; ++pt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Ms[((p0 + pt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[pt][tg][ct][r];
-        __syncthreads();
-        const bool ocv = n0 + ct * 32 + oc < g.Cout;
-        const float bv = (g.bias && ocv) ? g.bias[n0 + ct * 32 + oc] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int tl = (t >> 5) + 16 * i;
-            float m[16];
-#pragma unroll
-            for (int p = 0; p < 16; ++p) m[p] = Ms[(p * 32 + tl) * 32 + oc];
-            float s0[4], s1[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { s0[c] = m[c] + m[4 + c] + m[8 + c]; s1[c] = m[4 + c] - m[8 + c] - m[12 + c]; }
-            float yv[2][2];
-            yv[0][0] = s0[0] + s0[1] + s0[2]; yv[0][1] = s0[1] - s0[2] - s0[3];
-            yv[1][0] = s1[0] + s1[1] + s1[2]; yv[1][1] = s1[1] - s1[2] - s1[3];
-            const int tile = tg * 32 + tl, ty = tile >> 3, tx = tile & 7;
-            const int on = g.pack ? n + 2 * (ty >> 2) + (tx >> 2) : n;
-            const int oy = g.pack ? 2 * (ty & 3) : oy0 + 2 * ty, ox = g.pack ? 2 * (tx & 3) : ox0 + 2 * tx;
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    float v = yv[dy][dx] + bv;
-                    if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
-                    if (ocv) g.y[((size_t)(on * g.H + oy + dy) * g.W + ox + dx) * g.ldy + n0 + ct * 32 + oc] = v;
-                }
-        }
-    }
-}
-
 
 // ---- v2 forward / dgrad kernel ----------------------------------------------------------------------------------------------------
 // Same tile (16x16 output pixels x 32*MODE output channels x all 16 Winograd points per workgroup of 8 wavefronts) and the same
@@ -550,62 +333,119 @@ __global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) 
 
 static inline int w2_lds_bytes(int mode) { const int main = W2_MAIN * 4, epi = 4 * 2 * 64 * 32 * mode * 4; return main > epi ? main : epi; }
 
-static inline int w8_lds_bytes(int ct) { const int main = (W8_RAW + W8_U(ct) + W8_V) * 4; return main > 65536 ? main : 65536; }
-static unsigned long long wino_attr_mask = 0;
+static std::atomic<unsigned long long> wino_attr_mask{0};
 
 // shape / alignment eligibility (stride-1 3x3 SAME only); K = channels of the gathered tensor, Nn = produced channels
-extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
-    if (getenv("KPX_NO_WINO")) return 0;
+extern "C" int kpx_conv3x3_wino_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
+    static const bool off = getenv("KPX_NO_WINO") != nullptr;
+    if (off || N <= 0 || K <= 0 || Nn <= 0) return 0;
     // K is padded to a multiple of 8 (the pad channels must exist in the row: ldin >= Kp) and Nn to a multiple of 32
     const bool shape = (H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8 && N % 4 == 0);      // 8x8 images are packed four to a workgroup
     static const int kmin = getenv("KPX_WINO_KMIN") ? atoi(getenv("KPX_WINO_KMIN")) : 4, nmin = getenv("KPX_WINO_NMIN") ? atoi(getenv("KPX_WINO_NMIN")) : 4;
     const bool kfit = ldin >= ((K + 7) & ~7) || K == 4;          // K = 4: only the lower 16-B half of the chunk is ever loaded
     return shape && K >= kmin && Nn >= nmin && (K >= 16 || K == 4 || K == 8) && kfit && (ldin % 4 == 0) && (((uintptr_t)in_ptr) & 15) == 0;
 }
+extern "C" __attribute__((visibility("hidden"))) int kpx_wino_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
+    return kpx_conv3x3_wino_eligible(N, H, W, K, Nn, ldin, in_ptr);
+}
 
-// forward: in = x (K = Cin), out = y (Nn = Cout);  dgrad: in = dy (K = Cout), out = dx (Nn = Cin), w always HWIO [3][3][Cin][Cout]
-extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int Cin, int Cout, int dgrad,
-                                const float* bias, int act, float* out, int Nn, int ldout, float* U_ws, hipStream_t s) {
+extern "C" size_t kpx_wino_u_bytes(int Cin, int Cout) {           // U[16][K padded to 8][Nn padded to 32], either direction
+    const size_t a = (size_t)((Cin + 7) & ~7) * ((Cout + 31) & ~31), b = (size_t)((Cout + 7) & ~7) * ((Cin + 31) & ~31);
+    return 16 * 4 * (a > b ? a : b);
+}
+
+extern "C" int kpx_wino_filter_transform_f32(const float* w_hwio, int Cin, int Cout, int dgrad, float* U, void* stream) {
+    if (!w_hwio || !U || Cin <= 0 || Cout <= 0) return KPX_EINVAL;
+    const int K = dgrad ? Cout : Cin, Nn = dgrad ? Cin : Cout;
     const int Kp = (K + 7) & ~7, Np = (Nn + 31) & ~31;
     const size_t pairs = (size_t)Kp * Np;
     size_t nb = (pairs + 255) / 256; if (nb > 1024) nb = 1024;
-    static const int version = getenv("KPX_WINO_V") ? atoi(getenv("KPX_WINO_V")) : 2;
-    if (version == 2) {
-        if (dgrad) hipLaunchKernelGGL(wino_filter_transform_frag_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
-        else hipLaunchKernelGGL(wino_filter_transform_frag_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
-    } else {
-        if (dgrad) hipLaunchKernelGGL(wino_filter_transform_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
-        else hipLaunchKernelGGL(wino_filter_transform_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U_ws);
+    hipStream_t s = kpx_stream(stream);
+    if (dgrad) hipLaunchKernelGGL(wino_filter_transform_frag_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U);
+    else hipLaunchKernelGGL(wino_filter_transform_frag_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, w_hwio, Cin, Cout, Kp, Np, U);
+    return kpx_launch_status();
+}
+
+// Many filters in one launch: `descs` is a DEVICE array of n KpxWinoDesc (include/kpx.h); blockIdx.y = filter.
+__global__ __launch_bounds__(256) void wino_filter_transform_batch_kernel(const KpxWinoDesc* __restrict__ descs) {
+    const KpxWinoDesc d = descs[blockIdx.y];
+    const int Cin = d.cin, Cout = d.cout;
+    const bool dg = d.dgrad != 0;
+    const int K = dg ? Cout : Cin, Nn = dg ? Cin : Cout;
+    const int Kp = (K + 7) & ~7, Np = (Nn + 31) & ~31, KC = Kp >> 3, NB = Np >> 5;
+    const size_t total = (size_t)Kp * Np, pstride = (size_t)KC * NB * 256;
+    const float* __restrict__ w = d.w;
+    float* __restrict__ Uf = d.u;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int j = (int)(idx & 3), li = (int)((idx >> 2) & 31), lh = (int)((idx >> 7) & 1);
+        const size_t blk = idx >> 8;
+        const int nb = (int)(blk % NB), kc = (int)(blk / NB);
+        const int c = 8 * kc + 4 * lh + j, n = 32 * nb + li;
+        const bool real = c < K && n < Nn;
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                g[r][q] = !real ? 0.f : (dg ? w[((size_t)((2 - r) * 3 + (2 - q)) * Cin + n) * Cout + c] : w[((size_t)(r * 3 + q) * Cin + c) * Cout + n]);
+        float t[4][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            t[0][q] = g[0][q];
+            t[1][q] = 0.5f * (g[0][q] + g[1][q] + g[2][q]);
+            t[2][q] = 0.5f * (g[0][q] - g[1][q] + g[2][q]);
+            t[3][q] = g[2][q];
+        }
+        float* o = Uf + blk * 256 + (idx & 255);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[(size_t)(i * 4 + 0) * pstride] = t[i][0];
+            o[(size_t)(i * 4 + 1) * pstride] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+            o[(size_t)(i * 4 + 2) * pstride] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+            o[(size_t)(i * 4 + 3) * pstride] = t[i][2];
+        }
     }
-    int rc = kpx_launch_status();
-    if (rc) return rc;
+}
+extern "C" int kpx_wino_filter_transform_batch_f32(const void* descs_dev, int n, void* stream) {
+    if (!descs_dev || n <= 0 || n > 65535) return KPX_EINVAL;
+    hipLaunchKernelGGL(wino_filter_transform_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, kpx_stream(stream), (const KpxWinoDesc*)descs_dev);
+    return kpx_launch_status();
+}
+
+// forward: in = x (K = Cin), out = y (Nn = Cout);  dgrad: in = dy (K = Cout), out = dx (Nn = Cin); U: fragment-ordered filters for (K, Nn)
+extern "C" int kpx_conv3x3_wino_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
+                                    float* out, int Nn, int ldout, int act, void* stream) {
+    if (!in || !U || !out || ldin < (K == 4 ? 4 : K) || ldout < Nn || act < 0 || act > 2 || !kpx_conv3x3_wino_eligible(N, H, W, K, Nn, ldin, in)) return KPX_EINVAL;
+    hipStream_t s = kpx_stream(stream);
     if (kpx_first_use_on_device(&wino_attr_mask)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, w8_lds_bytes(1));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino8_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, w8_lds_bytes(2));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_v2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, w2_lds_bytes(1));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_v2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, w2_lds_bytes(1));
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_v2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, w2_lds_bytes(2));
         if (e != hipSuccess) return -(int)e;
     }
     WinoGeom g{};
-    g.x = in; g.y = out; g.U = U_ws; g.bias = bias;
+    g.x = in; g.y = out; g.U = U; g.bias = bias;
     g.N = N; g.H = H; g.W = W; g.Cin = K; g.ldx = ldin; g.Cout = Nn; g.ldy = ldout; g.act = act;
-    g.Kp = Kp; g.Np = Np;
+    g.Kp = (K + 7) & ~7; g.Np = (Nn + 31) & ~31;
     g.pack = (H == 8 && W == 8) ? 1 : 0;
-    g.tiles_y = g.pack ? 1 : H / 16; g.tiles_x = g.pack ? 1 : W / 16; g.nt = Np / 32;
+    g.tiles_y = g.pack ? 1 : H / 16; g.tiles_x = g.pack ? 1 : W / 16; g.nt = g.Np / 32;
     const unsigned blocks = (unsigned)((size_t)(g.pack ? N / 4 : N) * g.tiles_y * g.tiles_x * g.nt);
     // 64 output channels per workgroup when that still fills the 256 CUs, else 32
     static const int force_ct = getenv("KPX_WINO_CT") ? atoi(getenv("KPX_WINO_CT")) : 0;
-    const bool wide = (force_ct ? force_ct == 2 : (blocks / 2 >= 256)) && Np % 64 == 0;
+    const bool wide = (force_ct ? force_ct == 2 : (blocks / 2 >= 256)) && g.Np % 64 == 0;
     static const int stagger = getenv("KPX_WINO_STAGGER") ? atoi(getenv("KPX_WINO_STAGGER")) : 1;
     g.stagger = stagger;
-    if (version == 2) {
-        if (wide) hipLaunchKernelGGL(conv_wino_v2_kernel<2>, dim3(blocks / 2), dim3(512), w2_lds_bytes(2), s, g);
-        else hipLaunchKernelGGL(conv_wino_v2_kernel<1>, dim3(blocks), dim3(512), w2_lds_bytes(1), s, g);
-    } else {
-        if (wide) hipLaunchKernelGGL(conv_wino8_kernel<2>, dim3(blocks / 2), dim3(512), w8_lds_bytes(2), s, g);
-        else hipLaunchKernelGGL(conv_wino8_kernel<1>, dim3(blocks), dim3(512), w8_lds_bytes(1), s, g);
-    }
+    if (wide) hipLaunchKernelGGL(conv_wino_v2_kernel<2>, dim3(blocks / 2), dim3(512), w2_lds_bytes(2), s, g);
+    else hipLaunchKernelGGL(conv_wino_v2_kernel<1>, dim3(blocks), dim3(512), w2_lds_bytes(1), s, g);
     return kpx_launch_status();
+}
+
+// used by kpx_conv2d_fwd_f32 / kpx_conv2d_dgrad_f32 (conv_igemm.hip) when the caller did not pre-transform: transform into the
+// workspace, then run
+extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int Cin, int Cout, int dgrad,
+                                const float* bias, int act, float* out, int Nn, int ldout, float* U_ws, hipStream_t s) {
+    int rc = kpx_wino_filter_transform_f32(w_hwio, Cin, Cout, dgrad, U_ws, (void*)s);
+    if (rc) return rc;
+    return kpx_conv3x3_wino_f32(in, N, H, W, K, ldin, U_ws, bias, out, Nn, ldout, act, (void*)s);
 }
 
 // ------------------------------------------------------------------------------------------ Winograd weight gradient
@@ -627,7 +467,7 @@ struct WinoWgradGeom {
 template <int CIT, int COT>
 __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const WinoWgradGeom g) {
     constexpr int CI = 32 * CIT, CO = 32 * COT, SI = CI / 4, SO = CO / 4;     // channels and 16-B slots per pixel
-    constexpr int RAWX = 60 * CI, RAWD = 32 * CO, VF = 16 * 8 * CI, DF = 16 * 8 * CO;
+    constexpr int RAWX = 60 * CI, RAWD = 32 * CO, VF = 16 * 8 * CI;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* rawx = smem;                    // [6 rows][10 pixels][CI]
     float* rawd = smem + RAWX;             // [4 rows][8 pixels][CO]
@@ -813,7 +653,7 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N
 
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad3x3(const float* x, int N, int H, int W, int Cin, int ldx, const float* dy, int Cout, int lddy,
                                                                    float* slabs, int S, hipStream_t s) {
-    static unsigned long long attr_mask = 0;
+    static std::atomic<unsigned long long> attr_mask{0};
     const int lds22 = (60 * 64 + 32 * 64 + 2 * 16 * 8 * 64) * 4, lds21 = (60 * 64 + 32 * 32 + 16 * 8 * 64 + 16 * 8 * 32) * 4,
               lds12 = (60 * 32 + 32 * 64 + 16 * 8 * 32 + 16 * 8 * 64) * 4;
     if (kpx_first_use_on_device(&attr_mask)) {

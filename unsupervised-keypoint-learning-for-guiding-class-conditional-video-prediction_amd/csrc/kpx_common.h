@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include "../../include/kpx.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -41,10 +42,11 @@ __device__ __forceinline__ float kpx_wave_max(float v) {
 }
 
 // Large-LDS kernels need hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per device; `mask` is a per-kernel-family bitmask.
-static inline bool kpx_first_use_on_device(unsigned long long* mask) {
+// Thread-safe: the bit is claimed with an atomic fetch_or (two racing first callers both set the attribute, which is idempotent).
+static inline bool kpx_first_use_on_device(std::atomic<unsigned long long>* mask) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-    if ((*mask >> dev) & 1ULL) return false;
-    *mask |= 1ULL << dev;
+    if ((mask->load(std::memory_order_acquire) >> dev) & 1ULL) return false;
+    mask->fetch_or(1ULL << dev, std::memory_order_acq_rel);
     return true;
 }

@@ -104,6 +104,7 @@ class MotionGeneratorModel(BaseModel):
         alpha = np.float32(np.float32(lr) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p))
         ops.adam_tf_flat_(bucket.params, bucket.grads, bucket.m, bucket.v, alpha, self.beta1, self.beta2, self.adam_eps,
                           gscale=1.0 / self.world_size)
+        self.store.touch()
         self.beta_power[which] = [np.float32(b1p * self.beta1), np.float32(b2p * self.beta2)]
 
     def _noise(self, feed_dict, key, b):

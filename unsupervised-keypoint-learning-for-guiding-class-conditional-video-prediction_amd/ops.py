@@ -163,12 +163,96 @@ def _bf16_conv(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad):
     return True
 
 
+# ----------------------------------------------------------------------------------------------- pre-transformed Winograd filters
+# U = G g G^T is a function of the filter only.  Constant filters (VGG19) are transformed once; the trainable 3x3 filters of a
+# VariableStore are transformed together in ONE launch (kpx_wino_filter_transform_batch_f32) the first time a convolution needs
+# them after the store changed (optimiser update / restore), instead of once per convolution call.
+import ctypes as _ctypes
+import struct as _struct
+
+_wino_u = {}          # (filter data_ptr, dgrad) -> (U tensor, owning FilterBank or None)
+
+
+class FilterBank:
+    def __init__(self, named_filters, device):
+        """named_filters: iterable of (name, [3,3,Cin,Cout] tensor views whose storage never moves)."""
+        self.version = 0            # bumped by whoever writes the filters (Adam step, restore)
+        self.synced = -1
+        self.filters = [(n, w) for n, w in named_filters if w.dim() == 4 and w.shape[0] == 3 and w.shape[1] == 3]
+        self.device = device
+        if not self.filters or torch.device(device).type != 'cuda':
+            self.filters = []
+            return
+        sizes = [lib.kpx_wino_u_bytes(int(w.shape[2]), int(w.shape[3])) // 4 for _, w in self.filters]
+        self.arena = torch.empty(2 * sum(sizes), dtype=torch.float32, device=device)
+        table, off = b'', 0
+        for (_, w), n in zip(self.filters, sizes):
+            for dgrad in (0, 1):
+                u = self.arena[off:off + n]
+                off += n
+                _wino_u[(w.data_ptr(), dgrad)] = (u, self)
+                table += _struct.pack('<QQiiii', w.data_ptr(), u.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, 0)
+        self.n_desc = 2 * len(self.filters)
+        self.table = torch.frombuffer(bytearray(table), dtype=torch.uint8).to(device)
+
+    def touch(self):
+        self.version += 1
+
+    def ensure_fresh(self):
+        if self.synced != self.version and self.filters:
+            check(lib.kpx_wino_filter_transform_batch_f32(self.table.data_ptr(), self.n_desc, _stream()), 'kpx_wino_filter_transform_batch_f32')
+            self.synced = self.version
+
+    def keys(self):
+        return [(w.data_ptr(), dgrad) for _, w in self.filters for dgrad in (0, 1)]
+
+
+def register_constant_filter(w):
+    """Transform a filter that never changes (VGG19, reference vgg.py:57-61 tf.constant) once, for both directions.
+    Returns the cache keys; the owner must pass them to release_filters() when the filter memory is given up."""
+    if w.dim() != 4 or w.shape[0] != 3 or w.shape[1] != 3 or not w.is_cuda:
+        return []
+    n = lib.kpx_wino_u_bytes(int(w.shape[2]), int(w.shape[3])) // 4
+    keys = []
+    for dgrad in (0, 1):
+        u = torch.empty(n, dtype=torch.float32, device=w.device)
+        check(lib.kpx_wino_filter_transform_f32(w.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, u.data_ptr(), _stream()), 'kpx_wino_filter_transform_f32')
+        _wino_u[(w.data_ptr(), dgrad)] = (u, None)
+        keys.append((w.data_ptr(), dgrad))
+    return keys
+
+
+def release_filters(keys):
+    """Forget cached Winograd forms (the address of a freed filter may be handed to an unrelated tensor later)."""
+    for k in keys:
+        _wino_u.pop(k, None)
+
+
+def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad):
+    """Run the fused Winograd kernel on a cached U; False when there is none for this filter or the shape is not eligible."""
+    ent = _wino_u.get((w.data_ptr(), 1 if dgrad else 0))
+    if ent is None:
+        return False
+    n, h, wd = inp.shape[0], inp.shape[1], inp.shape[2]
+    if not lib.kpx_conv3x3_wino_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr()):
+        return False
+    u, bank = ent
+    if bank is not None:
+        bank.ensure_fresh()
+    check(lib.kpx_conv3x3_wino_f32(inp.data_ptr(), n, h, wd, k, ld_in, u.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                   out.data_ptr(), nn, ld_out, act, _stream()), 'kpx_conv3x3_wino_f32')
+    return True
+
+
 # ----------------------------------------------------------------------------------------------- raw launchers
 def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act):
     n, hi, wi = x.shape[0], x.shape[1], x.shape[2]
     kh, kw, _, cout = w.shape
     if (_compute_dtype[0] == 'bf16' and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cin >= 8
             and y.shape[1] == hi and y.shape[2] == wi and _bf16_conv(x, ldx, cin, w, bias, y, ldy, cout, act, False)):
+        return
+    if (kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and act != ACT_TANH and y.shape[1] == hi and y.shape[2] == wi
+            and _wino_pretransformed(x, ldx, cin, w, bias, y, ldy, cout, act, False)):
         return
     nbytes = lib.kpx_conv2d_fwd_workspace_bytes(n, y.shape[1], y.shape[2], cin, cout, kh, kw)
     ws = scratch.get('splitk', nbytes, x.device) if nbytes else None
@@ -184,6 +268,9 @@ def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l):
     kh, kw, _, cout = w.shape
     if (_compute_dtype[0] == 'bf16' and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cout >= 8
             and dx.shape[1] == ho and dx.shape[2] == wo and _bf16_conv(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True)):
+        return
+    if (kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and dx.shape[1] == ho and dx.shape[2] == wo
+            and _wino_pretransformed(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True)):
         return
     nbytes = lib.kpx_conv2d_dgrad_workspace_bytes(n, dx.shape[1], dx.shape[2], cin, cout, kh, kw, stride)
     ws = scratch.get('splitk', nbytes, dy.device) if nbytes else None

@@ -8,6 +8,7 @@ the data-parallel exchange is a single RCCL all-reduce and the optimiser a singl
 """
 import contextlib
 import math
+import weakref
 from collections import OrderedDict
 
 import numpy as np
@@ -136,6 +137,16 @@ class VariableStore:
                 self.vars[name] = val.to(self.device)
         self.init_values.clear()
         self.materialised = True
+        if self.device.type == 'cuda':
+            from . import ops                            # pre-transformed Winograd filters of every trainable 3x3 kernel
+            self.filter_bank = ops.FilterBank([(n, v.detach()) for n, v in self.vars.items() if n.endswith('/kernel')], self.device)
+            weakref.finalize(self, ops.release_filters, self.filter_bank.keys())     # the bucket's addresses may be reused later
+
+    def touch(self):
+        """Call after writing parameters behind torch's back (fused Adam kernel, restore): derived filter forms are refreshed lazily."""
+        bank = getattr(self, 'filter_bank', None)
+        if bank is not None:
+            bank.touch()
 
     # ---- access ------------------------------------------------------------------------------------------------
     def __getitem__(self, name):
@@ -165,6 +176,7 @@ class VariableStore:
                         raise KeyError(name)
                     continue
                 v.copy_(torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)).to(v.device))
+        self.touch()
 
     def export_numpy(self, include_slots=False, beta_powers=None):
         """{TF name: array} in the reference's checkpoint naming, splitting the fused head."""

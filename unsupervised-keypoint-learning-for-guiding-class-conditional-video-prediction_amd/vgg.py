@@ -7,6 +7,7 @@ images exactly as the reference does (detector_translator_model.py:278), backwar
 """
 import math
 import os
+import weakref
 from collections import OrderedDict
 
 import numpy as np
@@ -50,10 +51,14 @@ class Vgg19:
             weights = np.load(vgg19_path, encoding='latin1', allow_pickle=True).item()              # vgg.py:11
         self.device = torch.device(device)
         self.params = OrderedDict()
+        keys = []
         for name, _, _ in VGG_LAYERS:
             w, b = weights[name][0], weights[name][1]
             self.params[name] = (torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(self.device),
                                  torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(self.device))
+            if self.device.type == 'cuda':
+                keys += ops.register_constant_filter(self.params[name][0])     # tf.constant filters (vgg.py:57-61): Winograd form once
+        weakref.finalize(self, ops.release_filters, keys)
 
     def build(self, rgb01):
         """Forward only: images in [-1,1] (the (x+1)/2*255, BGR, mean shift of :262-263 / vgg.py:16-19 is fused into the
