@@ -5,6 +5,8 @@ import kpx_amd
 from kpx_amd import ops
 dev = torch.device('cuda:0')
 shapes = [(32, 128, 128, 64), (32, 64, 64, 128), (32, 32, 32, 256), (64, 128, 128, 16), (64, 64, 64, 32), (64, 16, 16, 128), (64, 65, 65, 128)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(v) for v in sys.argv[1:5])]
 for shp in shapes:
     n, h, w, c = shp
     x = torch.randn(*shp, device=dev, requires_grad=True)

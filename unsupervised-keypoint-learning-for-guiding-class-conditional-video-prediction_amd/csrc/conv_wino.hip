@@ -337,8 +337,7 @@ static std::atomic<unsigned long long> wino_attr_mask{0};
 
 // shape / alignment eligibility (stride-1 3x3 SAME only); K = channels of the gathered tensor, Nn = produced channels
 extern "C" int kpx_conv3x3_wino_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
-    static const bool off = getenv("KPX_NO_WINO") != nullptr;
-    if (off || N <= 0 || K <= 0 || Nn <= 0) return 0;
+    if (getenv("KPX_NO_WINO") || N <= 0 || K <= 0 || Nn <= 0) return 0;       // (read per call: bench.py flips it to time the direct kernel)
     // K is padded to a multiple of 8 (the pad channels must exist in the row: ldin >= Kp) and Nn to a multiple of 32
     const bool shape = (H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8 && N % 4 == 0);      // 8x8 images are packed four to a workgroup
     static const int kmin = getenv("KPX_WINO_KMIN") ? atoi(getenv("KPX_WINO_KMIN")) : 4, nmin = getenv("KPX_WINO_NMIN") ? atoi(getenv("KPX_WINO_NMIN")) : 4;

@@ -204,6 +204,10 @@ __global__ __launch_bounds__(256) void gauss_fwd_flat_kernel(const float* __rest
 // contiguous output, K >= 4, no LDS and no barrier: the workgroup has T = K*m threads, so a thread's float4 index advances by a
 // multiple of K floats per iteration and its four channels k0..k0+3 (mod K) never change -- their (mu_x, mu_y) live in registers,
 // loaded once.  blockIdx.x covers `iters` consecutive T-float4 slabs of image blockIdx.y; streaming (non-temporal) 16-B stores.
+// WFIX: the float4 index advances by a whole number of image rows per iteration (4*T/K is a multiple of W, e.g. K = 15, W = 128,
+// T = 480), so a thread's four pixels keep their COLUMN as well: (x - mu_x)^2 is loop-invariant and an element costs six VALU ops + exp.
+// The rounding sequence is kpx_gauss's, operation for operation (same bits as the strided renderer).
+template <bool NT, bool WFIX>
 __global__ __launch_bounds__(512) void gauss_fwd_reg_kernel(const float* __restrict__ mu, int K, int H, int W, float inv2,
                                                             float* __restrict__ out, int iters) {
     const int b = blockIdx.y, T = blockDim.x;
@@ -223,6 +227,34 @@ __global__ __launch_bounds__(512) void gauss_fwd_reg_kernel(const float* __restr
     }
     const int step_pix = (4 * T) / K;
     f32x4* ob = reinterpret_cast<f32x4*>(out + (size_t)b * H * W * K);
+    if (WFIX) {
+        float dx2[4]; int rowc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int wj = w + carry[j];
+            rowc[j] = wj >= W;
+            if (rowc[j]) wj -= W;
+            const float dx = __fsub_rn(kpx_linspace(wj, W), mx[j]);
+            dx2[j] = __fmul_rn(dx, dx);
+        }
+        const int step_rows = step_pix / W;
+        for (int it = 0; it < iters; ++it) {
+            if (i < n4) {
+                const float y0 = kpx_linspace(h, H), y1 = kpx_linspace(h + 1, H);
+                f32x4 r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float dy = __fsub_rn(rowc[j] ? y1 : y0, my[j]);
+                    const float dist = __fmul_rn(__fadd_rn(__fmul_rn(dy, dy), dx2[j]), inv2);
+                    r[j] = __expf(-dist);
+                }
+                if (NT) __builtin_nontemporal_store(r, ob + i); else ob[i] = r;
+            }
+            i += T;
+            h += step_rows;
+        }
+        return;
+    }
     for (int it = 0; it < iters; ++it) {
         if (i < n4) {
             f32x4 r;
@@ -232,7 +264,7 @@ __global__ __launch_bounds__(512) void gauss_fwd_reg_kernel(const float* __restr
                 if (wj >= W) { wj -= W; ++hj; }
                 r[j] = kpx_gauss(kpx_linspace(hj, H), kpx_linspace(wj, W), my[j], mx[j], inv2);
             }
-            __builtin_nontemporal_store(r, ob + i);
+            if (NT) __builtin_nontemporal_store(r, ob + i); else ob[i] = r;
         }
         i += T;
         w += step_pix;
@@ -261,16 +293,27 @@ extern "C" int kpx_gaussian_maps_fwd_f32(const float* mu, int B, int K, int H, i
     const bool flat = ldy == K && (((uintptr_t)maps) & 15) == 0 && ((size_t)H * W * K) % 4 == 0 && (size_t)H * W * K < (1u << 23);
     if (flat && K >= 4 && K <= 512) {
         int m = 1, best = 0;                                  // T = K*m threads: fullest last wavefront among T in [128, 512]
+        bool wfix = false;
         for (int mm = 1; K * mm <= 512; ++mm) {
-            const int T = K * mm, fill = T * 1000 / (((T + 63) / 64) * 64) + (T >= 192 ? 1000 : 0);
-            if (fill >= best) { best = fill; m = mm; }
+            const int T = K * mm;
+            const bool wf = (4 * mm) % W == 0;                // whole rows per iteration: the cheaper loop body
+            const int fill = T * 1000 / (((T + 63) / 64) * 64) + (T >= 192 ? 1000 : 0) + (wf ? 500 : 0);
+            if (fill >= best) { best = fill; m = mm; wfix = wf; }
         }
         const int T = K * m, n4 = (int)(((size_t)H * W * K) >> 2);
-        static const int target = getenv("KPX_GAUSS_BLOCKS") ? atoi(getenv("KPX_GAUSS_BLOCKS")) : 2048;
+        static const int target = getenv("KPX_GAUSS_BLOCKS") ? atoi(getenv("KPX_GAUSS_BLOCKS")) : 768;
         int G = target / B; if (G < 1) G = 1;
         int iters = (n4 + T * G - 1) / (T * G); if (iters < 1) iters = 1;
         G = (n4 + T * iters - 1) / (T * iters);
-        hipLaunchKernelGGL(gauss_fwd_reg_kernel, dim3((unsigned)G, (unsigned)B), dim3((unsigned)T), 0, s, mu, K, H, W, inv2, maps, iters);
+        static const int nt = getenv("KPX_GAUSS_NT") ? atoi(getenv("KPX_GAUSS_NT")) : 1;
+        const dim3 grid((unsigned)G, (unsigned)B), block((unsigned)T);
+        if (wfix) {
+            if (nt) hipLaunchKernelGGL((gauss_fwd_reg_kernel<true, true>), grid, block, 0, s, mu, K, H, W, inv2, maps, iters);
+            else hipLaunchKernelGGL((gauss_fwd_reg_kernel<false, true>), grid, block, 0, s, mu, K, H, W, inv2, maps, iters);
+        } else {
+            if (nt) hipLaunchKernelGGL((gauss_fwd_reg_kernel<true, false>), grid, block, 0, s, mu, K, H, W, inv2, maps, iters);
+            else hipLaunchKernelGGL((gauss_fwd_reg_kernel<false, false>), grid, block, 0, s, mu, K, H, W, inv2, maps, iters);
+        }
     } else if (flat && K <= 256 && W <= 512 && H <= 512) {
         const int n4 = (int)(((size_t)H * W * K) >> 2);
         int per_block = 1024;                                 // 4 float4 per thread; fewer when that would leave CUs idle

@@ -124,30 +124,42 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const RedArgs a) {
         }
     }
     if (active) {
-        for (size_t p = (size_t)blockIdx.x * PPB + prow; p < a.P; p += (size_t)gridDim.x * PPB) {
-            float xv[W], gv[W];
-            if (VEC) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + p * a.ldx + cg * 4);
+        // four pixels per trip: eight independent 16-B loads in flight per thread (the loop is latency-bound otherwise)
+        constexpr int U = VEC ? 4 : 1;
+        const size_t step = (size_t)gridDim.x * PPB;
+        for (size_t p0 = (size_t)blockIdx.x * PPB + prow; p0 < a.P; p0 += step * U) {
+            float xv[U][W], gv[U][W];
 #pragma unroll
-                for (int j = 0; j < W; ++j) xv[j] = v[j];
-                if (MODE == 2) {
-                    const f32x4 d = *reinterpret_cast<const f32x4*>(a.dy + p * a.lddy + cg * 4);
+            for (int u = 0; u < U; ++u) {
+                const size_t p = p0 + u * step;
+                const bool in = p < a.P;
+                if (VEC) {
+                    const f32x4 v = in ? *reinterpret_cast<const f32x4*>(a.x + p * a.ldx + cg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int j = 0; j < W; ++j) gv[j] = d[j];
+                    for (int j = 0; j < W; ++j) xv[u][j] = v[j];
+                    if (MODE == 2) {
+                        const f32x4 d = in ? *reinterpret_cast<const f32x4*>(a.dy + p * a.lddy + cg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int j = 0; j < W; ++j) gv[u][j] = d[j];
+                    }
+                } else {
+                    xv[u][0] = a.x[p * a.ldx + cg];
+                    if (MODE == 2) gv[u][0] = a.dy[p * a.lddy + cg];
                 }
-            } else {
-                xv[0] = a.x[p * a.ldx + cg];
-                if (MODE == 2) gv[0] = a.dy[p * a.lddy + cg];
             }
 #pragma unroll
-            for (int j = 0; j < W; ++j) {
-                if (MODE == 0) s0[j] += (double)xv[j];
-                if (MODE == 1) { s0[j] += (double)xv[j]; s1[j] += (double)xv[j] * (double)xv[j]; }
-                if (MODE == 2) {
-                    const float xh = (xv[j] - mu[j]) * is[j];
-                    const float yv = fmaf(xh, ga[j], be[j]);
-                    const float dz = (a.act == KPX_ACT_RELU && !(yv > 0.f)) ? 0.f : gv[j];
-                    s0[j] += (double)dz; s1[j] += (double)dz * (double)xh;
+            for (int u = 0; u < U; ++u) {
+                if (p0 + u * step >= a.P) break;
+#pragma unroll
+                for (int j = 0; j < W; ++j) {
+                    if (MODE == 0) s0[j] += (double)xv[u][j];
+                    if (MODE == 1) { s0[j] += (double)xv[u][j]; s1[j] += (double)xv[u][j] * (double)xv[u][j]; }
+                    if (MODE == 2) {
+                        const float xh = (xv[u][j] - mu[j]) * is[j];
+                        const float yv = fmaf(xh, ga[j], be[j]);
+                        const float dz = (a.act == KPX_ACT_RELU && !(yv > 0.f)) ? 0.f : gv[u][j];
+                        s0[j] += (double)dz; s1[j] += (double)dz * (double)xh;
+                    }
                 }
             }
         }
@@ -298,12 +310,90 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, size_t P,
         } else y[p * ldy + c0] = v[0];
     }
 }
+// Strip mapping for the 16-B-vector case: a thread keeps ONE channel group (4 channels) for its whole life, so the per-channel
+// parameters are read once into registers instead of six scalar loads per element, and walks pixels four at a time (independent
+// loads in flight).  256 threads = Gb channel groups x PPB pixels; blockIdx.y slices channel counts beyond 1024.
+__global__ __launch_bounds__(256) void bn_apply_strip_kernel(const float* __restrict__ x, size_t P, int C, int ldx, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ y, int ldy, int act) {
+    const int G = C >> 2, Gb = G < 256 ? G : 256, PPB = 256 / Gb;
+    const int t = threadIdx.x, cgl = t % Gb, prow = t / Gb;
+    const int cg = blockIdx.y * Gb + cgl;
+    if (prow >= PPB || cg >= G) return;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cg * 4), is = *reinterpret_cast<const f32x4*>(invstd + cg * 4);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + cg * 4), be = *reinterpret_cast<const f32x4*>(beta + cg * 4);
+    const size_t step = (size_t)gridDim.x * PPB;
+    for (size_t p0 = (size_t)blockIdx.x * PPB + prow; p0 < P; p0 += step * 4) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const size_t p = p0 + u * step; if (p < P) v[u] = *reinterpret_cast<const f32x4*>(x + p * ldx + cg * 4); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t p = p0 + u * step;
+            if (p >= P) break;
+            f32x4 r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (v[u][j] - mu[j]) * is[j];
+                r[j] = fmaf(xh, ga[j], be[j]);
+                if (act == KPX_ACT_RELU) r[j] = fmaxf(r[j], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(y + p * ldy + cg * 4) = r;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_strip_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx, size_t P, int C,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, int act, const float* __restrict__ sums, float inv_count,
+                                                                 float* __restrict__ dx, int lddx) {
+    const int G = C >> 2, Gb = G < 256 ? G : 256, PPB = 256 / Gb;
+    const int t = threadIdx.x, cgl = t % Gb, prow = t / Gb;
+    const int cg = blockIdx.y * Gb + cgl;
+    if (prow >= PPB || cg >= G) return;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cg * 4), is = *reinterpret_cast<const f32x4*>(invstd + cg * 4);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + cg * 4), be = *reinterpret_cast<const f32x4*>(beta + cg * 4);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + cg * 4), s1 = *reinterpret_cast<const f32x4*>(sums + C + cg * 4);
+    f32x4 gi, m0, m1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gi[j] = ga[j] * is[j]; m0[j] = s0[j] * inv_count; m1[j] = s1[j] * inv_count; }
+    const size_t step = (size_t)gridDim.x * PPB;
+    for (size_t p0 = (size_t)blockIdx.x * PPB + prow; p0 < P; p0 += step * 4) {
+        f32x4 xv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t p = p0 + u * step;
+            if (p < P) { xv[u] = *reinterpret_cast<const f32x4*>(x + p * ldx + cg * 4); gv[u] = *reinterpret_cast<const f32x4*>(dy + p * lddy + cg * 4); }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t p = p0 + u * step;
+            if (p >= P) break;
+            f32x4 r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (xv[u][j] - mu[j]) * is[j];
+                const float yv = fmaf(xh, ga[j], be[j]);
+                const float dz = (act == KPX_ACT_RELU && !(yv > 0.f)) ? 0.f : gv[u][j];
+                r[j] = gi[j] * (dz - m0[j] - xh * m1[j]);
+            }
+            *reinterpret_cast<f32x4*>(dx + p * lddx + cg * 4) = r;
+        }
+    }
+}
+static inline dim3 strip_grid(size_t P, int C) {
+    const int G = C >> 2, Gb = G < 256 ? G : 256, PPB = 256 / Gb;
+    size_t nb = (P + (size_t)PPB * 4 - 1) / ((size_t)PPB * 4);
+    if (nb < 1) nb = 1;
+    if (nb > KPX_MAX_BLOCKS) nb = KPX_MAX_BLOCKS;
+    return dim3((unsigned)nb, (unsigned)((G + Gb - 1) / Gb));
+}
+
 extern "C" int kpx_bn_apply_f32(const float* x, size_t P, int C, int ldx, const float* mean, const float* invstd,
                                 const float* gamma, const float* beta, float* y, int ldy, int act, void* stream) {
     if (!x || !y || !mean || !invstd || !gamma || !beta || C <= 0 || ldx < C || ldy < C || act < 0 || act > 1) return KPX_EINVAL;
     if (P == 0) return 0;
     const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
-    if (vec) hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(grid_for(P * (C / 4))), dim3(256), 0, kpx_stream(stream), x, P, C, ldx, mean, invstd, gamma, beta, y, ldy, act);
+    if (vec) hipLaunchKernelGGL(bn_apply_strip_kernel, strip_grid(P, C), dim3(256), 0, kpx_stream(stream), x, P, C, ldx, mean, invstd, gamma, beta, y, ldy, act);
     else hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(P * C)), dim3(256), 0, kpx_stream(stream), x, P, C, ldx, mean, invstd, gamma, beta, y, ldy, act);
     return kpx_launch_status();
 }
@@ -366,7 +456,7 @@ extern "C" int kpx_bn_bwd_f32(const float* dy, int lddy, const float* x, int ldx
     const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) &&
                      ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
     const float inv_count = (float)(1.0 / (double)P);
-    if (vec) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(P * (C / 4))), dim3(256), 0, s, dy, lddy, x, ldx, P, C, mean, invstd, gamma, beta, act, sums, inv_count, dx, lddx);
+    if (vec) hipLaunchKernelGGL(bn_bwd_apply_strip_kernel, strip_grid(P, C), dim3(256), 0, s, dy, lddy, x, ldx, P, C, mean, invstd, gamma, beta, act, sums, inv_count, dx, lddx);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(P * C)), dim3(256), 0, s, dy, lddy, x, ldx, P, C, mean, invstd, gamma, beta, act, sums, inv_count, dx, lddx);
     return kpx_launch_status();
 }
