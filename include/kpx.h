@@ -121,10 +121,12 @@ int kpx_bn_invstd_f32(const float* var, int C, float eps, float* invstd, void* s
 /* step 2: y = act((x-mean)*invstd*gamma + beta), act in {NONE, RELU} (tf.nn.relu networks/__init__.py:12...). */
 int kpx_bn_apply_f32(const float* x, size_t P, int C, int ldx, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, float* y, int ldy, int act, void* stream);
-/* backward of y = act(BN_train(x)): dx, dgamma, dbeta from dy (gradient wrt y) and the saved x, mean, invstd. */
+/* backward of y = act(BN_train(x)): dx, dgamma, dbeta from dy (gradient wrt y) and the saved x, mean, invstd.
+ * accumulate != 0: dgamma / dbeta are ADDED to (a second call of a weight-sharing batch norm with its own statistics,
+ * models/detector_translator_model.py:166-167). */
 int kpx_bn_bwd_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int C,
                    const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
-                   float* dx, int lddx, float* dgamma, float* dbeta, void* scratch, void* stream);
+                   float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* scratch, void* stream);
 
 /* ---- tf.image.resize_images(x, 2x) legacy bilinear (models/networks/__init__.py:63,98). */
 int kpx_resize2x_fwd_f32(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, void* stream);

@@ -55,7 +55,7 @@ SIGNATURES = {
     'kpx_bn_stats_f32': (c_int, [P, c_size_t, c_int, c_int, c_float, P, P, P, P, P, c_float, P, P]),
     'kpx_bn_invstd_f32': (c_int, [P, c_int, c_float, P, P]),
     'kpx_bn_apply_f32': (c_int, [P, c_size_t, c_int, c_int, P, P, P, P, P, c_int, c_int, P]),
-    'kpx_bn_bwd_f32': (c_int, [P, c_int, P, c_int, c_size_t, c_int, P, P, P, P, c_int, P, c_int, P, P, P, P]),
+    'kpx_bn_bwd_f32': (c_int, [P, c_int, P, c_int, c_size_t, c_int, P, P, P, P, c_int, P, c_int, P, P, c_int, P, P]),
     'kpx_resize2x_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     'kpx_resize2x_bwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     'kpx_copy_channels_f32': (c_int, [P, c_int, P, c_int, c_size_t, c_int, P]),

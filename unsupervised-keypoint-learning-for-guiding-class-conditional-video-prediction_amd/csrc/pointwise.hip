@@ -398,12 +398,12 @@ extern "C" int kpx_bn_apply_f32(const float* x, size_t P, int C, int ldx, const 
     return kpx_launch_status();
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* part, int nb, int C, float* dgamma, float* dbeta, float* sums) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* part, int nb, int C, float* dgamma, float* dbeta, float* sums, int accumulate) {
     const int c = blockIdx.x;
     double s, q;
     kpx_sum_partials(part, nb, C, c, s, q);
     if (threadIdx.x != 0) return;
-    dbeta[c] = (float)s; dgamma[c] = (float)q;
+    if (accumulate) { dbeta[c] += (float)s; dgamma[c] += (float)q; } else { dbeta[c] = (float)s; dgamma[c] = (float)q; }
     sums[c] = (float)s; sums[C + c] = (float)q;
 }
 template <bool VEC>
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* dy, int 
 }
 extern "C" int kpx_bn_bwd_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int C,
                               const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
-                              float* dx, int lddx, float* dgamma, float* dbeta, void* scratch, void* stream) {
+                              float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* scratch, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !scratch || C <= 0 ||
         ldx < C || lddy < C || lddx < C || act < 0 || act > 1 || P == 0)
         return KPX_EINVAL;
@@ -450,7 +450,7 @@ extern "C" int kpx_bn_bwd_f32(const float* dy, int lddy, const float* x, int ldx
     if (rc) return rc;
     // the per-channel sums are parked (as floats) behind the partials in the scratch buffer
     float* sums = reinterpret_cast<float*>((double*)scratch + (size_t)KPX_RED_BLOCKS * 2 * C);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)scratch, nb, C, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)scratch, nb, C, dgamma, dbeta, sums, accumulate);
     rc = kpx_launch_status();
     if (rc) return rc;
     const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) &&
