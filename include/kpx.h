@@ -65,6 +65,13 @@ int kpx_wino_filter_transform_batch_f32(const void* descs, int n, void* stream);
 int kpx_conv3x3_wino_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in);
 int kpx_conv3x3_wino_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u, const float* bias,
                          float* out, int Nn, int ldout, int act, void* stream);
+/* The same convolution, additionally writing the batch-norm statistics of its OUTPUT (tf.contrib.layers.batch_norm follows every
+ * generator conv, models/networks/layers.py:13-14): tile_stats[N * (H/16) * (W/16)][2][Nn] = per 16x16-pixel tile and channel, the
+ * sum and the sum of squares of out (fp32, fixed summation order).  kpx_bn_stats_from_tiles_f32 turns a tile range into mean /
+ * invstd / moving statistics, replacing kpx_bn_stats_f32's pass over the activation.  H, W multiples of 16. */
+size_t kpx_conv3x3_wino_stats_tiles(int N, int H, int W);
+int kpx_conv3x3_wino_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u, const float* bias,
+                               float* out, int Nn, int ldout, int act, float* tile_stats, void* stream);
 
 /* ---- bf16-MFMA variant of the 3x3 stride-1 SAME convolution (BASELINE configs[2]: "bf16"; same reference call sites as above:
  *      models/networks/layers.py:6-9 for kernel=3, stride=1; models/networks/vgg.py:51-54).  Tensors stay float32 in HBM (fp32
@@ -116,6 +123,11 @@ int kpx_bn_stats_f32(const float* x, size_t P, int C, int ldx, float eps,
                      float* mean, float* invstd, float* var_biased,
                      float* moving_mean, float* moving_var, float decay,
                      void* scratch, void* stream);
+/* kpx_bn_stats_f32 from per-tile sums (tile_stats[tile][2][C], `tile_pixels` pixels per tile) over tiles [tile0, tile0 + ntiles):
+ * fp64 fixed-order reduction; same outputs and moving-statistics rule. */
+int kpx_bn_stats_from_tiles_f32(const float* tile_stats, size_t tile0, size_t ntiles, int tile_pixels, int C, float eps,
+                                float* mean, float* invstd, float* var_biased,
+                                float* moving_mean, float* moving_var, float decay, void* stream);
 /* invstd[c] = rsqrt(moving_var[c]+eps) for inference-mode BN (models/keypoint_model.py:48-50). */
 int kpx_bn_invstd_f32(const float* var, int C, float eps, float* invstd, void* stream);
 /* step 2: y = act((x-mean)*invstd*gamma + beta), act in {NONE, RELU} (tf.nn.relu networks/__init__.py:12...). */

@@ -439,3 +439,37 @@ def test_conv3x3_bf16_fwd_dgrad_tolerance(kpx, dev, n, h, w, cin, cout, act):
     # the fp32 path on the same inputs is unaffected by the mode switch
     y32 = kpx.ops.conv2d(torch.from_numpy(x).to(dev), torch.from_numpy(wt).to(dev), torch.from_numpy(b).to(dev), stride=1, pad=0, act=0, cin=cin)
     assert rel_l2(t2n(y32), t2n(zo)) < 1e-5
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,groups', [(4, 32, 32, 32, 64, 1), (4, 16, 48, 64, 40, 2), (2, 64, 64, 128, 128, 1)])
+def test_batch_norm_statistics_from_the_conv_epilogue(kpx, dev, n, h, w, cin, cout, groups):
+    """conv -> train-mode batch norm with the per-tile channel sums written by the Winograd epilogue (kpx_conv3x3_wino_stats_f32 +
+    kpx_bn_stats_from_tiles_f32) against the oracle AND against the separate statistics pass: same normalised output, same
+    moving-statistics update, per-call statistics for ``groups`` weight-sharing calls (reference detector_translator_model.py:166-167)."""
+    ops = kpx.ops
+    rs = np.random.RandomState(cin + cout)
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    x[n // 2:] += 0.5                                   # the two groups see different statistics
+    wt = (rs.randn(3, 3, cin, cout) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32)
+    ga = rs.uniform(0.5, 1.5, cout).astype(np.float32); be = rs.randn(cout).astype(np.float32)
+    xg, wg, bg = (torch.from_numpy(a).to(dev) for a in (x, wt, b))
+    gg, beg = torch.from_numpy(ga).to(dev), torch.from_numpy(be).to(dev)
+    keys = ops.register_constant_filter(wg)
+    try:
+        y = ops.conv2d(xg, wg, bg, stride=1, pad=0, act=0, bn_stats=True)
+        assert hasattr(y, '_kpx_tile_stats') and y._kpx_tile_stats[1] == (h // 16) * (w // 16)
+        mm1, mv1 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+        out1 = ops.batch_norm(y, gg, beg, mm1, mv1, train=True, act=1, groups=groups)
+        y2 = y.detach().clone()                         # no tile statistics attached: the separate statistics pass
+        mm2, mv2 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+        out2 = ops.batch_norm(y2, gg, beg, mm2, mv2, train=True, act=1, groups=groups)
+    finally:
+        ops.release_filters(keys)
+    assert rel_l2(t2n(out1), t2n(out2)) < 2e-6
+    np.testing.assert_allclose(t2n(mm1), t2n(mm2), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(t2n(mv1), t2n(mv2), rtol=1e-6)
+    zo = R.conv(torch.from_numpy(x), torch.from_numpy(wt), torch.from_numpy(b), 1, 0)
+    ng = n // groups
+    want = torch.cat([torch.relu(R.batch_norm_train(zo[g * ng:(g + 1) * ng], torch.from_numpy(ga), torch.from_numpy(be))[0]) for g in range(groups)])
+    assert rel_l2(t2n(out1), t2n(want)) < 1e-5

@@ -24,6 +24,7 @@ struct WinoGeom {
     int Kp, Np;                                 // U is [16][Kp][Np]: Kp = Cin rounded up to 8, Np = Cout rounded up to 32 (zero padded)
     int tiles_y, tiles_x, nt;          // 16x16-pixel blocks per image, cout tiles of 32
     int stagger;                       // v2: wavefronts 4-7 run the MFMA half of a chunk first
+    float* stats;                      // optional [N * tiles][2][Cout]: per-tile, per-channel sum and sum of squares of the OUTPUT (batch-norm statistics)
 };
 
 static __device__ __attribute__((aligned(16))) float wino_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) 
     }
     __syncthreads();
     const bool vec_ok = (g.ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.y) & 15) == 0);
+    f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};      // this thread's 4 couts: sum / sum of squares over its pixels
 #pragma unroll
     for (int it = 0; it < MODE; ++it) {
         const int idx = t + 512 * it;
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
                 }
+                st_s += v; st_q += v * v;
                 float* o = g.y + ((size_t)(on * g.H + oy + dy) * g.W + ox + dx) * g.ldy + c0;
                 if (vec_ok && c0 + 3 < g.Cout) *reinterpret_cast<f32x4*>(o) = v;
                 else {
@@ -325,6 +328,23 @@ __global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) 
                     for (int e = 0; e < 4; ++e) if (c0 + e < g.Cout) o[e] = v[e];
                 }
             }
+    }
+    if (g.stats) {
+        // batch-norm statistics of this 16x16-pixel tile: the 512 per-thread partials go through LDS once and 2*NC threads add them
+        // in a fixed order (threads cq, cq + NC/4, ...), so the slab -- and everything derived from it -- is bitwise reproducible.
+        __syncthreads();                                 // P has been consumed by every thread
+        float* const S = smem;                           // [512][8]
+        *reinterpret_cast<f32x4*>(&S[t * 8]) = st_s;
+        *reinterpret_cast<f32x4*>(&S[t * 8 + 4]) = st_q;
+        __syncthreads();
+        if (t < 2 * NC) {
+            const int stat = t / NC, c = t - stat * NC, cq = c >> 2, e = c & 3;
+            float r = 0.f;
+#pragma unroll 8
+            for (int m = 0; m < 512 / (NC / 4); ++m) r += S[(cq + (NC / 4) * m) * 8 + stat * 4 + e];
+            const size_t tile_id = ((size_t)n * g.tiles_y + by) * g.tiles_x + bx;
+            if (n0 + c < g.Cout) g.stats[(tile_id * 2 + stat) * g.Cout + n0 + c] = r;
+        }
     }
 #ifdef KPX_WINO_STAMP
     if (dbg) { dbg[3] = __builtin_amdgcn_s_memtime(); dbg[4] = __builtin_amdgcn_s_memrealtime(); }
@@ -412,8 +432,22 @@ extern "C" int kpx_wino_filter_transform_batch_f32(const void* descs_dev, int n,
 }
 
 // forward: in = x (K = Cin), out = y (Nn = Cout);  dgrad: in = dy (K = Cout), out = dx (Nn = Cin); U: fragment-ordered filters for (K, Nn)
+static int wino_launch(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
+                       float* out, int Nn, int ldout, int act, float* tile_stats, void* stream);
 extern "C" int kpx_conv3x3_wino_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
                                     float* out, int Nn, int ldout, int act, void* stream) {
+    return wino_launch(in, N, H, W, K, ldin, U, bias, out, Nn, ldout, act, nullptr, stream);
+}
+extern "C" size_t kpx_conv3x3_wino_stats_tiles(int N, int H, int W) {
+    return (H % 16 || W % 16 || N <= 0) ? 0 : (size_t)N * (H / 16) * (W / 16);
+}
+extern "C" int kpx_conv3x3_wino_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
+                                          float* out, int Nn, int ldout, int act, float* tile_stats, void* stream) {
+    if (!tile_stats || H % 16 || W % 16) return KPX_EINVAL;       // (8x8 images are packed four to a workgroup: no per-image tiles)
+    return wino_launch(in, N, H, W, K, ldin, U, bias, out, Nn, ldout, act, tile_stats, stream);
+}
+static int wino_launch(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
+                       float* out, int Nn, int ldout, int act, float* tile_stats, void* stream) {
     if (!in || !U || !out || ldin < (K == 4 ? 4 : K) || ldout < Nn || act < 0 || act > 2 || !kpx_conv3x3_wino_eligible(N, H, W, K, Nn, ldin, in)) return KPX_EINVAL;
     hipStream_t s = kpx_stream(stream);
     if (kpx_first_use_on_device(&wino_attr_mask)) {
@@ -422,7 +456,7 @@ extern "C" int kpx_conv3x3_wino_f32(const float* in, int N, int H, int W, int K,
         if (e != hipSuccess) return -(int)e;
     }
     WinoGeom g{};
-    g.x = in; g.y = out; g.U = U; g.bias = bias;
+    g.x = in; g.y = out; g.U = U; g.bias = bias; g.stats = tile_stats;
     g.N = N; g.H = H; g.W = W; g.Cin = K; g.ldx = ldin; g.Cout = Nn; g.ldy = ldout; g.act = act;
     g.Kp = (K + 7) & ~7; g.Np = (Nn + 31) & ~31;
     g.pack = (H == 8 && W == 8) ? 1 : 0;

@@ -272,6 +272,46 @@ extern "C" int kpx_bn_stats_f32(const float* x, size_t P, int C, int ldx, float 
     return kpx_launch_status();
 }
 
+// Batch statistics from the per-tile sums a convolution epilogue wrote (kpx_conv3x3_wino_stats_f32): tile_stats[tile][2][C] floats.
+// One workgroup per channel adds the tiles [tile0, tile0 + ntiles) in a fixed order in fp64 (same tree as kpx_sum_partials).
+__global__ __launch_bounds__(256) void bn_stats_from_tiles_kernel(const float* __restrict__ ts, size_t tile0, size_t ntiles, int C, double count, float eps,
+                                                                 float* mean, float* invstd, float* var_biased, float* mm, float* mv, float decay) {
+    const int c = blockIdx.x;
+    double a0 = 0.0, a1 = 0.0;
+    for (size_t b = threadIdx.x; b < ntiles; b += 256) {
+        a0 += (double)ts[((tile0 + b) * 2) * C + c];
+        a1 += (double)ts[((tile0 + b) * 2 + 1) * C + c];
+    }
+    a0 = kpx_wave_sum_d(a0);
+    a1 = kpx_wave_sum_d(a1);
+    __shared__ double sm[2][4];
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a0; sm[1][threadIdx.x >> 6] = a1; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double s = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]), q = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
+    const double m = s / count;
+    double v = q / count - m * m;
+    if (v < 0.0) v = 0.0;
+    const float mf = (float)m, vf = (float)v;
+    mean[c] = mf;
+    if (var_biased) var_biased[c] = vf;
+    invstd[c] = 1.0f / sqrtf(vf + eps);
+    if (mm && mv) {
+        const float one_minus = 1.0f - decay;
+        const float unb = (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+        mm[c] = mm[c] - (mm[c] - mf) * one_minus;
+        mv[c] = mv[c] - (mv[c] - unb) * one_minus;
+    }
+}
+extern "C" int kpx_bn_stats_from_tiles_f32(const float* tile_stats, size_t tile0, size_t ntiles, int tile_pixels, int C, float eps,
+                                           float* mean, float* invstd, float* var_biased,
+                                           float* moving_mean, float* moving_var, float decay, void* stream) {
+    if (!tile_stats || !mean || !invstd || C <= 0 || ntiles == 0 || tile_pixels <= 0) return KPX_EINVAL;
+    hipLaunchKernelGGL(bn_stats_from_tiles_kernel, dim3(C), dim3(256), 0, kpx_stream(stream), tile_stats, tile0, ntiles, C,
+                       (double)ntiles * (double)tile_pixels, eps, mean, invstd, var_biased, moving_mean, moving_var, decay);
+    return kpx_launch_status();
+}
+
 __global__ void bn_invstd_kernel(const float* var, int C, float eps, float* invstd) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) invstd[c] = 1.0f / sqrtf(var[c] + eps);

@@ -14,7 +14,7 @@ ACT_NONE, ACT_RELU, ACT_LRELU = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LRELU
 EXACT_ZERO_BIAS_GRAD = True      # see conv_bn_relu
 
 
-def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', act=ACT_NONE, cin=None, head31=False, bias_grad=True):
+def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', act=ACT_NONE, cin=None, head31=False, bias_grad=True, bn_stats=False):
     """reference layers.conv (layers.py:4-10): tf.pad(pad) + tf.layers.conv2d(padding='same', xavier, bias)."""
     st = default_store()
     channels = int(channels)          # the reference passes float filter counts after `filters /= 2` ([TF-sem 9])
@@ -29,7 +29,7 @@ def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', 
         return Sym(n, ho, wo, channels)
     w_, wg = st.param(kname)
     b_, bg = st.param(bname) if use_bias else (None, None)
-    return ops.conv2d(x, w_, b_, stride=stride, pad=pad, act=act, cin=cin, w_grad_out=wg, b_grad_out=bg, bias_grad=bias_grad)
+    return ops.conv2d(x, w_, b_, stride=stride, pad=pad, act=act, cin=cin, w_grad_out=wg, b_grad_out=bg, bias_grad=bias_grad, bn_stats=bn_stats)
 
 
 def batch_norm(x, train_mode, scope='batch_norm', act=ACT_NONE, groups=1, update_moving=True):
@@ -56,7 +56,8 @@ def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, 
     zero when a train-mode batch norm follows (the batch mean removes any per-channel constant), so it is not computed: the
     flat gradient bucket holds 0 there and Adam leaves those biases at their initial value.  The reference computes fp32
     rounding noise for them, which its Adam turns into a +-lr random walk that batch norm again cancels in the forward."""
-    x = conv(x, channels, kernel=kernel, stride=stride, scope=conv_scope, cin=cin, bias_grad=not (EXACT_ZERO_BIAS_GRAD and train_mode))
+    x = conv(x, channels, kernel=kernel, stride=stride, scope=conv_scope, cin=cin, bias_grad=not (EXACT_ZERO_BIAS_GRAD and train_mode),
+             bn_stats=bool(train_mode))       # the conv epilogue delivers the batch statistics when it can
     return batch_norm(x, train_mode, scope=bn_scope, act=ACT_RELU, groups=groups, update_moving=update_moving)
 
 

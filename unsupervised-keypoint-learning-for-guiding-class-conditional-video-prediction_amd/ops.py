@@ -236,8 +236,9 @@ def release_filters(keys):
         _wino_u.pop(k, None)
 
 
-def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad):
-    """Run the fused Winograd kernel on a cached U; False when there is none for this filter or the shape is not eligible."""
+def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, want_stats=False):
+    """Run the fused Winograd kernel on a cached U; False when there is none for this filter or the shape is not eligible.
+    want_stats: also have the epilogue write the per-tile batch-norm sums of the output; returns (slab, tiles per image) then."""
     ent = _wino_u.get((w.data_ptr(), 1 if dgrad else 0))
     if ent is None:
         return False
@@ -247,21 +248,30 @@ def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad):
     u, bank = ent
     if bank is not None:
         bank.ensure_fresh()
-    check(lib.kpx_conv3x3_wino_f32(inp.data_ptr(), n, h, wd, k, ld_in, u.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                   out.data_ptr(), nn, ld_out, act, _stream()), 'kpx_conv3x3_wino_f32')
+    bptr = bias.data_ptr() if bias is not None else None
+    if want_stats and h % 16 == 0 and wd % 16 == 0:
+        tiles = lib.kpx_conv3x3_wino_stats_tiles(n, h, wd)
+        slab = torch.empty(tiles * 2 * nn, dtype=torch.float32, device=inp.device)
+        check(lib.kpx_conv3x3_wino_stats_f32(inp.data_ptr(), n, h, wd, k, ld_in, u.data_ptr(), bptr, out.data_ptr(), nn, ld_out, act,
+                                             slab.data_ptr(), _stream()), 'kpx_conv3x3_wino_stats_f32')
+        return slab, tiles // n
+    check(lib.kpx_conv3x3_wino_f32(inp.data_ptr(), n, h, wd, k, ld_in, u.data_ptr(), bptr, out.data_ptr(), nn, ld_out, act, _stream()),
+          'kpx_conv3x3_wino_f32')
     return True
 
 
 # ----------------------------------------------------------------------------------------------- raw launchers
-def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act):
+def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act, want_stats=False):
+    """Returns None, or (tile-statistics slab, tiles per image) when ``want_stats`` and the layer ran on the kernel that provides them."""
     n, hi, wi = x.shape[0], x.shape[1], x.shape[2]
     kh, kw, _, cout = w.shape
     if (_compute_dtype[0] == 'bf16' and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cin >= 8
             and y.shape[1] == hi and y.shape[2] == wi and _bf16_conv(x, ldx, cin, w, bias, y, ldy, cout, act, False)):
         return
-    if (kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and act != ACT_TANH and y.shape[1] == hi and y.shape[2] == wi
-            and _wino_pretransformed(x, ldx, cin, w, bias, y, ldy, cout, act, False)):
-        return
+    if kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and act != ACT_TANH and y.shape[1] == hi and y.shape[2] == wi:
+        r = _wino_pretransformed(x, ldx, cin, w, bias, y, ldy, cout, act, False, want_stats=want_stats)
+        if r:
+            return r if isinstance(r, tuple) else None
     nbytes = lib.kpx_conv2d_fwd_workspace_bytes(n, y.shape[1], y.shape[2], cin, cout, kh, kw)
     ws = scratch.get('splitk', nbytes, x.device) if nbytes else None
     check(lib.kpx_conv2d_fwd_f32(x.data_ptr(), n, hi, wi, cin, ldx, w.data_ptr(), kh, kw,
@@ -339,7 +349,7 @@ class Conv2dFn(torch.autograd.Function):
     """layers.conv: tf.pad(pad) + conv2d(SAME) + bias [+ activation] (reference models/networks/layers.py:4-10)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad):
+    def forward(ctx, x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad, bn_stats=False):
         x, ldx = _nhwc(x)
         _require_gpu(w)
         w = w.contiguous()
@@ -351,7 +361,9 @@ class Conv2dFn(torch.autograd.Function):
         pl, _, wo = same_pad(wd + 2 * pad, kw, stride)
         pad_t, pad_l = pad + pt, pad + pl
         y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
-        conv_fwd_raw(x, ldx, cin, w, b, y, cout, stride, pad_t, pad_l, act)
+        st = conv_fwd_raw(x, ldx, cin, w, b, y, cout, stride, pad_t, pad_l, act, want_stats=bn_stats and act == ACT_NONE)
+        if st is not None:
+            _pending_stats[y.data_ptr()] = st
         ctx.geom = (stride, pad_t, pad_l, act, cin, ldx)
         ctx.has_bias = b is not None and bias_grad
         ctx.w_grad_out, ctx.b_grad_out = w_grad_out, b_grad_out
@@ -405,12 +417,22 @@ class Conv2dFn(torch.autograd.Function):
                 if ctx.b_grad_out is not None and not direct:
                     axpy_raw_(ctx.b_grad_out, db_buf)
                 db = None if ctx.b_grad_out is not None else db_buf
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, cin=None, w_grad_out=None, b_grad_out=None, bias_grad=True):
-    """bias_grad=False: the bias gradient is known to be exactly zero (conv feeding a batch norm) and is not computed."""
-    return Conv2dFn.apply(x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad)
+_pending_stats = {}      # output data_ptr -> (tile-statistics slab, tiles per image), handed from Conv2dFn.forward to conv2d()
+
+
+def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, cin=None, w_grad_out=None, b_grad_out=None, bias_grad=True, bn_stats=False):
+    """bias_grad=False: the bias gradient is known to be exactly zero (conv feeding a batch norm) and is not computed.
+    bn_stats=True: a train-mode batch norm consumes the output next; when the layer runs on the fused Winograd kernel its epilogue
+    also writes the per-tile channel sums, which ``batch_norm`` then uses instead of a statistics pass over the activation."""
+    y = Conv2dFn.apply(x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad, bn_stats)
+    if bn_stats:
+        st = _pending_stats.pop(y.data_ptr(), None)
+        if st is not None:
+            y._kpx_tile_stats = st
+    return y
 
 
 # ----------------------------------------------------------------------------------------------- batch norm
@@ -423,7 +445,7 @@ class BatchNormFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving):
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving, tile_stats=None):
         _require_gpu(x)
         x = x.contiguous()
         n, h, w, c = x.shape
@@ -438,10 +460,16 @@ class BatchNormFn(torch.autograd.Function):
             pix = ng * h * w
             for g in range(groups):
                 xg, yg = x[g * ng:(g + 1) * ng], y[g * ng:(g + 1) * ng]
-                check(lib.kpx_bn_stats_f32(xg.data_ptr(), pix, c, c, BN_EPS, mean[g].data_ptr(), invstd[g].data_ptr(), None,
-                                           moving_mean.data_ptr() if update_moving else None,
-                                           moving_var.data_ptr() if update_moving else None,
-                                           BN_DECAY, sc.data_ptr(), _stream()), 'kpx_bn_stats_f32')
+                mmp = moving_mean.data_ptr() if update_moving else None
+                mvp = moving_var.data_ptr() if update_moving else None
+                if tile_stats is not None:               # sums from the producing convolution's epilogue: no pass over x
+                    slab, tpi = tile_stats
+                    check(lib.kpx_bn_stats_from_tiles_f32(slab.data_ptr(), g * ng * tpi, ng * tpi, (h * w) // tpi, c, BN_EPS,
+                                                          mean[g].data_ptr(), invstd[g].data_ptr(), None, mmp, mvp, BN_DECAY, _stream()),
+                          'kpx_bn_stats_from_tiles_f32')
+                else:
+                    check(lib.kpx_bn_stats_f32(xg.data_ptr(), pix, c, c, BN_EPS, mean[g].data_ptr(), invstd[g].data_ptr(), None,
+                                               mmp, mvp, BN_DECAY, sc.data_ptr(), _stream()), 'kpx_bn_stats_f32')
                 check(lib.kpx_bn_apply_f32(xg.data_ptr(), pix, c, c, mean[g].data_ptr(), invstd[g].data_ptr(),
                                            gamma.data_ptr(), beta.data_ptr(), yg.data_ptr(), c, act, _stream()), 'kpx_bn_apply_f32')
         else:
@@ -481,12 +509,15 @@ class BatchNormFn(torch.autograd.Function):
                                      gamma.data_ptr(), beta.data_ptr(), ctx.act, dx[sl].data_ptr(), c,
                                      dg.data_ptr(), db.data_ptr(), 0 if (g == 0 and fresh) else 1, sc.data_ptr(), _stream()), 'kpx_bn_bwd_f32')
         return (dx, None if ctx.g_grad_out is not None else dg, None if ctx.b_grad_out is not None else db,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None)
 
 
 def batch_norm(x, gamma, beta, moving_mean, moving_var, train=True, act=ACT_RELU, groups=1, update_moving=True,
                g_grad_out=None, b_grad_out=None):
-    return BatchNormFn.apply(x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving)
+    ts = getattr(x, '_kpx_tile_stats', None) if train else None
+    if ts is not None and (x.shape[0] % groups or tuple(ts[0].shape) != (x.shape[0] * ts[1] * 2 * x.shape[3],)):
+        ts = None
+    return BatchNormFn.apply(x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving, ts)
 
 
 # ----------------------------------------------------------------------------------------------- resize + concat
