@@ -123,6 +123,17 @@ int kpx_bn_stats_f32(const float* x, size_t P, int C, int ldx, float eps,
                      float* mean, float* invstd, float* var_biased,
                      float* moving_mean, float* moving_var, float decay,
                      void* scratch, void* stream);
+/* Data gradient of a 3x3 layer whose INPUT was y = relu(BN(x)): out = dgrad (written as usual) and, per 16x16-pixel tile and channel,
+ * tile_stats[tile][2][Nn] = sum(dz), sum(dz * (bn_y - bn_beta)) with dz = out * [bn_y > 0] -- the two reductions of that batch norm's
+ * backward (bn_y: its output at the same pixels / channels, pixel stride ld_bn_y).  kpx_bn_bwd_from_tiles_f32 consumes them. */
+int kpx_conv3x3_wino_bnbwd_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u,
+                                     float* out, int Nn, int ldout, const float* bn_y, int ld_bn_y, const float* bn_beta,
+                                     float* tile_stats, void* stream);
+/* kpx_bn_bwd_f32 (act must be KPX_ACT_RELU) with the channel reductions taken from those tile sums over tiles [tile0, tile0+ntiles). */
+int kpx_bn_bwd_from_tiles_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int C,
+                              const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                              float* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
+                              const float* tile_stats, size_t tile0, size_t ntiles, void* scratch, void* stream);
 /* kpx_bn_stats_f32 from per-tile sums (tile_stats[tile][2][C], `tile_pixels` pixels per tile) over tiles [tile0, tile0 + ntiles):
  * fp64 fixed-order reduction; same outputs and moving-statistics rule. */
 int kpx_bn_stats_from_tiles_f32(const float* tile_stats, size_t tile0, size_t ntiles, int tile_pixels, int C, float eps,

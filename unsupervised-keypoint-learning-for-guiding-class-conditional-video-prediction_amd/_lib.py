@@ -47,6 +47,8 @@ SIGNATURES = {
     'kpx_conv3x3_wino_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
     'kpx_conv3x3_wino_stats_tiles': (c_size_t, [c_int, c_int, c_int]),
     'kpx_conv3x3_wino_stats_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P, P]),
+    'kpx_conv3x3_wino_bnbwd_stats_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, c_int, P, P, P]),
+    'kpx_bn_bwd_from_tiles_f32': (c_int, [P, c_int, P, c_int, c_size_t, c_int, P, P, P, P, c_int, P, c_int, P, P, c_int, P, c_size_t, c_size_t, P, P]),
     'kpx_bn_stats_from_tiles_f32': (c_int, [P, c_size_t, c_size_t, c_int, c_int, c_float, P, P, P, P, P, c_float, P]),
     'kpx_conv3x3_bf16_weights_bytes': (c_size_t, [c_int, c_int]),
     'kpx_conv3x3_bf16_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P]),

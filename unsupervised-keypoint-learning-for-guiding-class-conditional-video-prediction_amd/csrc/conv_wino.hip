@@ -25,6 +25,8 @@ struct WinoGeom {
     int tiles_y, tiles_x, nt;          // 16x16-pixel blocks per image, cout tiles of 32
     int stagger;                       // v2: wavefronts 4-7 run the MFMA half of a chunk first
     float* stats;                      // optional [N * tiles][2][Cout]: per-tile, per-channel sum and sum of squares of the OUTPUT (batch-norm statistics)
+    const float* mask_y; int ld_mask;  // optional (data gradient feeding a ReLU'd batch norm): y of that batch norm at the output's pixels / channels ...
+    const float* bn_beta;              // ... and its beta: stats become sum(dz), sum(dz * (y - beta)) with dz = out * [y > 0]
 };
 
 static __device__ __attribute__((aligned(16))) float wino_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -287,6 +289,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) 
             P[((wa * 2 + 1) * 64 + tile) * NC + col] = m1 - m2 - m3;
         }
     }
+    // (data gradient feeding a ReLU'd batch norm) that batch norm's output at this thread's pixels: issued now, so the loads fly
+    // under the barrier and the P reads instead of stalling the statistics code at the end of the epilogue
+    const bool mask_vec = g.mask_y && (g.ld_mask & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.mask_y) & 15) == 0);
+    f32x4 ym[MODE][4];
+    if (g.mask_y) {
+#pragma unroll
+        for (int it = 0; it < MODE; ++it) {
+            const int idx = t + 512 * it;
+            const int tile = idx / (NC / 4), cq = idx - tile * (NC / 4), c0 = n0 + cq * 4;
+            const int oy = oy0 + 2 * (tile >> 3), ox = ox0 + 2 * (tile & 7);
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const float* my = g.mask_y + ((size_t)(n * g.H + oy + (px >> 1)) * g.W + ox + (px & 1)) * g.ld_mask + c0;
+                ym[it][px] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (mask_vec && c0 + 3 < g.Cout) ym[it][px] = *reinterpret_cast<const f32x4*>(my);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (c0 + e < g.Cout) ym[it][px][e] = my[e];
+                }
+            }
+        }
+    }
     __syncthreads();
     const bool vec_ok = (g.ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.y) & 15) == 0);
     f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};      // this thread's 4 couts: sum / sum of squares over its pixels
@@ -305,6 +329,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (c0 + e < g.Cout) bv[e] = g.bias[c0 + e];
         }
+        f32x4 bvec = {0.f, 0.f, 0.f, 0.f};
+        if (g.mask_y) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (c0 + e < g.Cout) bvec[e] = g.bn_beta[c0 + e];
+        }
         const int ty = tile >> 3, tx = tile & 7;
         const int on = g.pack ? n + 2 * (ty >> 2) + (tx >> 2) : n;
         const int oy = g.pack ? 2 * (ty & 3) : oy0 + 2 * ty, ox = g.pack ? 2 * (tx & 3) : ox0 + 2 * tx;
@@ -320,7 +349,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
                 }
-                st_s += v; st_q += v * v;
+                if (g.mask_y) {
+                    const f32x4 yv = ym[it][dy * 2 + dx];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dz = yv[e] > 0.f ? v[e] : 0.f;
+                        st_s[e] += dz; st_q[e] += dz * (yv[e] - bvec[e]);
+                    }
+                } else { st_s += v; st_q += v * v; }
                 float* o = g.y + ((size_t)(on * g.H + oy + dy) * g.W + ox + dx) * g.ldy + c0;
                 if (vec_ok && c0 + 3 < g.Cout) *reinterpret_cast<f32x4*>(o) = v;
                 else {
@@ -433,7 +469,8 @@ extern "C" int kpx_wino_filter_transform_batch_f32(const void* descs_dev, int n,
 
 // forward: in = x (K = Cin), out = y (Nn = Cout);  dgrad: in = dy (K = Cout), out = dx (Nn = Cin); U: fragment-ordered filters for (K, Nn)
 static int wino_launch(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
-                       float* out, int Nn, int ldout, int act, float* tile_stats, void* stream);
+                       float* out, int Nn, int ldout, int act, float* tile_stats, void* stream,
+                       const float* mask_y = nullptr, int ld_mask = 0, const float* bn_beta = nullptr);
 extern "C" int kpx_conv3x3_wino_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
                                     float* out, int Nn, int ldout, int act, void* stream) {
     return wino_launch(in, N, H, W, K, ldin, U, bias, out, Nn, ldout, act, nullptr, stream);
@@ -446,8 +483,15 @@ extern "C" int kpx_conv3x3_wino_stats_f32(const float* in, int N, int H, int W, 
     if (!tile_stats || H % 16 || W % 16) return KPX_EINVAL;       // (8x8 images are packed four to a workgroup: no per-image tiles)
     return wino_launch(in, N, H, W, K, ldin, U, bias, out, Nn, ldout, act, tile_stats, stream);
 }
+extern "C" int kpx_conv3x3_wino_bnbwd_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U,
+                                                float* out, int Nn, int ldout, const float* bn_y, int ld_bn_y, const float* bn_beta,
+                                                float* tile_stats, void* stream) {
+    if (!tile_stats || !bn_y || !bn_beta || ld_bn_y < Nn || H % 16 || W % 16) return KPX_EINVAL;
+    return wino_launch(in, N, H, W, K, ldin, U, nullptr, out, Nn, ldout, KPX_ACT_NONE, tile_stats, stream, bn_y, ld_bn_y, bn_beta);
+}
 static int wino_launch(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
-                       float* out, int Nn, int ldout, int act, float* tile_stats, void* stream) {
+                       float* out, int Nn, int ldout, int act, float* tile_stats, void* stream,
+                       const float* mask_y, int ld_mask, const float* bn_beta) {
     if (!in || !U || !out || ldin < (K == 4 ? 4 : K) || ldout < Nn || act < 0 || act > 2 || !kpx_conv3x3_wino_eligible(N, H, W, K, Nn, ldin, in)) return KPX_EINVAL;
     hipStream_t s = kpx_stream(stream);
     if (kpx_first_use_on_device(&wino_attr_mask)) {
@@ -457,6 +501,7 @@ static int wino_launch(const float* in, int N, int H, int W, int K, int ldin, co
     }
     WinoGeom g{};
     g.x = in; g.y = out; g.U = U; g.bias = bias; g.stats = tile_stats;
+    g.mask_y = mask_y; g.ld_mask = ld_mask; g.bn_beta = bn_beta;
     g.N = N; g.H = H; g.W = W; g.Cin = K; g.ldx = ldin; g.Cout = Nn; g.ldy = ldout; g.act = act;
     g.Kp = (K + 7) & ~7; g.Np = (Nn + 31) & ~31;
     g.pack = (H == 8 && W == 8) ? 1 : 0;

@@ -272,6 +272,29 @@ extern "C" int kpx_bn_stats_f32(const float* x, size_t P, int C, int ldx, float 
     return kpx_launch_status();
 }
 
+// Batch-norm backward sums from per-tile sums written by the epilogue of the data-gradient kernel that PRODUCED dy
+// (kpx_conv3x3_wino_bnbwd_stats_f32): tile_stats[tile][2][C] = sum(dz), sum(dz * (y - beta)); x_hat = (y - beta) / gamma wherever dz != 0.
+__global__ __launch_bounds__(256) void bn_bwd_from_tiles_kernel(const float* __restrict__ ts, size_t tile0, size_t ntiles, int C,
+                                                               const float* __restrict__ gamma, float* dgamma, float* dbeta, float* sums, int accumulate) {
+    const int c = blockIdx.x;
+    double a0 = 0.0, a1 = 0.0;
+    for (size_t b = threadIdx.x; b < ntiles; b += 256) {
+        a0 += (double)ts[((tile0 + b) * 2) * C + c];
+        a1 += (double)ts[((tile0 + b) * 2 + 1) * C + c];
+    }
+    a0 = kpx_wave_sum_d(a0);
+    a1 = kpx_wave_sum_d(a1);
+    __shared__ double sm[2][4];
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a0; sm[1][threadIdx.x >> 6] = a1; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double s = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]);
+    const double ga = (double)gamma[c];
+    const double q = ga != 0.0 ? ((sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3])) / ga : 0.0;
+    if (accumulate) { dbeta[c] += (float)s; dgamma[c] += (float)q; } else { dbeta[c] = (float)s; dgamma[c] = (float)q; }
+    sums[c] = (float)s; sums[C + c] = (float)q;
+}
+
 // Batch statistics from the per-tile sums a convolution epilogue wrote (kpx_conv3x3_wino_stats_f32): tile_stats[tile][2][C] floats.
 // One workgroup per channel adds the tiles [tile0, tile0 + ntiles) in a fixed order in fp64 (same tree as kpx_sum_partials).
 __global__ __launch_bounds__(256) void bn_stats_from_tiles_kernel(const float* __restrict__ ts, size_t tile0, size_t ntiles, int C, double count, float eps,
@@ -492,6 +515,27 @@ extern "C" int kpx_bn_bwd_f32(const float* dy, int lddy, const float* x, int ldx
     float* sums = reinterpret_cast<float*>((double*)scratch + (size_t)KPX_RED_BLOCKS * 2 * C);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, s, (const double*)scratch, nb, C, dgamma, dbeta, sums, accumulate);
     rc = kpx_launch_status();
+    if (rc) return rc;
+    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) &&
+                     ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
+    const float inv_count = (float)(1.0 / (double)P);
+    if (vec) hipLaunchKernelGGL(bn_bwd_apply_strip_kernel, strip_grid(P, C), dim3(256), 0, s, dy, lddy, x, ldx, P, C, mean, invstd, gamma, beta, act, sums, inv_count, dx, lddx);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(P * C)), dim3(256), 0, s, dy, lddy, x, ldx, P, C, mean, invstd, gamma, beta, act, sums, inv_count, dx, lddx);
+    return kpx_launch_status();
+}
+
+/* kpx_bn_bwd_f32 with the two channel reductions taken from per-tile sums (see bn_bwd_from_tiles_kernel) instead of a pass over (dy, x). */
+extern "C" int kpx_bn_bwd_from_tiles_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int C,
+                                         const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                                         float* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
+                                         const float* tile_stats, size_t tile0, size_t ntiles, void* scratch, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !scratch || !tile_stats || C <= 0 ||
+        ldx < C || lddy < C || lddx < C || act != KPX_ACT_RELU || P == 0 || ntiles == 0)
+        return KPX_EINVAL;
+    hipStream_t s = kpx_stream(stream);
+    float* sums = reinterpret_cast<float*>((double*)scratch + (size_t)KPX_RED_BLOCKS * 2 * C);
+    hipLaunchKernelGGL(bn_bwd_from_tiles_kernel, dim3(C), dim3(256), 0, s, tile_stats, tile0, ntiles, C, gamma, dgamma, dbeta, sums, accumulate);
+    int rc = kpx_launch_status();
     if (rc) return rc;
     const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) &&
                      ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;

@@ -84,6 +84,11 @@ scratch = _Scratch()
 # HIP stream where they fill the ramp-up / tail gaps of the dgrad chain on the main stream.  join_side_stream() is called
 # before the gradient exchange / Adam update.  KPX_SIDE_WGRAD=0 disables it.
 SIDE_WGRAD = _os.environ.get('KPX_SIDE_WGRAD', '1') != '0'
+FUSE_BN_STATS = _os.environ.get('KPX_FUSE_BN_STATS', '1') != '0'     # batch statistics from the conv epilogue
+# batch-norm backward sums from the dgrad epilogue: built and tested, OFF by default -- measured 31.4-31.7 ms per step against
+# 31.3 ms without it: the reduction passes it removes ran concurrently with the weight-gradient stream, while the longer
+# epilogue sits on the MFMA-bound critical path
+FUSE_BN_BWD = _os.environ.get('KPX_FUSE_BN_BWD', '0') != '0'
 _side_streams = {}
 _side_dirty = set()
 _side_keep = []          # tensors read by kernels on the side stream: kept alive until join_side_stream() (cheaper than
@@ -110,6 +115,7 @@ def begin_backward():
     _grad_epoch[0] += 1
     if len(_grad_written) > 4096:
         _grad_written.clear()
+    _pending_bwd_stats.clear()
 
 
 def _claim_grad(dst):
@@ -236,7 +242,7 @@ def release_filters(keys):
         _wino_u.pop(k, None)
 
 
-def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, want_stats=False):
+def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, want_stats=False, bn_src=None):
     """Run the fused Winograd kernel on a cached U; False when there is none for this filter or the shape is not eligible.
     want_stats: also have the epilogue write the per-tile batch-norm sums of the output; returns (slab, tiles per image) then."""
     ent = _wino_u.get((w.data_ptr(), 1 if dgrad else 0))
@@ -249,6 +255,14 @@ def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, wa
     if bank is not None:
         bank.ensure_fresh()
     bptr = bias.data_ptr() if bias is not None else None
+    if bn_src is not None and dgrad and h % 16 == 0 and wd % 16 == 0:
+        bn_y, beta = bn_src                              # the gathered tensor's consumer-side twin: y = relu(BN(.)) that this conv read
+        tiles = lib.kpx_conv3x3_wino_stats_tiles(n, h, wd)
+        slab = torch.empty(tiles * 2 * nn, dtype=torch.float32, device=inp.device)
+        check(lib.kpx_conv3x3_wino_bnbwd_stats_f32(inp.data_ptr(), n, h, wd, k, ld_in, u.data_ptr(), out.data_ptr(), nn, ld_out,
+                                                   bn_y.data_ptr(), bn_y.shape[3], beta.data_ptr(), slab.data_ptr(), _stream()),
+              'kpx_conv3x3_wino_bnbwd_stats_f32')
+        return slab, tiles // n
     if want_stats and h % 16 == 0 and wd % 16 == 0:
         tiles = lib.kpx_conv3x3_wino_stats_tiles(n, h, wd)
         slab = torch.empty(tiles * 2 * nn, dtype=torch.float32, device=inp.device)
@@ -281,15 +295,18 @@ def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act, want_s
           'kpx_conv2d_fwd_f32')
 
 
-def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l):
+def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l, bn_src=None):
+    """bn_src = (y, beta) of the ReLU'd batch norm whose output this convolution read: when the layer runs on the fused Winograd kernel
+    its epilogue also reduces that batch norm's backward sums; returns (slab, tiles per image) then, else None."""
     n, ho, wo = dy.shape[0], dy.shape[1], dy.shape[2]
     kh, kw, _, cout = w.shape
     if (_compute_dtype[0] == 'bf16' and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cout >= 8
             and dx.shape[1] == ho and dx.shape[2] == wo and _bf16_conv(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True)):
         return
-    if (kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and dx.shape[1] == ho and dx.shape[2] == wo
-            and _wino_pretransformed(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True)):
-        return
+    if kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and dx.shape[1] == ho and dx.shape[2] == wo:
+        r = _wino_pretransformed(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True, bn_src=bn_src)
+        if r:
+            return r if isinstance(r, tuple) else None
     nbytes = lib.kpx_conv2d_dgrad_workspace_bytes(n, dx.shape[1], dx.shape[2], cin, cout, kh, kw, stride)
     ws = scratch.get('splitk', nbytes, dy.device) if nbytes else None
     check(lib.kpx_conv2d_dgrad_f32(dy.data_ptr(), n, ho, wo, cout, lddy, w.data_ptr(), kh, kw,
@@ -349,8 +366,9 @@ class Conv2dFn(torch.autograd.Function):
     """layers.conv: tf.pad(pad) + conv2d(SAME) + bias [+ activation] (reference models/networks/layers.py:4-10)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad, bn_stats=False):
+    def forward(ctx, x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad, bn_stats=False, bn_src=None):
         x, ldx = _nhwc(x)
+        ctx.bn_src = bn_src if (bn_src is not None and x.is_contiguous() and (cin is None or cin == x.shape[3])) else None
         _require_gpu(w)
         w = w.contiguous()
         n, h, wd, cx = x.shape
@@ -386,7 +404,10 @@ class Conv2dFn(torch.autograd.Function):
             dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
             if cin < cx:
                 fill_raw_(dx, 0.0)
-            conv_dgrad_raw(dy, cout, w, dx, cx, cin, stride, pad_t, pad_l)
+            st = conv_dgrad_raw(dy, cout, w, dx, cx, cin, stride, pad_t, pad_l,
+                                bn_src=(x, ctx.bn_src[0]) if ctx.bn_src is not None else None)
+            if st is not None:
+                _pending_bwd_stats[dx.data_ptr()] = (st[0], st[1], ctx.bn_src[1])
         want_w = ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
         # side stream only when the gradient goes straight into the flat bucket (nobody on the main stream reads it
@@ -417,17 +438,21 @@ class Conv2dFn(torch.autograd.Function):
                 if ctx.b_grad_out is not None and not direct:
                     axpy_raw_(ctx.b_grad_out, db_buf)
                 db = None if ctx.b_grad_out is not None else db_buf
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 _pending_stats = {}      # output data_ptr -> (tile-statistics slab, tiles per image), handed from Conv2dFn.forward to conv2d()
+_pending_bwd_stats = {}  # dx data_ptr -> (slab, tiles per image, id of the batch norm it belongs to), from Conv2dFn.backward to BatchNormFn.backward
+_bn_counter = [0]
+fused_bn_uses = {'stats_from_conv_epilogue': 0, 'backward_sums_from_dgrad_epilogue': 0}    # diagnostics: how often the fused paths ran
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, cin=None, w_grad_out=None, b_grad_out=None, bias_grad=True, bn_stats=False):
     """bias_grad=False: the bias gradient is known to be exactly zero (conv feeding a batch norm) and is not computed.
     bn_stats=True: a train-mode batch norm consumes the output next; when the layer runs on the fused Winograd kernel its epilogue
     also writes the per-tile channel sums, which ``batch_norm`` then uses instead of a statistics pass over the activation."""
-    y = Conv2dFn.apply(x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad, bn_stats)
+    y = Conv2dFn.apply(x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad, bn_stats and FUSE_BN_STATS,
+                       getattr(x, '_kpx_bn', None) if FUSE_BN_BWD else None)
     if bn_stats:
         st = _pending_stats.pop(y.data_ptr(), None)
         if st is not None:
@@ -445,7 +470,8 @@ class BatchNormFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving, tile_stats=None):
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving, tile_stats=None, bn_id=0):
+        ctx.bn_id = bn_id
         _require_gpu(x)
         x = x.contiguous()
         n, h, w, c = x.shape
@@ -464,6 +490,7 @@ class BatchNormFn(torch.autograd.Function):
                 mvp = moving_var.data_ptr() if update_moving else None
                 if tile_stats is not None:               # sums from the producing convolution's epilogue: no pass over x
                     slab, tpi = tile_stats
+                    fused_bn_uses['stats_from_conv_epilogue'] += 1
                     check(lib.kpx_bn_stats_from_tiles_f32(slab.data_ptr(), g * ng * tpi, ng * tpi, (h * w) // tpi, c, BN_EPS,
                                                           mean[g].data_ptr(), invstd[g].data_ptr(), None, mmp, mvp, BN_DECAY, _stream()),
                           'kpx_bn_stats_from_tiles_f32')
@@ -502,14 +529,23 @@ class BatchNormFn(torch.autograd.Function):
             fresh = _claim_grad(ctx.g_grad_out)
             _claim_grad(ctx.b_grad_out)
         sc = scratch.reduce(c, dev)
+        ent = _pending_bwd_stats.pop(dy.data_ptr(), None)        # sums reduced by the epilogue of the dgrad kernel that produced dy
+        if ent is not None and (ent[2] != ctx.bn_id or ctx.act != ACT_RELU or tuple(ent[0].shape) != (n * ent[1] * 2 * c,)):
+            ent = None
         for g in range(groups):
             sl = slice(g * ng, (g + 1) * ng)
-            # later groups (and a variable already written in this backward epoch) accumulate inside the finalize kernel
-            check(lib.kpx_bn_bwd_f32(dy[sl].data_ptr(), c, x[sl].data_ptr(), c, pix, c, mean[g].data_ptr(), invstd[g].data_ptr(),
-                                     gamma.data_ptr(), beta.data_ptr(), ctx.act, dx[sl].data_ptr(), c,
-                                     dg.data_ptr(), db.data_ptr(), 0 if (g == 0 and fresh) else 1, sc.data_ptr(), _stream()), 'kpx_bn_bwd_f32')
+            acc = 0 if (g == 0 and fresh) else 1        # later groups (and a variable already written this epoch) accumulate in the finalize kernel
+            if ent is not None:
+                fused_bn_uses['backward_sums_from_dgrad_epilogue'] += 1
+                check(lib.kpx_bn_bwd_from_tiles_f32(dy[sl].data_ptr(), c, x[sl].data_ptr(), c, pix, c, mean[g].data_ptr(), invstd[g].data_ptr(),
+                                                    gamma.data_ptr(), beta.data_ptr(), ctx.act, dx[sl].data_ptr(), c, dg.data_ptr(), db.data_ptr(), acc,
+                                                    ent[0].data_ptr(), g * ng * ent[1], ng * ent[1], sc.data_ptr(), _stream()), 'kpx_bn_bwd_from_tiles_f32')
+            else:
+                check(lib.kpx_bn_bwd_f32(dy[sl].data_ptr(), c, x[sl].data_ptr(), c, pix, c, mean[g].data_ptr(), invstd[g].data_ptr(),
+                                         gamma.data_ptr(), beta.data_ptr(), ctx.act, dx[sl].data_ptr(), c,
+                                         dg.data_ptr(), db.data_ptr(), acc, sc.data_ptr(), _stream()), 'kpx_bn_bwd_f32')
         return (dx, None if ctx.g_grad_out is not None else dg, None if ctx.b_grad_out is not None else db,
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
 
 
 def batch_norm(x, gamma, beta, moving_mean, moving_var, train=True, act=ACT_RELU, groups=1, update_moving=True,
@@ -517,7 +553,11 @@ def batch_norm(x, gamma, beta, moving_mean, moving_var, train=True, act=ACT_RELU
     ts = getattr(x, '_kpx_tile_stats', None) if train else None
     if ts is not None and (x.shape[0] % groups or tuple(ts[0].shape) != (x.shape[0] * ts[1] * 2 * x.shape[3],)):
         ts = None
-    return BatchNormFn.apply(x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving, ts)
+    _bn_counter[0] += 1
+    y = BatchNormFn.apply(x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving, ts, _bn_counter[0])
+    if train and act == ACT_RELU:
+        y._kpx_bn = (beta.detach(), _bn_counter[0])      # a 3x3 conv reading y can reduce this batch norm's backward sums in its dgrad epilogue
+    return y
 
 
 # ----------------------------------------------------------------------------------------------- resize + concat
