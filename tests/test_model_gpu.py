@@ -553,3 +553,38 @@ def test_bf16_mode_forward_and_train_step_tolerance():
         assert abs(got[key] - want[key]) <= 2e-2 * max(1.0, abs(want[key])), (key, got[key], want[key])
     assert g_cos > 0.3                      # direction check only (see the docstring)
     assert fr_err > 1e-5                    # the bf16 kernels really ran
+
+
+def test_exact_zero_bias_grad_switch_both_ways():
+    """layers.EXACT_ZERO_BIAS_GRAD (default True): biases of convs that feed a train-mode batch norm get gradient exactly 0 (their true
+    value) and stay at their initial 0.  With the switch off the bias gradient is computed like the reference does (fp32 rounding noise,
+    |g| tiny) and Adam walks the bias by +-lr per step, exactly as the CPU restatement's biases do; the forward is unaffected either way
+    because the batch norm cancels the bias."""
+    from kpx_amd import layers
+    dev = torch.device('cuda:0')
+    res, k, b = 32, 3, 2
+    im, fut = R.synthetic_pair(b, res=res, seed0=21, seed1=22)
+    feed = {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}
+    outs = {}
+    for flag in (True, False):
+        layers.EXACT_ZERO_BIAS_GRAD = flag
+        try:
+            model = make_model(res, k, b, dev)
+            model.train_step(None, feed, 0, b)
+            outs[flag] = (model.loss_values(), model.last['fwd']['final_output'].cpu().numpy(), model.store.export_numpy())
+        finally:
+            layers.EXACT_ZERO_BIAS_GRAD = True
+    for key in ('loss_D', 'loss_G'):
+        assert outs[True][0][key] == outs[False][0][key]                       # same forward, same losses, bit for bit
+    assert np.array_equal(outs[True][1], outs[False][1])
+    names = [n for n in outs[True][2] if _bias_before_bn(n) and not n.startswith('pose_encoder/conv_0')]
+    assert len(names) == 8 + 8 + 14 + 10
+    for n in names:
+        assert np.all(outs[True][2][n] == 0.0), n                                # exact: never moved
+        walked = outs[False][2][n]
+        assert np.all(np.abs(walked) <= 1.01e-4), n                              # reference behaviour: each element moved by at most lr ...
+    moved = sum(float(np.count_nonzero(outs[False][2][n])) for n in names) / sum(outs[False][2][n].size for n in names)
+    assert moved > 0.5                                                           # ... and most of them did (Adam's first step is lr * sign(g))
+    for n in outs[True][2]:                                                      # everything else is identical
+        if n not in names and not n.endswith('/bias'):
+            assert np.array_equal(outs[True][2][n], outs[False][2][n]), n

@@ -74,7 +74,7 @@ def _train_motion_generator(args, config, dev, rank, world):
         feed = next(train_it) if train_it is not None else synthetic(step * world + rank)
         model.train_step(None, feed, step, batch_size, should_write_log=step % train_config['log_interval'] == 0 and rank == 0)
         if step % train_config['checkpoint_interval'] == 0 and rank == 0:
-            model.save_checkpoint(None, step)
+            model.save_checkpoint(None, step, fmt=args.ckpt_format)
         if step % train_config['test_interval'] == 0 and rank == 0:
             feeds = test_batches() if test_batches is not None else [synthetic(10 ** 6)]
             model.collect_test_results([model.test_step(None, f, step, i, f['keypoints'].shape[0]) for i, f in enumerate(feeds)], step)
@@ -89,6 +89,10 @@ def main(argv=None):
     parser.add_argument('--synthetic', action='store_true', help='synthetic Penn-shaped pairs instead of the JPEG pipeline')
     parser.add_argument('--synthetic-vgg', action='store_true', help='He-normal VGG19 weights when paths.vggnet is absent')
     parser.add_argument('--steps', type=int, default=None, help='override training.n_steps')
+    parser.add_argument('--ckpt-format', choices=['npz', 'tf'], default=os.environ.get('KPX_CKPT_FORMAT', 'npz'),
+                        help="checkpoint container: 'tf' = TensorFlow V2 bundle (model.ckpt-N.index / .data-00000-of-00001 + `checkpoint`, the "
+                             "layout tf.train.Saver writes and the reference restores, models/base_model.py:74-91); 'npz' (default) = one "
+                             "numpy archive with the same variable names -- readable by this repo only")
     parser.add_argument('--batch-per-run', action='store_true',
                         help="feed a NEW batch to the G update like the reference's two sess.run (train.py:46-50); default: one batch per "
                              'step with a shared generator forward')
@@ -150,7 +154,7 @@ def main(argv=None):
         model.train_step(None, feed_dict, step, batch_size, should_write_log=should_write_log and rank == 0,
                          should_write_summary=False)
         if step % train_config['checkpoint_interval'] == 0 and rank == 0:
-            model.save_checkpoint(None, step)
+            model.save_checkpoint(None, step, fmt=args.ckpt_format)
         if step % train_config['test_interval'] == 0 and rank == 0:
             if test_it is not None:                  # reference train.py:97-110: one pass over the test subset
                 results = [model.test_step(None, fd, step, i, fd['image'].shape[0]) for i, fd in enumerate(test_it())]
