@@ -67,6 +67,19 @@ def _time_conv_3_1(dev, pretransformed=False):
     return ms, 2.0 * 603979776 * n
 
 
+def _rocprof_avg_ms(kernel_substr, csv_name='r02_roofline_only_kernel_stats.csv'):
+    """Average kernel duration from the committed rocprofv3 --kernel-trace --stats summary of `bench.py --roofline-only` (same command, same
+    kernels): the live HIP-event figure includes the launch-to-launch gap (~1.5-3 us), which matters for a 12 us kernel."""
+    import csv
+    try:
+        for r in csv.DictReader(open(os.path.join(ROOT, 'profiles', csv_name))):
+            if kernel_substr in r['Name']:
+                return round(float(r['AverageNs']) / 1e6, 5), 'profiles/' + csv_name
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
 def _pmc_traffic(name):
     """HBM bytes per launch from a committed rocprofv3 PMC summary of this same kernel / shape (profiles/<name>); the
     counters cannot be collected inside a normal bench run, so the JSON line names the file they come from."""
@@ -88,7 +101,9 @@ def roofline_conv(dev):
     alg = flops / (ms * 1e-3) / 1e12
     ach = alg / 2.25
     traffic, src = _pmc_traffic(WINO_PMC)
-    return {'bound': 'mfma', 'kernel': 'conv_wino_v2_kernel<2> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), filter pre-transformed as in the train step',
+    rp_ms, rp_src = _rocprof_avg_ms('conv_wino_v2_kernel<2, 0>')
+    return {'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'frac_at_rocprof_avg': round(flops / 2.25 / (rp_ms * 1e-3) / 157.3e12, 4) if rp_ms else None,
+            'bound': 'mfma', 'kernel': 'conv_wino_v2_kernel<2, 0> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), filter pre-transformed as in the train step',
             'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4),
             'traffic': traffic, 'traffic_source': src, 'avg_launch_ms': round(ms, 4),
             'flops_per_launch_executed': flops / 2.25, 'flops_per_launch_algorithmic': flops,
@@ -144,7 +159,10 @@ def roofline_render(dev):
     nbytes = b * (RES * RES * K_PTS * 4 + K_PTS * 8)
     ach = nbytes / (ms * 1e-3) / 1e9
     traffic, src = _pmc_traffic(RENDER_PMC)
-    return {'bound': 'hbm', 'kernel': 'gauss_fwd kernel [64,128,128,15] (current+future maps of 32 pairs), 9 rotating outputs', 'achieved': round(ach, 1),
+    rp_ms, rp_src = _rocprof_avg_ms('gauss_fwd_reg_kernel')
+    return {'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'frac_at_rocprof_avg': round(nbytes / (rp_ms * 1e-3) / 8e12, 4) if rp_ms else None,
+            'avg_launch_ms_note': 'HIP events over back-to-back launches include the launch-to-launch gap of this 12 us kernel',
+            'bound': 'hbm', 'kernel': 'gauss_fwd kernel [64,128,128,15] (current+future maps of 32 pairs), 9 rotating outputs', 'achieved': round(ach, 1),
             'peak': 8000.0, 'unit': 'GB/s', 'frac': round(ach / 8000.0, 4), 'traffic': traffic, 'traffic_source': src,
             'avg_launch_ms': round(ms, 5), 'bytes_per_launch': nbytes}
 

@@ -26,7 +26,7 @@ for f, dst in (('bench.json', 'r02_bench.json'), ('bench_bf16.json', 'r02_bench_
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(O + '/pmc_*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
-        for key, tag in (('conv_wino_v2_kernel<2>', 'wino'), ('gauss_fwd', 'render'), ('conv3x3_bf16_kernel', 'bf16'), ('conv_igemm_kernel<128, 128', 'direct')):
+        for key, tag in (('conv_wino_v2_kernel<2, 0>', 'wino'), ('gauss_fwd', 'render'), ('conv3x3_bf16_kernel', 'bf16'), ('conv_igemm_kernel<128, 128', 'direct')):
             if key in r['Kernel_Name']:
                 pmc[tag][r['Counter_Name']].append(float(r['Counter_Value']))
 def mean(v): return sum(v) / len(v) if v else None
@@ -39,7 +39,7 @@ w, r = out.get('wino', {}), out.get('render', {})
 if w.get('FETCH_SIZE') is not None and w.get('WRITE_SIZE') is not None:
     # guide: FETCH_SIZE is in KB and counts 64 B per 128-B request on gfx950 wide reads -> x2; WRITE_SIZE (KB) is exact for 16-B stores
     fetch, write = w['FETCH_SIZE'] * 1024 * 2, w['WRITE_SIZE'] * 1024
-    json.dump({'kernel': 'conv_wino_v2_kernel<2> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
+    json.dump({'kernel': 'conv_wino_v2_kernel<2, 0> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
                'source': 'rocprofv3 --pmc, separate passes (profiles/collect_r02.sh), mean over the dispatches of `bench.py --roofline-only`',
                **{k: v for k, v in w.items() if k != 'dispatches'}, 'dispatches': w['dispatches'],
                'fetch_bytes_corrected': fetch, 'write_bytes': write, 'algorithmic_bytes': 134807552,

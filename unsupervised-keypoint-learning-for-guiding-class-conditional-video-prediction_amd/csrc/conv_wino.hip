@@ -100,7 +100,8 @@ extern "C" int kpx_debug_wino_stamps(unsigned long long* buf) { return -(int)hip
 #define W2_STAMP(slot) do { } while (0)
 #endif
 
-template <int MODE>
+// STATS 0: plain; 1: per-tile sum / sum of squares of the output (batch-norm statistics); 2: batch-norm backward sums (g.mask_y, g.bn_beta)
+template <int MODE, int STATS>
 __global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NC = 32 * MODE, NTG = MODE;
@@ -291,9 +292,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) 
     }
     // (data gradient feeding a ReLU'd batch norm) that batch norm's output at this thread's pixels: issued now, so the loads fly
     // under the barrier and the P reads instead of stalling the statistics code at the end of the epilogue
-    const bool mask_vec = g.mask_y && (g.ld_mask & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.mask_y) & 15) == 0);
+    const bool mask_vec = STATS == 2 && (g.ld_mask & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.mask_y) & 15) == 0);
     f32x4 ym[MODE][4];
-    if (g.mask_y) {
+    if (STATS == 2) {
 #pragma unroll
         for (int it = 0; it < MODE; ++it) {
             const int idx = t + 512 * it;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) 
             for (int e = 0; e < 4; ++e) if (c0 + e < g.Cout) bv[e] = g.bias[c0 + e];
         }
         f32x4 bvec = {0.f, 0.f, 0.f, 0.f};
-        if (g.mask_y) {
+        if (STATS == 2) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) if (c0 + e < g.Cout) bvec[e] = g.bn_beta[c0 + e];
         }
@@ -349,14 +350,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) 
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
                 }
-                if (g.mask_y) {
+                if (STATS == 2) {
                     const f32x4 yv = ym[it][dy * 2 + dx];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float dz = yv[e] > 0.f ? v[e] : 0.f;
                         st_s[e] += dz; st_q[e] += dz * (yv[e] - bvec[e]);
                     }
-                } else { st_s += v; st_q += v * v; }
+                } else if (STATS == 1) { st_s += v; st_q += v * v; }
                 float* o = g.y + ((size_t)(on * g.H + oy + dy) * g.W + ox + dx) * g.ldy + c0;
                 if (vec_ok && c0 + 3 < g.Cout) *reinterpret_cast<f32x4*>(o) = v;
                 else {
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_v2_kernel(const WinoGeom g) 
                 }
             }
     }
-    if (g.stats) {
+    if (STATS != 0) {
         // batch-norm statistics of this 16x16-pixel tile: the 512 per-thread partials go through LDS once and 2*NC threads add them
         // in a fixed order (threads cq, cq + NC/4, ...), so the slab -- and everything derived from it -- is bitwise reproducible.
         __syncthreads();                                 // P has been consumed by every thread
@@ -495,8 +496,10 @@ static int wino_launch(const float* in, int N, int H, int W, int K, int ldin, co
     if (!in || !U || !out || ldin < (K == 4 ? 4 : K) || ldout < Nn || act < 0 || act > 2 || !kpx_conv3x3_wino_eligible(N, H, W, K, Nn, ldin, in)) return KPX_EINVAL;
     hipStream_t s = kpx_stream(stream);
     if (kpx_first_use_on_device(&wino_attr_mask)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_v2_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, w2_lds_bytes(1));
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_v2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, w2_lds_bytes(2));
+        hipError_t e = hipSuccess;
+#define W2_ATTR(M, S) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_v2_kernel<M, S>), hipFuncAttributeMaxDynamicSharedMemorySize, w2_lds_bytes(M))
+        W2_ATTR(1, 0); W2_ATTR(2, 0); W2_ATTR(1, 1); W2_ATTR(2, 1); W2_ATTR(1, 2); W2_ATTR(2, 2);
+#undef W2_ATTR
         if (e != hipSuccess) return -(int)e;
     }
     WinoGeom g{};
@@ -512,8 +515,11 @@ static int wino_launch(const float* in, int N, int H, int W, int K, int ldin, co
     const bool wide = (force_ct ? force_ct == 2 : (blocks / 2 >= 256)) && g.Np % 64 == 0;
     static const int stagger = getenv("KPX_WINO_STAGGER") ? atoi(getenv("KPX_WINO_STAGGER")) : 1;
     g.stagger = stagger;
-    if (wide) hipLaunchKernelGGL(conv_wino_v2_kernel<2>, dim3(blocks / 2), dim3(512), w2_lds_bytes(2), s, g);
-    else hipLaunchKernelGGL(conv_wino_v2_kernel<1>, dim3(blocks), dim3(512), w2_lds_bytes(1), s, g);
+    const int st = !tile_stats ? 0 : (mask_y ? 2 : 1);
+#define W2_GO(M, S) hipLaunchKernelGGL((conv_wino_v2_kernel<M, S>), dim3(M == 2 ? blocks / 2 : blocks), dim3(512), w2_lds_bytes(M), s, g)
+    if (wide) { if (st == 0) W2_GO(2, 0); else if (st == 1) W2_GO(2, 1); else W2_GO(2, 2); }
+    else { if (st == 0) W2_GO(1, 0); else if (st == 1) W2_GO(1, 1); else W2_GO(1, 2); }
+#undef W2_GO
     return kpx_launch_status();
 }
 
