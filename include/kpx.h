@@ -129,6 +129,17 @@ int kpx_bn_stats_f32(const float* x, size_t P, int C, int ldx, float eps,
 int kpx_conv3x3_wino_bnbwd_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u,
                                      float* out, int Nn, int ldout, const float* bn_y, int ld_bn_y, const float* bn_beta,
                                      float* tile_stats, void* stream);
+/* Fused Winograd F(4x4,3x3): the same contract as kpx_conv3x3_wino_f32 (forward, or data gradient with dgrad-transformed filters) with
+ * 36 instead of 144 multiplies per 4x4 outputs; fp32 error ~2-3e-6 rel-L2 (F(2x2,3x3): ~4e-7).  Eligible when H % 16 == 0, W % 32 == 0,
+ * K >= 16, Nn > 32 and the usual 16-B alignment; `u` comes from kpx_wino43_filter_transform(_batch)_f32 (kpx_wino43_u_bytes bytes,
+ * descriptors as for kpx_wino_filter_transform_batch_f32).  Replaces the same tf.layers.conv2d call sites (reference
+ * models/networks/__init__.py:13,22,80-97; models/networks/vgg.py:51). */
+int kpx_conv3x3_wino43_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr);
+size_t kpx_wino43_u_bytes(int Cin, int Cout);
+int kpx_wino43_filter_transform_f32(const float* w_hwio, int Cin, int Cout, int dgrad, float* u, void* stream);
+int kpx_wino43_filter_transform_batch_f32(const void* descs_dev, int n, void* stream);
+int kpx_conv3x3_wino43_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u, const float* bias,
+                           float* out, int Nn, int ldout, int act, void* stream);
 /* kpx_bn_bwd_f32 (act must be KPX_ACT_RELU) with the channel reductions taken from those tile sums over tiles [tile0, tile0+ntiles). */
 int kpx_bn_bwd_from_tiles_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int C,
                               const float* mean, const float* invstd, const float* gamma, const float* beta, int act,

@@ -185,6 +185,17 @@ import ctypes as _ctypes
 import struct as _struct
 
 _wino_u = {}          # (filter data_ptr, dgrad) -> (U tensor, owning FilterBank or None)
+_wino43_u = {}        # the same for the F(4x4,3x3) form of the filters whose layers may use it
+
+# F(4x4,3x3) (csrc/conv_wino43.hip) does 2.25x fewer multiplies than F(2x2,3x3) at ~6x its rounding error (2-3e-6 rel-L2, still inside
+# the 1e-5 bar of one layer).  The key-point detector keeps F(2x2,3x3): its soft-argmax output feeds every other loss term.
+WINO43 = _os.environ.get('KPX_WINO43', '1') != '0'
+WINO43_EXCLUDE = ('pose_encoder',)
+
+
+def _wino43_wanted(name, cin, cout, dgrad):
+    k, nn = (cout, cin) if dgrad else (cin, cout)
+    return WINO43 and k >= 16 and nn >= 33 and not any(name.startswith(p) for p in WINO43_EXCLUDE)
 
 
 class FilterBank:
@@ -198,16 +209,25 @@ class FilterBank:
             self.filters = []
             return
         sizes = [lib.kpx_wino_u_bytes(int(w.shape[2]), int(w.shape[3])) // 4 for _, w in self.filters]
-        self.arena = torch.empty(2 * sum(sizes), dtype=torch.float32, device=device)
-        table, off = b'', 0
-        for (_, w), n in zip(self.filters, sizes):
+        sizes43 = [lib.kpx_wino43_u_bytes(int(w.shape[2]), int(w.shape[3])) // 4 for _, w in self.filters]
+        want43 = [[_wino43_wanted(n, int(w.shape[2]), int(w.shape[3]), d) for d in (0, 1)] for n, w in self.filters]
+        self.arena = torch.empty(2 * sum(sizes) + sum(n43 * sum(wt) for n43, wt in zip(sizes43, want43)), dtype=torch.float32, device=device)
+        table, table43, off = b'', b'', 0
+        for (_, w), n, n43, wt in zip(self.filters, sizes, sizes43, want43):
             for dgrad in (0, 1):
                 u = self.arena[off:off + n]
                 off += n
                 _wino_u[(w.data_ptr(), dgrad)] = (u, self)
                 table += _struct.pack('<QQiiii', w.data_ptr(), u.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, 0)
+                if wt[dgrad]:
+                    u = self.arena[off:off + n43]
+                    off += n43
+                    _wino43_u[(w.data_ptr(), dgrad)] = (u, self)
+                    table43 += _struct.pack('<QQiiii', w.data_ptr(), u.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, 0)
         self.n_desc = 2 * len(self.filters)
         self.table = torch.frombuffer(bytearray(table), dtype=torch.uint8).to(device)
+        self.n_desc43 = len(table43) // 32
+        self.table43 = torch.frombuffer(bytearray(table43), dtype=torch.uint8).to(device) if table43 else None
 
     def touch(self):
         self.version += 1
@@ -215,13 +235,15 @@ class FilterBank:
     def ensure_fresh(self):
         if self.synced != self.version and self.filters:
             check(lib.kpx_wino_filter_transform_batch_f32(self.table.data_ptr(), self.n_desc, _stream()), 'kpx_wino_filter_transform_batch_f32')
+            if self.n_desc43:
+                check(lib.kpx_wino43_filter_transform_batch_f32(self.table43.data_ptr(), self.n_desc43, _stream()), 'kpx_wino43_filter_transform_batch_f32')
             self.synced = self.version
 
     def keys(self):
         return [(w.data_ptr(), dgrad) for _, w in self.filters for dgrad in (0, 1)]
 
 
-def register_constant_filter(w):
+def register_constant_filter(w, name=''):
     """Transform a filter that never changes (VGG19, reference vgg.py:57-61 tf.constant) once, for both directions.
     Returns the cache keys; the owner must pass them to release_filters() when the filter memory is given up."""
     if w.dim() != 4 or w.shape[0] != 3 or w.shape[1] != 3 or not w.is_cuda:
@@ -233,6 +255,10 @@ def register_constant_filter(w):
         check(lib.kpx_wino_filter_transform_f32(w.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, u.data_ptr(), _stream()), 'kpx_wino_filter_transform_f32')
         _wino_u[(w.data_ptr(), dgrad)] = (u, None)
         keys.append((w.data_ptr(), dgrad))
+        if _wino43_wanted(name, int(w.shape[2]), int(w.shape[3]), dgrad):
+            u = torch.empty(lib.kpx_wino43_u_bytes(int(w.shape[2]), int(w.shape[3])) // 4, dtype=torch.float32, device=w.device)
+            check(lib.kpx_wino43_filter_transform_f32(w.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, u.data_ptr(), _stream()), 'kpx_wino43_filter_transform_f32')
+            _wino43_u[(w.data_ptr(), dgrad)] = (u, None)
     return keys
 
 
@@ -240,6 +266,7 @@ def release_filters(keys):
     """Forget cached Winograd forms (the address of a freed filter may be handed to an unrelated tensor later)."""
     for k in keys:
         _wino_u.pop(k, None)
+        _wino43_u.pop(k, None)
 
 
 def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, want_stats=False, bn_src=None):
@@ -255,6 +282,11 @@ def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, wa
     if bank is not None:
         bank.ensure_fresh()
     bptr = bias.data_ptr() if bias is not None else None
+    ent43 = _wino43_u.get((w.data_ptr(), 1 if dgrad else 0)) if WINO43 else None
+    if ent43 is not None and bn_src is None and not want_stats and lib.kpx_conv3x3_wino43_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr()):
+        check(lib.kpx_conv3x3_wino43_f32(inp.data_ptr(), n, h, wd, k, ld_in, ent43[0].data_ptr(), bptr, out.data_ptr(), nn, ld_out, act, _stream()),
+              'kpx_conv3x3_wino43_f32')
+        return True
     if bn_src is not None and dgrad and h % 16 == 0 and wd % 16 == 0:
         bn_y, beta = bn_src                              # the gathered tensor's consumer-side twin: y = relu(BN(.)) that this conv read
         tiles = lib.kpx_conv3x3_wino_stats_tiles(n, h, wd)

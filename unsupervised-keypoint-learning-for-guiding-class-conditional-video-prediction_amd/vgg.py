@@ -57,7 +57,7 @@ class Vgg19:
             self.params[name] = (torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)).to(self.device),
                                  torch.from_numpy(np.ascontiguousarray(b, dtype=np.float32)).to(self.device))
             if self.device.type == 'cuda':
-                keys += ops.register_constant_filter(self.params[name][0])     # tf.constant filters (vgg.py:57-61): Winograd form once
+                keys += ops.register_constant_filter(self.params[name][0], 'vgg/' + name)     # tf.constant filters (vgg.py:57-61): Winograd form once
         weakref.finalize(self, ops.release_filters, keys)
 
     def build(self, rgb01):
