@@ -358,6 +358,73 @@ def test_winograd_fuzz_against_oracle(kpx, dev, n, h, w, cin, cout, k, s, pad, a
     test_conv_fwd_dgrad_wgrad(kpx, dev, n, h, w, cin, cout, k, s, pad, act, gtol=2e-5)
 
 
+W43_CASES = [  # n, h, w, cin, cout, act
+    (2, 16, 32, 16, 64, 0), (2, 32, 32, 64, 64, 1), (1, 16, 64, 24, 40, 2), (3, 48, 96, 136, 128, 0), (2, 32, 64, 64, 128, 1),
+    (1, 16, 32, 256, 72, 0), (2, 128, 128, 64, 64, 1), (5, 32, 32, 40, 200, 2)]
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,act', W43_CASES)
+def test_winograd_f43_forward_and_data_gradient_against_oracle(kpx, dev, n, h, w, cin, cout, act):
+    """The F(4x4,3x3) kernel (csrc/conv_wino43.hip) through ops.conv2d with pre-transformed filters: forward and data gradient against the
+    oracle convolution at the 1e-5 bar of a layer, ragged channel counts (K tail chunk, cout tail of a 64-wide block), all activations,
+    and a check that it IS the kernel that ran.  Weight / bias gradients come from the shared wgrad kernel."""
+    ops = kpx.ops
+    if not ops.WINO43:
+        pytest.skip('KPX_WINO43=0')
+    rs = np.random.RandomState(cin * 3 + cout)
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    wt = (rs.randn(3, 3, cin, cout) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32)
+    xg = torch.from_numpy(x).to(dev).requires_grad_(True); wg = torch.from_numpy(wt).to(dev).requires_grad_(True); bg = torch.from_numpy(b).to(dev).requires_grad_(True)
+    keys = ops.register_constant_filter(wg.detach(), 'test/f43')
+    try:
+        used = ops.conv_kernel_uses['wino43']
+        yg = ops.conv2d(xg, wg, bg, stride=1, pad=0, act=act)
+        assert ops.conv_kernel_uses['wino43'] == used + 1
+        xo = torch.from_numpy(x).requires_grad_(True); wo = torch.from_numpy(wt).requires_grad_(True); bo = torch.from_numpy(b).requires_grad_(True)
+        zo = R.conv(xo, wo, bo, 1, 0)
+        yo = torch.relu(zo) if act == 1 else torch.nn.functional.leaky_relu(zo, 0.01) if act == 2 else zo
+        assert rel_l2(t2n(yg), t2n(yo)) < 1e-5
+        gy = rs.randn(*yo.shape).astype(np.float32)
+        if act:
+            pos = yg.detach().cpu() > 0
+            assert int((pos != (zo.detach() > 0)).sum()) <= 2 + 1e-4 * pos.numel()
+            zo.backward(torch.from_numpy(gy) * torch.where(pos, torch.tensor(1.0), torch.tensor(0.0 if act == 1 else 0.01)))
+        else:
+            zo.backward(torch.from_numpy(gy))
+        yg.backward(torch.from_numpy(gy).to(dev))
+        eligible_back = cout >= 16 and cin >= 33
+        assert ops.conv_kernel_uses['wino43'] == used + (2 if eligible_back else 1)
+    finally:
+        ops.release_filters(keys)
+    assert rel_l2(t2n(xg.grad), t2n(xo.grad)) < 1e-5
+    assert rel_l2(t2n(wg.grad), t2n(wo.grad)) < 1e-5
+    assert rel_l2(t2n(bg.grad), t2n(bo.grad)) < 1e-5
+
+
+def test_winograd_f43_reads_a_channel_slice_and_writes_a_strided_destination(kpx, dev):
+    """K = 158 of a 160-wide joint buffer (translator conv_1_0) into a channel slice of a wider output, raw launcher."""
+    ops = kpx.ops
+    if not ops.WINO43:
+        pytest.skip('KPX_WINO43=0')
+    rs = np.random.RandomState(5)
+    full = rs.randn(2, 32, 32, 160).astype(np.float32)
+    wt = (rs.randn(3, 3, 158, 96) * 0.03).astype(np.float32)
+    xg = torch.from_numpy(full).to(dev); wg = torch.from_numpy(wt).to(dev)
+    out = torch.full((2, 32, 32, 128), 7.0, device=dev)
+    keys = ops.register_constant_filter(wg, 'test/slice')
+    try:
+        used = ops.conv_kernel_uses['wino43']
+        ops.conv_fwd_raw(xg, 160, 158, wg, None, out[..., 16:], 128, 1, 1, 1, 0)
+        assert ops.conv_kernel_uses['wino43'] == used + 1
+    finally:
+        ops.release_filters(keys)
+    want = R.conv(torch.from_numpy(full[..., :158].copy()), torch.from_numpy(wt), None, 1)
+    got = t2n(out)
+    assert rel_l2(got[..., 16:112], t2n(want)) < 1e-5
+    assert (got[..., :16] == 7.0).all() and (got[..., 112:] == 7.0).all()
+
+
 @pytest.mark.parametrize('n,h,w,cin,cout,k,s,pad,act', _fuzz_cases())
 def test_conv_fuzz_against_oracle(kpx, dev, n, h, w, cin, cout, k, s, pad, act):
     """Seeded random geometries (ragged channels, odd sizes, strides, explicit pads) through fwd / dgrad / wgrad."""
@@ -441,7 +508,7 @@ def test_conv3x3_bf16_fwd_dgrad_tolerance(kpx, dev, n, h, w, cin, cout, act):
     assert rel_l2(t2n(y32), t2n(zo)) < 1e-5
 
 
-@pytest.mark.parametrize('n,h,w,cin,cout,groups', [(4, 32, 32, 32, 64, 1), (4, 16, 48, 64, 40, 2), (2, 64, 64, 128, 128, 1)])
+@pytest.mark.parametrize('n,h,w,cin,cout,groups', [(4, 32, 32, 32, 64, 1), (4, 16, 48, 64, 40, 2), (2, 64, 64, 128, 128, 1), (4, 16, 32, 24, 70, 2), (2, 32, 32, 16, 32, 1)])
 def test_batch_norm_statistics_from_the_conv_epilogue(kpx, dev, n, h, w, cin, cout, groups):
     """conv -> train-mode batch norm with the per-tile channel sums written by the Winograd epilogue (kpx_conv3x3_wino_stats_f32 +
     kpx_bn_stats_from_tiles_f32) against the oracle AND against the separate statistics pass: same normalised output, same
@@ -458,7 +525,8 @@ def test_batch_norm_statistics_from_the_conv_epilogue(kpx, dev, n, h, w, cin, co
     keys = ops.register_constant_filter(wg)
     try:
         y = ops.conv2d(xg, wg, bg, stride=1, pad=0, act=0, bn_stats=True)
-        assert hasattr(y, '_kpx_tile_stats') and y._kpx_tile_stats[1] == (h // 16) * (w // 16)
+        f43 = w % 32 == 0 and cin >= 16 and cout >= 33          # these shapes run the F(4x4,3x3) kernel: statistics per 4x32-pixel strip
+        assert hasattr(y, '_kpx_tile_stats') and y._kpx_tile_stats[1] == ((h // 16) * (w // 32) * 4 if f43 else (h // 16) * (w // 16))
         mm1, mv1 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
         used = ops.fused_bn_uses['stats_from_conv_epilogue']
         out1 = ops.batch_norm(y, gg, beg, mm1, mv1, train=True, act=1, groups=groups)
@@ -491,10 +559,12 @@ def test_batch_norm_backward_sums_from_the_dgrad_epilogue(kpx, dev, n, h, w, c0,
 
     def run(fused):
         ops.FUSE_BN_BWD = True                  # (off by default: slower on the train step, see ops.py)
+        keep43, ops.WINO43 = ops.WINO43, False  # the fused reduction lives in the F(2x2,3x3) epilogue: keep every layer of this test on it
         try:
             return _run(fused)
         finally:
             ops.FUSE_BN_BWD = False
+            ops.WINO43 = keep43
 
     def _run(fused):
         t = {k_: torch.from_numpy(v).to(dev).requires_grad_(True) for k_, v in dict(x=x, wa=wa, wb=wb, ga=ga, be=be).items()}

@@ -26,6 +26,7 @@ struct Wino43Geom {
     int N, H, W, Cin, ldx, Cout, ldy, act;
     int Kp, Np;                              // U is [36][Kp/8][Np/32][2][32][4]
     int tiles_y, tiles_x;                    // 16 x 32-pixel regions per image
+    float* stats;                            // STATS: [N * tiles_y * tiles_x * 4 strips of 4 x 32 pixels][2][Cout] sum / sum of squares of the output
 };
 
 
@@ -108,6 +109,7 @@ extern "C" int kpx_debug_w43_stamps(unsigned long long* buf) { return -(int)hipM
 
 #define W4_LOADER_UNITS 10                     // 1224 (pixel, half) units of a raw patch over the 128 threads of wavefronts 6-7
 
+template <int STATS>
 __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const rawb = smem;
@@ -319,6 +321,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
     float* const obase = g.y + ((size_t)(n * g.H + oy) * g.W + ox) * g.ldy + c0o;
     const size_t cstr = (size_t)g.ldy, rstr = (size_t)g.W * g.ldy;
     const bool fast = (g.ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.y) & 15) == 0) && n0 + 64 <= g.Cout;    // block-uniform
+    f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
     if (fast) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -327,6 +330,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
                 f32x4 v = Y[i][j] + bv;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { const float z = fmaxf(v[q], lo); v[q] = z > 0.f ? z : z * slope; }
+                if (STATS) { st_s += v; st_q += v * v; }
                 *reinterpret_cast<f32x4*>(obase + i * rstr + j * cstr) = v;
             }
     } else {
@@ -337,10 +341,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
                 f32x4 v = Y[i][j] + bv;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { const float z = fmaxf(v[q], lo); v[q] = z > 0.f ? z : z * slope; }
+                if (STATS) { st_s += v; st_q += v * v; }
                 float* o = obase + i * rstr + j * cstr;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) if (c0o + q < g.Cout) o[q] = v[q];
             }
+    }
+    if (STATS) {
+        // batch-norm statistics: this wavefront's 64 threads cover one 4 x 32-pixel strip (8 tiles) x 32 couts; the 8 tiles are the lane
+        // bits 3-5, added in a fixed butterfly order, so the slab -- and everything derived from it -- is bitwise reproducible.
+#pragma unroll
+        for (int sh = 8; sh <= 32; sh <<= 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { st_s[q] += __shfl_xor(st_s[q], sh); st_q[q] += __shfl_xor(st_q[q], sh); }
+        if (lane < 8) {
+            const size_t strip = (((size_t)n * g.tiles_y + by) * g.tiles_x + bx) * 4 + pg;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c0o + q < g.Cout) { g.stats[(strip * 2) * g.Cout + c0o + q] = st_s[q]; g.stats[(strip * 2 + 1) * g.Cout + c0o + q] = st_q[q]; }
+        }
     }
     W4_STAMP(7);
 #ifdef KPX_WINO_STAMP
@@ -372,11 +391,12 @@ extern "C" int kpx_wino43_filter_transform_batch_f32(const void* descs_dev, int 
     hipLaunchKernelGGL(wino43_filter_transform_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, kpx_stream(stream), (const KpxWino43Desc*)descs_dev);
     return kpx_launch_status();
 }
-extern "C" int kpx_conv3x3_wino43_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
-                                      float* out, int Nn, int ldout, int act, void* stream) {
+static int w43_launch(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
+                      float* out, int Nn, int ldout, int act, float* tile_stats, void* stream) {
     if (!in || !U || !out || ldin < K || ldout < Nn || act < 0 || act > 2 || !kpx_conv3x3_wino43_eligible(N, H, W, K, Nn, ldin, in)) return KPX_EINVAL;
     if (kpx_first_use_on_device(&w43_attr_mask)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
         if (e != hipSuccess) return -(int)e;
     }
     Wino43Geom g{};
@@ -384,7 +404,22 @@ extern "C" int kpx_conv3x3_wino43_f32(const float* in, int N, int H, int W, int 
     g.N = N; g.H = H; g.W = W; g.Cin = K; g.ldx = ldin; g.Cout = Nn; g.ldy = ldout; g.act = act;
     g.Kp = (K + 7) & ~7; g.Np = (Nn + 63) & ~63;
     g.tiles_y = H / 16; g.tiles_x = W / 32;
+    g.stats = tile_stats;
     const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x * (g.Np / 64));
-    hipLaunchKernelGGL(conv_wino43_kernel, dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
+    if (tile_stats) hipLaunchKernelGGL(conv_wino43_kernel<1>, dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
+    else hipLaunchKernelGGL(conv_wino43_kernel<0>, dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
     return kpx_launch_status();
+}
+extern "C" int kpx_conv3x3_wino43_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
+                                      float* out, int Nn, int ldout, int act, void* stream) {
+    return w43_launch(in, N, H, W, K, ldin, U, bias, out, Nn, ldout, act, nullptr, stream);
+}
+// 4 x 32-pixel strips per tensor: the unit of the statistics slab (kpx_bn_stats_from_tiles_f32 with tile_pixels = 128)
+extern "C" size_t kpx_conv3x3_wino43_stats_tiles(int N, int H, int W) {
+    return (H % 16 || W % 32 || N <= 0) ? 0 : (size_t)N * (H / 16) * (W / 32) * 4;
+}
+extern "C" int kpx_conv3x3_wino43_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
+                                            float* out, int Nn, int ldout, int act, float* tile_stats, void* stream) {
+    if (!tile_stats) return KPX_EINVAL;
+    return w43_launch(in, N, H, W, K, ldin, U, bias, out, Nn, ldout, act, tile_stats, stream);
 }

@@ -186,16 +186,24 @@ import struct as _struct
 
 _wino_u = {}          # (filter data_ptr, dgrad) -> (U tensor, owning FilterBank or None)
 _wino43_u = {}        # the same for the F(4x4,3x3) form of the filters whose layers may use it
+conv_kernel_uses = {'wino43': 0}      # diagnostics / tests: launches of the F(4x4,3x3) kernel
 
-# F(4x4,3x3) (csrc/conv_wino43.hip) does 2.25x fewer multiplies than F(2x2,3x3) at ~6x its rounding error (2-3e-6 rel-L2, still inside
-# the 1e-5 bar of one layer).  The key-point detector keeps F(2x2,3x3): its soft-argmax output feeds every other loss term.
+# F(4x4,3x3) (csrc/conv_wino43.hip) does 2.25x fewer multiplies than F(2x2,3x3) at ~6x its rounding error (2-3e-6 rel-L2 per layer, still
+# inside the 1e-5 bar of one layer).  Where it runs is decided per filter NAME and direction, from the measured effect on a whole train
+# step against the float64 arbiter (tests/test_model_gpu.py::test_configs0..., scratch/w43_policy.py):
+#   * data gradients: everywhere except the key-point detector;
+#   * forward: VGG19 and the translator's 64x64 / 128x128 layers (conv_3_* .. conv_5_*).  The detector, the image encoder and the
+#     translator's 32x32 layers (256-deep sums feeding batch norms over few pixels) stay on F(2x2,3x3): with them on F(4x4,3x3) the
+#     generated frame moves 3e-5 instead of 1.7e-5 from the oracle's and the discriminator gradient 4.6x instead of 1.2x as far from the
+#     float64 gradient as the fp32 oracle's own.
 WINO43 = _os.environ.get('KPX_WINO43', '1') != '0'
-WINO43_EXCLUDE = ('pose_encoder',)
+WINO43_EXCLUDE_FWD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_FWD', 'pose_encoder,image_encoder,translator/conv_1,translator/conv_2').split(',') if p)
+WINO43_EXCLUDE_DGRAD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_DGRAD', 'pose_encoder').split(',') if p)
 
 
 def _wino43_wanted(name, cin, cout, dgrad):
     k, nn = (cout, cin) if dgrad else (cin, cout)
-    return WINO43 and k >= 16 and nn >= 33 and not any(name.startswith(p) for p in WINO43_EXCLUDE)
+    return WINO43 and k >= 16 and nn >= 33 and not any(name.startswith(p) for p in (WINO43_EXCLUDE_DGRAD if dgrad else WINO43_EXCLUDE_FWD))
 
 
 class FilterBank:
@@ -283,7 +291,14 @@ def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, wa
         bank.ensure_fresh()
     bptr = bias.data_ptr() if bias is not None else None
     ent43 = _wino43_u.get((w.data_ptr(), 1 if dgrad else 0)) if WINO43 else None
-    if ent43 is not None and bn_src is None and not want_stats and lib.kpx_conv3x3_wino43_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr()):
+    if ent43 is not None and bn_src is None and lib.kpx_conv3x3_wino43_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr()):
+        conv_kernel_uses['wino43'] += 1
+        if want_stats:
+            tiles = lib.kpx_conv3x3_wino43_stats_tiles(n, h, wd)
+            slab = torch.empty(tiles * 2 * nn, dtype=torch.float32, device=inp.device)
+            check(lib.kpx_conv3x3_wino43_stats_f32(inp.data_ptr(), n, h, wd, k, ld_in, ent43[0].data_ptr(), bptr, out.data_ptr(), nn, ld_out, act,
+                                                   slab.data_ptr(), _stream()), 'kpx_conv3x3_wino43_stats_f32')
+            return slab, tiles // n
         check(lib.kpx_conv3x3_wino43_f32(inp.data_ptr(), n, h, wd, k, ld_in, ent43[0].data_ptr(), bptr, out.data_ptr(), nn, ld_out, act, _stream()),
               'kpx_conv3x3_wino43_f32')
         return True
