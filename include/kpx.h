@@ -140,8 +140,8 @@ int kpx_wino43_filter_transform_f32(const float* w_hwio, int Cin, int Cout, int 
 int kpx_wino43_filter_transform_batch_f32(const void* descs_dev, int n, void* stream);
 int kpx_conv3x3_wino43_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u, const float* bias,
                            float* out, int Nn, int ldout, int act, void* stream);
-/* The same with the batch-norm statistics of the output from the epilogue, as kpx_conv3x3_wino_stats_f32 but per 4 x 32-pixel strip:
- * tile_stats[strip][2][Nn], kpx_conv3x3_wino43_stats_tiles(N, H, W) strips, consumed by kpx_bn_stats_from_tiles_f32 (tile_pixels 128). */
+/* The same with the batch-norm statistics of the output from the epilogue, as kpx_conv3x3_wino_stats_f32 but per 4 x 16-pixel strip:
+ * tile_stats[strip][2][Nn], kpx_conv3x3_wino43_stats_tiles(N, H, W) strips, consumed by kpx_bn_stats_from_tiles_f32 (tile_pixels 64). */
 size_t kpx_conv3x3_wino43_stats_tiles(int N, int H, int W);
 int kpx_conv3x3_wino43_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u, const float* bias,
                                  float* out, int Nn, int ldout, int act, float* tile_stats, void* stream);

@@ -18,22 +18,29 @@ clib.kpx_debug_w43_stamps.argtypes = [ctypes.c_void_p]
 for dbg in [int(v) for v in sys.argv[1:]] or [0]:
     os.environ['KPX_W43_DBG'] = str(dbg)
     run = lambda: lib.kpx_conv3x3_wino43_f32(x.data_ptr(), n, h, wd, ci, ci, u43.data_ptr(), None, y.data_ptr(), co, co, 0, s)
-    buf = torch.zeros(64 * 8 * 16, dtype=torch.int64, device=dev)
+    buf = torch.zeros(64 * 8 * 64, dtype=torch.int64, device=dev)
     clib.kpx_debug_w43_stamps(None)
     for _ in range(100): run()
     torch.cuda.synchronize()
     clib.kpx_debug_w43_stamps(buf.data_ptr())
     run(); torch.cuda.synchronize()
     clib.kpx_debug_w43_stamps(None)
-    d = buf.cpu().numpy().reshape(64, 8, 16)
+    d = buf.cpu().numpy().reshape(64, 8, 64)
     print('dbg', dbg)
     for wv in range(8):
         q = d[:, wv]
-        tot = q[:, 7 if wv < 4 else 6] - q[:, 0]
+        tot = q[:, 7] - q[:, 0]
         clk = tot / np.maximum(q[:, 9] - q[:, 8], 1) * 100.0
         f = lambda a, b: np.median(q[:, b] - q[:, a])
-        if wv < 4:
+        if True:
             print(' wave %d: prologue %6.0f loop %7.0f (%.0f/chunk) bar %5.0f deposit %5.0f bar %5.0f outxf %6.0f store %6.0f | total %7.0f  clk %.0f MHz' %
                   (wv, f(0, 1), f(1, 2), f(1, 2) / 16, f(2, 3), f(3, 4), f(4, 5), f(5, 6), f(6, 7), np.median(tot), np.median(clk)))
         else:
             print(' wave %d: prologue %6.0f loop %7.0f (%.0f/chunk) bar %5.0f rest %6.0f | total %7.0f  clk %.0f MHz' % (wv, f(0, 1), f(1, 2), f(1, 2) / 16, f(2, 3), f(3, 6), np.median(tot), np.median(clk)))
+
+    print(' per chunk (median over chunks 4-11, workgroups): wait-at-barrier | phase 1 | phase 2 | whole chunk')
+    for wv in range(8):
+        q = d[:, wv, 16:48].reshape(64, 8, 4).astype(np.float64)
+        bar = np.median(q[:, :, 1] - q[:, :, 0]); p1 = np.median(q[:, :, 2] - q[:, :, 1]); p2 = np.median(q[:, :, 3] - q[:, :, 2])
+        whole = np.median(q[:, 1:, 0] - q[:, :-1, 0])
+        print('  wave %d (%s): %6.0f | %6.0f | %6.0f | %6.0f' % (wv, 'T then M' if wv < 4 else 'M then T' if wv < 6 else 'L then M', bar, p1, p2, whole))

@@ -525,8 +525,8 @@ def test_batch_norm_statistics_from_the_conv_epilogue(kpx, dev, n, h, w, cin, co
     keys = ops.register_constant_filter(wg)
     try:
         y = ops.conv2d(xg, wg, bg, stride=1, pad=0, act=0, bn_stats=True)
-        f43 = w % 32 == 0 and cin >= 16 and cout >= 33          # these shapes run the F(4x4,3x3) kernel: statistics per 4x32-pixel strip
-        assert hasattr(y, '_kpx_tile_stats') and y._kpx_tile_stats[1] == ((h // 16) * (w // 32) * 4 if f43 else (h // 16) * (w // 16))
+        f43 = w % 32 == 0 and cin >= 16 and cout >= 33          # these shapes run the F(4x4,3x3) kernel: statistics per 4x16-pixel strip
+        assert hasattr(y, '_kpx_tile_stats') and y._kpx_tile_stats[1] == ((h // 16) * (w // 32) * 8 if f43 else (h // 16) * (w // 16))
         mm1, mv1 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
         used = ops.fused_bn_uses['stats_from_conv_epilogue']
         out1 = ops.batch_norm(y, gg, beg, mm1, mv1, train=True, act=1, groups=groups)

@@ -26,7 +26,7 @@ struct Wino43Geom {
     int N, H, W, Cin, ldx, Cout, ldy, act;
     int Kp, Np;                              // U is [36][Kp/8][Np/32][2][32][4]
     int tiles_y, tiles_x;                    // 16 x 32-pixel regions per image
-    float* stats;                            // STATS: [N * tiles_y * tiles_x * 4 strips of 4 x 32 pixels][2][Cout] sum / sum of squares of the output
+    float* stats;                            // STATS: [N * tiles_y * tiles_x * 8 strips of 4 x 16 pixels][2][Cout] sum / sum of squares of the output
 };
 
 
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void wino43_filter_transform_kernel(const floa
 #define W4_RAW (2 * W4_PLANE * 4)              // floats per raw buffer (6048)
 #define W4_V (36 * 32 * 8)                     // floats per V buffer (9216)
 #define W4_MAIN (2 * W4_RAW + 2 * W4_V)
-#define W4_EPI (36 * 32 * 32)
+#define W4_EPI (18 * 32 * 64)
 
 // rows of B^T (= rows of the input transform): value = sum_m A[m] * d[R[m]]
 __constant__ int w43_R[6][4] = {{0, 2, 4, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 2, 3, 4}, {1, 3, 5, 5}};
@@ -103,7 +103,9 @@ __constant__ float w43_AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1
 static __device__ unsigned long long* w43_dbg = nullptr;
 extern "C" int kpx_debug_w43_stamps(unsigned long long* buf) { return -(int)hipMemcpyToSymbol(HIP_SYMBOL(w43_dbg), &buf, sizeof(buf)); }
 #define W4_STAMP(slot) do { if (dbgp) dbgp[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define W4_KSTAMP(k, j) do { if (dbgp && (k) >= 4 && (k) < 12) dbgp[16 + ((k) - 4) * 4 + (j)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
+#define W4_KSTAMP(k, j) do { } while (0)
 #define W4_STAMP(slot) do { } while (0)
 #endif
 
@@ -126,16 +128,27 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
     const int n = L / g.tiles_y;
     const int oy0 = by * 16, ox0 = bx * 32, n0 = nti * 64;
 
-    // MFMA operands (all wavefronts)
-    const int a_rd = (9 * pg) * 256 + li * 8 + ((lh ^ ((li >> 3) & 1)) << 2);
+    // MFMA operands (all wavefronts).  Points 0-17 (rows 0-2 of the 6x6 grid) and 18-35 are each spread over the four wavefronts of a
+    // cout half as 5,5,4,4 and 4,4,5,5, so that BOTH epilogue passes (one per half of the grid) have work for every wavefront:
+    // block b of wavefront pg is point b + offA (b < 4), b + offB (b > 4); block 4 belongs to the first half for pg < 2.
+    const int offA = pg == 0 ? 0 : pg == 1 ? 5 : pg == 2 ? 10 : 14;
+    const int offB = pg == 0 ? 13 : pg == 1 ? 17 : pg == 2 ? 22 : 27;
+    const int nfirst = pg < 2 ? 5 : 4;                   // blocks [0, nfirst) are first-half points
+    const int off4 = pg < 2 ? offA : offB;
+    const int a_rd0 = li * 8 + ((lh ^ ((li >> 3) & 1)) << 2);
+    const int a_rdA = a_rd0 + offA * 256, a_rd4 = a_rd0 + off4 * 256, a_rdB = a_rd0 + offB * 256;
     const int KC = g.Kp >> 3, NB = g.Np >> 5;
     const int nb = nti * 2 + ct;
     const size_t ub_pstride = (size_t)KC * NB * 256, ub_step = (size_t)NB * 256;
-    const float* ubp = g.U + ((size_t)(9 * pg) * KC * NB + nb) * 256 + lane * 4;
+    const float* ubpA = g.U + ((size_t)offA * KC * NB + nb) * 256 + lane * 4;
+    const float* ubp4 = g.U + ((size_t)off4 * KC * NB + nb) * 256 + lane * 4;
+    const float* ubpB = g.U + ((size_t)offB * KC * NB + nb) * 256 + lane * 4;
+#define W4_AOFF(b) (((b) < 4 ? a_rdA : (b) == 4 ? a_rd4 : a_rdB) + (b) * 256)
+#define W4_UPTR(b) (((b) < 4 ? ubpA : (b) == 4 ? ubp4 : ubpB) + (size_t)(b) * ub_pstride)
     const int nchunks = g.Kp / 8;
 
 #ifdef KPX_WINO_STAMP
-    unsigned long long* dbgp = (w43_dbg && lane == 0 && blockIdx.x < 64) ? w43_dbg + ((size_t)blockIdx.x * 8 + wave) * 16 : nullptr;
+    unsigned long long* dbgp = (w43_dbg && lane == 0 && blockIdx.x < 64) ? w43_dbg + ((size_t)blockIdx.x * 8 + wave) * 64 : nullptr;
     if (dbgp) { dbgp[0] = __builtin_amdgcn_s_memtime(); dbgp[8] = __builtin_amdgcn_s_memrealtime(); }
 #endif
     f32x16 acc[9];
@@ -145,24 +158,24 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
     f32x4 ub[3];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) ub[b] = *reinterpret_cast<const f32x4*>(ubp + (size_t)b * ub_pstride);
+    for (int b = 0; b < 3; ++b) ub[b] = *reinterpret_cast<const f32x4*>(W4_UPTR(b));
 
     // B fragments: a ring of 3 points, each refilled in place (for the point 3 ahead, possibly of the next chunk) right after its MFMAs
     auto mfma = [&](const float* Vr, bool refill_next) {
         f32x4 av[2];
-        av[0] = *reinterpret_cast<const f32x4*>(&Vr[a_rd]);
-        const float* const ubn = ubp + (refill_next ? ub_step : 0);      // (last chunk: harmless re-read instead of a branch)
+        av[0] = *reinterpret_cast<const f32x4*>(&Vr[W4_AOFF(0)]);
+        const size_t nx = refill_next ? ub_step : 0;                     // (last chunk: harmless re-read instead of a branch)
 #pragma unroll
         for (int b = 0; b < 9; ++b) {
-            if (b < 8) av[(b + 1) & 1] = *reinterpret_cast<const f32x4*>(&Vr[a_rd + (b + 1) * 256]);
+            if (b < 8) av[(b + 1) & 1] = *reinterpret_cast<const f32x4*>(&Vr[W4_AOFF(b + 1)]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][j], ub[b % 3][j], acc[b], 0, 0, 0);
-            if (b < 6) ub[b % 3] = *reinterpret_cast<const f32x4*>(ubp + (size_t)(b + 3) * ub_pstride);
-            else ub[b % 3] = *reinterpret_cast<const f32x4*>(ubn + (size_t)(b - 6) * ub_pstride);
+            if (b < 6) ub[b % 3] = *reinterpret_cast<const f32x4*>(W4_UPTR(b + 3));
+            else ub[b % 3] = *reinterpret_cast<const f32x4*>(W4_UPTR(b - 6) + nx);
             __builtin_amdgcn_sched_barrier(0);           // or the scheduler sinks each refill to its use, 3 points later, and waits for it there
         }
-        ubp += ub_step;
+        ubpA += ub_step; ubp4 += ub_step; ubpB += ub_step;
     };
 
     // The two roles run separate copies of the chunk loop (their register needs differ: 44 transient transform registers vs 40 of
@@ -208,10 +221,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
             constexpr bool LATE = decltype(late_tag)::value;
             for (int k = 0; k < nchunks; ++k) {
                 const int cur = k & 1;
+                W4_KSTAMP(k, 0);
                 __syncthreads();                         // V[cur] (chunk k) and raw[cur^1] (chunk k+1) are complete
-                if (LATE) mfma(Vb + cur * W4_V, k + 1 < nchunks);
+                W4_KSTAMP(k, 1);
+                if (LATE) { mfma(Vb + cur * W4_V, k + 1 < nchunks); W4_KSTAMP(k, 2); }
                 if (k + 1 < nchunks) transform(rawb + (cur ^ 1) * W4_RAW, Vb + (cur ^ 1) * W4_V, k + 1 == nchunks - 1 && ktail < 4);
-                if (!LATE) mfma(Vb + cur * W4_V, k + 1 < nchunks);
+                if (!LATE) { W4_KSTAMP(k, 2); mfma(Vb + cur * W4_V, k + 1 < nchunks); }
+                W4_KSTAMP(k, 3);
             }
         };
         if (wave >= 4) chunk_loop(std::true_type{}); else chunk_loop(std::false_type{});
@@ -252,63 +268,71 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
         W4_STAMP(1);
         for (int k = 0; k < nchunks; ++k) {
             const int cur = k & 1;
+            W4_KSTAMP(k, 0);
             __syncthreads();
+            W4_KSTAMP(k, 1);
             if (k + 2 < nchunks) stage(rawb + cur * W4_RAW);
             if (k + 3 < nchunks) load_raw();
+            W4_KSTAMP(k, 2);
             mfma(Vb + cur * W4_V, k + 1 < nchunks);
+            W4_KSTAMP(k, 3);
         }
     }
 
-    // epilogue: two passes through LDS, one per 32-cout half: the four wavefronts of a half deposit all 36 points of their accumulators
-    // (P[point][tile][32 couts], 147 KB), then each of their 256 threads applies A^T . A for (tile, 4 couts) and stores 4x4 pixels.
-    // The second half waits until the first has read its points; the first half's stores overlap the second half's pass.  The branches
-    // are wave-uniform; a wavefront that has exited no longer counts at a barrier.
+    // epilogue: two passes through LDS, one per half of the 6x6 point grid (rows 0-2, rows 3-5): every wavefront deposits its 4-5 blocks
+    // of that half (P[point][tile][64 couts], 147 KB), then each of the 512 threads applies the three point rows to its (tile, 4 couts)
+    // and keeps the 4x4 output pixels in registers between the passes.  Rows written by the upper lane half (tile rows 4-7 of each 8)
+    // have their two 32-cout halves swapped, so that one ds_write_b32 covers all 64 banks.
     float* const P = smem;
-    W4_STAMP(2);
-    __syncthreads();                                     // main-loop LDS reads are done
-    W4_STAMP(3);
-    if (ct == 1) { __syncthreads(); __syncthreads(); }   // first half deposited / consumed
-#pragma unroll
-    for (int b = 0; b < 9; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int trow = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            P[((9 * pg + b) * 32 + (trow ^ ((trow >> 2) & 1))) * 32 + li] = acc[b][r];      // row swizzle: the lane halves hit different banks
-        }
-    W4_STAMP(4);
-    __syncthreads();
-    W4_STAMP(5);
-    const int oid = pg * 64 + lane, otile = oid >> 3, ocq = oid & 7;
-    const float* const Pr = P + (otile ^ ((otile >> 2) & 1)) * 32 + ocq * 4;
+    const int otile = t >> 4, ocq = t & 15;
+    const float* const Pr = P + otile * 64 + ((ocq * 4) ^ (((otile >> 2) & 1) << 5));
     f32x4 Y[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) Y[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    W4_STAMP(2);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();                                 // main-loop LDS reads (h = 0) / the first pass's P reads (h = 1) are done
+        if (h == 0) W4_STAMP(3);
+#pragma unroll
+        for (int b = 0; b < 9; ++b) {
+            if (b == 4 ? (nfirst == 5) == (h == 0) : (b < 4) == (h == 0)) {
+                const int hp = b + (b < 4 ? offA : b == 4 ? off4 : offB) - 18 * h;      // point inside the half
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    P[(hp * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + ((ct * 32 + li) ^ (lh << 5))] = acc[b][r];
+            }
+        }
+        if (h == 0) W4_STAMP(4);
+        __syncthreads();
+        if (h == 0) W4_STAMP(5);
 #pragma unroll 1
-    for (int a = 0; a < 6; ++a) {                        // point row; Y[ii][jj] += A^T[ii][a] * Q[jj]   (rolled: bounds the registers)
-        const float c0 = w43_AT[0][a], c1 = w43_AT[1][a], c2 = w43_AT[2][a], c3 = w43_AT[3][a];
-        f32x4 m[6];
+        for (int al = 0; al < 3; ++al) {                 // point row a = 3h + al; Y[ii][jj] += A^T[ii][a] * Q[jj]   (rolled: bounds the registers)
+            const int a = 3 * h + al;
+            const float c0 = w43_AT[0][a], c1 = w43_AT[1][a], c2 = w43_AT[2][a], c3 = w43_AT[3][a];
+            f32x4 m[6];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) m[b] = *reinterpret_cast<const f32x4*>(&Pr[(a * 6 + b) * 1024]);
-        // Q[jj] = sum_b M[a][b] A[b][jj]   (A^T rows: [1,1,1,1,1,0], [0,1,-1,2,-2,0], [0,1,1,4,4,0], [0,1,-1,8,-8,1])
-        const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
-        f32x4 Q[4];
-        Q[0] = m[0] + s12 + s34;
-        Q[1] = d12 + 2.f * d34;
-        Q[2] = s12 + 4.f * s34;
-        Q[3] = d12 + 8.f * d34 + m[5];
+            for (int b = 0; b < 6; ++b) m[b] = *reinterpret_cast<const f32x4*>(&Pr[(al * 6 + b) * 2048]);
+            // Q[jj] = sum_b M[a][b] A[b][jj]   (A^T rows: [1,1,1,1,1,0], [0,1,-1,2,-2,0], [0,1,1,4,4,0], [0,1,-1,8,-8,1])
+            const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+            f32x4 Q[4];
+            Q[0] = m[0] + s12 + s34;
+            Q[1] = d12 + 2.f * d34;
+            Q[2] = s12 + 4.f * s34;
+            Q[3] = d12 + 8.f * d34 + m[5];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            Y[0][jj] += c0 * Q[jj];
-            Y[1][jj] += c1 * Q[jj];
-            Y[2][jj] += c2 * Q[jj];
-            Y[3][jj] += c3 * Q[jj];
+            for (int jj = 0; jj < 4; ++jj) {
+                Y[0][jj] += c0 * Q[jj];
+                Y[1][jj] += c1 * Q[jj];
+                Y[2][jj] += c2 * Q[jj];
+                Y[3][jj] += c3 * Q[jj];
+            }
         }
     }
     W4_STAMP(6);
-    if (ct == 0) __syncthreads();                        // first half consumed: the second half may deposit
-    const int c0o = n0 + ct * 32 + ocq * 4;
+    const int c0o = n0 + ocq * 4;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (g.bias) {
 #pragma unroll
@@ -348,14 +372,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
             }
     }
     if (STATS) {
-        // batch-norm statistics: this wavefront's 64 threads cover one 4 x 32-pixel strip (8 tiles) x 32 couts; the 8 tiles are the lane
-        // bits 3-5, added in a fixed butterfly order, so the slab -- and everything derived from it -- is bitwise reproducible.
+        // batch-norm statistics: this wavefront's 64 threads cover one 4 x 16-pixel strip (4 tiles) x 64 couts; the 4 tiles are the lane
+        // bits 4-5, added in a fixed butterfly order, so the slab -- and everything derived from it -- is bitwise reproducible.
 #pragma unroll
-        for (int sh = 8; sh <= 32; sh <<= 1)
+        for (int sh = 16; sh <= 32; sh <<= 1)
 #pragma unroll
             for (int q = 0; q < 4; ++q) { st_s[q] += __shfl_xor(st_s[q], sh); st_q[q] += __shfl_xor(st_q[q], sh); }
-        if (lane < 8) {
-            const size_t strip = (((size_t)n * g.tiles_y + by) * g.tiles_x + bx) * 4 + pg;
+        if (lane < 16) {
+            const size_t strip = (((size_t)n * g.tiles_y + by) * g.tiles_x + bx) * 8 + wave;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (c0o + q < g.Cout) { g.stats[(strip * 2) * g.Cout + c0o + q] = st_s[q]; g.stats[(strip * 2 + 1) * g.Cout + c0o + q] = st_q[q]; }
@@ -414,9 +438,9 @@ extern "C" int kpx_conv3x3_wino43_f32(const float* in, int N, int H, int W, int 
                                       float* out, int Nn, int ldout, int act, void* stream) {
     return w43_launch(in, N, H, W, K, ldin, U, bias, out, Nn, ldout, act, nullptr, stream);
 }
-// 4 x 32-pixel strips per tensor: the unit of the statistics slab (kpx_bn_stats_from_tiles_f32 with tile_pixels = 128)
+// 4 x 16-pixel strips per tensor: the unit of the statistics slab (kpx_bn_stats_from_tiles_f32 with tile_pixels = 64)
 extern "C" size_t kpx_conv3x3_wino43_stats_tiles(int N, int H, int W) {
-    return (H % 16 || W % 32 || N <= 0) ? 0 : (size_t)N * (H / 16) * (W / 32) * 4;
+    return (H % 16 || W % 32 || N <= 0) ? 0 : (size_t)N * (H / 16) * (W / 32) * 8;
 }
 extern "C" int kpx_conv3x3_wino43_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
                                             float* out, int Nn, int ldout, int act, float* tile_stats, void* stream) {
