@@ -52,14 +52,15 @@ def time_kernel(fn, iters, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def _time_conv_3_1(dev, pretransformed=False):
+def _time_conv_3_1(dev, pretransformed=False, name='translator/conv_3_1'):
+    """name: the filter's variable name, which selects F(4x4,3x3) or F(2x2,3x3) exactly as in the train step (ops.WINO43_EXCLUDE_*)."""
     from kpx_amd import ops
     n, h, c = BATCH, 64, 128
     x = torch.randn(n, h, h, c, device=dev)
     w = torch.randn(3, 3, c, c, device=dev) * 0.03
     b = torch.zeros(c, device=dev)
     y = torch.empty(n, h, h, c, device=dev)
-    keys = ops.register_constant_filter(w) if pretransformed else []     # the train step runs the kernel on filters transformed once per update
+    keys = ops.register_constant_filter(w, name) if pretransformed else []     # the train step runs the kernel on filters transformed once per update
     try:
         ms = time_kernel(lambda: ops.conv_fwd_raw(x, c, c, w, b, y, c, 1, 1, 1, 0), iters=100, warm=20)
     finally:
@@ -89,25 +90,38 @@ def _pmc_traffic(name):
         return None, None
 
 
-WINO_PMC, DIRECT_PMC, RENDER_PMC = 'r02_wino_pmc.json', 'r01_conv_pmc.json', 'r02_render_pmc.json'
+WINO43_PMC, WINO_PMC, DIRECT_PMC, RENDER_PMC = 'r02_wino43_pmc.json', 'r02_wino_pmc.json', 'r01_conv_pmc.json', 'r02_render_pmc.json'
+
+
+def _roofline_wino(dev, name, kernel_substr, kernel_desc, reduction, pmc):
+    ms, flops = _time_conv_3_1(dev, pretransformed=True, name=name)
+    alg = flops / (ms * 1e-3) / 1e12
+    ach = alg / reduction
+    traffic, src = _pmc_traffic(pmc)
+    rp_ms, rp_src = _rocprof_avg_ms(kernel_substr)
+    return {'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'frac_at_rocprof_avg': round(flops / reduction / (rp_ms * 1e-3) / 157.3e12, 4) if rp_ms else None,
+            'bound': 'mfma', 'kernel': kernel_desc,
+            'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4),
+            'traffic': traffic, 'traffic_source': src, 'avg_launch_ms': round(ms, 4),
+            'flops_per_launch_executed': flops / reduction, 'flops_per_launch_algorithmic': flops,
+            'algorithmic_tflops': round(alg, 2), 'algorithmic_frac': round(alg / 157.3, 4)}
 
 
 def roofline_conv(dev):
-    """Dominant kernel: the fused Winograd F(2x2,3x3) conv (fp32 MFMA) on the translator's 3x3 128->128 layer at 64x64
+    """Dominant kernel: the fused Winograd F(4x4,3x3) conv (fp32 MFMA) on the translator's 3x3 128->128 layer at 64x64
     (conv_3_1 / 4_0 / 4_1, SURVEY Appendix A: 603 979 776 MAC per image), batch 32.  `achieved` / `frac` count the MFMA FLOPs the
-    kernel EXECUTES (algorithmic / 2.25: 16 instead of 36 multiplies per 2x2 output tile) against the fp32 MFMA peak;
-    `algorithmic_tflops` / `algorithmic_frac` count direct-convolution FLOPs and may exceed 1."""
-    ms, flops = _time_conv_3_1(dev, pretransformed=True)
-    alg = flops / (ms * 1e-3) / 1e12
-    ach = alg / 2.25
-    traffic, src = _pmc_traffic(WINO_PMC)
-    rp_ms, rp_src = _rocprof_avg_ms('conv_wino_v2_kernel<2, 0>')
-    return {'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'frac_at_rocprof_avg': round(flops / 2.25 / (rp_ms * 1e-3) / 157.3e12, 4) if rp_ms else None,
-            'bound': 'mfma', 'kernel': 'conv_wino_v2_kernel<2, 0> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), filter pre-transformed as in the train step',
-            'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4),
-            'traffic': traffic, 'traffic_source': src, 'avg_launch_ms': round(ms, 4),
-            'flops_per_launch_executed': flops / 2.25, 'flops_per_launch_algorithmic': flops,
-            'algorithmic_tflops': round(alg, 2), 'algorithmic_frac': round(alg / 157.3, 4)}
+    kernel EXECUTES (algorithmic / 4: 36 instead of 144 multiplies per 4x4 output tile) against the fp32 MFMA peak;
+    `algorithmic_tflops` / `algorithmic_frac` count direct-convolution FLOPs and exceed 1."""
+    return _roofline_wino(dev, 'translator/conv_3_1', 'conv_wino43_kernel<0>',
+                          'conv_wino43_kernel<0> F(4x4,3x3) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), filter pre-transformed as in the train step',
+                          4.0, WINO43_PMC)
+
+
+def roofline_conv_f23(dev):
+    """The F(2x2,3x3) kernel on the same layer shape (what the key-point detector, the image encoder and the translator's 32x32 layers
+    run): executed FLOPs = algorithmic / 2.25."""
+    return _roofline_wino(dev, 'pose_encoder/same_shape', 'conv_wino_v2_kernel<2, 0>',
+                          'conv_wino_v2_kernel<2, 0> F(2x2,3x3) fwd 3x3 s1 128->128 @64x64 B=32, filter pre-transformed', 2.25, WINO_PMC)
 
 
 def roofline_conv_direct(dev):
@@ -280,7 +294,7 @@ def main():
     kops.set_compute_dtype(args.dtype)
     if args.roofline_only:
         kops.set_compute_dtype('f32')
-        print(json.dumps({'roofline': roofline_conv(dev), 'roofline_direct_conv': roofline_conv_direct(dev),
+        print(json.dumps({'roofline': roofline_conv(dev), 'roofline_wino_f23': roofline_conv_f23(dev), 'roofline_direct_conv': roofline_conv_direct(dev),
                           'roofline_hbm_render': roofline_render(dev), 'roofline_bf16_conv': roofline_conv_bf16(dev)}), flush=True)
         return
     cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': args.batch},
@@ -346,6 +360,7 @@ def main():
             if args.dtype == 'bf16':
                 out['roofline_bf16_conv'] = roofline_conv_bf16(dev)
             out['roofline'] = roofline_conv(dev)
+            out['roofline_wino_f23'] = roofline_conv_f23(dev)
             out['roofline_direct_conv'] = roofline_conv_direct(dev)
             out['roofline_hbm_render'] = roofline_render(dev)
             if not args.no_cpu_baseline:

@@ -26,7 +26,7 @@ for f, dst in (('bench.json', 'r02_bench.json'), ('bench_bf16.json', 'r02_bench_
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(O + '/pmc_*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
-        for key, tag in (('conv_wino_v2_kernel<2, 0>', 'wino'), ('gauss_fwd', 'render'), ('conv3x3_bf16_kernel', 'bf16'), ('conv_igemm_kernel<128, 128', 'direct')):
+        for key, tag in (('conv_wino43_kernel<0>', 'wino43'), ('conv_wino_v2_kernel<2, 0>', 'wino'), ('gauss_fwd', 'render'), ('conv3x3_bf16_kernel', 'bf16'), ('conv_igemm_kernel<128, 128', 'direct')):
             if key in r['Kernel_Name']:
                 pmc[tag][r['Counter_Name']].append(float(r['Counter_Value']))
 def mean(v): return sum(v) / len(v) if v else None
@@ -35,7 +35,14 @@ for tag, d in pmc.items():
     out[tag] = {c: mean(v) for c, v in d.items()}
     out[tag]['dispatches'] = {c: len(v) for c, v in d.items()}
 json.dump(out, open(O + '/pmc_raw.json', 'w'), indent=1)
-w, r = out.get('wino', {}), out.get('render', {})
+w, r, w43 = out.get('wino', {}), out.get('render', {}), out.get('wino43', {})
+if w43.get('FETCH_SIZE') is not None and w43.get('WRITE_SIZE') is not None:
+    fetch, write = w43['FETCH_SIZE'] * 1024 * 2, w43['WRITE_SIZE'] * 1024
+    json.dump({'kernel': 'conv_wino43_kernel<0> F(4x4,3x3) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
+               'source': 'rocprofv3 --pmc, separate passes (profiles/collect_r02.sh), mean over the dispatches of `bench.py --roofline-only`',
+               **{k: v for k, v in w43.items() if k != 'dispatches'}, 'dispatches': w43['dispatches'],
+               'fetch_bytes_corrected': fetch, 'write_bytes': write, 'algorithmic_bytes': 134807552,
+               'traffic_bytes_per_launch': fetch + write}, open('profiles/r02_wino43_pmc.json', 'w'), indent=1)
 if w.get('FETCH_SIZE') is not None and w.get('WRITE_SIZE') is not None:
     # guide: FETCH_SIZE is in KB and counts 64 B per 128-B request on gfx950 wide reads -> x2; WRITE_SIZE (KB) is exact for 16-B stores
     fetch, write = w['FETCH_SIZE'] * 1024 * 2, w['WRITE_SIZE'] * 1024
@@ -54,6 +61,6 @@ if r.get('WRITE_SIZE') is not None:
 print(json.dumps(out, indent=1)[:3000])
 for f in ('profiles/r02_roofline_only_kernel_stats.csv',):
     for row in csv.DictReader(open(f)):
-        if any(k in row['Name'] for k in ('wino_v2', 'gauss_fwd', 'bf16_kernel', 'conv_igemm')):
+        if any(k in row['Name'] for k in ('wino43', 'wino_v2', 'gauss_fwd', 'bf16_kernel', 'conv_igemm')):
             print(row['Name'][:70], row['Calls'], 'avg_us', float(row['AverageNs']) / 1e3)
 PY

@@ -44,3 +44,7 @@ for dbg in [int(v) for v in sys.argv[1:]] or [0]:
         bar = np.median(q[:, :, 1] - q[:, :, 0]); p1 = np.median(q[:, :, 2] - q[:, :, 1]); p2 = np.median(q[:, :, 3] - q[:, :, 2])
         whole = np.median(q[:, 1:, 0] - q[:, :-1, 0])
         print('  wave %d (%s): %6.0f | %6.0f | %6.0f | %6.0f' % (wv, 'T then M' if wv < 4 else 'M then T' if wv < 6 else 'L then M', bar, p1, p2, whole))
+    print(' prologue: setup | (loaders: first patch landed + staged) | first barrier passed | transform(0) / second stage')
+    for wv in (0, 4, 6):
+        q = d[:, wv].astype(np.float64)
+        print('  wave %d: %6.0f | %6.0f | %6.0f | %6.0f' % (wv, np.median(q[:, 10] - q[:, 0]), np.median(q[:, 11] - q[:, 0]) if wv >= 6 else 0, np.median(q[:, 12] - q[:, 0]), np.median(q[:, 1] - q[:, 0])))

@@ -515,6 +515,8 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const floa
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW,
                                                                   const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
                                                                   int pad_t, int pad_l, int act, hipStream_t s);
+extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
+                                                                    float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, hipStream_t s);
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N, int H, int W, int Cin, int Cout);
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad3x3(const float* x, int N, int H, int W, int Cin, int ldx, const float* dy, int Cout, int lddy,
                                                                    float* slabs, int S, hipStream_t s);
@@ -579,6 +581,10 @@ extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int 
         KH <= 0 || KW <= 0 || stride <= 0 || lddy < Cout || lddx < Cin)
         return KPX_EINVAL;
     if (stride > 2) return KPX_EINVAL;             // at most 4 parity classes per launch (the path has strides 1 and 2)
+    if (Cin <= 4) {                                // gradient towards an image: VALU kernel (conv_rgb.hip)
+        const int rc = kpx_conv_rgb_dgrad(dy, N, Ho, Wo, Cout, lddy, w, KH, KW, dx, Hi, Wi, Cin, lddx, stride, pad_t, pad_l, kpx_stream(stream));
+        if (rc != -2) return rc;
+    }
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi &&
         workspace && workspace_bytes >= wino_ws_bytes(Cin, Cout) && kpx_wino_eligible(N, Hi, Wi, Cout, Cin, lddy, dy))
         return kpx_wino_conv3x3(dy, N, Hi, Wi, Cout, lddy, w, Cin, Cout, 1, nullptr, KPX_ACT_NONE, dx, Cin, lddx, (float*)workspace, kpx_stream(stream));

@@ -116,3 +116,108 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const floa
     else hipLaunchKernelGGL(conv_rgb_kernel<2>, dim3(blocks), dim3(256), lds, s, g);
     return kpx_launch_status();
 }
+
+
+// ------------------------------------------------------------------------------------------ data gradient towards an image (Cin <= 4)
+// dx[n, iy, ix, c] = sum_{ky, kx, co} dy[n, (iy + pad - ky) / S, (ix + pad - kx) / S, co] * w[ky][kx][c][co] for VGG19 conv1_1 (3x3 s1,
+// 64 -> 3: the perceptual loss's gradient towards the generated frame, reference models/networks/vgg.py:51) and img_discr conv_0 (4x4 s2,
+// 64 -> 3: the adversarial loss's, models/networks/__init__.py:143).  The implicit-GEMM kernel pads the 3 produced channels to an MFMA
+// tile of 32-64 and runs at ~8 TFLOP/s; this one is plain VALU work over LDS: one workgroup stages the dy patch of a (16 S)^2 input
+// tile 16 channels at a time (18 x 18 pixels, 20 floats per pixel: conflict-free ds_read_b128 at a 16-lane pixel stride), each thread
+// owns S x S input pixels, and the filter taps are wave-uniform scalar operands.
+struct RgbDgradGeom {
+    const float* dy; const float* w; float* dx;
+    int N, Ho, Wo, Cout, lddy, Hi, Wi, Cin, lddx, pad_t, pad_l, tiles_y, tiles_x;
+};
+
+template <int KS, int S, int CIN>
+__global__ __launch_bounds__(256) void conv_rgb_dgrad_kernel(const RgbDgradGeom g) {
+    constexpr int TI = 16 * S, PR = 18, PS = 20;
+    static_assert((TI + KS - 2) / S + 1 <= PR, "dy patch does not fit");      // floor((m + TI - 1) / S) - floor((m - KS + 1) / S) + 1
+    __shared__ __attribute__((aligned(16))) float patch[PR * PR * PS];
+    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+    int L = blockIdx.x;
+    const int bx = L % g.tiles_x; L /= g.tiles_x;
+    const int by = L % g.tiles_y;
+    const int n = L / g.tiles_y;
+    const int iy0 = by * TI, ix0 = bx * TI;
+    // first dy row / column any pixel of the tile can touch: floor((i0 + pad - (KS - 1)) / S)
+    const int ny = iy0 + g.pad_t - (KS - 1), nx = ix0 + g.pad_l - (KS - 1);
+    const int oy_min = ny >= 0 ? ny / S : -((-ny + S - 1) / S), ox_min = nx >= 0 ? nx / S : -((-nx + S - 1) / S);
+    float acc[S][S][CIN];
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+        for (int b = 0; b < S; ++b)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) acc[a][b][c] = 0.f;
+
+    for (int c0 = 0; c0 < g.Cout; c0 += 16) {
+        __syncthreads();
+        for (int i = t; i < PR * PR * 4; i += 256) {
+            const int px = i >> 2, q = i & 3, pr = px / PR, pc = px - pr * PR;
+            const int oy = oy_min + pr, ox = ox_min + pc;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)oy < (unsigned)g.Ho && (unsigned)ox < (unsigned)g.Wo)
+                v = *reinterpret_cast<const f32x4*>(g.dy + (((size_t)n * g.Ho + oy) * g.Wo + ox) * g.lddy + c0 + 4 * q);
+            *reinterpret_cast<f32x4*>(&patch[px * PS + 4 * q]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < S; ++a) {
+            const int iyp = iy0 + S * ty + a + g.pad_t;
+#pragma unroll
+            for (int b = 0; b < S; ++b) {
+                const int ixp = ix0 + S * tx + b + g.pad_l;
+                for (int ky = (a + g.pad_t) % S; ky < KS; ky += S) {              // (iy0 is a multiple of S: the parity is the thread's a)
+                    const int pr = (iyp - ky) / S - oy_min;
+                    for (int kx = (b + g.pad_l) % S; kx < KS; kx += S) {
+                        const int pc = (ixp - kx) / S - ox_min;
+                        const float* pp = &patch[(pr * PR + pc) * PS];
+                        const float* wp = g.w + (size_t)((ky * KS + kx) * CIN) * g.Cout + c0;       // wave-uniform: scalar loads
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 d = *reinterpret_cast<const f32x4*>(pp + 4 * q);
+#pragma unroll
+                            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[a][b][c] = fmaf(d[e], wp[(size_t)c * g.Cout + 4 * q + e], acc[a][b][c]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < S; ++a)
+#pragma unroll
+        for (int b = 0; b < S; ++b) {
+            const int iy = iy0 + S * ty + a, ix = ix0 + S * tx + b;
+            if (iy < g.Hi && ix < g.Wi) {
+                float* o = g.dx + (((size_t)n * g.Hi + iy) * g.Wi + ix) * g.lddx;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) o[c] = acc[a][b][c];
+            }
+        }
+}
+
+// 3x3 stride-1 and 4x4 stride-2 data gradients towards Cin <= 4 channels, Cout a multiple of 16; returns -2 when the shape is not handled
+extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
+                                                                    float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, hipStream_t s) {
+    const bool k3 = KH == 3 && KW == 3 && stride == 1, k4 = KH == 4 && KW == 4 && stride == 2;
+    if (!(k3 || k4) || (Cin != 3 && Cin != 4) || Cout % 16 || lddy % 4 || (((uintptr_t)dy) & 15) || (((uintptr_t)w) & 15) || pad_t < 0 || pad_l < 0 ||
+        pad_t >= KH || pad_l >= KW || getenv("KPX_NO_RGB"))
+        return -2;
+    // every input pixel's taps must land inside the 18-pixel patch: true for Ho = ceil-type SAME / explicit pads of this path (checked per launch)
+    RgbDgradGeom g{};
+    g.dy = dy; g.w = w; g.dx = dx;
+    g.N = N; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.lddy = lddy; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.lddx = lddx; g.pad_t = pad_t; g.pad_l = pad_l;
+    const int TI = 16 * stride;
+    g.tiles_y = (Hi + TI - 1) / TI; g.tiles_x = (Wi + TI - 1) / TI;
+    const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x);
+    if (k3 && Cin == 3) hipLaunchKernelGGL((conv_rgb_dgrad_kernel<3, 1, 3>), dim3(blocks), dim3(256), 0, s, g);
+    else if (k3) hipLaunchKernelGGL((conv_rgb_dgrad_kernel<3, 1, 4>), dim3(blocks), dim3(256), 0, s, g);
+    else if (Cin == 3) hipLaunchKernelGGL((conv_rgb_dgrad_kernel<4, 2, 3>), dim3(blocks), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((conv_rgb_dgrad_kernel<4, 2, 4>), dim3(blocks), dim3(256), 0, s, g);
+    return kpx_launch_status();
+}

@@ -181,14 +181,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
     // The two roles run separate copies of the chunk loop (their register needs differ: 44 transient transform registers vs 40 of
     // patch data in flight); both pass exactly one barrier per chunk, after one in the prologue.
     if (wave < 6) {
-        // ---- input transform: row `wave` of B^T d B for (tile = lane & 31, channel half = lane >> 5) ----
+        // ---- input transform: one row of B^T d B per wavefront for (tile = lane & 31, channel half = lane >> 5); wavefronts 4 and 5 take
+        // rows 0 and 5, whose three-term sums need one LDS read less per column ----
+        const int trow = wave < 4 ? wave + 1 : wave == 4 ? 0 : 5;
         const int ttile = lane & 31, thf = lane >> 5, tty = ttile >> 3, ttx = ttile & 7;
         const int trd = (thf * W4_PLANE + 4 * tty * W4_RS + 5 * ttx) * 4;
-        const int r0 = w43_R[wave][0] * W4_RS * 4, r1 = w43_R[wave][1] * W4_RS * 4, r2 = w43_R[wave][2] * W4_RS * 4, r3 = w43_R[wave][3] * W4_RS * 4;
-        const float a0 = w43_A[wave][0], a1 = w43_A[wave][1], a2 = w43_A[wave][2], a3 = w43_A[wave][3];
-        const int vwr = (6 * wave) * 256 + ttile * 8 + ((thf ^ ((ttile >> 3) & 1)) << 2);
+        const int r0 = w43_R[trow][0] * W4_RS * 4, r1 = w43_R[trow][1] * W4_RS * 4, r2 = w43_R[trow][2] * W4_RS * 4, r3 = w43_R[trow][3] * W4_RS * 4;
+        const float a0 = w43_A[trow][0], a1 = w43_A[trow][1], a2 = w43_A[trow][2], a3 = w43_A[trow][3];
+        const int vwr = (6 * trow) * 256 + ttile * 8 + ((thf ^ ((ttile >> 3) & 1)) << 2);
         const int ktail = g.Cin - (nchunks - 1) * 8 - thf * 4;       // valid channels of this thread's half in the LAST chunk
-        auto transform = [&](const float* rawR, float* Vw, bool mask_tail) {
+        auto transform = [&](const float* rawR, float* Vw, bool mask_tail, auto three_tag) {
+            constexpr bool THREE = decltype(three_tag)::value;
             f32x4 tc[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
                 const f32x4 d0 = *reinterpret_cast<const f32x4*>(&rawR[co + r0]);
                 const f32x4 d1 = *reinterpret_cast<const f32x4*>(&rawR[co + r1]);
                 const f32x4 d2 = *reinterpret_cast<const f32x4*>(&rawR[co + r2]);
-                const f32x4 d3 = *reinterpret_cast<const f32x4*>(&rawR[co + r3]);
-                tc[c] = a0 * d0 + a1 * d1 + a2 * d2 + a3 * d3;
+                if (THREE) tc[c] = a0 * d0 + a1 * d1 + a2 * d2;
+                else tc[c] = a0 * d0 + a1 * d1 + a2 * d2 + a3 * *reinterpret_cast<const f32x4*>(&rawR[co + r3]);
             }
             if (mask_tail) {
 #pragma unroll
@@ -212,8 +215,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
             *reinterpret_cast<f32x4*>(&Vw[vwr + 1024]) = 2.f * (tc[1] - tc[3]) - tc[2] + tc[4];
             *reinterpret_cast<f32x4*>(&Vw[vwr + 1280]) = 4.f * tc[1] - 5.f * tc[3] + tc[5];
         };
+        W4_STAMP(10);
         __syncthreads();                                 // raw[0] (chunk 0) staged by the loaders
-        transform(rawb, Vb, nchunks == 1 && ktail < 4);
+        W4_STAMP(12);
+        transform(rawb, Vb, nchunks == 1 && ktail < 4, std::false_type{});
         W4_STAMP(1);
         // wavefronts 4-5 (the second transform wavefront of SIMD 0 / 1) multiply first and transform afterwards, so that one of the two
         // always has MFMAs to issue while the other waits for LDS; separate loop copies keep the register allocation of each tight
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
                 __syncthreads();                         // V[cur] (chunk k) and raw[cur^1] (chunk k+1) are complete
                 W4_KSTAMP(k, 1);
                 if (LATE) { mfma(Vb + cur * W4_V, k + 1 < nchunks); W4_KSTAMP(k, 2); }
-                if (k + 1 < nchunks) transform(rawb + (cur ^ 1) * W4_RAW, Vb + (cur ^ 1) * W4_V, k + 1 == nchunks - 1 && ktail < 4);
+                if (k + 1 < nchunks) transform(rawb + (cur ^ 1) * W4_RAW, Vb + (cur ^ 1) * W4_V, k + 1 == nchunks - 1 && ktail < 4, late_tag);
                 if (!LATE) { W4_KSTAMP(k, 2); mfma(Vb + cur * W4_V, k + 1 < nchunks); }
                 W4_KSTAMP(k, 3);
             }
@@ -259,10 +264,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
 #pragma unroll
             for (int i = 0; i < W4_LOADER_UNITS; ++i) *reinterpret_cast<f32x4*>(&rawW[rdst[i]]) = rr[i];
         };
+        W4_STAMP(10);
         load_raw();
         stage(rawb);
+        W4_STAMP(11);
         if (nchunks > 1) load_raw();
         __syncthreads();
+        W4_STAMP(12);
         if (nchunks > 1) stage(rawb + W4_RAW);
         if (nchunks > 2) load_raw();
         W4_STAMP(1);
