@@ -191,14 +191,14 @@ conv_kernel_uses = {'wino43': 0}      # diagnostics / tests: launches of the F(4
 # F(4x4,3x3) (csrc/conv_wino43.hip) does 2.25x fewer multiplies than F(2x2,3x3) at ~6x its rounding error (2-3e-6 rel-L2 per layer, still
 # inside the 1e-5 bar of one layer).  Where it runs is decided per filter NAME and direction, from the measured effect on a whole train
 # step against the float64 arbiter (tests/test_model_gpu.py::test_configs0..., scratch/w43_policy.py):
-#   * data gradients: everywhere except the key-point detector;
+#   * data gradients: everywhere (the detector's included: its eight eligible layers change no digit of the gradient-error figures);
 #   * forward: VGG19 and the translator's 64x64 / 128x128 layers (conv_3_* .. conv_5_*).  The detector, the image encoder and the
 #     translator's 32x32 layers (256-deep sums feeding batch norms over few pixels) stay on F(2x2,3x3): with them on F(4x4,3x3) the
 #     generated frame moves 3e-5 instead of 1.7e-5 from the oracle's and the discriminator gradient 4.6x instead of 1.2x as far from the
 #     float64 gradient as the fp32 oracle's own.
 WINO43 = _os.environ.get('KPX_WINO43', '1') != '0'
 WINO43_EXCLUDE_FWD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_FWD', 'pose_encoder,image_encoder,translator/conv_1,translator/conv_2').split(',') if p)
-WINO43_EXCLUDE_DGRAD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_DGRAD', 'pose_encoder').split(',') if p)
+WINO43_EXCLUDE_DGRAD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_DGRAD', '').split(',') if p)
 
 
 def _wino43_wanted(name, cin, cout, dgrad):
