@@ -62,3 +62,15 @@ for shp, ci, co in [((32, 128, 128), 128, 128), ((32, 128, 128), 64, 64), ((32, 
     t23 = t(lambda: lib.kpx_conv3x3_wino_f32(x.data_ptr(), n, h, wd, ci, ci, u23.data_ptr(), None, y.data_ptr(), co, co, 0, s))
     fl = 2.0 * n * h * wd * 9 * ci * co
     print(shp, ci, co, 'F(4,3) %.4f ms (%.1f eff TF, executed frac %.2f) | F(2,3) %.4f ms (%.1f eff TF)' % (t43, fl / t43 / 1e9, fl / 4 / t43 / 1e9 / 157.3, t23, fl / t23 / 1e9))
+print('packed 16x16:')
+for shp, ci, co in [((64, 16, 16), 512, 512), ((64, 16, 16), 256, 512), ((32, 16, 16), 512, 512), ((64, 16, 16), 128, 128)]:
+    n, h, wd = shp
+    x = torch.randn(n, h, wd, ci, device=dev); w = torch.randn(3, 3, ci, co, device=dev) * 0.05; y = torch.empty(n, h, wd, co, device=dev)
+    u43 = torch.empty(lib.kpx_wino43_u_bytes(ci, co) // 4, device=dev); u23 = torch.empty(lib.kpx_wino_u_bytes(ci, co) // 4, device=dev)
+    check(lib.kpx_wino43_filter_transform_f32(w.data_ptr(), ci, co, 0, u43.data_ptr(), ops._stream()), 'xf')
+    check(lib.kpx_wino_filter_transform_f32(w.data_ptr(), ci, co, 0, u23.data_ptr(), ops._stream()), 'xf')
+    s = ops._stream()
+    t43 = t(lambda: check(lib.kpx_conv3x3_wino43_f32(x.data_ptr(), n, h, wd, ci, ci, u43.data_ptr(), None, y.data_ptr(), co, co, 0, s), 'c43'))
+    t23 = t(lambda: check(lib.kpx_conv3x3_wino_f32(x.data_ptr(), n, h, wd, ci, ci, u23.data_ptr(), None, y.data_ptr(), co, co, 0, s), 'c23'))
+    fl = 2.0 * n * h * wd * 9 * ci * co
+    print(shp, ci, co, 'F(4,3) %.4f ms (%.1f eff TF, executed frac %.2f) | F(2,3) %.4f ms (%.1f eff TF)' % (t43, fl / t43 / 1e9, fl / 4 / t43 / 1e9 / 157.3, t23, fl / t23 / 1e9))

@@ -360,17 +360,19 @@ def test_winograd_fuzz_against_oracle(kpx, dev, n, h, w, cin, cout, k, s, pad, a
 
 W43_CASES = [  # n, h, w, cin, cout, act
     (2, 16, 32, 16, 64, 0), (2, 32, 32, 64, 64, 1), (1, 16, 64, 24, 40, 2), (3, 48, 96, 136, 128, 0), (2, 32, 64, 64, 128, 1),
-    (1, 16, 32, 256, 72, 0), (2, 128, 128, 64, 64, 1), (5, 32, 32, 40, 200, 2)]
+    (1, 16, 32, 256, 72, 0), (2, 128, 128, 64, 64, 1), (5, 32, 32, 40, 200, 2),
+    (4, 16, 16, 64, 128, 1), (2, 16, 16, 256, 72, 0), (6, 16, 16, 40, 64, 2)]          # 16x16 images, two to a workgroup
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout,act', W43_CASES)
-def test_winograd_f43_forward_and_data_gradient_against_oracle(kpx, dev, n, h, w, cin, cout, act):
+def test_winograd_f43_forward_and_data_gradient_against_oracle(kpx, dev, monkeypatch, n, h, w, cin, cout, act):
     """The F(4x4,3x3) kernel (csrc/conv_wino43.hip) through ops.conv2d with pre-transformed filters: forward and data gradient against the
     oracle convolution at the 1e-5 bar of a layer, ragged channel counts (K tail chunk, cout tail of a 64-wide block), all activations,
     and a check that it IS the kernel that ran.  Weight / bias gradients come from the shared wgrad kernel."""
     ops = kpx.ops
     if not ops.WINO43:
         pytest.skip('KPX_WINO43=0')
+    monkeypatch.setattr(ops, 'WINO43_MIN_WORKGROUPS', 0)        # (the step only uses the kernel for launches of more than 128 workgroups)
     rs = np.random.RandomState(cin * 3 + cout)
     x = rs.randn(n, h, w, cin).astype(np.float32)
     wt = (rs.randn(3, 3, cin, cout) / np.sqrt(9 * cin)).astype(np.float32)
@@ -402,11 +404,12 @@ def test_winograd_f43_forward_and_data_gradient_against_oracle(kpx, dev, n, h, w
     assert rel_l2(t2n(bg.grad), t2n(bo.grad)) < 1e-5
 
 
-def test_winograd_f43_reads_a_channel_slice_and_writes_a_strided_destination(kpx, dev):
+def test_winograd_f43_reads_a_channel_slice_and_writes_a_strided_destination(kpx, dev, monkeypatch):
     """K = 158 of a 160-wide joint buffer (translator conv_1_0) into a channel slice of a wider output, raw launcher."""
     ops = kpx.ops
     if not ops.WINO43:
         pytest.skip('KPX_WINO43=0')
+    monkeypatch.setattr(ops, 'WINO43_MIN_WORKGROUPS', 0)
     rs = np.random.RandomState(5)
     full = rs.randn(2, 32, 32, 160).astype(np.float32)
     wt = (rs.randn(3, 3, 158, 96) * 0.03).astype(np.float32)
@@ -509,11 +512,12 @@ def test_conv3x3_bf16_fwd_dgrad_tolerance(kpx, dev, n, h, w, cin, cout, act):
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout,groups', [(4, 32, 32, 32, 64, 1), (4, 16, 48, 64, 40, 2), (2, 64, 64, 128, 128, 1), (4, 16, 32, 24, 70, 2), (2, 32, 32, 16, 32, 1)])
-def test_batch_norm_statistics_from_the_conv_epilogue(kpx, dev, n, h, w, cin, cout, groups):
+def test_batch_norm_statistics_from_the_conv_epilogue(kpx, dev, monkeypatch, n, h, w, cin, cout, groups):
     """conv -> train-mode batch norm with the per-tile channel sums written by the Winograd epilogue (kpx_conv3x3_wino_stats_f32 +
     kpx_bn_stats_from_tiles_f32) against the oracle AND against the separate statistics pass: same normalised output, same
     moving-statistics update, per-call statistics for ``groups`` weight-sharing calls (reference detector_translator_model.py:166-167)."""
     ops = kpx.ops
+    monkeypatch.setattr(ops, 'WINO43_MIN_WORKGROUPS', 0)        # small launches too: both kernels' epilogues are covered by the shape list
     rs = np.random.RandomState(cin + cout)
     x = rs.randn(n, h, w, cin).astype(np.float32)
     x[n // 2:] += 0.5                                   # the two groups see different statistics
@@ -525,7 +529,7 @@ def test_batch_norm_statistics_from_the_conv_epilogue(kpx, dev, n, h, w, cin, co
     keys = ops.register_constant_filter(wg)
     try:
         y = ops.conv2d(xg, wg, bg, stride=1, pad=0, act=0, bn_stats=True)
-        f43 = w % 32 == 0 and cin >= 16 and cout >= 33          # these shapes run the F(4x4,3x3) kernel: statistics per 4x16-pixel strip
+        f43 = ops.WINO43 and w % 32 == 0 and cin >= 16 and cout >= 33          # these shapes run the F(4x4,3x3) kernel: statistics per 4x16-pixel strip
         assert hasattr(y, '_kpx_tile_stats') and y._kpx_tile_stats[1] == ((h // 16) * (w // 32) * 8 if f43 else (h // 16) * (w // 16))
         mm1, mv1 = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
         used = ops.fused_bn_uses['stats_from_conv_epilogue']

@@ -86,11 +86,13 @@ __global__ __launch_bounds__(256) void wino43_filter_transform_kernel(const floa
         w43_transform_filter(w, Cin, Cout, dgrad != 0, idx, Kp, Np, Uf);
 }
 
-#define W4_RS 42
-#define W4_PLANE (18 * W4_RS)                  // 16-B slots per channel-half plane
-#define W4_RAW (2 * W4_PLANE * 4)              // floats per raw buffer (6048)
+// PACK: two 16 x 16 images side by side in one 16 x 32 region (VGG19 conv4_*, the 16 x 16 layers of the encoders): each image has its own
+// 18-column patch; the second one starts 36 slots after the first (row stride 58), which keeps the reads conflict-free (the tile
+// origins of the second image are 16 slots = one full bank sweep further than they would be in a 34-column patch).
+#define W4_RS_OF(PACK) ((PACK) ? 58 : 42)
 #define W4_V (36 * 32 * 8)                     // floats per V buffer (9216)
-#define W4_MAIN (2 * W4_RAW + 2 * W4_V)
+#define W4_RAW_OF(PACK) (2 * 18 * W4_RS_OF(PACK) * 4)      // floats per raw buffer (6048 / 8352)
+#define W4_MAIN (2 * W4_RAW_OF(true) + 2 * W4_V)
 #define W4_EPI (18 * 32 * 64)
 
 // rows of B^T (= rows of the input transform): value = sum_m A[m] * d[R[m]]
@@ -109,10 +111,11 @@ extern "C" int kpx_debug_w43_stamps(unsigned long long* buf) { return -(int)hipM
 #define W4_STAMP(slot) do { } while (0)
 #endif
 
-#define W4_LOADER_UNITS 10                     // 1224 (pixel, half) units of a raw patch over the 128 threads of wavefronts 6-7
 
-template <int STATS>
+template <int STATS, bool PACK>
 __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g) {
+    constexpr int W4_RS = W4_RS_OF(PACK), W4_PLANE = 18 * W4_RS, W4_RAW = W4_RAW_OF(PACK);
+    constexpr int W4_LOADER_UNITS = PACK ? 8 : 10;       // (pixel, half) units of a raw patch per thread of wavefronts 6-7: 1224 / 1024 in all
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const rawb = smem;
     float* const Vb = smem + 2 * W4_RAW;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
     const int nti = L % ntc; L /= ntc;
     const int bx = L % g.tiles_x; L /= g.tiles_x;
     const int by = L % g.tiles_y;
-    const int n = L / g.tiles_y;
+    const int n = PACK ? 2 * (L / g.tiles_y) : L / g.tiles_y;      // PACK: tiles_y = tiles_x = 1, the region holds images n and n + 1
     const int oy0 = by * 16, ox0 = bx * 32, n0 = nti * 64;
 
     // MFMA operands (all wavefronts).  Points 0-17 (rows 0-2 of the 6x6 grid) and 18-35 are each spread over the four wavefronts of a
@@ -160,6 +163,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
 #pragma unroll
     for (int b = 0; b < 3; ++b) ub[b] = *reinterpret_cast<const f32x4*>(W4_UPTR(b));
 
+    if (PACK) {                                          // the halo slots of both raw buffers are never written again
+        for (int i = t; i < 2 * W4_RAW / 4; i += 512) *reinterpret_cast<f32x4*>(&rawb[i * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+    }
     // B fragments: a ring of 3 points, each refilled in place (for the point 3 ahead, possibly of the next chunk) right after its MFMAs
     auto mfma = [&](const float* Vr, bool refill_next) {
         f32x4 av[2];
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
         // rows 0 and 5, whose three-term sums need one LDS read less per column ----
         const int trow = wave < 4 ? wave + 1 : wave == 4 ? 0 : 5;
         const int ttile = lane & 31, thf = lane >> 5, tty = ttile >> 3, ttx = ttile & 7;
-        const int trd = (thf * W4_PLANE + 4 * tty * W4_RS + 5 * ttx) * 4;
+        const int trd = (thf * W4_PLANE + 4 * tty * W4_RS + 5 * ttx + (PACK && ttx >= 4 ? 16 : 0)) * 4;
         const int r0 = w43_R[trow][0] * W4_RS * 4, r1 = w43_R[trow][1] * W4_RS * 4, r2 = w43_R[trow][2] * W4_RS * 4, r3 = w43_R[trow][3] * W4_RS * 4;
         const float a0 = w43_A[trow][0], a1 = w43_A[trow][1], a2 = w43_A[trow][2], a3 = w43_A[trow][3];
         const int vwr = (6 * trow) * 256 + ttile * 8 + ((thf ^ ((ttile >> 3) & 1)) << 2);
@@ -240,18 +247,24 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
         // ---- patch loader: the whole 18 x 34-pixel x 8-channel patch of a chunk, 10 (pixel, half) units per thread, through a buffer
         // descriptor of image n: out-of-image units carry an out-of-range offset and read as zero ----
         const int tl = t - 384;
-        const unsigned img_bytes = (unsigned)g.H * g.W * g.ldx * 4u;
+        const unsigned img_bytes = (unsigned)g.H * g.W * g.ldx * 4u * (PACK ? 2u : 1u);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x) + (size_t)n * g.H * g.W * g.ldx, 0, img_bytes, 0x00020000);
         int voff[W4_LOADER_UNITS], rdst[W4_LOADER_UNITS];
 #pragma unroll
         for (int i = 0; i < W4_LOADER_UNITS; ++i) {
             const int u = tl + 128 * i;
-            const int uu = u < 1224 ? u : tl;            // the 56 missing units of the last round re-store the thread's first unit
-            const int px = uu >> 1, hf = uu & 1, row = px / 34, col = px - row * 34;
-            const int iy = oy0 - 1 + row, ix = ox0 - 1 + col;
-            const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-            voff[i] = ok ? ((iy * g.W + ix) * g.ldx + hf * 4) * 4 : (int)0x80000000;
-            rdst[i] = (hf * W4_PLANE + row * W4_RS + col + (col >> 2)) * 4;
+            if (PACK) {                                  // only the 16 x 16 in-image pixels of the two images: the halo slots stay zero
+                const int hf = u & 1, px = u >> 1, img = px >> 8, iy = (px >> 4) & 15, ix = px & 15;
+                voff[i] = (((img * 16 + iy) * 16 + ix) * g.ldx + hf * 4) * 4;
+                rdst[i] = (hf * W4_PLANE + (iy + 1) * W4_RS + (ix + 1) + ((ix + 1) >> 2) + img * 36) * 4;
+            } else {
+                const int uu = u < 1224 ? u : tl;        // the 56 missing units of the last round re-store the thread's first unit
+                const int px = uu >> 1, hf = uu & 1, row = px / 34, col = px - row * 34;
+                const int iy = oy0 - 1 + row, ix = ox0 - 1 + col;
+                const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+                voff[i] = ok ? ((iy * g.W + ix) * g.ldx + hf * 4) * 4 : (int)0x80000000;
+                rdst[i] = (hf * W4_PLANE + row * W4_RS + col + (col >> 2)) * 4;
+            }
         }
         f32x4 rr[W4_LOADER_UNITS];
         int soff = 0;
@@ -349,8 +362,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
     // activation without branches: max(v, lo) then v > 0 ? v : slope * v   (none: lo = -inf, slope 1; relu: lo = 0; leaky: slope 0.01)
     const float lo = g.act == KPX_ACT_RELU ? 0.f : -__builtin_inff();
     const float slope = g.act == KPX_ACT_LRELU ? 0.01f : 1.f;
-    const int oy = oy0 + 4 * (otile >> 3), ox = ox0 + 4 * (otile & 7);
-    float* const obase = g.y + ((size_t)(n * g.H + oy) * g.W + ox) * g.ldy + c0o;
+    const int oy = oy0 + 4 * (otile >> 3), ox = PACK ? 4 * (otile & 3) : ox0 + 4 * (otile & 7);
+    const int on = PACK ? n + ((otile >> 2) & 1) : n;
+    float* const obase = g.y + ((size_t)(on * g.H + oy) * g.W + ox) * g.ldy + c0o;
     const size_t cstr = (size_t)g.ldy, rstr = (size_t)g.W * g.ldy;
     const bool fast = (g.ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.y) & 15) == 0) && n0 + 64 <= g.Cout;    // block-uniform
     f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
@@ -404,7 +418,9 @@ static inline int w43_lds_bytes() { return (W4_MAIN > W4_EPI ? W4_MAIN : W4_EPI)
 
 extern "C" int kpx_conv3x3_wino43_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
     if (getenv("KPX_NO_WINO43") || getenv("KPX_NO_WINO") || N <= 0) return 0;
-    return H % 16 == 0 && W % 32 == 0 && K >= 16 && Nn >= 33 && ldin >= ((K + 7) & ~7) && ldin % 4 == 0 && (((uintptr_t)in_ptr) & 15) == 0;
+    const bool shape = (H % 16 == 0 && W % 32 == 0) || (H == 16 && W == 16 && N % 2 == 0);      // 16 x 16 images are packed two to a workgroup
+    return shape && K >= 16 && Nn >= 33 && ldin >= ((K + 7) & ~7) && ldin % 4 == 0 && (((uintptr_t)in_ptr) & 15) == 0 &&
+           (size_t)H * W * ldin * 8 < 0x7fffffffu;
 }
 extern "C" size_t kpx_wino43_u_bytes(int Cin, int Cout) {
     const size_t a = (size_t)((Cin + 7) & ~7) * ((Cout + 63) & ~63), b = (size_t)((Cout + 7) & ~7) * ((Cin + 63) & ~63);
@@ -427,19 +443,23 @@ static int w43_launch(const float* in, int N, int H, int W, int K, int ldin, con
                       float* out, int Nn, int ldout, int act, float* tile_stats, void* stream) {
     if (!in || !U || !out || ldin < K || ldout < Nn || act < 0 || act > 2 || !kpx_conv3x3_wino43_eligible(N, H, W, K, Nn, ldin, in)) return KPX_EINVAL;
     if (kpx_first_use_on_device(&w43_attr_mask)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
         if (e != hipSuccess) return -(int)e;
     }
     Wino43Geom g{};
     g.x = in; g.y = out; g.U = U; g.bias = bias;
     g.N = N; g.H = H; g.W = W; g.Cin = K; g.ldx = ldin; g.Cout = Nn; g.ldy = ldout; g.act = act;
     g.Kp = (K + 7) & ~7; g.Np = (Nn + 63) & ~63;
-    g.tiles_y = H / 16; g.tiles_x = W / 32;
+    const bool pack = W == 16;
+    if (pack && tile_stats) return KPX_EINVAL;           // (no batch-norm layer of the path is 16 x 16 with a forward on this kernel)
+    g.tiles_y = H / 16; g.tiles_x = pack ? 1 : W / 32;
     g.stats = tile_stats;
-    const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x * (g.Np / 64));
-    if (tile_stats) hipLaunchKernelGGL(conv_wino43_kernel<1>, dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
-    else hipLaunchKernelGGL(conv_wino43_kernel<0>, dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
+    const unsigned blocks = (unsigned)((size_t)(pack ? N / 2 : N) * g.tiles_y * g.tiles_x * (g.Np / 64));
+    if (pack) hipLaunchKernelGGL((conv_wino43_kernel<0, true>), dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
+    else if (tile_stats) hipLaunchKernelGGL((conv_wino43_kernel<1, false>), dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
+    else hipLaunchKernelGGL((conv_wino43_kernel<0, false>), dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
     return kpx_launch_status();
 }
 extern "C" int kpx_conv3x3_wino43_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
@@ -448,7 +468,7 @@ extern "C" int kpx_conv3x3_wino43_f32(const float* in, int N, int H, int W, int 
 }
 // 4 x 16-pixel strips per tensor: the unit of the statistics slab (kpx_bn_stats_from_tiles_f32 with tile_pixels = 64)
 extern "C" size_t kpx_conv3x3_wino43_stats_tiles(int N, int H, int W) {
-    return (H % 16 || W % 32 || N <= 0) ? 0 : (size_t)N * (H / 16) * (W / 32) * 8;
+    return (H % 16 || W % 32 || N <= 0) ? 0 : (size_t)N * (H / 16) * (W / 32) * 8;          // (0: no statistics for packed 16 x 16 images)
 }
 extern "C" int kpx_conv3x3_wino43_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
                                             float* out, int Nn, int ldout, int act, float* tile_stats, void* stream) {

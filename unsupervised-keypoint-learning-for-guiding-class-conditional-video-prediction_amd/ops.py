@@ -198,6 +198,7 @@ conv_kernel_uses = {'wino43': 0}      # diagnostics / tests: launches of the F(4
 #     float64 gradient as the fp32 oracle's own.
 WINO43 = _os.environ.get('KPX_WINO43', '1') != '0'
 WINO43_EXCLUDE_FWD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_FWD', 'pose_encoder,image_encoder,translator/conv_1,translator/conv_2').split(',') if p)
+WINO43_MIN_WORKGROUPS = int(_os.environ.get('KPX_WINO43_MIN_WGS', '128'))
 WINO43_EXCLUDE_DGRAD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_DGRAD', '').split(',') if p)
 
 
@@ -291,10 +292,14 @@ def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, wa
         bank.ensure_fresh()
     bptr = bias.data_ptr() if bias is not None else None
     ent43 = _wino43_u.get((w.data_ptr(), 1 if dgrad else 0)) if WINO43 else None
-    if ent43 is not None and bn_src is None and lib.kpx_conv3x3_wino43_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr()):
+    tiles = lib.kpx_conv3x3_wino43_stats_tiles(n, h, wd) if want_stats else 1      # 0: no statistics from this kernel for the shape (16 x 16)
+    # one F(4x4,3x3) workgroup covers 16 x 32 pixels x 64 channels and lives alone on its CU: below ~half a chip of them the
+    # F(2x2,3x3) kernel's twice as many, half as large workgroups finish sooner (measured: 128 workgroups 0.187 vs 0.158 ms)
+    wgs43 = (n // 2 if wd == 16 else n * (h // 16) * (wd // 32)) * ((nn + 63) // 64)
+    if (ent43 is not None and bn_src is None and tiles and wgs43 > WINO43_MIN_WORKGROUPS
+            and lib.kpx_conv3x3_wino43_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr())):
         conv_kernel_uses['wino43'] += 1
         if want_stats:
-            tiles = lib.kpx_conv3x3_wino43_stats_tiles(n, h, wd)
             slab = torch.empty(tiles * 2 * nn, dtype=torch.float32, device=inp.device)
             check(lib.kpx_conv3x3_wino43_stats_f32(inp.data_ptr(), n, h, wd, k, ld_in, ent43[0].data_ptr(), bptr, out.data_ptr(), nn, ld_out, act,
                                                    slab.data_ptr(), _stream()), 'kpx_conv3x3_wino43_stats_f32')
