@@ -112,8 +112,8 @@ def roofline_conv(dev):
     (conv_3_1 / 4_0 / 4_1, SURVEY Appendix A: 603 979 776 MAC per image), batch 32.  `achieved` / `frac` count the MFMA FLOPs the
     kernel EXECUTES (algorithmic / 4: 36 instead of 144 multiplies per 4x4 output tile) against the fp32 MFMA peak;
     `algorithmic_tflops` / `algorithmic_frac` count direct-convolution FLOPs and exceed 1."""
-    return _roofline_wino(dev, 'translator/conv_3_1', 'conv_wino43_kernel<0>',
-                          'conv_wino43_kernel<0> F(4x4,3x3) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), filter pre-transformed as in the train step',
+    return _roofline_wino(dev, 'translator/conv_3_1', 'conv_wino43_kernel<0, false>',
+                          'conv_wino43_kernel<0, false> F(4x4,3x3) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), filter pre-transformed as in the train step',
                           4.0, WINO43_PMC)
 
 

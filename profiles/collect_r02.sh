@@ -26,7 +26,7 @@ for f, dst in (('bench.json', 'r02_bench.json'), ('bench_bf16.json', 'r02_bench_
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(O + '/pmc_*/**/*counter_collection.csv', recursive=True)):
     for r in csv.DictReader(open(f)):
-        for key, tag in (('conv_wino43_kernel<0>', 'wino43'), ('conv_wino_v2_kernel<2, 0>', 'wino'), ('gauss_fwd', 'render'), ('conv3x3_bf16_kernel', 'bf16'), ('conv_igemm_kernel<128, 128', 'direct')):
+        for key, tag in (('conv_wino43_kernel<0, false>', 'wino43'), ('conv_wino_v2_kernel<2, 0>', 'wino'), ('gauss_fwd', 'render'), ('conv3x3_bf16_kernel', 'bf16'), ('conv_igemm_kernel<128, 128', 'direct')):
             if key in r['Kernel_Name']:
                 pmc[tag][r['Counter_Name']].append(float(r['Counter_Value']))
 def mean(v): return sum(v) / len(v) if v else None
@@ -38,7 +38,7 @@ json.dump(out, open(O + '/pmc_raw.json', 'w'), indent=1)
 w, r, w43 = out.get('wino', {}), out.get('render', {}), out.get('wino43', {})
 if w43.get('FETCH_SIZE') is not None and w43.get('WRITE_SIZE') is not None:
     fetch, write = w43['FETCH_SIZE'] * 1024 * 2, w43['WRITE_SIZE'] * 1024
-    json.dump({'kernel': 'conv_wino43_kernel<0> F(4x4,3x3) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
+    json.dump({'kernel': 'conv_wino43_kernel<0, false> F(4x4,3x3) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
                'source': 'rocprofv3 --pmc, separate passes (profiles/collect_r02.sh), mean over the dispatches of `bench.py --roofline-only`',
                **{k: v for k, v in w43.items() if k != 'dispatches'}, 'dispatches': w43['dispatches'],
                'fetch_bytes_corrected': fetch, 'write_bytes': write, 'algorithmic_bytes': 134807552,
