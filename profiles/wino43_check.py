@@ -1,6 +1,6 @@
 """F(4x4,3x3) kernel: accuracy against a float64 convolution and timing beside the F(2x2,3x3) kernel."""
-import sys, torch
-sys.path.insert(0, '.')
+import os, sys, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import kpx_amd
 from kpx_amd import ops
 from kpx_amd._lib import lib, check

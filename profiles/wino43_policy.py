@@ -1,6 +1,6 @@
 """Gradient error against the float64 arbiter (as tests/test_model_gpu.py::test_configs0...) under the current KPX_WINO43* policy."""
 import os, sys, torch, numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from test_model_gpu import make_model, grad_error_vs_f64, R, rel_l2
 dev = torch.device('cuda:0')
 res, k, b = 128, 15, 4

@@ -1,5 +1,7 @@
+"""In-kernel s_memtime stamps of conv_wino43_kernel (diagnostic build: profiles/wino43_stamps.sh): per wavefront, cycles of the prologue,
+the chunk loop, the two epilogue passes and the stores; per chunk the barrier wait and the two phases of each role; the shader clock."""
 import sys, os, torch, ctypes, numpy as np
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import kpx_amd
 from kpx_amd import ops
 from kpx_amd._lib import lib, check
@@ -11,7 +13,7 @@ check(lib.kpx_wino43_filter_transform_f32(w.data_ptr(), ci, co, 0, u43.data_ptr(
 s = ops._stream()
 
 import kpx_amd._lib as L
-clib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libkpx_hip_dbg.so'))
+clib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libkpx_hip_dbg43.so'))
 clib.kpx_conv3x3_wino43_f32.argtypes = lib.kpx_conv3x3_wino43_f32.argtypes
 lib = clib
 clib.kpx_debug_w43_stamps.argtypes = [ctypes.c_void_p]

@@ -101,7 +101,7 @@ __constant__ float w43_A[6][4] = {{4.f, -5.f, 1.f, 0.f}, {-4.f, -4.f, 1.f, 1.f},
 
 __constant__ float w43_AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
 
-#ifdef KPX_WINO_STAMP      // diagnostic build only (profiles/wino_stamps.sh): s_memtime stamps of every wavefront of the first 64 workgroups
+#ifdef KPX_WINO_STAMP      // diagnostic build only (profiles/wino43_stamps.sh): s_memtime stamps of every wavefront of the first 64 workgroups
 static __device__ unsigned long long* w43_dbg = nullptr;
 extern "C" int kpx_debug_w43_stamps(unsigned long long* buf) { return -(int)hipMemcpyToSymbol(HIP_SYMBOL(w43_dbg), &buf, sizeof(buf)); }
 #define W4_STAMP(slot) do { if (dbgp) dbgp[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)

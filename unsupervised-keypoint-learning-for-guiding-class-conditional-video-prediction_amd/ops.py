@@ -190,7 +190,7 @@ conv_kernel_uses = {'wino43': 0}      # diagnostics / tests: launches of the F(4
 
 # F(4x4,3x3) (csrc/conv_wino43.hip) does 2.25x fewer multiplies than F(2x2,3x3) at ~6x its rounding error (2-3e-6 rel-L2 per layer, still
 # inside the 1e-5 bar of one layer).  Where it runs is decided per filter NAME and direction, from the measured effect on a whole train
-# step against the float64 arbiter (tests/test_model_gpu.py::test_configs0..., scratch/w43_policy.py):
+# step against the float64 arbiter (tests/test_model_gpu.py::test_configs0..., profiles/wino43_policy.py):
 #   * data gradients: everywhere (the detector's included: its eight eligible layers change no digit of the gradient-error figures);
 #   * forward: VGG19 and the translator's 64x64 / 128x128 layers (conv_3_* .. conv_5_*).  The detector, the image encoder and the
 #     translator's 32x32 layers (256-deep sums feeding batch norms over few pixels) stay on F(2x2,3x3): with them on F(4x4,3x3) the
