@@ -55,7 +55,9 @@ CONV_CASES = [
     (4, 128, 128, 16, 16, 3, 1, 0, 0),     # multi-tap small-channel wgrad kernel (pose conv_7_1)
     (4, 128, 128, 64, 16, 3, 1, 0, 1),     # same, two 32-channel input tiles per wave (pose conv_7_0)
     (16, 64, 64, 128, 32, 3, 1, 0, 0),     # same, two channel tiles of 64 (pose conv_5_0)
-    (4, 128, 128, 64, 4, 3, 1, 0, 0),      # same, translator crude+mask head
+    (4, 128, 128, 64, 4, 3, 1, 0, 0),      # same, translator crude+mask head (forward: VALU kernel for few produced channels)
+    (5, 128, 128, 32, 3, 3, 1, 0, 1),      # few-channel forward kernel, Cout = 3, relu, ragged tile count
+    (3, 160, 144, 16, 4, 3, 1, 1, 2),      # same with an explicit pad (output 162 x 146), lrelu
     (2, 64, 64, 256, 128, 3, 1, 0, 0),     # 8-wave 128x128 wgrad tiles
     (4, 128, 128, 3, 32, 7, 1, 0, 0),      # row-merged multi-tap wgrad (encoder conv_1 at full resolution)
     (8, 8, 8, 512, 512, 3, 1, 0, 1),       # split-K forward/dgrad (VGG conv5 shape), relu epilogue in the reduce

@@ -517,6 +517,9 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const floa
                                                                   int pad_t, int pad_l, int act, hipStream_t s);
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
                                                                     float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, hipStream_t s);
+extern "C" __attribute__((visibility("hidden"))) int kpx_conv_few_fwd(const float* x, int N, int Hi, int Wi, int Cin, int ldx, const float* w, int KH, int KW,
+                                                                  const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
+                                                                  int stride, int pad_t, int pad_l, int act, hipStream_t s);
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N, int H, int W, int Cin, int Cout);
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad3x3(const float* x, int N, int H, int W, int Cin, int ldx, const float* dy, int Cout, int lddy,
                                                                    float* slabs, int S, hipStream_t s);
@@ -547,6 +550,10 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
     if (!x || !w || !y || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || ldy < Cout || act < 0 || act > 3)
         return KPX_EINVAL;
+    if (Cout <= 4 && Cin <= 128 && (size_t)N * Ho * Wo >= 65536) {            // few produced channels over a large image: VALU kernel (conv_rgb.hip)
+        const int rc = kpx_conv_few_fwd(x, N, Hi, Wi, Cin, ldx, w, KH, KW, bias, y, Ho, Wo, Cout, ldy, stride, pad_t, pad_l, act, kpx_stream(stream));
+        if (rc != -2) return rc;
+    }
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && act != KPX_ACT_TANH && aligned16(w) &&
         workspace && workspace_bytes >= wino_ws_bytes(Cin, Cout) && kpx_wino_eligible(N, Hi, Wi, Cin, Cout, ldx, x))
         return kpx_wino_conv3x3(x, N, Hi, Wi, Cin, ldx, w, Cin, Cout, 0, bias, act, y, Cout, ldy, (float*)workspace, kpx_stream(stream));

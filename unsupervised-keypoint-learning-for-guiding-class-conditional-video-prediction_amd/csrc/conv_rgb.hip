@@ -125,12 +125,17 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const floa
 // tile of 32-64 and runs at ~8 TFLOP/s; this one is plain VALU work over LDS: one workgroup stages the dy patch of a (16 S)^2 input
 // tile 16 channels at a time (18 x 18 pixels, 20 floats per pixel: conflict-free ds_read_b128 at a 16-lane pixel stride), each thread
 // owns S x S input pixels, and the filter taps are wave-uniform scalar operands.
+//
+// FWD = true runs the same loop as a FORWARD convolution with few output channels (the translator's fused crude + mask head, 3x3 s1
+// 64 -> 4, reference models/networks/__init__.py:97-99): y[oy, ox, n] = sum x[oy + ky - pad, ox + kx - pad, ci] w[ky][kx][ci][n] is the
+// gradient form above with dy := x, co := ci, c := n, the taps mirrored (ky' = KS - 1 - ky, pad' = KS - 1 - pad) and the filter read as
+// [tap][ci][n]; bias and activation are applied at the store.
 struct RgbDgradGeom {
-    const float* dy; const float* w; float* dx;
-    int N, Ho, Wo, Cout, lddy, Hi, Wi, Cin, lddx, pad_t, pad_l, tiles_y, tiles_x;
+    const float* dy; const float* w; float* dx; const float* bias;
+    int N, Ho, Wo, Cout, lddy, Hi, Wi, Cin, lddx, pad_t, pad_l, tiles_y, tiles_x, act;
 };
 
-template <int KS, int S, int CIN>
+template <int KS, int S, int CIN, bool FWD>
 __global__ __launch_bounds__(256) void conv_rgb_dgrad_kernel(const RgbDgradGeom g) {
     constexpr int TI = 16 * S, PR = 18, PS = 20;
     static_assert((TI + KS - 2) / S + 1 <= PR, "dy patch does not fit");      // floor((m + TI - 1) / S) - floor((m - KS + 1) / S) + 1
@@ -174,14 +179,17 @@ __global__ __launch_bounds__(256) void conv_rgb_dgrad_kernel(const RgbDgradGeom 
                     for (int kx = (b + g.pad_l) % S; kx < KS; kx += S) {
                         const int pc = (ixp - kx) / S - ox_min;
                         const float* pp = &patch[(pr * PR + pc) * PS];
-                        const float* wp = g.w + (size_t)((ky * KS + kx) * CIN) * g.Cout + c0;       // wave-uniform: scalar loads
+                        // wave-uniform filter addresses: scalar loads.  gradient: w[tap][c][co]; forward: w[mirrored tap][ci = co][n = c]
+                        const float* wp = FWD ? g.w + ((size_t)((KS - 1 - ky) * KS + (KS - 1 - kx)) * g.Cout + c0) * CIN
+                                              : g.w + (size_t)((ky * KS + kx) * CIN) * g.Cout + c0;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const f32x4 d = *reinterpret_cast<const f32x4*>(pp + 4 * q);
 #pragma unroll
                             for (int c = 0; c < CIN; ++c)
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) acc[a][b][c] = fmaf(d[e], wp[(size_t)c * g.Cout + 4 * q + e], acc[a][b][c]);
+                                for (int e = 0; e < 4; ++e)
+                                    acc[a][b][c] = fmaf(d[e], FWD ? wp[(4 * q + e) * CIN + c] : wp[(size_t)c * g.Cout + 4 * q + e], acc[a][b][c]);
                         }
                     }
                 }
@@ -196,7 +204,16 @@ __global__ __launch_bounds__(256) void conv_rgb_dgrad_kernel(const RgbDgradGeom 
             if (iy < g.Hi && ix < g.Wi) {
                 float* o = g.dx + (((size_t)n * g.Hi + iy) * g.Wi + ix) * g.lddx;
 #pragma unroll
-                for (int c = 0; c < CIN; ++c) o[c] = acc[a][b][c];
+                for (int c = 0; c < CIN; ++c) {
+                    float v = acc[a][b][c];
+                    if (FWD) {
+                        if (g.bias) v += g.bias[c];
+                        if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+                        else if (g.act == KPX_ACT_TANH) v = tanhf(v);
+                    }
+                    o[c] = v;
+                }
             }
         }
 }
@@ -215,9 +232,28 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_dgrad(const fl
     const int TI = 16 * stride;
     g.tiles_y = (Hi + TI - 1) / TI; g.tiles_x = (Wi + TI - 1) / TI;
     const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x);
-    if (k3 && Cin == 3) hipLaunchKernelGGL((conv_rgb_dgrad_kernel<3, 1, 3>), dim3(blocks), dim3(256), 0, s, g);
-    else if (k3) hipLaunchKernelGGL((conv_rgb_dgrad_kernel<3, 1, 4>), dim3(blocks), dim3(256), 0, s, g);
-    else if (Cin == 3) hipLaunchKernelGGL((conv_rgb_dgrad_kernel<4, 2, 3>), dim3(blocks), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((conv_rgb_dgrad_kernel<4, 2, 4>), dim3(blocks), dim3(256), 0, s, g);
+    if (k3 && Cin == 3) hipLaunchKernelGGL((conv_rgb_dgrad_kernel<3, 1, 3, false>), dim3(blocks), dim3(256), 0, s, g);
+    else if (k3) hipLaunchKernelGGL((conv_rgb_dgrad_kernel<3, 1, 4, false>), dim3(blocks), dim3(256), 0, s, g);
+    else if (Cin == 3) hipLaunchKernelGGL((conv_rgb_dgrad_kernel<4, 2, 3, false>), dim3(blocks), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((conv_rgb_dgrad_kernel<4, 2, 4, false>), dim3(blocks), dim3(256), 0, s, g);
+    return kpx_launch_status();
+}
+
+// 3x3 stride-1 forward convolutions with Cout <= 4 and Cin a multiple of 16 (the translator's 64 -> 4 head); -2 when the shape is not handled
+extern "C" __attribute__((visibility("hidden"))) int kpx_conv_few_fwd(const float* x, int N, int Hi, int Wi, int Cin, int ldx, const float* w, int KH, int KW,
+                                                                  const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
+                                                                  int stride, int pad_t, int pad_l, int act, hipStream_t s) {
+    if (KH != 3 || KW != 3 || stride != 1 || (Cout != 3 && Cout != 4) || Cin % 16 || ldx % 4 || (((uintptr_t)x) & 15) || (((uintptr_t)w) & 15) ||
+        pad_t < 0 || pad_l < 0 || pad_t > 2 || pad_l > 2 || Ho != Hi + 2 * pad_t - 2 || Wo != Wi + 2 * pad_l - 2 || getenv("KPX_NO_RGB"))
+        return -2;
+    RgbDgradGeom g{};
+    g.dy = x; g.w = w; g.dx = y; g.bias = bias; g.act = act;
+    g.N = N; g.Ho = Hi; g.Wo = Wi; g.Cout = Cin; g.lddy = ldx;          // the gathered tensor
+    g.Hi = Ho; g.Wi = Wo; g.Cin = Cout; g.lddx = ldy;                   // the produced one
+    g.pad_t = 2 - pad_t; g.pad_l = 2 - pad_l;
+    g.tiles_y = (Ho + 15) / 16; g.tiles_x = (Wo + 15) / 16;
+    const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x);
+    if (Cout == 3) hipLaunchKernelGGL((conv_rgb_dgrad_kernel<3, 1, 3, true>), dim3(blocks), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((conv_rgb_dgrad_kernel<3, 1, 4, true>), dim3(blocks), dim3(256), 0, s, g);
     return kpx_launch_status();
 }

@@ -334,7 +334,8 @@ def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act, want_s
     if (_compute_dtype[0] == 'bf16' and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cin >= 8
             and y.shape[1] == hi and y.shape[2] == wi and _bf16_conv(x, ldx, cin, w, bias, y, ldy, cout, act, False)):
         return
-    if kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and act != ACT_TANH and y.shape[1] == hi and y.shape[2] == wi:
+    if (kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and act != ACT_TANH and y.shape[1] == hi and y.shape[2] == wi
+            and not (cout <= 4 and cin <= 128 and n * hi * wi >= 65536)):        # (few produced channels over a large image: VALU kernel inside the library)
         r = _wino_pretransformed(x, ldx, cin, w, bias, y, ldy, cout, act, False, want_stats=want_stats)
         if r:
             return r if isinstance(r, tuple) else None
