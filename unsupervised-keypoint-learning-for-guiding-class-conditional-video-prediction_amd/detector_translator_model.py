@@ -7,7 +7,9 @@ generator forward -- identical in both runs because the D update does not touch 
 term exactly as the second sess.run would.  Data parallelism: one process per GPU, per-replica BN statistics, one
 all-reduce (RCCL) per flat gradient bucket per optimiser update, 1/world scaling inside the fused Adam kernel.
 """
+import contextlib
 import logging
+import os
 import time
 from datetime import datetime
 
@@ -18,6 +20,9 @@ from . import model_utils, networks, ops, variables
 from .base_model import BaseModel
 from .variables import Sym
 from .vgg import Vgg19
+
+# the discriminator update on an auxiliary HIP stream beside the VGG19 forward of the G run (KPX_AUX_STREAM=0: one stream)
+AUX_STREAM = os.environ.get('KPX_AUX_STREAM', '1') != '0'
 
 log = logging.getLogger('kpx')
 
@@ -141,6 +146,12 @@ class DetectorTranslatorModel(BaseModel):
             return work if async_op else None
         return None
 
+    def _aux_stream(self):
+        st = getattr(self, '_aux', None)
+        if st is None:
+            st = self._aux = torch.cuda.Stream(device=self.device)
+        return st
+
     def _apply_adam(self, which, lr, pending=None, exchanged=False):
         bucket = self.store.buckets[which]
         if pending is not None:
@@ -174,17 +185,30 @@ class DetectorTranslatorModel(BaseModel):
             else:
                 fwd = self._define_forward_pass(im, future_im)
                 final_d = fwd['final_output'].detach()
-            d_losses = self._loss_D(final_d, future_im)
-            ops.begin_backward()
-            torch.autograd.backward([d_losses], [self._e0])
-            pending = self.exchange_gradients('D', async_op=True)          # overlaps the VGG forward below
+            # The whole discriminator update (forward on real + fake, backward, exchange, Adam) is independent of the perceptual half of
+            # the G run (VGG19 on fake + real): with one shared batch it runs on an auxiliary stream beside it.  (With a separate G
+            # batch the generator forward below re-derives every Winograd filter form, the discriminator's included, so the D update
+            # must be complete first: no overlap there.)
+            aux = self._aux_stream() if (AUX_STREAM and not separate and self.device.type == 'cuda') else None
+            if aux is not None:
+                aux.wait_stream(torch.cuda.current_stream(self.device))
+            with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
+                d_losses = self._loss_D(final_d, future_im)
+                ops.begin_backward()
+                torch.autograd.backward([d_losses], [self._e0])
+                pending = self.exchange_gradients('D', async_op=True)      # overlaps the VGG forward below
+                if aux is not None:
+                    self._apply_adam('D', lr, pending=pending, exchanged=True)
             # ---- G run (:94): the perceptual forward does not involve the discriminator, so it runs first ...
             if separate:
                 im, future_im = feed_dict['image_G'], feed_dict['future_image_G']
                 fwd = self._define_forward_pass(im, future_im)
             final = fwd['final_output']
             recon = self._loss_G_recon(final, future_im)
-            self._apply_adam('D', lr, pending=pending, exchanged=True)
+            if aux is not None:
+                torch.cuda.current_stream(self.device).wait_stream(aux)
+            else:
+                self._apply_adam('D', lr, pending=pending, exchanged=True)
             # ... and the adversarial term sees the UPDATED discriminator, exactly as the reference's second sess.run
             adv = self._loss_G_adv(final)
             ops.begin_backward()
