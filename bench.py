@@ -148,7 +148,7 @@ def roofline_conv_bf16(dev):
     finally:
         ops.set_compute_dtype('f32')
     nbytes = 2 * BATCH * 64 * 64 * 128 * 4 + 9 * 128 * 128 * 4
-    return {'bound': 'hbm', 'kernel': 'conv3x3_bf16_kernel<2> (+ weight prepare) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
+    return {'bound': 'hbm', 'kernel': 'conv3x3_bf16_wide_kernel<4> (16x32 pixels x 128 couts per workgroup; + weight prepare) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
             'achieved': round(nbytes / (ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(nbytes / (ms * 1e-3) / 8e12, 4),
             'traffic': None, 'avg_launch_ms': round(ms, 4), 'bytes_per_launch': nbytes,
             'mfma_tflops_bf16': round(flops / (ms * 1e-3) / 1e12, 1), 'mfma_frac_of_bf16_peak': round(flops / (ms * 1e-3) / 2.5e15, 4)}

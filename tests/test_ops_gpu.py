@@ -476,6 +476,10 @@ BF16_CASES = [
     (2, 16, 48, 24, 40, 2),         # ragged: K = 24 (second chunk half empty), Nn = 40 (two blocks, 24 couts masked), lrelu
     (1, 32, 32, 134, 96, 0),        # K = 134 = translator conv_1_0 at K=3 (not a multiple of 4: element-wise tail), 3 cout blocks -> 32-cout workgroups
     (2, 64, 64, 128, 128, 1),       # translator conv_3_1 shape
+    (16, 64, 64, 128, 128, 1),      # the same on the wide-tile kernel (>= 256 workgroups of 16x32 pixels x 128 couts)
+    (9, 32, 96, 70, 64, 2),         # wide tiles, 64-cout variant, ragged K
+    (8, 64, 64, 134, 200, 0),       # wide tiles with a cout tail (200 -> 7 blocks: odd count falls back to the narrow kernel)
+    (8, 64, 64, 134, 250, 0),       # 250 -> 8 blocks, partly empty last block on the wide kernel
     (2, 16, 16, 16, 4, 0),          # head-like: 4 produced channels; dgrad gathers 4 channels (falls back to fp32: K < 8)
 ]
 

@@ -189,7 +189,151 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_kernel(const Bf16Geom g) 
     }
 }
 
+
+// ---- wide variant: one workgroup (8 wavefronts) = 16 x 32 output pixels x 32*NBW output channels (NBW = 2 or 4).  The narrow kernel moves
+// 38.7 KB (patch + filter fragments) per chunk for 256 pixels x 64 couts and, with one chunk of MFMAs (2 304 cycles for both resident
+// workgroups) to cover an HBM round trip, is latency-bound at 9.3 k cycles per chunk; here a chunk is 76 KB for four times the work and
+// 4 608 cycles of MFMAs.  Wavefront w owns pixel rows 2w, 2w+1 (two 32-pixel blocks of 2 rows x 16 columns) x all NBW cout blocks.
+#define B16W_RAWB (18 * 34 * 32)           // bytes of one staged patch: 18 x 34 pixels x 16 bf16
+
+template <int NBW>
+__global__ __launch_bounds__(512, 2) void conv3x3_bf16_wide_kernel(const Bf16Geom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BTILE = 9 * NBW * 1024;
+    unsigned char* const rawb = smem;                         // [2][B16W_RAWB]
+    unsigned char* const Bb = smem + 2 * B16W_RAWB;           // [2][BTILE]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    const int ntc = g.NB / NBW;
+    const int nti = L % ntc; L /= ntc;
+    const int bx = L % g.tiles_x; L /= g.tiles_x;
+    const int by = L % g.tiles_y;
+    const int n = L / g.tiles_y;
+    const int oy0 = by * 16, ox0 = bx * 32, n0 = nti * 32 * NBW;
+
+    // raw staging: 1224 half-pixels (pixel, 8-channel half) over 512 threads -> 3 units per thread (the last one partial)
+    const float* rp[3]; int rdst[3]; bool rok[3]; int rvalid[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int u = t + 512 * i, px = u >> 1, half = u & 1, py = px / 34, pxx = px - py * 34;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + pxx;
+        rok[i] = u < 1224 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        rp[i] = rok[i] ? g.x + ((size_t)(n * g.H + iy) * g.W + ix) * g.ldx + half * 8 : bf16_zero16;
+        rdst[i] = u < 1224 ? px * 32 + ((half ^ (py & 1)) << 4) : -1;
+        rvalid[i] = g.K - half * 8;
+    }
+    constexpr int BU = BTILE / 16, BPT = (BU + 511) / 512;
+    const u32x4* bsrc = g.Wf + (size_t)nti * NBW * 64;
+    const size_t tap_stride = (size_t)g.KC * g.NB * 64, kc_stride = (size_t)g.NB * 64;
+
+    int a_off[2][9];                                          // block p = columns 16p .. 16p+15 of rows 2 wave, 2 wave + 1
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int row = 2 * wave + (li >> 4) + tap / 3, col = 16 * p + (li & 15) + tap % 3;
+            a_off[p][tap] = (row * 34 + col) * 32 + ((lh ^ (row & 1)) << 4);
+        }
+
+    f32x16 acc[2][NBW];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int b = 0; b < NBW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][b][r] = 0.f;
+
+    f32x4 rr[3][2];
+    u32x4 rb[BPT];
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int valid = rvalid[i] - 16 * kc;
+            const bool lo = rok[i] && valid >= 4, hi = rok[i] && valid >= 8;
+            rr[i][0] = *reinterpret_cast<const f32x4*>(lo ? rp[i] + 16 * kc : bf16_zero16);
+            rr[i][1] = *reinterpret_cast<const f32x4*>(hi ? rp[i] + 16 * kc + 4 : bf16_zero16);
+            if (rok[i] && valid > 0 && valid < 8 && (valid & 3)) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = e < valid ? rp[i][16 * kc + e] : 0.f;
+                    if (e < 4) rr[i][0][e] = v; else rr[i][1][e - 4] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int u = t + 512 * i;
+            if (BU % 512 == 0 || u < BU) {
+                const int tap = u / (NBW * 64), loc = u - tap * (NBW * 64);
+                rb[i] = bsrc[(size_t)tap * tap_stride + (size_t)kc * kc_stride + loc];
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        unsigned char* const rw = rawb + buf * B16W_RAWB;
+        unsigned char* const bw = Bb + buf * BTILE;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = (__bf16)rr[i][0][e]; v[4 + e] = (__bf16)rr[i][1][e]; }
+            if (rdst[i] >= 0) *reinterpret_cast<bf16x8*>(rw + rdst[i]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int u = t + 512 * i;
+            if (BU % 512 == 0 || u < BU) *reinterpret_cast<u32x4*>(bw + u * 16) = rb[i];
+        }
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int kc = 0; kc < g.KC; ++kc) {
+        const int cur = kc & 1;
+        if (kc + 1 < g.KC) load_chunk(kc + 1);
+        const unsigned char* const rr_ = rawb + cur * B16W_RAWB;
+        const unsigned char* const br_ = Bb + cur * BTILE + lane * 16;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            bf16x8 av[2], bv[NBW];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) av[p] = *reinterpret_cast<const bf16x8*>(rr_ + a_off[p][tap]);
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) bv[b] = *reinterpret_cast<const bf16x8*>(br_ + (tap * NBW + b) * 1024);
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int b = 0; b < NBW; ++b)
+                    acc[p][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[p], bv[b], acc[p][b], 0, 0, 0);
+        }
+        if (kc + 1 < g.KC) store_chunk(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+        const int oc = n0 + 32 * b + li;
+        const bool ocv = oc < g.Nn;
+        const float bvv = (g.bias && ocv) ? g.bias[oc] : 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix = (r & 3) + 8 * (r >> 2) + 4 * lh;          // 0..31 inside the block: row pix>>4, column pix&15
+                const int oy = oy0 + 2 * wave + (pix >> 4), ox = ox0 + 16 * p + (pix & 15);
+                float v = acc[p][b][r] + bvv;
+                if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+                if (ocv) g.y[((size_t)(n * g.H + oy) * g.W + ox) * g.ldy + oc] = v;
+            }
+    }
+}
+
 static std::atomic<unsigned long long> bf16_attr_mask{0};
+static inline int bf16_wide_lds_bytes(int nbw) { return 2 * B16W_RAWB + 2 * 9 * nbw * 1024; }
 static inline int bf16_lds_bytes(int nbw) { return 2 * B16_RAWB + 2 * 9 * nbw * 1024; }
 
 extern "C" size_t kpx_conv3x3_bf16_weights_bytes(int Cin, int Cout) {
@@ -222,6 +366,8 @@ extern "C" int kpx_conv3x3_bf16_f32(const float* in, int N, int H, int W, int K,
     if (kpx_first_use_on_device(&bf16_attr_mask)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, bf16_lds_bytes(1));
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bf16_lds_bytes(2));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, bf16_wide_lds_bytes(2));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16_wide_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, bf16_wide_lds_bytes(4));
         if (e != hipSuccess) return -(int)e;
     }
     Bf16Geom g{};
@@ -231,6 +377,20 @@ extern "C" int kpx_conv3x3_bf16_f32(const float* in, int N, int H, int W, int K,
     g.tiles_y = H / 16; g.tiles_x = W / 16;
     const size_t tiles = (size_t)N * g.tiles_y * g.tiles_x;
     hipStream_t s = kpx_stream(stream);
+    // wide tiles (16 x 32 pixels, 8 wavefronts) when the launch still fills the chip with them
+    static const int wide_mode = getenv("KPX_BF16_WIDE") ? atoi(getenv("KPX_BF16_WIDE")) : 1;
+    if (wide_mode && W % 32 == 0 && g.NB % 2 == 0) {
+        const int nbw = (g.NB % 4 == 0 && wide_mode != 2) ? 4 : 2;
+        const size_t wgs = (size_t)N * g.tiles_y * (W / 32) * (g.NB / nbw);
+        if (wgs >= 256 || (nbw == 4 && (size_t)N * g.tiles_y * (W / 32) * (g.NB / 2) >= 256)) {
+            const int use = wgs >= 256 ? nbw : 2;
+            g.tiles_x = W / 32;
+            const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x * (g.NB / use));
+            if (use == 4) hipLaunchKernelGGL(conv3x3_bf16_wide_kernel<4>, dim3(blocks), dim3(512), bf16_wide_lds_bytes(4), s, g);
+            else hipLaunchKernelGGL(conv3x3_bf16_wide_kernel<2>, dim3(blocks), dim3(512), bf16_wide_lds_bytes(2), s, g);
+            return kpx_launch_status();
+        }
+    }
     if (g.NB % 2 == 0) hipLaunchKernelGGL(conv3x3_bf16_kernel<2>, dim3((unsigned)(tiles * (g.NB / 2))), dim3(256), bf16_lds_bytes(2), s, g);
     else hipLaunchKernelGGL(conv3x3_bf16_kernel<1>, dim3((unsigned)(tiles * g.NB)), dim3(256), bf16_lds_bytes(1), s, g);
     return kpx_launch_status();
