@@ -23,6 +23,8 @@ from .vgg import Vgg19
 
 # the discriminator update on an auxiliary HIP stream beside the VGG19 forward of the G run (KPX_AUX_STREAM=0: one stream)
 AUX_STREAM = os.environ.get('KPX_AUX_STREAM', '1') != '0'
+AUX_STREAM_FWD = os.environ.get('KPX_AUX_STREAM_FWD', '1') != '0'      # the image encoder (forward and backward) beside the key-point detector
+AUX_STREAM_ADV = os.environ.get('KPX_AUX_STREAM_ADV', '1') != '0'      # the G run's adversarial branch on that stream as well
 
 log = logging.getLogger('kpx')
 
@@ -76,7 +78,16 @@ class DetectorTranslatorModel(BaseModel):
         train = self.is_training
         sym = variables.is_sym(im)
         b = im.shape[0]
-        embeddings = networks.image_encoder(im, train, update_moving=update_moving)        # :165
+        # :165 -- the image encoder (half-batch, small launches) is independent of the key-point detector: on the auxiliary stream beside it.
+        # The Winograd filter forms are re-derived (one batched launch) BEFORE the fork: both branches read them.
+        aux = self._aux_stream() if (AUX_STREAM_FWD and not sym and im.is_cuda) else None
+        if aux is not None:
+            bank = getattr(self.store, 'filter_bank', None)
+            if bank is not None:
+                bank.ensure_fresh()
+            aux.wait_stream(torch.cuda.current_stream(im.device))
+        with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
+            embeddings = networks.image_encoder(im, train, update_moving=update_moving)
         # :166-167 -- the two weight-sharing pose_encoder calls as one batched launch, BN statistics per call
         both = Sym(2 * b, *im.shape[1:]) if sym else ops.concat_batch(im, future_im)
         pts, logits = networks.pose_encoder(both, self.n_points, train, final_res=self.image_size, bn_groups=2,
@@ -86,6 +97,8 @@ class DetectorTranslatorModel(BaseModel):
             cur_pt = fut_pt = None
         else:
             cur_pt, fut_pt = pts[:b], pts[b:]
+            if aux is not None:
+                torch.cuda.current_stream(im.device).wait_stream(aux)
             joint = ops.joint_embedding(embeddings[-2], cur_pt, fut_pt)                    # :168-170
         raw4 = networks.translator(joint, train, final_res=self.image_size,
                                    cin=embeddings[-2].shape[-1] + 2 * self.n_points,
@@ -199,6 +212,11 @@ class DetectorTranslatorModel(BaseModel):
                 pending = self.exchange_gradients('D', async_op=True)      # overlaps the VGG forward below
                 if aux is not None:
                     self._apply_adam('D', lr, pending=pending, exchanged=True)
+                    if AUX_STREAM_ADV:
+                        # ... and so is the adversarial term of the G run (discriminator forward on the generated frame with the UPDATED
+                        # weights): recorded on the auxiliary stream, its backward runs there too (autograd replays each node on its
+                        # forward's stream), beside the VGG19 data-gradient chain -- both are half-batch launches that underfill the chip
+                        adv = self._loss_G_adv(fwd['final_output'])
             # ---- G run (:94): the perceptual forward does not involve the discriminator, so it runs first ...
             if separate:
                 im, future_im = feed_dict['image_G'], feed_dict['future_image_G']
@@ -210,9 +228,12 @@ class DetectorTranslatorModel(BaseModel):
             else:
                 self._apply_adam('D', lr, pending=pending, exchanged=True)
             # ... and the adversarial term sees the UPDATED discriminator, exactly as the reference's second sess.run
-            adv = self._loss_G_adv(final)
+            if aux is None or not AUX_STREAM_ADV:
+                adv = self._loss_G_adv(final)
             ops.begin_backward()
             torch.autograd.backward([recon, adv], [self._one, self._e0])
+            if self.device.type == 'cuda' and getattr(self, '_aux', None) is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self._aux)      # backward nodes recorded on the auxiliary stream ran there
             self._apply_adam('G', lr)
         self.global_step += 1                                             # incremented by the G optimiser (:201-202)
         self.last = dict(d_losses=d_losses.detach(), recon=recon.detach(), adv=adv.detach(), lr=float(lr),
