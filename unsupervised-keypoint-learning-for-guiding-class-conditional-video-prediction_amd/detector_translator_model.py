@@ -212,26 +212,33 @@ class DetectorTranslatorModel(BaseModel):
                 pending = self.exchange_gradients('D', async_op=True)      # overlaps the VGG forward below
                 if aux is not None:
                     self._apply_adam('D', lr, pending=pending, exchanged=True)
-                    if AUX_STREAM_ADV:
-                        # ... and so is the adversarial term of the G run (discriminator forward on the generated frame with the UPDATED
-                        # weights): recorded on the auxiliary stream, its backward runs there too (autograd replays each node on its
-                        # forward's stream), beside the VGG19 data-gradient chain -- both are half-batch launches that underfill the chip
-                        adv = self._loss_G_adv(fwd['final_output'])
             # ---- G run (:94): the perceptual forward does not involve the discriminator, so it runs first ...
             if separate:
                 im, future_im = feed_dict['image_G'], feed_dict['future_image_G']
                 fwd = self._define_forward_pass(im, future_im)
             final = fwd['final_output']
             recon = self._loss_G_recon(final, future_im)
-            if aux is not None:
+            if aux is not None and AUX_STREAM_ADV:
+                # Two-stream G loss: the gradient of each term with respect to the generated frame is taken on its own stream -- the VGG19
+                # data-gradient chain on the main stream straight after the VGG19 forward, without waiting for the discriminator update; the
+                # adversarial branch (discriminator forward with the UPDATED weights + its data gradients) on the auxiliary stream behind
+                # that update -- and the generator is walked once with their sum.  Both chains are half-batch launches that underfill the chip.
+                g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
+                with torch.cuda.stream(aux):
+                    adv = self._loss_G_adv(final)
+                    g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
                 torch.cuda.current_stream(self.device).wait_stream(aux)
+                ops.begin_backward()
+                final.backward(g_recon + g_adv)
             else:
-                self._apply_adam('D', lr, pending=pending, exchanged=True)
-            # ... and the adversarial term sees the UPDATED discriminator, exactly as the reference's second sess.run
-            if aux is None or not AUX_STREAM_ADV:
+                if aux is not None:
+                    torch.cuda.current_stream(self.device).wait_stream(aux)
+                else:
+                    self._apply_adam('D', lr, pending=pending, exchanged=True)
+                # ... and the adversarial term sees the UPDATED discriminator, exactly as the reference's second sess.run
                 adv = self._loss_G_adv(final)
-            ops.begin_backward()
-            torch.autograd.backward([recon, adv], [self._one, self._e0])
+                ops.begin_backward()
+                torch.autograd.backward([recon, adv], [self._one, self._e0])
             if self.device.type == 'cuda' and getattr(self, '_aux', None) is not None:
                 torch.cuda.current_stream(self.device).wait_stream(self._aux)      # backward nodes recorded on the auxiliary stream ran there
             self._apply_adam('G', lr)
