@@ -588,3 +588,28 @@ def test_exact_zero_bias_grad_switch_both_ways():
     for n in outs[True][2]:                                                      # everything else is identical
         if n not in names and not n.endswith('/bias'):
             assert np.array_equal(outs[True][2][n], outs[False][2][n]), n
+
+
+def test_three_stream_step_is_bit_identical_to_the_one_stream_step(monkeypatch):
+    """The auxiliary stream (image encoder beside the key-point detector, discriminator update beside the VGG19 forward, adversarial
+    branch beside the VGG19 data gradients) only re-orders independent work: after three train steps every variable and optimiser
+    slot must equal the one-stream run's bit for bit -- any missing fork / join shows up here as a difference (or as run-to-run noise)."""
+    import kpx_amd.detector_translator_model as dtm
+    dev = torch.device('cuda:0')
+    res, k, b = 128, 3, 4                     # 128x128 so that the F(4x4,3x3) layers and the wide launches take part
+
+    def run(aux):
+        for flag in ('AUX_STREAM', 'AUX_STREAM_FWD', 'AUX_STREAM_ADV'):
+            monkeypatch.setattr(dtm, flag, aux)
+        model = make_model(res, k, b, dev, width_div=4)
+        for step in range(3):
+            im, fut = R.synthetic_pair(b, res=res, seed0=30 + step, seed1=40 + step)
+            model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, step, b)
+        out = model.store.export_numpy(include_slots=True)
+        out['_losses'] = np.asarray(list(model.loss_values().values()), np.float64)
+        return out
+    one, three, again = run(False), run(True), run(True)
+    assert set(one) == set(three)
+    for name in one:
+        assert np.array_equal(three[name], again[name]), ('run-to-run', name)
+        assert np.array_equal(one[name], three[name]), ('streams', name)
