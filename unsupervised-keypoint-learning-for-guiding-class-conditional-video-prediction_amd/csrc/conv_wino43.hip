@@ -4,20 +4,26 @@
 //
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        d: 6x6 input patch, g: 3x3 filter, Y: 4x4 outputs   (Lavin & Gray points 0, +-1, +-2, inf)
 //
-// fp32 accuracy: rel-L2 1.9e-6 .. 3.3e-6 against float64 (F(2x2,3x3): 2.8e-7 .. 4.9e-7, direct fp32 chain: 4.4e-7 .. 8.9e-7), i.e.
-// inside the 1e-5 parity bar of a layer but 7x looser than F(2x2,3x3): the key-point detector keeps F(2x2,3x3).
+// fp32 accuracy: rel-L2 1.5e-6 .. 3.3e-6 against float64 (F(2x2,3x3): 2.8e-7 .. 4.9e-7, direct fp32 chain: 4.4e-7 .. 8.9e-7), i.e.
+// inside the 1e-5 parity bar of a layer but ~6x looser than F(2x2,3x3): which layers run it is the caller's per-layer policy
+// (ops.WINO43_EXCLUDE_*); the library never picks it on its own.
 //
 // One workgroup (8 wavefronts) = 16 x 32 output pixels (4 x 8 tiles = one 32-row MFMA block) x 64 output channels x all 36 points.
-// Same structure as conv_wino_v2_kernel -- B fragments straight from the fragment-ordered, pre-transformed filters, raw patch and
+// Same skeleton as conv_wino_v2_kernel -- B fragments straight from the fragment-ordered, pre-transformed filters, raw patch and
 // V double buffered with ONE barrier per 8-channel chunk -- with these differences:
-//   * wavefront w multiplies 9 points (9 * (w >> 1) ..) of cout half w & 1: 9 accumulators of 32x32 (144 VGPRs);
-//   * the input transform is done by wavefronts 0-5, wavefront i producing row i of B^T d B (its coefficients are wave-uniform) for
-//     (tile = lane & 31, channel half = lane >> 5): 24 ds_read_b128 of the raw patch, 6 ds_write_b128 of V;
+//   * every wavefront multiplies 9 (point, cout half) accumulator blocks of 32x32 (144 VGPRs); its B fragments are a 3-deep ring
+//     refilled in place, pinned by a sched_barrier per point (under register pressure hipcc otherwise sinks each refill to its use);
+//   * roles, each with its own copy of the chunk loop so that their live registers never add up: wavefronts 0-5 produce one row of
+//     B^T d B each (wave-uniform coefficients; tile = lane & 31, channel half = lane >> 5; 18-24 ds_read_b128 of the raw patch,
+//     6 ds_write_b128 of V; 4-5 multiply first and transform afterwards), wavefronts 6-7 fetch the whole patch of a chunk through a
+//     buffer descriptor (out-of-image units read as zero by the range check);
 //   * the raw patch is stored as two channel-half planes of 16-B pixels with one slot of skew per 4 columns (column c at slot
 //     c + c/4, row stride 42 slots): tile origins are 5 slots apart in x and 8 (mod 16) in y, so the 16 lanes of a ds_read_b128
 //     group -- tiles {0-3, 12-15, 20-27} -- hit 16 different 16-B bank groups for every patch element (checked exhaustively);
-//   * the epilogue runs in two passes of 18 points through LDS (147 KB): each thread owns (tile, 4 couts), applies A^T . A to the
-//     three point rows of the pass and keeps its 16 output pixels in registers between the passes.
+//   * the epilogue runs in two passes of 18 points (rows 0-2 / 3-5 of the point grid) through LDS (147 KB); the points of each half
+//     are spread 5,5,4,4 / 4,4,5,5 over the wavefronts of a cout half, so all eight deposit in both passes; each thread owns
+//     (tile, 4 couts), applies A^T . A to the three point rows of the pass and keeps its 16 output pixels in registers between them;
+//   * STATS: per-strip batch-norm sums from the epilogue; PACK: two 16 x 16 images per workgroup.
 #include "kpx_common.h"
 #include <stdlib.h>
 
