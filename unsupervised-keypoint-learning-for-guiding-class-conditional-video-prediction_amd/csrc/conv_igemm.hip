@@ -577,6 +577,11 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
     }
     if (!getenv("KPX_NO_SMALLCOUT") && Cout <= 4 && Cin % 4 == 0 && Cin >= 256 && g.vecA && g.vecB == (Cout == 4))
         return launch_small_cout(g, kpx_stream(stream));
+    if (g.vecA && g.vecB && !g.merge && Cin % 4 == 0) {        // small-M / long-K layers (the discriminator's 10x10 .. 4x4 maps): split K over workgroups
+        const int S = conv_splitk_plan((long)N * Ho * Wo, Cout, (long)KH * KW * ((Cin + 31) / 32));
+        g.ws_slab = (size_t)N * Ho * Wo * Cout;
+        if (S > 1 && workspace && workspace_bytes >= (size_t)S * g.ws_slab * 4) { g.ksplit = S; g.ws = (float*)workspace; }
+    }
     return launch_gather_conv<false>(g, kpx_stream(stream));
 }
 
