@@ -72,11 +72,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--filter', default='')
+    ap.add_argument('--unregistered', action='store_true', help='3x3 layers through the plain C entry (filter transformed inside the call, F(2x2,3x3) only)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
     flops_tot = 0.0
-    print('%-28s %5s %4s %5s %5s k s | %9s %6s | %9s %6s | %9s %6s' % ('layer', 'N', 'H', 'Cin', 'Cout', 'fwd ms', 'TF', 'dgrad ms', 'TF', 'wgrad ms', 'TF'))
+    print('%-36s %5s %4s %5s %5s k s | %9s %6s | %9s %6s | %9s %6s' % ('layer', 'N', 'H', 'Cin', 'Cout', 'fwd ms', 'TF', 'dgrad ms', 'TF', 'wgrad ms', 'TF'))
     for (name, n, h, ci, co, k, s, pad, ld, wf, wd, ww) in layers(args.batch):
         if args.filter and args.filter not in name:
             continue
@@ -94,13 +95,25 @@ def main():
         dx = torch.empty(n, h, h, ld, device=dev)
         dw = torch.empty_like(w)
         flops = 2.0 * n * ho * ho * co * k * k * ci
-        tf = timeit(lambda: ops.conv_fwd_raw(x, ld, ci, w, b, y, co, s, pad_t, pad_t, 0))
-        td = timeit(lambda: ops.conv_dgrad_raw(dy, co, w, dx, ld, ci, s, pad_t, pad_t)) if wd else 0.0
+        # the filter is registered under the layer's variable name, so that the 3x3 layers run on the kernel the train step picks for
+        # them (pre-transformed filters; F(4x4,3x3) or F(2x2,3x3) by ops.WINO43_EXCLUDE_* and the launch size)
+        vname = name.replace('pose/', 'pose_encoder/').replace('pose_encoder/enc/', 'pose_encoder/encoder/')
+        keys = ops.register_constant_filter(w, vname) if (k == 3 and not args.unregistered) else []
+        used = ops.conv_kernel_uses['wino43']
+        try:
+            tf = timeit(lambda: ops.conv_fwd_raw(x, ld, ci, w, b, y, co, s, pad_t, pad_t, 0))
+            f43_f = ops.conv_kernel_uses['wino43'] > used
+            used = ops.conv_kernel_uses['wino43']
+            td = timeit(lambda: ops.conv_dgrad_raw(dy, co, w, dx, ld, ci, s, pad_t, pad_t)) if wd else 0.0
+            f43_d = ops.conv_kernel_uses['wino43'] > used
+        finally:
+            ops.release_filters(keys)
+        name = name + (' [F43 ' + ('f' if f43_f else '-') + ('d' if f43_d else '-') + ']' if (f43_f or f43_d) else '')
         tw = timeit(lambda: ops.conv_wgrad_raw(x, ld, ci, dy, co, dw, s, pad_t, pad_t)) if ww else 0.0
         tot['fwd'] += wf * tf; tot['dgrad'] += wd * td; tot['wgrad'] += ww * tw
         flops_tot += flops * (wf + wd + ww)
         f = lambda t: flops / (t * 1e-3) / 1e12 if t else 0.0
-        print('%-28s %5d %4d %5d %5d %d %d | %9.3f %6.1f | %9.3f %6.1f | %9.3f %6.1f' % (name, n, h, ci, co, k, s, tf, f(tf), td, f(td), tw, f(tw)))
+        print('%-36s %5d %4d %5d %5d %d %d | %9.3f %6.1f | %9.3f %6.1f | %9.3f %6.1f' % (name, n, h, ci, co, k, s, tf, f(tf), td, f(td), tw, f(tw)))
     t = sum(tot.values())
     print('weighted per-step totals: fwd %.2f ms, dgrad %.2f ms, wgrad %.2f ms, all %.2f ms; %.1f TF = %.1f%% of fp32 MFMA peak'
           % (tot['fwd'], tot['dgrad'], tot['wgrad'], t, flops_tot / (t * 1e-3) / 1e12, 100 * flops_tot / (t * 1e-3) / 1e12 / PEAK))
