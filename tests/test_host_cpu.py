@@ -119,3 +119,28 @@ def test_data_parallel_gradient_exchange_two_gloo_ranks():
         assert p.exitcode == 0
     for rank, out in results:
         assert out == {'D': True, 'G': True, 'alias': True}, (rank, out)
+
+
+def test_f43_layer_policy_follows_the_float64_arbiter_findings():
+    """Which layers may run the F(4x4,3x3) kernel is host logic (ops.WINO43_EXCLUDE_*): data gradients everywhere, forward only on VGG19
+    and the translator's 64x64 / 128x128 layers; the key-point detector, the image encoder and the translator's 32x32 layers keep
+    F(2x2,3x3) in the forward direction.  Channel limits: K >= 16 gathered, more than 32 produced."""
+    from kpx_amd import ops
+    if not ops.WINO43:
+        pytest.skip('KPX_WINO43=0')
+    m = build_cpu_model()
+    fwd, dgrad = set(), set()
+    for name, v in m.store.vars.items():
+        if name.endswith('/kernel') and v.dim() == 4 and v.shape[0] == 3:
+            cin, cout = int(v.shape[2]), int(v.shape[3])
+            if ops._wino43_wanted(name, cin, cout, 0):
+                fwd.add(name.split('/conv2d')[0])
+            if ops._wino43_wanted(name, cin, cout, 1):
+                dgrad.add(name.split('/conv2d')[0])
+    assert fwd == {'translator/conv_%d_%d' % (i, j) for i in (3, 4, 5) for j in (0, 1)}
+    assert not any(n.startswith(('pose_encoder', 'image_encoder', 'translator/conv_1', 'translator/conv_2', 'img_discr')) for n in fwd)
+    # data gradients: every 3x3 layer gathering >= 16 and producing > 32 channels, the detector's included; never the 4-channel head's input side
+    assert {'translator/conv_1_0', 'translator/conv_2_1', 'pose_encoder/encoder/conv_4', 'pose_encoder/conv_7_0', 'image_encoder/encoder/conv_6'} <= dgrad
+    assert not any(n.startswith('translator/conv_6') for n in dgrad | fwd)          # the 4-channel head: K = 4 gathered in the gradient, 4 produced in the forward
+    assert ops._wino43_wanted('vgg/conv3_2', 256, 256, 0) and ops._wino43_wanted('vgg/conv3_2', 256, 256, 1)
+    assert not ops._wino43_wanted('vgg/conv1_1', 3, 64, 0)
