@@ -362,7 +362,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 static int conv_splitk_plan(long M, int Cout, long nchunks_total) {
     if (getenv("KPX_NO_SPLITK") || Cout % 4 != 0 || Cout < 64) return 1;
     const long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
-    if (tiles >= 384) return 1;
+    static const long max_tiles = getenv("KPX_SPLITK_MAXTILES") ? atol(getenv("KPX_SPLITK_MAXTILES")) : 256;   // a full round of 128x128 tiles: splitting only adds the reduce pass
+    if (tiles >= max_tiles) return 1;
     long S = 512 / tiles;
     if (S > 8) S = 8;
     while (S > 1 && nchunks_total / S < 6) --S;         // keep >= 6 chunks (192 channels-taps) per split
