@@ -175,7 +175,7 @@ class DetectorTranslatorModel(BaseModel):
         alpha = np.float32(np.float32(lr) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p))
         ops.adam_tf_flat_(bucket.params, bucket.grads, bucket.m, bucket.v, alpha, self.beta1, self.beta2, self.adam_eps,
                           gscale=1.0 / self.world_size)
-        self.store.touch()                      # the filters changed: their Winograd forms are re-derived before the next use
+        self.store.touch(which)                 # the filters changed: their Winograd forms are re-derived before the next use
         self.beta_power[which] = [np.float32(b1p * self.beta1), np.float32(b2p * self.beta2)]
 
     # ------------------------------------------------------------------------------------------------ steps

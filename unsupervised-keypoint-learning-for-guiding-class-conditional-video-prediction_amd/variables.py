@@ -139,14 +139,23 @@ class VariableStore:
         self.materialised = True
         if self.device.type == 'cuda':
             from . import ops                            # pre-transformed Winograd filters of every trainable 3x3 kernel
-            self.filter_bank = ops.FilterBank([(n, v.detach()) for n, v in self.vars.items() if n.endswith('/kernel')], self.device)
+            # (only filters a Winograd kernel can ever take: >= 4 produced channels in at least one direction; the discriminator's single
+            # 3x3 layer, D_logit 2048 -> 1, is not one -- so an update of the D bucket never invalidates anything here, see touch())
+            named = [(n, v.detach()) for n, v in self.vars.items()
+                     if n.endswith('/kernel') and v.dim() == 4 and v.shape[0] == 3 and min(v.shape[2], v.shape[3]) >= 4]
+            self.filter_bank = ops.FilterBank(named, self.device)
+            self._bank_buckets = {'D' if 'discr' in n else 'G' for n, _ in named}        # same split as the buckets above
             weakref.finalize(self, ops.release_filters, self.filter_bank.keys())     # the bucket's addresses may be reused later
 
-    def touch(self):
-        """Call after writing parameters behind torch's back (fused Adam kernel, restore): derived filter forms are refreshed lazily."""
+    def touch(self, bucket=None):
+        """Call after writing parameters behind torch's back (fused Adam kernel, restore): derived filter forms are refreshed lazily.
+        ``bucket``: the flat bucket that was written ('G' / 'D' / ...); an update of a bucket none of whose filters has a derived form
+        (the discriminator's) leaves the forms valid."""
         bank = getattr(self, 'filter_bank', None)
         if bank is not None:
-            bank.touch()
+            owners = getattr(self, '_bank_buckets', None)
+            if bucket is None or owners is None or bucket in owners:
+                bank.touch()
 
     # ---- access ------------------------------------------------------------------------------------------------
     def __getitem__(self, name):
