@@ -145,6 +145,13 @@ int kpx_conv3x3_wino43_f32(const float* in, int N, int H, int W, int K, int ldin
 size_t kpx_conv3x3_wino43_stats_tiles(int N, int H, int W);
 int kpx_conv3x3_wino43_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u, const float* bias,
                                  float* out, int Nn, int ldout, int act, float* tile_stats, void* stream);
+/* 3x3 stride-1 SAME convolution PRODUCING exactly 16 channels on 16x16x4 MFMA blocks (no cout padding): the forward of the key-point
+ * detector's last decoder block (64 -> 16, 16 -> 16 at full resolution, reference models/networks/__init__.py:50-54) and the data gradient
+ * of its 16 -> 16 layer.  w_hwio is the layer's own filter: [3][3][K][16] forward, [3][3][16][K] for dgrad (K = gathered channels, a
+ * multiple of 16; H, W multiples of 16).  tile_stats (or NULL): per 16x16-pixel tile sums as kpx_conv3x3_wino_stats_f32 writes them. */
+int kpx_conv3x3_c16_eligible(int N, int H, int W, int K, int Nn, int ldin, int ldout, const void* in_ptr);
+int kpx_conv3x3_c16_f32(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int dgrad, const float* bias,
+                        float* out, int ldout, int act, float* tile_stats, void* stream);
 /* kpx_bn_bwd_f32 (act must be KPX_ACT_RELU) with the channel reductions taken from those tile sums over tiles [tile0, tile0+ntiles). */
 int kpx_bn_bwd_from_tiles_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int C,
                               const float* mean, const float* invstd, const float* gamma, const float* beta, int act,

@@ -52,7 +52,8 @@ CONV_CASES = [
     (2, 4, 4, 256, 1, 3, 1, 1, 0),         # D_logit-shaped: wave-per-pixel small-Cout kernel
     (2, 6, 6, 512, 4, 3, 1, 0, 1),         # small-Cout kernel, Cout=4, relu
     (2, 20, 20, 3, 64, 3, 1, 0, 1),        # VGG conv1_1 shape (row-merged Cin=3)
-    (4, 128, 128, 16, 16, 3, 1, 0, 0),     # multi-tap small-channel wgrad kernel (pose conv_7_1)
+    (4, 128, 128, 16, 16, 3, 1, 0, 0),     # multi-tap small-channel wgrad kernel (pose conv_7_1); fwd + dgrad on the 16-cout kernel
+    (3, 48, 80, 32, 16, 3, 1, 0, 2),       # 16-cout kernel: two chunks, lrelu, non-square
     (4, 128, 128, 64, 16, 3, 1, 0, 1),     # same, two 32-channel input tiles per wave (pose conv_7_0)
     (16, 64, 64, 128, 32, 3, 1, 0, 0),     # same, two channel tiles of 64 (pose conv_5_0)
     (4, 128, 128, 64, 4, 3, 1, 0, 0),      # same, translator crude+mask head (forward: VALU kernel for few produced channels)
@@ -517,7 +518,8 @@ def test_conv3x3_bf16_fwd_dgrad_tolerance(kpx, dev, n, h, w, cin, cout, act):
     assert rel_l2(t2n(y32), t2n(zo)) < 1e-5
 
 
-@pytest.mark.parametrize('n,h,w,cin,cout,groups', [(4, 32, 32, 32, 64, 1), (4, 16, 48, 64, 40, 2), (2, 64, 64, 128, 128, 1), (4, 16, 32, 24, 70, 2), (2, 32, 32, 16, 32, 1)])
+@pytest.mark.parametrize('n,h,w,cin,cout,groups', [(4, 32, 32, 32, 64, 1), (4, 16, 48, 64, 40, 2), (2, 64, 64, 128, 128, 1), (4, 16, 32, 24, 70, 2), (2, 32, 32, 16, 32, 1),
+                                                     (2, 32, 32, 16, 16, 1), (4, 32, 48, 64, 16, 2)])      # the last two: 16-cout kernel (conv_c16.hip)
 def test_batch_norm_statistics_from_the_conv_epilogue(kpx, dev, monkeypatch, n, h, w, cin, cout, groups):
     """conv -> train-mode batch norm with the per-tile channel sums written by the Winograd epilogue (kpx_conv3x3_wino_stats_f32 +
     kpx_bn_stats_from_tiles_f32) against the oracle AND against the separate statistics pass: same normalised output, same

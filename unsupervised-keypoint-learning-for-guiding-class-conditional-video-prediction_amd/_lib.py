@@ -45,6 +45,8 @@ SIGNATURES = {
     'kpx_wino_filter_transform_batch_f32': (c_int, [P, c_int, P]),
     'kpx_conv3x3_wino_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'kpx_conv3x3_wino_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
+    'kpx_conv3x3_c16_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'kpx_conv3x3_c16_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_int, P, P]),
     'kpx_conv3x3_wino43_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P]),
     'kpx_wino43_u_bytes': (c_size_t, [c_int, c_int]),
     'kpx_wino43_filter_transform_f32': (c_int, [P, c_int, c_int, c_int, P, P]),

@@ -334,6 +334,13 @@ def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act, want_s
     if (_compute_dtype[0] == 'bf16' and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cin >= 8
             and y.shape[1] == hi and y.shape[2] == wi and _bf16_conv(x, ldx, cin, w, bias, y, ldy, cout, act, False)):
         return
+    if (kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and act != ACT_TANH and cout == 16 and y.shape[1] == hi and y.shape[2] == wi
+            and lib.kpx_conv3x3_c16_eligible(n, hi, wi, cin, cout, ldx, ldy, x.data_ptr())):
+        # exactly 16 produced channels: 16x16x4 MFMA blocks, no cout padding (csrc/conv_c16.hip)
+        slab = torch.empty(n * (hi // 16) * (wi // 16) * 2 * 16, dtype=torch.float32, device=x.device) if want_stats else None
+        check(lib.kpx_conv3x3_c16_f32(x.data_ptr(), n, hi, wi, cin, ldx, w.data_ptr(), 0, bias.data_ptr() if bias is not None else None,
+                                      y.data_ptr(), ldy, act, slab.data_ptr() if slab is not None else None, _stream()), 'kpx_conv3x3_c16_f32')
+        return (slab, (hi // 16) * (wi // 16)) if want_stats else None
     if (kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and act != ACT_TANH and y.shape[1] == hi and y.shape[2] == wi
             and not (cout <= 4 and cin <= 128 and n * hi * wi >= 65536)):        # (few produced channels over a large image: VALU kernel inside the library)
         r = _wino_pretransformed(x, ldx, cin, w, bias, y, ldy, cout, act, False, want_stats=want_stats)
@@ -355,6 +362,11 @@ def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l, bn_src=None
     kh, kw, _, cout = w.shape
     if (_compute_dtype[0] == 'bf16' and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cout >= 8
             and dx.shape[1] == ho and dx.shape[2] == wo and _bf16_conv(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True)):
+        return
+    if (kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cin == 16 and bn_src is None and dx.shape[1] == ho and dx.shape[2] == wo
+            and lib.kpx_conv3x3_c16_eligible(n, ho, wo, cout, cin, lddy, lddx, dy.data_ptr())):
+        check(lib.kpx_conv3x3_c16_f32(dy.data_ptr(), n, ho, wo, cout, lddy, w.data_ptr(), 1, None, dx.data_ptr(), lddx, ACT_NONE, None, _stream()),
+              'kpx_conv3x3_c16_f32')
         return
     if kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and dx.shape[1] == ho and dx.shape[2] == wo:
         r = _wino_pretransformed(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True, bn_src=bn_src)
