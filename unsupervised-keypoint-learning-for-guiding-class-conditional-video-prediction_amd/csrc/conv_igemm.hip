@@ -518,6 +518,9 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const floa
                                                                   int pad_t, int pad_l, int act, hipStream_t s);
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
                                                                     float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, hipStream_t s);
+extern "C" int kpx_conv3x3_c16_eligible(int N, int H, int W, int K, int Nn, int ldin, int ldout, const void* in_ptr);
+extern "C" int kpx_conv3x3_c16_f32(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int dgrad, const float* bias,
+                                   float* out, int ldout, int act, float* tile_stats, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_few_fwd(const float* x, int N, int Hi, int Wi, int Cin, int ldx, const float* w, int KH, int KW,
                                                                   const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
                                                                   int stride, int pad_t, int pad_l, int act, hipStream_t s);
@@ -551,6 +554,9 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
     if (!x || !w || !y || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || ldy < Cout || act < 0 || act > 3)
         return KPX_EINVAL;
+    if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && act != KPX_ACT_TANH &&
+        kpx_conv3x3_c16_eligible(N, Hi, Wi, Cin, Cout, ldx, ldy, x))                 // exactly 16 produced channels: 16x16x4 MFMA blocks (conv_c16.hip)
+        return kpx_conv3x3_c16_f32(x, N, Hi, Wi, Cin, ldx, w, 0, bias, y, ldy, act, nullptr, stream);
     if (Cout <= 4 && Cin <= 128 && (size_t)N * Ho * Wo >= 65536) {            // few produced channels over a large image: VALU kernel (conv_rgb.hip)
         const int rc = kpx_conv_few_fwd(x, N, Hi, Wi, Cin, ldx, w, KH, KW, bias, y, Ho, Wo, Cout, ldy, stride, pad_t, pad_l, act, kpx_stream(stream));
         if (rc != -2) return rc;
@@ -594,6 +600,9 @@ extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int 
         KH <= 0 || KW <= 0 || stride <= 0 || lddy < Cout || lddx < Cin)
         return KPX_EINVAL;
     if (stride > 2) return KPX_EINVAL;             // at most 4 parity classes per launch (the path has strides 1 and 2)
+    if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi &&
+        kpx_conv3x3_c16_eligible(N, Hi, Wi, Cout, Cin, lddy, lddx, dy))
+        return kpx_conv3x3_c16_f32(dy, N, Hi, Wi, Cout, lddy, w, 1, nullptr, dx, lddx, KPX_ACT_NONE, nullptr, stream);
     if (Cin <= 4) {                                // gradient towards an image: VALU kernel (conv_rgb.hip)
         const int rc = kpx_conv_rgb_dgrad(dy, N, Ho, Wo, Cout, lddy, w, KH, KW, dx, Hi, Wi, Cin, lddx, stride, pad_t, pad_l, kpx_stream(stream));
         if (rc != -2) return rc;
