@@ -219,15 +219,23 @@ class DetectorTranslatorModel(BaseModel):
             final = fwd['final_output']
             recon = self._loss_G_recon(final, future_im)
             if aux is not None and AUX_STREAM_ADV:
-                # Two-stream G loss: the gradient of each term with respect to the generated frame is taken on its own stream -- the VGG19
-                # data-gradient chain on the main stream straight after the VGG19 forward, without waiting for the discriminator update; the
-                # adversarial branch (discriminator forward with the UPDATED weights + its data gradients) on the auxiliary stream behind
-                # that update -- and the generator is walked once with their sum.  Both chains are half-batch launches that underfill the chip.
+                # Two-stream G loss: the gradient of each term with respect to the generated frame is taken separately -- the VGG19
+                # data-gradient chain on the main stream straight after the VGG19 forward, without waiting for the discriminator update --
+                # and the generator is walked once with their sum.  On one GPU the adversarial branch (discriminator forward with the
+                # UPDATED weights + its data gradients) runs on the auxiliary stream behind that update, beside the VGG19 chain: both are
+                # half-batch launches that underfill the chip.  Data-parallel, the discriminator's 179 MB all-reduce sits between its
+                # backward and its Adam step: there the adversarial branch runs on the main stream AFTER the join, so that the exchange has
+                # the whole VGG19 forward + backward (~5 ms) to hide under instead of lengthening the auxiliary chain.
                 g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
-                with torch.cuda.stream(aux):
+                if not self.distributed:
+                    with torch.cuda.stream(aux):
+                        adv = self._loss_G_adv(final)
+                        g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
+                    torch.cuda.current_stream(self.device).wait_stream(aux)
+                else:
+                    torch.cuda.current_stream(self.device).wait_stream(aux)
                     adv = self._loss_G_adv(final)
                     g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
-                torch.cuda.current_stream(self.device).wait_stream(aux)
                 ops.begin_backward()
                 final.backward(g_recon + g_adv)
             else:
