@@ -215,6 +215,12 @@ int kpx_maxpool2_bwd_f32(const float* dy, const float* x, int N, int H, int W, i
  * g = gscale_host * (gscale_dev ? *gscale_dev : 1).  scratch >= 8 KiB. */
 int kpx_l1_pair_fwd_f32(const float* f, size_t half, float* loss_out, void* scratch, void* stream);
 int kpx_l1_pair_bwd_f32(const float* f, size_t half, const float* gscale_dev, float gscale_host, float* dpred, void* stream);
+/* Gradient arriving at a VGG19 feature y = relu(conv) in one pass: ReLU mask of (max-pool backward of dy_pooled + L1 backward), i.e.
+ * kpx_maxpool2_bwd_f32 + kpx_l1_pair_bwd_f32 + their sum + the ReLU backward fused (reference vgg.py:43,45-55 and
+ * detector_translator_model.py:274-289).  f = [gt; pred] halves of the feature [2B,H,W,C], C % 4 == 0; dy_pooled [B,ceil(H/2),ceil(W/2),C]
+ * or NULL for the last feature; d [B,H,W,C]. */
+int kpx_vgg_feat_bwd_f32(const float* f, size_t half, const float* gscale_dev, float gscale_host, const float* dy_pooled,
+                         int B, int H, int W, int C, float* d, void* stream);
 
 /* ---- tf.nn.sigmoid_cross_entropy_with_logits + reduce_mean (detector_translator_model.py:249-254,265-267).
  * labels: the first n0 logits get label0, the next n1 get label1 (n1 may be 0).

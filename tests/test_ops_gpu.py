@@ -606,3 +606,32 @@ def test_batch_norm_backward_sums_from_the_dgrad_epilogue(kpx, dev, n, h, w, c0,
     for k_ in ('x', 'wa', 'wb', 'ga', 'be'):
         assert rel_l2(g1[k_], t2n(to[k_].grad)) < 2e-4, (k_, rel_l2(g1[k_], t2n(to[k_].grad)))
         assert rel_l2(g1[k_], g0[k_]) < 2e-4, (k_, rel_l2(g1[k_], g0[k_]))
+
+
+@pytest.mark.parametrize('b,h,w,c,pooled', [(2, 16, 16, 8, True), (3, 10, 14, 12, True), (2, 7, 9, 4, True), (2, 8, 8, 16, False)])
+def test_vgg_feature_gradient_in_one_pass_equals_the_four_pass_chain(kpx, dev, b, h, w, c, pooled):
+    """kpx_vgg_feat_bwd_f32 = ReLU backward of (max-pool backward + L1 backward), bit for bit against the separate kernels it replaces
+    (kpx_maxpool2_bwd_f32, kpx_l1_pair_bwd_f32, the sum, the ReLU mask), ties (equal window maxima, zero differences, y = 0) included."""
+    from kpx_amd._lib import lib, check
+    ops = kpx.ops
+    rs = np.random.RandomState(b * 100 + h)
+    f = np.maximum(rs.randn(2 * b, h, w, c), 0).astype(np.float32)          # post-ReLU features: many exact zeros
+    f[b:][rs.rand(b, h, w, c) < 0.2] = 0.5                                   # equal maxima inside windows
+    f[0, 0, 0, :] = f[b, 0, 0, :]                                            # pred == gt: zero L1 gradient
+    ho, wo = (h + 1) // 2, (w + 1) // 2
+    fg = torch.from_numpy(f).to(dev)
+    gdev = torch.tensor([0.7], dtype=torch.float32, device=dev)
+    half = b * h * w * c
+    got = torch.empty(b, h, w, c, device=dev)
+    dyp = torch.from_numpy(rs.randn(b, ho, wo, c).astype(np.float32)).to(dev) if pooled else None
+    check(lib.kpx_vgg_feat_bwd_f32(fg.data_ptr(), half, gdev.data_ptr(), 0.125, dyp.data_ptr() if pooled else None, b, h, w, c, got.data_ptr(), ops._stream()), 'fused')
+    dl = torch.empty(b, h, w, c, device=dev)
+    check(lib.kpx_l1_pair_bwd_f32(fg.data_ptr(), half, gdev.data_ptr(), 0.125, dl.data_ptr(), ops._stream()), 'l1')
+    if pooled:
+        dx = torch.empty(b, h, w, c, device=dev)
+        check(lib.kpx_maxpool2_bwd_f32(dyp.data_ptr(), fg[b:].contiguous().data_ptr(), b, h, w, c, dx.data_ptr(), ops._stream()), 'pool')
+        want = dx + dl
+    else:
+        want = dl
+    want = torch.where(fg[b:] > 0, want, torch.zeros_like(want))
+    assert torch.equal(got, want)

@@ -86,6 +86,7 @@ SIGNATURES = {
     'kpx_maxpool2_bwd_f32': (c_int, [P, P, c_int, c_int, c_int, c_int, P, P]),
     'kpx_l1_pair_fwd_f32': (c_int, [P, c_size_t, P, P, P]),
     'kpx_l1_pair_bwd_f32': (c_int, [P, c_size_t, P, c_float, P, P]),
+    'kpx_vgg_feat_bwd_f32': (c_int, [P, c_size_t, P, c_float, P, c_int, c_int, c_int, c_int, P, P]),
     'kpx_sigmoid_xent_fwd_f32': (c_int, [P, c_size_t, c_float, c_size_t, c_float, P, P]),
     'kpx_sigmoid_xent_bwd_f32': (c_int, [P, c_size_t, c_float, c_size_t, c_float, P, c_float, P, P]),
     'kpx_adam_tf_flat_f32': (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),

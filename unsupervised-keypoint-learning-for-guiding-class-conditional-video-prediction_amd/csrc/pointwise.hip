@@ -779,6 +779,71 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* dy, cons
         }
     }
 }
+// Gradient arriving at a VGG19 feature tensor y = relu(conv) (reference models/networks/vgg.py:43,45-55; detector_translator_model.py:274-289),
+// in ONE pass instead of four (max-pool backward, L1 backward, their sum, ReLU backward):
+//   d[pix][c] = [y_pred > 0] * ( (pix is the first maximum of its 2x2 window ? dy_pooled : 0) + g * sign(y_pred - y_gt) )
+// f = [gt half ; pred half] of the feature ([2B,H,W,C]); dy_pooled = gradient w.r.t. the pooled tensor [B,Ho,Wo,C] or NULL for the last
+// feature (no pool behind it); g = gscale_host * *gscale_dev.  Four channels per thread.
+__global__ __launch_bounds__(256) void vgg_feat_bwd_kernel(const float* __restrict__ f, size_t half, const float* gdev, float ghost,
+                                                           const float* __restrict__ dyp, int B, int H, int W, int C, float* __restrict__ d) {
+    const float g = ghost * (gdev ? *gdev : 1.0f);
+    const int C4 = C >> 2, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const float* fp = f + half;                                    // pred half
+    if (!dyp) {
+        const size_t total = half >> 2;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const f32x4 yp = *reinterpret_cast<const f32x4*>(fp + 4 * i), yg = *reinterpret_cast<const f32x4*>(f + 4 * i);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float df = yg[e] - yp[e]; const float l1 = df > 0.f ? -g : (df < 0.f ? g : 0.f); o[e] = yp[e] > 0.f ? l1 : 0.f; }
+            *reinterpret_cast<f32x4*>(d + 4 * i) = o;
+        }
+        return;
+    }
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        size_t p = i / C4;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        f32x4 v[4], gt[4]; bool ok[4]; size_t off[4];
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int iy = 2 * oy + (k >> 1), ix = 2 * ox + (k & 1);
+            ok[k] = iy < H && ix < W;
+            off[k] = ((size_t)(n * H + iy) * W + ix) * C + c;
+            if (ok[k]) { v[k] = *reinterpret_cast<const f32x4*>(fp + off[k]); gt[k] = *reinterpret_cast<const f32x4*>(f + off[k]); }
+            else { v[k] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; gt[k] = v[k]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (ok[k] && v[k][e] > best[e]) { best[e] = v[k][e]; bi[e] = k; }      // first maximum in scan order
+        }
+        const f32x4 gp = *reinterpret_cast<const f32x4*>(dyp + (((size_t)(n * Ho + oy) * Wo + ox) * C + c));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float df = gt[k][e] - v[k][e];
+                const float l1 = df > 0.f ? -g : (df < 0.f ? g : 0.f);
+                o[e] = v[k][e] > 0.f ? ((bi[e] == k ? gp[e] : 0.f) + l1) : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(d + off[k]) = o;
+        }
+    }
+}
+extern "C" int kpx_vgg_feat_bwd_f32(const float* f, size_t half, const float* gscale_dev, float gscale_host, const float* dy_pooled,
+                                    int B, int H, int W, int C, float* d, void* stream) {
+    if (!f || !d || half == 0 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 4 || half != (size_t)B * H * W * C ||
+        ((((uintptr_t)f) | ((uintptr_t)d) | ((uintptr_t)dy_pooled)) & 15))
+        return KPX_EINVAL;
+    const size_t items = dy_pooled ? (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4) : half / 4;
+    hipLaunchKernelGGL(vgg_feat_bwd_kernel, dim3(grid_for(items)), dim3(256), 0, kpx_stream(stream), f, half, gscale_dev, gscale_host, dy_pooled, B, H, W, C, d);
+    return kpx_launch_status();
+}
 extern "C" int kpx_maxpool2_bwd_f32(const float* dy, const float* x, int N, int H, int W, int C, float* dx, void* stream) {
     if (!dy || !x || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return KPX_EINVAL;
     const size_t items = (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C;

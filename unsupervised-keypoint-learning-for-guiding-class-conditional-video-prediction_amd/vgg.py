@@ -97,6 +97,10 @@ def _vgg_forward(vgg, images):
     return feats, tape
 
 
+import os as _os
+FUSE_FEAT_BWD = _os.environ.get('KPX_FUSE_FEAT_BWD', '1') != '0'      # feature gradient (pool bwd + L1 bwd + ReLU bwd) in one pass
+
+
 class _PerceptualLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, gt, vgg):
@@ -121,9 +125,25 @@ class _PerceptualLossFn(torch.autograd.Function):
         nfeat = len(feats)
         feat_ids = {id(f): k for k, f in enumerate(feats)}
         d = None                                                      # gradient wrt the current tensor, pred half only
+        done = set()                                                  # features whose complete gradient (ReLU mask included) is already in d
+
+        def feat_grad(f, dy_pooled):
+            """ReLU mask of (max-pool backward of dy_pooled + L1 backward of feature f) in one pass (kpx_vgg_feat_bwd_f32)."""
+            half = f.numel() // 2
+            out = torch.empty((b,) + tuple(f.shape[1:]), dtype=torch.float32, device=f.device)
+            check(lib.kpx_vgg_feat_bwd_f32(f.data_ptr(), half, g.data_ptr(), 1.0 / (nfeat * half), dy_pooled.data_ptr() if dy_pooled is not None else None,
+                                           b, f.shape[1], f.shape[2], f.shape[3], out.data_ptr(), ops._stream()), 'kpx_vgg_feat_bwd_f32')
+            return out
         for kind, name, x, y in reversed(tape):
+            if kind == 'pool' and id(x) in feat_ids and x.shape[3] % 4 == 0 and FUSE_FEAT_BWD:
+                d = feat_grad(x, d)                                   # every pooled tensor of VGG_SEQ is a returned feature
+                done.add(id(x))
+                continue
             k = feat_ids.get(id(y))
-            if k is not None:                                         # y is a returned feature: add its L1 gradient
+            if k is not None and d is None and kind == 'conv' and y.shape[3] % 4 == 0 and FUSE_FEAT_BWD:
+                d = feat_grad(y, None)                                # the last feature: nothing behind it
+                done.add(id(y))
+            elif k is not None and id(y) not in done:                 # y is a returned feature: add its L1 gradient
                 half = y.numel() // 2
                 dl = torch.empty((b,) + tuple(y.shape[1:]), dtype=torch.float32, device=y.device)
                 check(lib.kpx_l1_pair_bwd_f32(y.data_ptr(), half, g.data_ptr(), 1.0 / (nfeat * half), dl.data_ptr(), ops._stream()),
@@ -139,7 +159,8 @@ class _PerceptualLossFn(torch.autograd.Function):
                 check(lib.kpx_maxpool2_bwd_f32(d.data_ptr(), xp.data_ptr(), nn_, hh, ww, cc, dx.data_ptr(), ops._stream()), 'kpx_maxpool2_bwd_f32')
             else:
                 wgt, _ = vgg.params[name]
-                ops.act_bwd_raw_(d, yp, ops.ACT_RELU)                 # d is ours: in place
+                if id(y) not in done:
+                    ops.act_bwd_raw_(d, yp, ops.ACT_RELU)             # d is ours: in place
                 dx = torch.empty(xp.shape, dtype=torch.float32, device=xp.device)
                 ops.conv_dgrad_raw(d, wgt.shape[3], wgt, dx, xp.shape[3], xp.shape[3], 1, 1, 1)
             d = dx
