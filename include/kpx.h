@@ -142,6 +142,10 @@ int kpx_conv3x3_wino43_f32(const float* in, int N, int H, int W, int K, int ldin
                            float* out, int Nn, int ldout, int act, void* stream);
 /* The same with the batch-norm statistics of the output from the epilogue, as kpx_conv3x3_wino_stats_f32 but per 4 x 16-pixel strip:
  * tile_stats[strip][2][Nn], kpx_conv3x3_wino43_stats_tiles(N, H, W) strips, consumed by kpx_bn_stats_from_tiles_f32 (tile_pixels 64). */
+/* ... and with VGG19's two epilogue options: mask_y (or NULL): the output is zeroed where mask_y <= 0 (the ReLU backward of the tensor this
+ * data gradient belongs to); pool_y (or NULL): the 2x2 max-pool of the activated output is written too ([N,H/2,W/2,Nn]).  Nn % 64 == 0. */
+int kpx_conv3x3_wino43_ex_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u, const float* bias,
+                              float* out, int Nn, int ldout, int act, const float* mask_y, int ld_mask, float* pool_y, int ld_pool, void* stream);
 size_t kpx_conv3x3_wino43_stats_tiles(int N, int H, int W);
 int kpx_conv3x3_wino43_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u, const float* bias,
                                  float* out, int Nn, int ldout, int act, float* tile_stats, void* stream);

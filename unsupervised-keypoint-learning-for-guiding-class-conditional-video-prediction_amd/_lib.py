@@ -52,6 +52,7 @@ SIGNATURES = {
     'kpx_wino43_filter_transform_f32': (c_int, [P, c_int, c_int, c_int, P, P]),
     'kpx_wino43_filter_transform_batch_f32': (c_int, [P, c_int, P]),
     'kpx_conv3x3_wino43_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
+    'kpx_conv3x3_wino43_ex_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P, c_int, P, c_int, P]),
     'kpx_conv3x3_wino43_stats_tiles': (c_size_t, [c_int, c_int, c_int]),
     'kpx_conv3x3_wino43_stats_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P, P]),
     'kpx_conv3x3_wino_stats_tiles': (c_size_t, [c_int, c_int, c_int]),

@@ -32,6 +32,8 @@ struct Wino43Geom {
     int N, H, W, Cin, ldx, Cout, ldy, act;
     int Kp, Np;                              // U is [36][Kp/8][Np/32][2][32][4]
     int tiles_y, tiles_x;                    // 16 x 32-pixel regions per image
+    const float* mask_y; int ld_mask;        // optional: zero the output where mask_y <= 0 (the ReLU backward of the tensor this gradient belongs to)
+    float* pool_y; int ld_pool;              // optional: also write the 2x2 max-pool of the (activated) output
     float* stats;                            // STATS: [N * tiles_y * tiles_x * 8 strips of 4 x 16 pixels][2][Cout] sum / sum of squares of the output
 };
 
@@ -374,7 +376,47 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
     const size_t cstr = (size_t)g.ldy, rstr = (size_t)g.W * g.ldy;
     const bool fast = (g.ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.y) & 15) == 0) && n0 + 64 <= g.Cout;    // block-uniform
     f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
-    if (fast) {
+    if (fast && !STATS && (g.mask_y || g.pool_y)) {              // block-uniform: VGG19's fused ReLU backward / max-pool forward
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = Y[i][j] + bv;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const float z = fmaxf(v[q], lo); v[q] = z > 0.f ? z : z * slope; }
+                Y[i][j] = v;
+            }
+        if (g.mask_y) {
+            const float* const mbase = g.mask_y + ((size_t)(on * g.H + oy) * g.W + ox) * g.ld_mask + c0o;
+            const size_t mc = (size_t)g.ld_mask, mr = (size_t)g.W * g.ld_mask;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 ym = *reinterpret_cast<const f32x4*>(mbase + i * mr + j * mc);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Y[i][j][q] = ym[q] > 0.f ? Y[i][j][q] : 0.f;
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(obase + i * rstr + j * cstr) = Y[i][j];
+        if (g.pool_y) {
+            const int Hp = g.H >> 1, Wp = g.W >> 1;
+            float* const pbase = g.pool_y + ((size_t)(on * Hp + (oy >> 1)) * Wp + (ox >> 1)) * g.ld_pool + c0o;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 p;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        p[q] = fmaxf(fmaxf(Y[2 * i][2 * j][q], Y[2 * i][2 * j + 1][q]), fmaxf(Y[2 * i + 1][2 * j][q], Y[2 * i + 1][2 * j + 1][q]));
+                    *reinterpret_cast<f32x4*>(pbase + ((size_t)i * Wp + j) * g.ld_pool) = p;
+                }
+        }
+    } else if (fast) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -446,7 +488,8 @@ extern "C" int kpx_wino43_filter_transform_batch_f32(const void* descs_dev, int 
     return kpx_launch_status();
 }
 static int w43_launch(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
-                      float* out, int Nn, int ldout, int act, float* tile_stats, void* stream) {
+                      float* out, int Nn, int ldout, int act, float* tile_stats, void* stream,
+                      const float* mask_y = nullptr, int ld_mask = 0, float* pool_y = nullptr, int ld_pool = 0) {
     if (!in || !U || !out || ldin < K || ldout < Nn || act < 0 || act > 2 || !kpx_conv3x3_wino43_eligible(N, H, W, K, Nn, ldin, in)) return KPX_EINVAL;
     if (kpx_first_use_on_device(&w43_attr_mask)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
@@ -462,6 +505,7 @@ static int w43_launch(const float* in, int N, int H, int W, int K, int ldin, con
     if (pack && tile_stats) return KPX_EINVAL;           // (no batch-norm layer of the path is 16 x 16 with a forward on this kernel)
     g.tiles_y = H / 16; g.tiles_x = pack ? 1 : W / 32;
     g.stats = tile_stats;
+    g.mask_y = mask_y; g.ld_mask = ld_mask; g.pool_y = pool_y; g.ld_pool = ld_pool;
     const unsigned blocks = (unsigned)((size_t)(pack ? N / 2 : N) * g.tiles_y * g.tiles_x * (g.Np / 64));
     if (pack) hipLaunchKernelGGL((conv_wino43_kernel<0, true>), dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
     else if (tile_stats) hipLaunchKernelGGL((conv_wino43_kernel<1, false>), dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
@@ -480,4 +524,15 @@ extern "C" int kpx_conv3x3_wino43_stats_f32(const float* in, int N, int H, int W
                                             float* out, int Nn, int ldout, int act, float* tile_stats, void* stream) {
     if (!tile_stats) return KPX_EINVAL;
     return w43_launch(in, N, H, W, K, ldin, U, bias, out, Nn, ldout, act, tile_stats, stream);
+}
+
+// The same with the two epilogue options VGG19 uses (reference models/networks/vgg.py:45-55): mask_y (or NULL) -- the output is zeroed
+// where mask_y <= 0, i.e. the ReLU backward of the tensor this data gradient belongs to; pool_y (or NULL) -- the 2x2 max-pool of the
+// activated output is written as well ([N,H/2,W/2,Nn], pixel stride ld_pool).  Needs Nn % 64 == 0 and 16-B aligned rows everywhere.
+extern "C" int kpx_conv3x3_wino43_ex_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
+                                         float* out, int Nn, int ldout, int act, const float* mask_y, int ld_mask, float* pool_y, int ld_pool, void* stream) {
+    if (Nn % 64 || ldout % 4 || (((uintptr_t)out) & 15) || (mask_y && (ld_mask % 4 || ld_mask < Nn || (((uintptr_t)mask_y) & 15))) ||
+        (pool_y && (ld_pool % 4 || ld_pool < Nn || (((uintptr_t)pool_y) & 15) || (H & 1) || (W & 1))))
+        return KPX_EINVAL;
+    return w43_launch(in, N, H, W, K, ldin, U, bias, out, Nn, ldout, act, nullptr, stream, mask_y, ld_mask, pool_y, ld_pool);
 }

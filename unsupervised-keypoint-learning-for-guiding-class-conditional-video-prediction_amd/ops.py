@@ -326,6 +326,30 @@ def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, wa
     return True
 
 
+def conv3x3_wino43_ex(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, mask=None, pool_out=None):
+    """The F(4x4,3x3) kernel with VGG19's epilogue options: ``mask`` -- zero the output where mask <= 0 (ReLU backward of the tensor the
+    data gradient belongs to), ``pool_out`` -- also write the 2x2 max-pool of the activated output.  True if it ran; False when the
+    layer / launch is not one the kernel takes (the caller then uses the plain path and the separate kernels)."""
+    ent43 = _wino43_u.get((w.data_ptr(), 1 if dgrad else 0)) if WINO43 else None
+    if ent43 is None or nn % 64:
+        return False
+    n, h, wd = inp.shape[0], inp.shape[1], inp.shape[2]
+    wgs43 = (n // 2 if wd == 16 else n * (h // 16) * (wd // 32)) * ((nn + 63) // 64)
+    if wgs43 <= WINO43_MIN_WORKGROUPS or not lib.kpx_conv3x3_wino43_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr()):
+        return False
+    if ent43[1] is not None:
+        ent43[1].ensure_fresh()
+    rc = lib.kpx_conv3x3_wino43_ex_f32(inp.data_ptr(), n, h, wd, k, ld_in, ent43[0].data_ptr(), bias.data_ptr() if bias is not None else None,
+                                       out.data_ptr(), nn, ld_out, act, mask.data_ptr() if mask is not None else None,
+                                       mask.shape[3] if mask is not None else 0, pool_out.data_ptr() if pool_out is not None else None,
+                                       pool_out.shape[3] if pool_out is not None else 0, _stream())
+    if rc == -1:                                         # KPX_EINVAL: alignment / channel-count preconditions of the options
+        return False
+    check(rc, 'kpx_conv3x3_wino43_ex_f32')
+    conv_kernel_uses['wino43'] += 1
+    return True
+
+
 # ----------------------------------------------------------------------------------------------- raw launchers
 def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act, want_stats=False):
     """Returns None, or (tile-statistics slab, tiles per image) when ``want_stats`` and the layer ran on the kernel that provides them."""

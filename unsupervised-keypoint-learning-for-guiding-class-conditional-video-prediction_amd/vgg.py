@@ -78,20 +78,32 @@ def _vgg_forward(vgg, images):
     x = torch.empty_like(images)
     check(lib.kpx_vgg_prep_fwd_f32(images.data_ptr(), n * h * w, x.data_ptr(), ops._stream()), 'kpx_vgg_prep_fwd_f32')
     feats, tape = [], []
-    for item in VGG_SEQ:
+    pooled = None                                        # max-pool of the last conv's output, when its epilogue already wrote it
+    for pos, item in enumerate(VGG_SEQ):
         if item == 'F':
             feats.append(x)
         elif item == 'P':
             nn_, hh, ww, cc = x.shape
-            y = torch.empty((nn_, (hh + 1) // 2, (ww + 1) // 2, cc), dtype=torch.float32, device=dev)
-            check(lib.kpx_maxpool2_fwd_f32(x.data_ptr(), nn_, hh, ww, cc, y.data_ptr(), ops._stream()), 'kpx_maxpool2_fwd_f32')
+            if pooled is not None:
+                y = pooled
+            else:
+                y = torch.empty((nn_, (hh + 1) // 2, (ww + 1) // 2, cc), dtype=torch.float32, device=dev)
+                check(lib.kpx_maxpool2_fwd_f32(x.data_ptr(), nn_, hh, ww, cc, y.data_ptr(), ops._stream()), 'kpx_maxpool2_fwd_f32')
             tape.append(('pool', None, x, y))
             x = y
+            pooled = None
         else:
             wgt, b = vgg.params[item]
             nn_, hh, ww, cc = x.shape
-            y = torch.empty((nn_, hh, ww, wgt.shape[3]), dtype=torch.float32, device=dev)
-            ops.conv_fwd_raw(x, cc, cc, wgt, b, y, wgt.shape[3], 1, 1, 1, ops.ACT_RELU)
+            cout = wgt.shape[3]
+            y = torch.empty((nn_, hh, ww, cout), dtype=torch.float32, device=dev)
+            pooled = None
+            if FUSE_POOL_FWD and 'P' in VGG_SEQ[pos + 1:pos + 3] and hh % 2 == 0 and ww % 2 == 0:      # conv -> ('F' ->) pool: pool in the epilogue
+                pooled = torch.empty((nn_, hh // 2, ww // 2, cout), dtype=torch.float32, device=dev)
+                if not ops.conv3x3_wino43_ex(x, cc, cc, wgt, b, y, cout, cout, ops.ACT_RELU, False, pool_out=pooled):
+                    pooled = None
+            if pooled is None:
+                ops.conv_fwd_raw(x, cc, cc, wgt, b, y, cout, 1, 1, 1, ops.ACT_RELU)
             tape.append(('conv', item, x, y))
             x = y
     return feats, tape
@@ -99,6 +111,8 @@ def _vgg_forward(vgg, images):
 
 import os as _os
 FUSE_FEAT_BWD = _os.environ.get('KPX_FUSE_FEAT_BWD', '1') != '0'      # feature gradient (pool bwd + L1 bwd + ReLU bwd) in one pass
+FUSE_POOL_FWD = _os.environ.get('KPX_FUSE_POOL_FWD', '1') != '0'      # 2x2 max-pool written by the producing conv's epilogue
+FUSE_RELU_BWD = _os.environ.get('KPX_FUSE_RELU_BWD', '1') != '0'      # ReLU backward applied in the epilogue of the data gradient above it
 
 
 class _PerceptualLossFn(torch.autograd.Function):
@@ -125,7 +139,8 @@ class _PerceptualLossFn(torch.autograd.Function):
         nfeat = len(feats)
         feat_ids = {id(f): k for k, f in enumerate(feats)}
         d = None                                                      # gradient wrt the current tensor, pred half only
-        done = set()                                                  # features whose complete gradient (ReLU mask included) is already in d
+        done = set()                                                  # tensors whose complete gradient (ReLU mask included) is already in d
+        conv_outputs = {id(yy) for kk, _, _, yy in tape if kk == 'conv'}
 
         def feat_grad(f, dy_pooled):
             """ReLU mask of (max-pool backward of dy_pooled + L1 backward of feature f) in one pass (kpx_vgg_feat_bwd_f32)."""
@@ -162,7 +177,12 @@ class _PerceptualLossFn(torch.autograd.Function):
                 if id(y) not in done:
                     ops.act_bwd_raw_(d, yp, ops.ACT_RELU)             # d is ours: in place
                 dx = torch.empty(xp.shape, dtype=torch.float32, device=xp.device)
-                ops.conv_dgrad_raw(d, wgt.shape[3], wgt, dx, xp.shape[3], xp.shape[3], 1, 1, 1)
+                # x is the ReLU output of the conv below (not a pooled tensor, not the image): its ReLU backward rides in this epilogue
+                if (FUSE_RELU_BWD and id(x) in conv_outputs and id(x) not in feat_ids
+                        and ops.conv3x3_wino43_ex(d, wgt.shape[3], wgt.shape[3], wgt, None, dx, xp.shape[3], xp.shape[3], ops.ACT_NONE, True, mask=xp)):
+                    done.add(id(x))
+                else:
+                    ops.conv_dgrad_raw(d, wgt.shape[3], wgt, dx, xp.shape[3], xp.shape[3], 1, 1, 1)
             d = dx
         dpred = torch.empty_like(d)
         check(lib.kpx_vgg_prep_bwd_f32(d.data_ptr(), d.shape[0] * d.shape[1] * d.shape[2], dpred.data_ptr(), ops._stream()), 'kpx_vgg_prep_bwd_f32')
