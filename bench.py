@@ -24,17 +24,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 RES, K_PTS, BATCH = 128, 15, 32
-# forward MACs per image pair
-GMAC_GEN_FWD, GMAC_D_PASS, GMAC_VGG_IMG = 11.370 + 0.227, 1.384, 6.370
+# forward MACs per image pair -- (generator forward without / dead image_encoder conv_7/8 branch, one img_discr
+# pass, VGG19 per image) at 128x128 K=15 and at the 256x256 K=40 generalisation (Appendix A, second table)
+GMAC = {128: (11.370, 0.227, 1.384, 6.370), 256: (3.630 - 0.908 + 2 * 7.296 + 28.689, 0.908, 3.956, 25.480)}
+# bench configurations: BASELINE.json configs[1] (the headline), [3] and [4]
+CONFIGS = {'c1': dict(res=128, k=15, batch=32, idx=1, metric='detector_translator train frames/sec @128x128 K=15'),
+           'c3': dict(res=256, k=40, batch=16, idx=3, metric='detector_translator train frames/sec @256x256 K=40'),
+           'c4': dict(res=128, k=15, batch=64, idx=4, metric='evaluate.py rollout (detector -> motion generator -> translator) predicted frames/sec @128x128 K=15, 32 frames per image')}
 
 
-def step_gmac_per_pair():
+def step_gmac_per_pair(res=128):
     """Algorithmic MACs of the restructured step per pair (shared generator forward; conv fwd = dgrad = wgrad):
     G fwd + bwd(dgrad+wgrad) ; D-run: 2 D fwd + 2 x (dgrad+wgrad) ; G-run: D fwd + D dgrad ; VGG: 2 fwd + 1 dgrad."""
-    gen = 11.370 * 3 + 0.227          # the dead image_encoder conv_7/8 branch runs forward only (BN moving stats)
-    d_run = 2 * GMAC_D_PASS * 3
-    g_adv = GMAC_D_PASS * 2
-    vgg = GMAC_VGG_IMG * 3
+    g_fwd, g_dead, d_pass, vgg_img = GMAC[res]
+    gen = g_fwd * 3 + g_dead          # the dead image_encoder conv_7/8 branch runs forward only (BN moving stats)
+    d_run = 2 * d_pass * 3
+    g_adv = d_pass * 2
+    vgg = vgg_img * 3
     return gen + d_run + g_adv + vgg
 
 
@@ -126,11 +132,14 @@ def roofline_conv_f23(dev):
 
 def roofline_conv_direct(dev):
     """The direct implicit-GEMM kernel on the same layer (what strided / 4x4 / odd-channel layers run): KPX_NO_WINO=1."""
+    from kpx_amd._lib import lib
     os.environ['KPX_NO_WINO'] = '1'
+    lib.kpx_reload_env()                    # the switches are parsed once; re-read them for this leg only
     try:
         ms, flops = _time_conv_3_1(dev)
     finally:
         del os.environ['KPX_NO_WINO']
+        lib.kpx_reload_env()
     ach = flops / (ms * 1e-3) / 1e12
     traffic, src = _pmc_traffic(DIRECT_PMC)
     return {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,128,2,4> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1, KPX_NO_WINO=1)',
@@ -154,15 +163,17 @@ def roofline_conv_bf16(dev):
             'mfma_tflops_bf16': round(flops / (ms * 1e-3) / 1e12, 1), 'mfma_frac_of_bf16_peak': round(flops / (ms * 1e-3) / 2.5e15, 4)}
 
 
-def roofline_render(dev):
+def roofline_render(dev, res=RES, k_pts=K_PTS, batch=BATCH):
     """HBM-bound kernel the north star singles out: Gaussian heat-map render at [128,128,K=15], batch 32:
     algorithmic bytes = B*H*W*K*4 written (+ K*8 read) per launch (983 040 B per image).  The launches rotate over
-    nine 62.9 MB outputs (566 MB > the 256 MB Infinity Cache) so that every launch's stores have to reach HBM."""
+    nine 62.9 MB outputs (566 MB > the 256 MB Infinity Cache) so that every launch's stores have to reach HBM.
+    (--config c3: [32,256,256,40] = 335.5 MB per launch, three rotating outputs.)"""
     from kpx_amd import ops
     from kpx_amd._lib import lib, check
-    b = 2 * BATCH                      # current + future key-point maps of one batch of 32 pairs
+    RES, K_PTS = res, k_pts
+    b = 2 * batch                      # current + future key-point maps of one batch of pairs
     mu = (torch.rand(b, K_PTS, 2, device=dev) * 2 - 1).contiguous()
-    outs = [torch.empty(b, RES, RES, K_PTS, device=dev) for _ in range(9)]
+    outs = [torch.empty(b, RES, RES, K_PTS, device=dev) for _ in range(9 if res == 128 else 3)]
     it = [0]
 
     def run():
@@ -172,11 +183,11 @@ def roofline_render(dev):
     ms = time_kernel(run, iters=198, warm=18)
     nbytes = b * (RES * RES * K_PTS * 4 + K_PTS * 8)
     ach = nbytes / (ms * 1e-3) / 1e9
-    traffic, src = _pmc_traffic(RENDER_PMC)
-    rp_ms, rp_src = _rocprof_avg_ms('gauss_fwd_reg_kernel')
+    traffic, src = _pmc_traffic(RENDER_PMC) if (res, k_pts, batch) == (128, 15, 32) else (None, None)
+    rp_ms, rp_src = _rocprof_avg_ms('gauss_fwd_reg_kernel') if (res, k_pts, batch) == (128, 15, 32) else (None, None)
     return {'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'frac_at_rocprof_avg': round(nbytes / (rp_ms * 1e-3) / 8e12, 4) if rp_ms else None,
             'avg_launch_ms_note': 'HIP events over back-to-back launches include the launch-to-launch gap of this 12 us kernel',
-            'bound': 'hbm', 'kernel': 'gauss_fwd kernel [64,128,128,15] (current+future maps of 32 pairs), 9 rotating outputs', 'achieved': round(ach, 1),
+            'bound': 'hbm', 'kernel': 'gauss_fwd kernel [%d,%d,%d,%d] (current+future maps of %d pairs), %d rotating outputs' % (b, RES, RES, K_PTS, batch, len(outs)), 'achieved': round(ach, 1),
             'peak': 8000.0, 'unit': 'GB/s', 'frac': round(ach / 8000.0, 4), 'traffic': traffic, 'traffic_source': src,
             'avg_launch_ms': round(ms, 5), 'bytes_per_launch': nbytes}
 
@@ -250,12 +261,69 @@ def self_launch(n):
     return rc
 
 
+def bench_rollout(args, conf, dev, rank, world, launched, backend):
+    """BASELINE configs[4]: the evaluate.py pipeline (reference models/final_model.py:49-122) -- key-point detector + image encoder on the
+    source image, vae_decoder (fc + 2 x LSTMCell(1024) x 32 steps + to_coord), translator on B*32 frames with inference-mode batch norm.
+    One step = one FinalModel.run on `batch` source images = batch*32 predicted frames.  No collective: replicas only."""
+    import kpx_amd
+    res, k, b = conf['res'], conf['k'], args.batch
+    cfg = {'model': {'n_pts': k, 'cell_info': [1024, 1024], 'vae_dim': 64, 'n_action': 9}, 'paths': {'log_dir': '/tmp/kpx_bench'}}
+    fm = kpx_amd.FinalModel(cfg, device=dev, image_size=res, frames_per_launch=256)
+    fm.build()
+    rs = np.random.RandomState(7 + rank)
+    im = torch.from_numpy((rs.randint(0, 256, size=(b, res, res, 3)).astype(np.float32) / 255.0 * 2 - 1).astype(np.float32)).to(dev)
+    act = torch.from_numpy(np.eye(9, dtype=np.float32)[rs.randint(0, 9, size=b)]).to(dev)
+    z = torch.from_numpy(rs.randn(b, 64).astype(np.float32)).to(dev)
+    feed = {'image': im, 'action_code': act}
+
+    def sync():
+        if launched:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        out = fm.run(None, feed, z=z)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = fm.run(None, feed, z=z)
+    t_enq = time.perf_counter() - t0
+    sync()
+    dt = time.perf_counter() - t0
+    if launched:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(out['pred_im_seq']).all())
+    if rank == 0:
+        frames = world * b * 32 * args.steps
+        # translator 7.054 GMAC per frame (Appendix A) + detector / image encoder once per source image
+        gmac_frame = 7.054 + (1.817 + 0.681) / 32.0
+        line = {'metric': conf['metric'], 'value': round(frames / dt, 1), 'unit': 'predicted frames/sec', 'n_gpus': world, 'steps': args.steps,
+                'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': 'evaluate.py rollout 128x128 K=15: %d source images per GPU -> %d frames per step, 2 x LSTM(1024), vae_dim 64, '
+                                       'inference-mode batch norm (BASELINE configs[4])' % (b, b * 32), 'global_batch': world * b, 'parallelism': 'replicas x%d' % world,
+                           'algorithmic_gmac_per_frame': round(gmac_frame, 3)},
+                'step_tflops': round(2 * gmac_frame * 1e9 * frames / dt / 1e12, 2),
+                'step_algorithmic_frac_of_f32_peak': round(2 * gmac_frame * 1e9 * frames / dt / world / 157.3e12, 4),
+                'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3), 'dist_backend': backend if launched else None}
+        if world == 1:
+            line['roofline'] = roofline_conv(dev)          # the translator's 3x3 layers dominate the rollout as they do the train step
+        print(json.dumps(line), flush=True)
+    if launched:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=BATCH, help='image pairs per GPU')
+    ap.add_argument('--batch', type=int, default=None, help='image pairs (c4: source images) per GPU; default: the configuration\'s')
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='c1',
+                    help='c1: BASELINE configs[1], the headline (128x128, K=15, 32 pairs per GPU).  c3: configs[3] (256x256, K=40, 16 pairs per GPU = 128 '
+                         'over 8).  c4: configs[4], the evaluate.py rollout (64 source images -> 2048 predicted frames per step, inference only)')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
                     help="f32: the headline / parity configuration (BASELINE configs[1]).  bf16: BASELINE configs[2]'s arithmetic -- forward and "
                          'data gradient of the 3x3 stride-1 layers on the bf16 matrix pipe (fp32 tensors, accumulate, master weights, BN '
@@ -292,6 +360,12 @@ def main():
     from kpx_amd import ops as kops
     from kpx_amd.synthetic import synthetic_pair
     kops.set_compute_dtype(args.dtype)
+    conf = CONFIGS[args.config]
+    RES, K_PTS = conf['res'], conf['k']
+    if args.batch is None:
+        args.batch = conf['batch']
+    if args.config == 'c4':
+        return bench_rollout(args, conf, dev, rank, world, launched, backend)
     if args.roofline_only:
         kops.set_compute_dtype('f32')
         print(json.dumps({'roofline': roofline_conv(dev), 'roofline_wino_f23': roofline_conv_f23(dev), 'roofline_direct_conv': roofline_conv_direct(dev),
@@ -316,10 +390,14 @@ def main():
     sync()
     if rank == 0:
         print('[bench] warmup %d steps: %.2fs' % (args.warmup, time.perf_counter() - tw), file=sys.stderr, flush=True)
+    from kpx_amd import _lib as klib
+    calls0 = klib.abi_calls[0]
     t0 = time.perf_counter()
     for i in range(args.steps):
         model.train_step(None, feed, args.warmup + i, args.batch)
     t_enq = time.perf_counter() - t0          # host wall time to enqueue K steps: includes waiting on a full launch queue
+    calls_per_step = (klib.abi_calls[0] - calls0) / max(args.steps, 1)
+    graphed = bool(getattr(model, '_graphs', None)) and not getattr(model, '_graph_failed', False)
     sync()
     dt = time.perf_counter() - t0
     enq = [t_enq / args.steps * 1e3]
@@ -338,22 +416,26 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
-        gmac = step_gmac_per_pair()
-        out = {'metric': 'detector_translator train frames/sec @128x128 K=15', 'value': round(value, 2),
+        gmac = step_gmac_per_pair(RES)
+        out = {'metric': conf['metric'], 'value': round(value, 2),
                'unit': 'image pairs/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f32' if args.dtype == 'f32' else 'bf16 operands on the 3x3 stride-1 fwd/dgrad convs (fp32 storage, accumulate, wgrad, BN, Adam)',
                'data': 'synthetic',
-               'config': {'workload': 'Penn 128x128 K=15 detector_translator %s, batch=%d per GPU (BASELINE configs[%d])'
-                                      % ('fp32' if args.dtype == 'f32' else 'bf16 + VGG19 perceptual loss', args.batch, 1 if args.dtype == 'f32' else 2),
+               'config': {'workload': 'Penn %dx%d K=%d detector_translator %s, batch=%d per GPU (BASELINE configs[%d])'
+                                      % (RES, RES, K_PTS, 'fp32' if args.dtype == 'f32' else 'bf16 + VGG19 perceptual loss', args.batch,
+                                         conf['idx'] if args.dtype == 'f32' else 2),
                           'global_batch': world * args.batch, 'parallelism': 'dp%d' % world,
                           'step': 'D update + G update on one batch (generator forward shared, SURVEY 8d restructured step), '
                                   'VGG19 perceptual loss with synthetic He-normal weights, two fused Adam updates',
                           'algorithmic_gmac_per_pair': round(gmac, 2)},
                'step_tflops': round(2 * gmac * 1e9 * value / 1e12, 2),
-               'step_mfma_frac_of_f32_peak': round(2 * gmac * 1e9 * value / world / 157.3e12, 4),
+               'step_algorithmic_frac_of_f32_peak': round(2 * gmac * 1e9 * value / world / 157.3e12, 4),
                'n_ranks_seen': n_ranks_seen, 'dist_backend': backend if launched else None,
                'host_enqueue_ms_per_step': round(max(enq), 3), 'host_enqueue_ms_per_step_by_rank': [round(x, 3) for x in enq],
+               'launch_mode': ('one HIP graph replay per step (captured after %d eager warm-up step(s); %d C-ABI kernel launches inside the graph)'
+                               % (1, getattr(model, '_graph_launches', 0))) if graphed else 'eager: every kernel enqueued from Python',
+               'host_abi_calls_per_step': round(calls_per_step, 1),
                'loss_D': round(losses['loss_D'], 5), 'loss_G': round(losses['loss_G'], 5)}
         if world == 1:
             kops.set_compute_dtype('f32')
@@ -362,7 +444,7 @@ def main():
             out['roofline'] = roofline_conv(dev)
             out['roofline_wino_f23'] = roofline_conv_f23(dev)
             out['roofline_direct_conv'] = roofline_conv_direct(dev)
-            out['roofline_hbm_render'] = roofline_render(dev)
+            out['roofline_hbm_render'] = roofline_render(dev, RES, K_PTS, args.batch)
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -15,8 +15,8 @@
  *   - asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *   - return 0 on success, KPX_EINVAL (-1) for a bad argument, or -(hipError_t) if the launch failed;
  *     nothing throws across the ABI; re-entrant, callable from any host thread.  The only process state is a per-device
- *     "large-LDS attribute already set" bit per kernel family (std::atomic, idempotent) and tuning switches read once from the
- *     environment (KPX_*, function-local statics: thread-safe initialisation).
+ *     "large-LDS attribute already set" bit per kernel family (std::atomic, idempotent) and the tuning switches (KPX_* environment
+ *     variables), which are parsed ONCE, on first use (csrc/kpx_env.hip; no launch path calls getenv); kpx_reload_env() parses them again.
  */
 #ifndef KPX_H
 #define KPX_H
@@ -34,6 +34,11 @@ extern "C" {
 enum { KPX_ACT_NONE = 0, KPX_ACT_RELU = 1, KPX_ACT_LRELU = 2 /* slope 0.01 */, KPX_ACT_TANH = 3 /* forward only */ };
 
 int kpx_abi_version(void);
+
+/* Parse the KPX_* tuning / debugging switches again (they are otherwise read once, on first use).  For harnesses that flip a switch
+ * between launches (bench.py: KPX_NO_WINO=1 to time the direct kernel on the roofline layer).  Call it from the launching thread, between
+ * launches.  Returns 0.  (No reference counterpart: TF-1.12 reads its TF_* switches the same way, once.) */
+int kpx_reload_env(void);
 
 /* ---- convolution: replaces tf.pad + tf.layers.conv2d(padding='same') (models/networks/layers.py:6-9)
  *      and tf.nn.conv2d + bias_add + relu (models/networks/vgg.py:51-54).
@@ -238,6 +243,10 @@ int kpx_sigmoid_xent_bwd_f32(const float* logits, size_t n0, float label0, size_
  * alpha = lr*sqrt(1-b2^t)/(1-b1^t) (host); g is pre-scaled by gscale (1/world_size for DP). */
 int kpx_adam_tf_flat_f32(float* p, const float* g, float* m, float* v, size_t n,
                          float alpha, float beta1, float beta2, float eps, float gscale, void* stream);
+/* The same update with alpha read from DEVICE memory (one float): for launches captured into a HIP graph, whose arguments are frozen at
+ * capture time while alpha (learning-rate decay :193-195, bias correction) changes every step; the caller refreshes *alpha_dev before each replay. */
+int kpx_adam_tf_flat_dev_alpha_f32(float* p, const float* g, float* m, float* v, size_t n,
+                                   const float* alpha_dev, float beta1, float beta2, float eps, float gscale, void* stream);
 
 /* ---- evaluate.py / FinalModel rollout (forward only).  Dense layers run as 1x1 kpx_conv2d_fwd_f32.
  * LSTMCell pointwise part (models/networks/layers.py:17-21): gates [B,4U] = (i,j,f,o) pre-activations. */

@@ -527,9 +527,62 @@ def train_step(state, im, future_im, same_batch=True, im_G=None, future_im_G=Non
     return dict(loss_D=f(l_d), loss_D_real=f(l_real), loss_D_fake=f(l_fake),
                 loss_G=f(l_g), loss_G_recon=f(l_recon), loss_G_adv=f(l_adv),
                 lr=float(lr), grads_D=g_d, grads_G=g_g,
-                final_output=fwd['final_output'].detach(),
+                final_output=fwd['final_output'].detach(), crude_output=fwd['crude_output'].detach(), mask=fwd['mask'].detach(),
                 current_points=fwd['current_points'].detach(),
                 future_points=fwd['future_points'].detach())
+
+
+def train_step_data_parallel(state, local_batches):
+    """One data-parallel train step over ``len(local_batches)`` replicas: every replica runs the reference's D-run and G-run
+    (:79-117) on ITS local batch from identical weights, batch-norm statistics are per replica (the reference has no cross-device batch
+    norm), the gradient of each optimiser update is the MEAN over the replicas (sum all-reduce, 1/world in the optimiser), and both Adam
+    updates are applied once.  ``local_batches`` = [(im, future_im), ...].  Returns per-replica losses / frames and the mean gradients;
+    the moving statistics kept are replica 0's (rank 0 writes the checkpoint)."""
+    p = state.params
+    dtype = getattr(state, 'dtype', torch.float32)
+    lr = state.lr()
+    world = len(local_batches)
+    for n in state.d_names + state.g_names:
+        p[n].requires_grad_(True)
+    batches = [(torch.as_tensor(a).to(dtype), torch.as_tensor(b).to(dtype)) for a, b in local_batches]
+    per = [dict() for _ in range(world)]
+    f = lambda t: float(t.detach())
+    # ---- D run on every replica, mean gradient, ONE Adam update
+    g_d = None
+    for r, (im, fut) in enumerate(batches):
+        net = Net(p, train_mode=True)
+        fwd = forward_pass(net, im, fut, with_vis_maps=False)
+        l_d, l_real, l_fake = loss_D(net, fwd['final_output'], fut)
+        g = _grads(l_d, p, state.d_names)
+        g_d = g if g_d is None else {n: g_d[n] + g[n] for n in g}
+        per[r].update(loss_D=f(l_d), loss_D_real=f(l_real), loss_D_fake=f(l_fake))
+    g_d = {n: t / world for n, t in g_d.items()}
+    state.opt_D.step(p, g_d, lr)
+    # ---- G run on every replica against the UPDATED discriminator, mean gradient, ONE Adam update
+    g_g, bn_log0 = None, None
+    for r, (im, fut) in enumerate(batches):
+        net = Net(p, train_mode=True)
+        fwd = forward_pass(net, im, fut, with_vis_maps=False)
+        l_g, l_recon, l_adv = loss_G(net, state.vgg, fwd['final_output'], fut)
+        g = _grads(l_g, p, state.g_names)
+        g_g = g if g_g is None else {n: g_g[n] + g[n] for n in g}
+        per[r].update(loss_G=f(l_g), loss_G_recon=f(l_recon), loss_G_adv=f(l_adv), final_output=fwd['final_output'].detach(),
+                      current_points=fwd['current_points'].detach(), future_points=fwd['future_points'].detach())
+        if r == 0:
+            bn_log0 = net.bn_log
+    g_g = {n: t / world for n, t in g_g.items()}
+    state.opt_G.step(p, g_g, lr)
+    with torch.no_grad():
+        for scope, mean, var, count in bn_log0:
+            if 'img_discr' in scope:
+                continue
+            mm, mv = moving_update(p[scope + '/moving_mean'], p[scope + '/moving_variance'], mean, var, count)
+            p[scope + '/moving_mean'].copy_(mm)
+            p[scope + '/moving_variance'].copy_(mv)
+    state.global_step += 1
+    for n in state.d_names + state.g_names:
+        p[n].requires_grad_(False)
+    return dict(replicas=per, grads_D=g_d, grads_G=g_g, lr=float(lr))
 
 
 # --------------------------------------------------------------------------- stage-2 decoder + evaluate.py rollout (SURVEY 8f row 1)

@@ -42,6 +42,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 REF = '/root/reference'
 sys.dont_write_bytecode = True
 sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))          # tests/gradproj.py
 
 RES, K, B, N_BATCHES = 128, 3, 2, 6
 VGG_SEED, VGG_WIDTH_DIV, INIT_SEED = 19, 8, 1234
@@ -73,6 +74,12 @@ def synthetic_vgg_file(path):
 def digest(t):
     a = np.asarray(t.detach().numpy() if torch.is_tensor(t) else t, dtype=np.float64).ravel()
     return np.array([np.sqrt((a * a).sum()), a.sum(), np.abs(a).max() if a.size else 0.0], np.float64)
+
+
+def projections(named):
+    """<gradient, fixed random direction> per variable (tests/gradproj.py): changes under a sign flip / transposition / permutation."""
+    from gradproj import projection
+    return np.array([projection(str(n), t.detach().numpy() if torch.is_tensor(t) else t) for n, t in named], np.float64)
 
 
 def sample(a, n=512):
@@ -169,6 +176,10 @@ def main():
                 assert rec_d[0] == opt_d.index and rec_g[0] == opt_g.index
                 out['step%d_grad_D_digest' % step] = np.stack([digest(t) for t in rec_d[2].values()])
                 out['step%d_grad_G_digest' % step] = np.stack([digest(t) for t in rec_g[2].values()])
+                # <gradient, fixed random direction> per variable, in var_list order (keys of the records are the variable names)
+                assert [str(k_) for k_ in rec_d[2]] == [v.var_name for v in opt_d.var_list] and [str(k_) for k_ in rec_g[2]] == [v.var_name for v in opt_g.var_list]
+                out['step%d_grad_D_proj' % step] = projections(rec_d[2].items())
+                out['step%d_grad_G_proj' % step] = projections(rec_g[2].items())
                 out['step%d_state_digest' % step] = state_digests()
                 out['step%d_global_step' % step] = np.int64(int(global_step.tensor))
                 out['step%d_log' % step] = np.array(g.log[-1].split(': ', 1)[1].split(' (')[0])     # 'step N, loss_D = .., loss_G = ..'

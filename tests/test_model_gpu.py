@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 
+from gradproj import projection
 from oracle import restatement as R
 
 pytestmark = pytest.mark.gpu
@@ -45,6 +46,25 @@ def make_model(res, k, b, dev, width_div=8, world=None):
     m = kpx_amd.DetectorTranslatorModel(cfg, device=dev, vgg=vgg, image_size=res)
     m.build()
     return m
+
+
+_oracle_cache = {}
+
+
+def oracle_first_step(res, k, b, width_div, seed0=0, seed1=1, with_f64=True):
+    """(images, fp32 oracle step, float64 oracle step) of the FIRST train step from the seeded initial state; memoised per case so that
+    the parametrised variants of one configuration pay for the CPU restatement once."""
+    key = (res, k, b, width_div, seed0, seed1)
+    ent = _oracle_cache.get(key)
+    if ent is None:
+        torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+        im, fut = R.synthetic_pair(b, res=res, seed0=seed0, seed1=seed1)
+        st = R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=width_div))
+        ent = _oracle_cache[key] = [im, fut, R.train_step(st, im, fut), None]
+    if with_f64 and ent[3] is None:
+        st64 = R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=width_div), dtype=torch.float64)
+        ent[3] = R.train_step(st64, ent[0], ent[1])
+    return tuple(ent)
 
 
 def test_tiny_train_steps_match_oracle():
@@ -101,6 +121,15 @@ def test_tiny_train_steps_match_oracle():
             if np.linalg.norm(w) > 1e-7:
                 assert rel_l2(g, w) < (5e-2 if step == 0 else 0.2), (step, n, rel_l2(g, w))
         assert (num / den) ** 0.5 < (2e-2 if step == 0 else 0.1), (step, (num / den) ** 0.5)
+        if step == 0:
+            # the float64 arbiter of the configs[0] / configs[3] tests on this case too: the HIP gradient may be no further from the exact
+            # (float64) gradient than a small multiple of the fp32 oracle's own distance
+            _, _, _, want64 = oracle_first_step(res, k, b, 8, seed0=10, seed1=20)
+            for which, g32, g64 in (('G', want['grads_G'], want64['grads_G']), ('D', want['grads_D'], want64['grads_D'])):
+                names = [n for n in g32 if n.endswith('/kernel') and 'conv_6' not in n]
+                err_hip, err_o32 = grad_error_vs_f64(model, g32, g64, names)
+                print('tiny %s: |g_hip - g_f64| = %.3e, |g_fp32oracle - g_f64| = %.3e' % (which, err_hip, err_o32))
+                assert err_hip <= 3.0 * err_o32 + 1e-4, (which, err_hip, err_o32)
         # Re-synchronise the model to the oracle's state (parameters + Adam slots) so that the next step is compared from
         # an identical starting point: sign flips of noise-level gradients under Adam would otherwise compound.
         arrays = {n: p.numpy() for n, p in st.params.items()}
@@ -211,6 +240,77 @@ def test_data_parallel_train_steps_keep_replicas_identical():
         assert out == {'D': True, 'G': True, 'finite': True}, (rank, out)
 
 
+def _dp_oracle_worker(rank, world, port, q):
+    import sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cuda:0')
+    res, k, b = 64, 5, 2
+    model = make_model(res, k, b, dev)
+    im, fut = R.synthetic_pair(b, res=res, seed0=200 + 2 * rank, seed1=201 + 2 * rank)
+    model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, 0, b)
+    out = dict(losses=model.loss_values(), final=model.last['fwd']['final_output'].cpu().numpy(),
+               points=model.last['fwd']['current_points'].cpu().numpy())
+    # the flat buckets hold the all-reduced SUM of the replicas' gradients (1/world lives in the Adam kernel)
+    out['grads_G'] = {n: model.store.grad(n).cpu().numpy() for n in model.store.buckets['G'].entries if n.endswith('/kernel')}
+    out['params'] = {n: a for n, a in model.store.export_numpy().items() if n.endswith('/kernel') or 'moving_' in n}
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_matches_the_oracle_mean_of_local_batch_gradients():
+    """SURVEY 8e against the oracle: two ranks (gloo, sharing cuda:0), a different local batch each.  Every rank's losses / frame /
+    key-points must be the restatement's for ITS batch (per-replica batch-norm statistics), the exchanged generator gradient the SUM of
+    the two local-batch gradients (the mean after the 1/world in Adam), and the parameters after the two Adam updates the
+    restatement's ``train_step_data_parallel``."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31200 + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_dp_oracle_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res, k, b = 64, 5, 2
+    torch.set_num_threads(min(8, len(os.sched_getaffinity(0))))
+    st = R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=8))
+    want = R.train_step_data_parallel(st, [R.synthetic_pair(b, res=res, seed0=200 + 2 * r, seed1=201 + 2 * r) for r in range(2)])
+    results = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in range(2):
+        got, rep = results[rank], want['replicas'][rank]
+        for key in ('loss_D', 'loss_D_real', 'loss_D_fake', 'loss_G_recon', 'loss_G_adv', 'loss_G'):
+            assert abs(got['losses'][key] - rep[key]) <= 1e-4 * max(1.0, abs(rep[key])), (rank, key, got['losses'][key], rep[key])
+        assert rel_l2(got['final'], rep['final_output'].numpy()) < 1e-4, rank
+        np.testing.assert_allclose(got['points'], rep['current_points'].numpy(), atol=2e-5)
+        # exchanged gradient = world * mean gradient; norm-weighted aggregate over the generator's kernels (discontinuous loss: 2 %)
+        num = den = 0.0
+        for n, g in got['grads_G'].items():
+            if 'conv_6' in n:
+                continue
+            w = 2.0 * want['grads_G'][n].numpy().astype(np.float64)
+            num += float(((g.astype(np.float64) - w) ** 2).sum()); den += float((w ** 2).sum())
+        assert (num / den) ** 0.5 < 2e-2, (rank, (num / den) ** 0.5)
+        # parameters after both updates: every element moved by ~lr; elements with a noise-level gradient may have stepped the other way
+        for n, a in got['params'].items():
+            ref = st.params[n.replace('_0+1/', '_0/')].numpy() if '_0+1/' in n else st.params[n].numpy()
+            if '_0+1/' in n:
+                a = a[..., :3]
+            if 'moving_' in n:
+                if rank == 0:                  # the oracle keeps replica 0's moving statistics (rank 0 writes the checkpoint)
+                    np.testing.assert_allclose(a, ref, rtol=1e-4, atol=1e-6, err_msg=n)
+                continue
+            diff = np.abs(a - ref)
+            assert diff.max() <= 2.05e-4 and np.sum(diff >= 1e-5) <= max(4, 0.03 * diff.size), (rank, n, float(diff.max()), int(np.sum(diff >= 1e-5)), diff.size)
+    for n in results[0]['params']:             # and the replicas stay identical to each other
+        if 'moving_' not in n:
+            assert np.array_equal(results[0]['params'][n], results[1]['params'][n]), n
+
+
 def test_forward_256_k40_matches_oracle():
     """BASELINE configs[3]-shaped forward (256x256, K=40; SURVEY 8d generalisation: low-res maps H/4, vis maps H) at B=1."""
     dev = torch.device('cuda:0')
@@ -294,19 +394,40 @@ def test_final_model_rollout_matches_oracle():
     assert float(out['pred_im_seq'].abs().max()) <= 1.0
 
 
-def test_configs0_train_step_128_k15_b4_matches_oracle():
+# F(4x4,3x3) launches of ONE train step when every policy layer takes the kernel (ops.WINO43_MIN_WORKGROUPS = 0), counted from SURVEY Appendix A
+# and the policy in ops.py (forward: translator conv_3_0..5_1 + VGG19; data gradients: every 3x3 stride-1 layer whose gathered tensor has >= 16
+# and produced tensor >= 33 channels, on H % 16 == 0 and W % 32 == 0 images or pairs of 16x16 images):
+#   configs[0] (128x128, full VGG19):  forward 6 translator + 11 VGG19 (conv1_2 .. conv4_4; conv5_* are 8x8)                         = 17
+#                                      dgrad  11 VGG19 + 10 translator + 13 key-point detector (encoder conv_4/6/8, conv_1_0 .. conv_5_0,
+#                                             conv_7_0) + 2 image encoder (conv_4, conv_6)                                            = 36
+#   configs[3] (256x256, VGG19 / 4):   forward 6 translator + 12 VGG19 (conv3_1 .. conv5_4: conv1_2 .. 2_2 produce < 33 channels;
+#                                             conv5_* are 16x16 now)                                                                 = 18
+#                                      dgrad  11 VGG19 (conv3_2 .. conv5_4) + 10 + 13 + 2                                            = 36
+F43_LAUNCHES_PER_STEP = {'configs0': 17 + 36, 'configs3': 18 + 36}
+
+
+@pytest.mark.parametrize('force_f43', [False, True], ids=['bench_policy', 'f43_on_every_policy_layer'])
+def test_configs0_train_step_128_k15_b4_matches_oracle(monkeypatch, force_f43):
     """BASELINE configs[0]: Penn 128x128 K=15, batch 4, full-width VGG19 (synthetic weights): one complete train step
     (D update + G update) against the CPU restatement -- all six loss terms, key-points, frame, and the norm-weighted
-    aggregate of every generator / discriminator kernel gradient."""
+    aggregate of every generator / discriminator kernel gradient.
+
+    ``force_f43``: at B=4 most policy layers launch <= 128 workgroups and fall back to F(2x2,3x3); the benchmark (B=32) runs them on
+    F(4x4,3x3).  With the threshold at 0 every policy layer takes the F(4x4,3x3) kernel here too -- the kernel selection of the bench
+    under the same float64-arbitrated bounds -- and the launch counter must show it."""
+    from kpx_amd import ops
     dev = torch.device('cuda:0')
     res, k, b = 128, 15, 4
+    if force_f43:
+        monkeypatch.setattr(ops, 'WINO43_MIN_WORKGROUPS', 0)
     model = make_model(res, k, b, dev, width_div=1)
-    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-    st = R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19))
-    im, fut = R.synthetic_pair(b, res=res)
+    used = ops.conv_kernel_uses['wino43']
+    im, fut, want, want64 = oracle_first_step(res, k, b, 1)
     model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, 0, b)
+    if ops.WINO43:
+        launched = ops.conv_kernel_uses['wino43'] - used
+        assert (launched == F43_LAUNCHES_PER_STEP['configs0']) if force_f43 else (0 < launched < F43_LAUNCHES_PER_STEP['configs0']), launched
     got = model.loss_values()
-    want = R.train_step(st, im, fut)
     for key in ('loss_D', 'loss_D_real', 'loss_D_fake', 'loss_G_recon', 'loss_G_adv', 'loss_G'):
         assert abs(got[key] - want[key]) <= 1e-4 * max(1.0, abs(want[key])), (key, got[key], want[key])
     fwd = model.last['fwd']
@@ -317,11 +438,10 @@ def test_configs0_train_step_128_k15_b4_matches_oracle():
     # perceptual L1 term behind VGG max-pools / ReLUs), so ANY fp32 implementation sits ~1e-3..1e-2 away from the exact gradient --
     # the fp32 oracle included.  What must hold is that the HIP gradient is no further from the truth than a small multiple of the
     # fp32 oracle's own distance: a wiring error (wrong skip, transposed filter, missing term) of that size cannot hide behind it.
-    st64 = R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19), dtype=torch.float64)
-    want64 = R.train_step(st64, im, fut)
     for which, g32, g64 in (('G', want['grads_G'], want64['grads_G']), ('D', want['grads_D'], want64['grads_D'])):
         names = [n for n in g32 if n.endswith('/kernel') and 'conv_6' not in n]
         err_hip, err_o32 = grad_error_vs_f64(model, g32, g64, names)
+        print('configs0 %s %s: |g_hip - g_f64| = %.3e, |g_fp32oracle - g_f64| = %.3e (relative to |g_f64|)' % ('F43-forced' if force_f43 else 'bench-policy', which, err_hip, err_o32))
         assert err_hip <= 3.0 * err_o32 + 1e-4, (which, err_hip, err_o32)
         for scope in ('image_encoder', 'pose_encoder', 'translator', 'img_discr'):          # and per network
             sub = [n for n in names if n.startswith(scope)]
@@ -433,6 +553,24 @@ def test_against_the_reference_graph_fixture(golden_dir):
             num += (dg(model.store.grad(n).cpu().numpy()) - want[i][0]) ** 2
             den += want[i][0] ** 2
         assert (num / den) ** 0.5 < (2e-2 if step == 0 else 5e-2), (step, (num / den) ** 0.5)     # (step 1 starts from separated weights)
+        # ... and their direction: <g, fixed random direction> per variable (tests/gradproj.py) -- a sign flip or a permuted / transposed
+        # filter gradient keeps the norm and moves this by ~|g|.  The fused crude+mask head is split back into the reference's two variables.
+        wantp = ref['step%d_grad_G_proj' % step]
+        pnum = 0.0
+        for i, n in enumerate(str(s) for s in ref['G_var_list']):
+            if n.endswith('/bias') and 'translator/conv_6' not in n:
+                continue                          # exact-zero gradients (bias in front of a batch norm / the key-point softmax)
+            if n.startswith('translator/conv_6_'):
+                fused = model.store.grad(n.replace('conv_6_0/', 'conv_6_0+1/').replace('conv_6_1/', 'conv_6_0+1/')).cpu().numpy()
+                g = fused[..., :3] if 'conv_6_0/' in n else fused[..., 3:]
+            else:
+                g = model.store.grad(n).cpu().numpy()
+            dp = projection(n, g) - wantp[i]
+            pnum += dp ** 2
+            # (the head biases are sums over every pixel of terms of both signs -- 1 and 3 numbers whose projection also scales with the
+            # drawn direction's few elements: 4x the bound of a filter)
+            assert abs(dp) <= (4 if n.endswith('/bias') else 1) * (5e-2 if step == 0 else 0.2) * want[i][0] + 1e-7, (step, n, dp, want[i][0])
+        assert (pnum / sum(w_[0] ** 2 for w_ in want)) ** 0.5 < (2e-2 if step == 0 else 5e-2), (step, 'projection')
         arrays = model.checkpoint_arrays()
         assert int(arrays['global_step']) == int(ref['step%d_global_step' % step])
         want = ref['step%d_state_digest' % step]
@@ -455,30 +593,70 @@ def test_against_the_reference_graph_fixture(golden_dir):
     assert abs(lg - float(ref['test_loss_G'])) <= 5e-3 * max(1.0, abs(float(ref['test_loss_G'])))
 
 
-def test_configs3_train_step_256_k40_matches_oracle():
+@pytest.mark.parametrize('force_f43', [False, True], ids=['bench_policy', 'f43_on_every_policy_layer'])
+def test_configs3_train_step_256_k40_matches_oracle(monkeypatch, force_f43):
     """BASELINE configs[3]: 256x256, K=40 (SURVEY 8d generalisation of the literals: final_res = H, low-res maps H/4), one complete
-    train step at B=2, width/4 VGG19: six loss terms, key-points, frame, and the float64-arbitrated gradient bound."""
+    train step at B=2, width/4 VGG19: six loss terms, key-points, frame, and the float64-arbitrated gradient bound -- with the
+    launch-size policy of the step and with F(4x4,3x3) on every policy layer (see test_configs0_...)."""
+    from kpx_amd import ops
     dev = torch.device('cuda:0')
     res, k, b = 256, 40, 2
+    if force_f43:
+        monkeypatch.setattr(ops, 'WINO43_MIN_WORKGROUPS', 0)
     model = make_model(res, k, b, dev, width_div=4)
-    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-    im, fut = R.synthetic_pair(b, res=res, seed0=11, seed1=12)
+    im, fut, want, want64 = oracle_first_step(res, k, b, 4, seed0=11, seed1=12)
+    used = ops.conv_kernel_uses['wino43']
     model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, 0, b)
+    if ops.WINO43:
+        launched = ops.conv_kernel_uses['wino43'] - used
+        assert (launched == F43_LAUNCHES_PER_STEP['configs3']) if force_f43 else (0 < launched < F43_LAUNCHES_PER_STEP['configs3']), launched
     got = model.loss_values()
-    st = R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=4))
-    want = R.train_step(st, im, fut)
     for key in ('loss_D', 'loss_D_real', 'loss_D_fake', 'loss_G_recon', 'loss_G_adv', 'loss_G'):
         assert abs(got[key] - want[key]) <= 1e-4 * max(1.0, abs(want[key])), (key, got[key], want[key])
     fwd = model.last['fwd']
     assert rel_l2(fwd['final_output'].cpu().numpy(), want['final_output'].numpy()) < 1e-4
     np.testing.assert_allclose(fwd['current_points'].cpu().numpy(), want['current_points'].numpy(), atol=2e-5)
     np.testing.assert_allclose(fwd['future_points'].cpu().numpy(), want['future_points'].numpy(), atol=2e-5)
-    st64 = R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=4), dtype=torch.float64)
-    want64 = R.train_step(st64, im, fut)
     for which, g32, g64 in (('G', want['grads_G'], want64['grads_G']), ('D', want['grads_D'], want64['grads_D'])):
         names = [n for n in g32 if n.endswith('/kernel') and 'conv_6' not in n]
         err_hip, err_o32 = grad_error_vs_f64(model, g32, g64, names)
+        print('configs3 %s %s: |g_hip - g_f64| = %.3e, |g_fp32oracle - g_f64| = %.3e (relative to |g_f64|)' % ('F43-forced' if force_f43 else 'bench-policy', which, err_hip, err_o32))
         assert err_hip <= 3.0 * err_o32 + 1e-4, (which, err_hip, err_o32)
+
+
+def test_configs1_train_step_at_the_bench_batch_32_matches_oracle():
+    """BASELINE configs[1] = THE benchmarked configuration (128x128, K=15, B=32, full-width VGG19, every kernel-selection policy at its
+    default: at this batch the translator / VGG19 layers launch 512-2048 F(4x4,3x3) workgroups): one complete train step against the fp32
+    CPU restatement -- six loss terms, key-points, generated frame, crude / mask heads, and the norm-weighted aggregate of every kernel
+    gradient (fp32 oracle as the reference here: the float64 arbiter at B=32 would need ~40 GB of host memory)."""
+    from kpx_amd import ops
+    dev = torch.device('cuda:0')
+    res, k, b = 128, 15, 32
+    model = make_model(res, k, b, dev, width_div=1)
+    im, fut, want, _ = oracle_first_step(res, k, b, 1, with_f64=False)
+    used = ops.conv_kernel_uses['wino43']
+    model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, 0, b)
+    if ops.WINO43 and ops.WINO43_MIN_WORKGROUPS == 128:
+        # at B=32 everything on the policy list launches > 128 workgroups except the 16x16 layers of the half-batch chains
+        assert ops.conv_kernel_uses['wino43'] - used >= 45, ops.conv_kernel_uses['wino43'] - used
+    got = model.loss_values()
+    for key in ('loss_D', 'loss_D_real', 'loss_D_fake', 'loss_G_recon', 'loss_G_adv', 'loss_G'):
+        assert abs(got[key] - want[key]) <= 1e-4 * max(1.0, abs(want[key])), (key, got[key], want[key])
+    fwd = model.last['fwd']
+    for key in ('final_output', 'crude_output', 'mask'):
+        assert rel_l2(fwd[key].cpu().numpy(), want[key].numpy()) < 1e-4, key
+    np.testing.assert_allclose(fwd['current_points'].cpu().numpy(), want['current_points'].numpy(), atol=2e-5)
+    np.testing.assert_allclose(fwd['future_points'].cpu().numpy(), want['future_points'].numpy(), atol=2e-5)
+    for which, g32 in (('G', want['grads_G']), ('D', want['grads_D'])):
+        names = [n for n in g32 if n.endswith('/kernel') and 'conv_6' not in n]
+        num = den = 0.0
+        for n in names:
+            h = model.store.grad(n).cpu().numpy().astype(np.float64)
+            o = g32[n].numpy().astype(np.float64)
+            num += float(((h - o) ** 2).sum()); den += float((o ** 2).sum())
+        print('configs1 B=32 %s: |g_hip - g_fp32oracle| / |g| = %.3e' % (which, (num / den) ** 0.5))
+        # two fp32 implementations of this discontinuous gradient sit ~1e-3..1e-2 apart (float64-arbitrated at B=4 above)
+        assert (num / den) ** 0.5 < 3e-2, (which, (num / den) ** 0.5)
 
 
 def test_configs4_rollout_128_lstm1024_matches_oracle():
@@ -613,3 +791,36 @@ def test_three_stream_step_is_bit_identical_to_the_one_stream_step(monkeypatch):
     for name in one:
         assert np.array_equal(three[name], again[name]), ('run-to-run', name)
         assert np.array_equal(one[name], three[name]), ('streams', name)
+
+
+def test_graph_replay_is_bit_identical_to_the_eager_step(monkeypatch):
+    """The captured HIP graph of the train step (detector_translator_model._train_step_graphed: one eager step, then capture + replay)
+    launches the kernels of the eager step with the same arguments in the same stream order: after four steps on changing batches every
+    variable, optimiser slot and loss must equal the all-eager run's bit for bit -- including the Adam step sizes, which a replay reads
+    from device memory, and the moving statistics.  Also: the graph path really ran (three replays), and an evaluation pass between
+    replays (eager, default stream) sees the replayed weights."""
+    import kpx_amd.detector_translator_model as dtm
+    dev = torch.device('cuda:0')
+    res, k, b = 128, 3, 4
+
+    def run(graph):
+        monkeypatch.setattr(dtm, 'GRAPH', graph)
+        model = make_model(res, k, b, dev, width_div=4)
+        losses = []
+        for step in range(4):
+            im, fut = R.synthetic_pair(b, res=res, seed0=50 + step, seed1=60 + step)
+            model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, step, b)
+            losses.append(list(model.loss_values().values()))
+            if step == 2:
+                im2, fut2 = R.synthetic_pair(b, res=res, seed0=70, seed1=71)
+                losses.append(list(model.test_step(None, {'image': torch.from_numpy(im2).to(dev), 'future_image': torch.from_numpy(fut2).to(dev)}, 0, 0, b)[:2]))
+        out = model.store.export_numpy(include_slots=True)
+        out['_losses'] = np.asarray([v for row in losses for v in row], np.float64)
+        out['_powers'] = np.asarray([float(v) for w in ('D', 'G') for v in model.beta_power[w]] + [model.global_step], np.float64)
+        return out, model
+    eager, _ = run(False)
+    graphed, model = run(True)
+    assert len(model._graphs) == 1 and not model._graph_failed          # captured once; steps 1..3 were replays
+    assert set(eager) == set(graphed)
+    for name in eager:
+        assert np.array_equal(eager[name], graphed[name]), name

@@ -364,7 +364,9 @@ def test_winograd_fuzz_against_oracle(kpx, dev, n, h, w, cin, cout, k, s, pad, a
 W43_CASES = [  # n, h, w, cin, cout, act
     (2, 16, 32, 16, 64, 0), (2, 32, 32, 64, 64, 1), (1, 16, 64, 24, 40, 2), (3, 48, 96, 136, 128, 0), (2, 32, 64, 64, 128, 1),
     (1, 16, 32, 256, 72, 0), (2, 128, 128, 64, 64, 1), (5, 32, 32, 40, 200, 2),
-    (4, 16, 16, 64, 128, 1), (2, 16, 16, 256, 72, 0), (6, 16, 16, 40, 64, 2)]          # 16x16 images, two to a workgroup
+    (4, 16, 16, 64, 128, 1), (2, 16, 16, 256, 72, 0), (6, 16, 16, 40, 64, 2),          # 16x16 images, two to a workgroup
+    (32, 64, 64, 128, 128, 1),          # THE bench / roofline launch (translator conv_3_1 at B=32): 2 048 workgroups, eight rounds of the chip
+    (128, 16, 16, 512, 512, 1)]         # packed 16x16 images (VGG19 conv4_2 shape) on two rounds of the chip: 64 image pairs x 8 cout blocks = 512 workgroups
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout,act', W43_CASES)

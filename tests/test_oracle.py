@@ -158,3 +158,22 @@ def test_tiny_e2e_golden(golden_dir):
     rel = np.abs(l2[big] - gold["grad_l2"][big]) / gold["grad_l2"][big]
     assert np.mean(rel < 2e-3) >= 0.85 and rel.max() < 0.3, (float(np.mean(rel < 2e-3)), float(rel.max()))
     assert abs(np.linalg.norm(l2[big]) - np.linalg.norm(gold["grad_l2"][big])) < 1e-2 * np.linalg.norm(gold["grad_l2"][big])
+
+
+def test_data_parallel_restatement_with_one_replica_is_the_plain_train_step():
+    """train_step_data_parallel (mean of per-replica gradients, per-replica batch-norm statistics) reduces to train_step for
+    one replica, bit for bit; with two replicas holding the SAME batch the mean gradient is that batch's gradient."""
+    res, k, b = 32, 3, 2
+    vgg = R.synthetic_vgg(seed=19, width_div=8)
+    im, fut = R.synthetic_pair(b, res=res)
+    s1, s2, s3 = (R.TrainState(R.init_variables(k, res=res, seed=1234), vgg) for _ in range(3))
+    a = R.train_step(s1, im, fut)
+    d = R.train_step_data_parallel(s2, [(im, fut)])
+    e = R.train_step_data_parallel(s3, [(im, fut), (im, fut)])
+    for key in ('loss_D', 'loss_G', 'loss_G_adv'):
+        assert a[key] == d['replicas'][0][key] == e['replicas'][1][key]
+    for n in s1.params:
+        assert torch.equal(s1.params[n], s2.params[n]), n
+        assert torch.allclose(s1.params[n], s3.params[n], rtol=0, atol=2.1e-4), n     # (g + g) / 2 == g exactly; Adam is then identical
+    for n, g in a['grads_G'].items():
+        assert torch.equal(g, e['grads_G'][n]), n

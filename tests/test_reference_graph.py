@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 import torch
 
+from gradproj import projection
 from oracle import restatement as R
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -169,6 +170,19 @@ def test_train_and_test_steps_match_reference_graph(ref, restated):
                 # runs of the SAME code with different thread counts already differ by ~1 %), norm-weighted aggregate tight
                 assert abs(got[0] - want[i][0]) <= (5e-2 if step == 0 else 0.15) * want[i][0] + 1e-9, (step, tag, n, got[0], want[i][0])
             assert (num / den) ** 0.5 < 1e-2, (step, tag, (num / den) ** 0.5)
+            # ... and the DIRECTION of every gradient: <g, fixed random direction> (tests/gradproj.py).  The norm above is blind to a sign
+            # flip or a permuted / transposed filter gradient; the projection moves by ~|g| under any of them.
+            wantp = ref['step%d_grad_%s_proj' % (step, tag)]
+            pnum = 0.0
+            for i, n in enumerate(names):
+                if n.endswith('/bias') and not n.startswith('img_discr') and 'translator/conv_6' not in n:
+                    continue
+                dp = projection(n, grads[n].detach().numpy()) - wantp[i]
+                pnum += dp ** 2
+                assert abs(dp) <= (5e-2 if step == 0 else 0.15) * want[i][0] + 1e-9, (step, tag, n, dp, want[i][0])
+            print('step %d %s: gradient projections off by %.2e of the gradient norm (aggregate)' % (step, tag, (pnum / den) ** 0.5))
+            # (step 1 starts from weights that two fp32 implementations have already separated by +-lr on noise-level elements)
+            assert (pnum / den) ** 0.5 < (1e-3 if step == 0 else 5e-2), (step, tag, 'projection', (pnum / den) ** 0.5)
         want = ref['step%d_state_digest' % step]
         for i, n in enumerate(state_names):
             got = digest(r['state'][n])

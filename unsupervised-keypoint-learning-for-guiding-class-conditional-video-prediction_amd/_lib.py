@@ -31,6 +31,7 @@ P = c_void_p
 # name -> (restype, argtypes); mirrors include/kpx.h one to one (tests/test_abi.py checks header vs this table)
 SIGNATURES = {
     'kpx_abi_version': (c_int, []),
+    'kpx_reload_env': (c_int, []),
     'kpx_conv2d_fwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P,
                                    P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
@@ -91,6 +92,7 @@ SIGNATURES = {
     'kpx_sigmoid_xent_fwd_f32': (c_int, [P, c_size_t, c_float, c_size_t, c_float, P, P]),
     'kpx_sigmoid_xent_bwd_f32': (c_int, [P, c_size_t, c_float, c_size_t, c_float, P, c_float, P, P]),
     'kpx_adam_tf_flat_f32': (c_int, [P, P, P, P, c_size_t, c_float, c_float, c_float, c_float, c_float, P]),
+    'kpx_adam_tf_flat_dev_alpha_f32': (c_int, [P, P, P, P, c_size_t, P, c_float, c_float, c_float, c_float, P]),
     'kpx_lstm_pointwise_f32': (c_int, [P, P, c_float, P, P, c_int, c_int, P]),
     'kpx_tile_batch_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     'kpx_head_blend_tiled_fwd_f32': (c_int, [P, P, c_size_t, c_int, c_int, c_int, P, P, P, P]),
@@ -117,6 +119,10 @@ if lib.kpx_abi_version() != 1:
     raise ImportError('libkpx_hip.so ABI version mismatch')
 
 
+abi_calls = [0]          # diagnostics: C-ABI calls checked so far (one kernel launch each, a few entries fan out to two or three)
+
+
 def check(rc, what):
+    abi_calls[0] += 1
     if rc != 0:
         raise KpxError('%s failed with code %d (%s)' % (what, rc, 'bad argument' if rc == -1 else 'hipError %d' % -rc))

@@ -13,6 +13,7 @@
 //   * LDS double buffered, global loads of chunk k+1 issued before the MFMAs of chunk k, one barrier per chunk, two workgroups per CU.
 // Data gradient = the same kernel on weights prepared flipped / transposed.  Master weights, bias, BN statistics stay fp32.
 #include "kpx_common.h"
+#include "kpx_env.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -378,7 +379,7 @@ extern "C" int kpx_conv3x3_bf16_f32(const float* in, int N, int H, int W, int K,
     const size_t tiles = (size_t)N * g.tiles_y * g.tiles_x;
     hipStream_t s = kpx_stream(stream);
     // wide tiles (16 x 32 pixels, 8 wavefronts) when the launch still fills the chip with them
-    static const int wide_mode = getenv("KPX_BF16_WIDE") ? atoi(getenv("KPX_BF16_WIDE")) : 1;
+    const int wide_mode = kpx_env()->bf16_wide;
     if (wide_mode && W % 32 == 0 && g.NB % 2 == 0) {
         const int nbw = (g.NB % 4 == 0 && wide_mode != 2) ? 4 : 2;
         const size_t wgs = (size_t)N * g.tiles_y * (W / 32) * (g.NB / nbw);

@@ -14,6 +14,7 @@
 // the B tile is staged [k][n] and read as ds_read_b32.  Within a 16-wide K chunk lane-half h consumes channels
 // {8u+4h+j}: a K permutation shared by A and B, so the product is unchanged.
 #include "kpx_common.h"
+#include "kpx_env.h"
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -360,9 +361,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // Split-K plan (shape only): used when the 128x128 tiling would leave most CUs idle (small M, long K).
 static int conv_splitk_plan(long M, int Cout, long nchunks_total) {
-    if (getenv("KPX_NO_SPLITK") || Cout % 4 != 0 || Cout < 64) return 1;
+    if (kpx_env()->no_splitk || Cout % 4 != 0 || Cout < 64) return 1;
     const long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
-    static const long max_tiles = getenv("KPX_SPLITK_MAXTILES") ? atol(getenv("KPX_SPLITK_MAXTILES")) : 256;   // a full round of 128x128 tiles: splitting only adds the reduce pass
+    const long max_tiles = kpx_env()->splitk_maxtiles;   // a full round of 128x128 tiles: splitting only adds the reduce pass
     if (tiles >= max_tiles) return 1;
     long S = 512 / tiles;
     if (S > 8) S = 8;
@@ -422,9 +423,9 @@ static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
             if (score > best) { best = score; BM = cs[i].bm; BN = cs[i].bn; }
         }
     }
-    if (const char* ov = getenv("KPX_TILE")) {            // debug / tuning override: "BM,BN" among the instantiated tiles
-        int obm = 0, obn = 0;
-        if (sscanf(ov, "%d,%d", &obm, &obn) == 2 && BN != 32 && (obm == 128 || obm == 64) && (obn == 128 || obn == 64) &&
+    if (kpx_env()->tile_bm) {                             // debug / tuning override KPX_TILE="BM,BN" among the instantiated tiles
+        const int obm = kpx_env()->tile_bm, obn = kpx_env()->tile_bn;
+        if (BN != 32 && (obm == 128 || obm == 64) && (obn == 128 || obn == 64) &&
             (obn == 64 || g.Cout > 64))
             { BM = obm; BN = obn; }
     }
@@ -579,10 +580,10 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
     g.wts = Cin * Cout; g.ldw = Cout; g.act = act;
     g.vecA = (ldx % 4 == 0) && aligned16(x);
     g.vecB = (Cout % 4 == 0) && aligned16(w);
-    if (!(getenv("KPX_NO_MERGE") && atoi(getenv("KPX_NO_MERGE")) == KH) && Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64) {      // image inputs (Cin = 3): merge each filter row
+    if (!(kpx_env()->no_merge_kh && kpx_env()->no_merge_kh == KH) && Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64) {      // image inputs (Cin = 3): merge each filter row
         g.merge = Cin; g.Tq = 1; g.KW = 1; g.Cin = KW * Cin; g.wts = KW * Cin * Cout; g.vecA = 0;
     }
-    if (!getenv("KPX_NO_SMALLCOUT") && Cout <= 4 && Cin % 4 == 0 && Cin >= 256 && g.vecA && g.vecB == (Cout == 4))
+    if (!kpx_env()->no_smallcout && Cout <= 4 && Cin % 4 == 0 && Cin >= 256 && g.vecA && g.vecB == (Cout == 4))
         return launch_small_cout(g, kpx_stream(stream));
     if (g.vecA && g.vecB && !g.merge && Cin % 4 == 0) {        // small-M / long-K layers (the discriminator's 10x10 .. 4x4 maps): split K over workgroups
         const int S = conv_splitk_plan((long)N * Ho * Wo, Cout, (long)KH * KW * ((Cin + 31) / 32));
@@ -1232,7 +1233,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_merged_kernel(const Wgrad
 }
 
 static bool wgrad_rows_merged_plan(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int* S, int* cpb) {
-    if (getenv("KPX_NO_WROWS")) return false;
+    if (kpx_env()->no_wrows) return false;
     if (Cin % 4 == 0 || KW * Cin > 32 || (32 + KW - 1) * Cin > 128 || KH > 8 || KW < 2 || Wo % 32 != 0 || Cout > 32 ||
         (long)N * Ho * Wo < 65536)
         return false;
@@ -1245,7 +1246,7 @@ static bool wgrad_rows_merged_plan(int N, int Ho, int Wo, int Cin, int Cout, int
 
 // shape-only eligibility + split plan of the rows kernel (alignment / stride are checked by the caller)
 static bool wgrad_rows_plan(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int* S, int* cpb, int* CT) {
-    if (getenv("KPX_NO_WROWS")) return false;
+    if (kpx_env()->no_wrows) return false;
     if (KH > 3 || KW > 3 || KH * KW < 2 || Wo % 32 != 0 || Cout > 32 || Cin > 128 || (long)N * Ho * Wo < 65536) return false;
     *CT = Cin > 32 ? 2 : 1;
     const int ct = (Cin + 32 * *CT - 1) / (32 * *CT);
@@ -1268,7 +1269,7 @@ static void wgrad_tiles(int Cin, int Cout, int& bm, int& bn) {
     if (bm != bn) { bm = 64; bn = 64; }   // only the square tiles are instantiated
 }
 
-static inline bool wgrad_merge(int Cin, int ldx, int KW) { return !getenv("KPX_NO_WMERGE") && Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64; }
+static inline bool wgrad_merge(int Cin, int ldx, int KW) { return !kpx_env()->no_wmerge && Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64; }
 
 static int wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
     int bm, bn;
@@ -1276,7 +1277,7 @@ static int wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW
     long tiles = (long)KH * KW * ((Cin + bm - 1) / bm) * ((Cout + bn - 1) / bn);
     if (wgrad_merge(Cin, Cin, KW)) tiles = (long)KH * ((Cout + bn - 1) / bn);
     const long P = (long)N * Ho * Wo;
-    const long target = getenv("KPX_WGRAD_TARGET") ? atol(getenv("KPX_WGRAD_TARGET")) : (bm == 128 ? 2560 : 4096);   // measured optimum: several short rounds balance better than one long one
+    const long target = kpx_env()->wgrad_target ? kpx_env()->wgrad_target : (bm == 128 ? 2560 : 4096);   // measured optimum: several short rounds balance better than one long one
     long S = target / tiles;                            // floor: never split a layer that already has enough tiles
     const long maxS_pix = P / 512 > 0 ? P / 512 : 1;   // >= 16 chunks of 32 pixels per split
     if (S > maxS_pix) S = maxS_pix;
@@ -1388,7 +1389,7 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     g.ct = (Cin + bm - 1) / bm; g.kt = (Cout + bn - 1) / bn;
     g.vecA = (ldx % 4 == 0) && aligned16(x);
     g.vecB = (lddy % 4 == 0) && aligned16(dy);
-    if (!getenv("KPX_NO_WTAPROWS") && g.vecA && g.vecB && Cin % 4 == 0 && Cout % 4 == 0 && Wo % 32 == 0 && !wgrad_merge(Cin, ldx, KW)) {
+    if (!kpx_env()->no_wtaprows && g.vecA && g.vecB && Cin % 4 == 0 && Cout % 4 == 0 && Wo % 32 == 0 && !wgrad_merge(Cin, ldx, KW)) {
         // chunk-aligned split: same S as the generic plan, but in units of 32-pixel row chunks
         WgradTapGeom r{};
         r.x = x; r.dy = dy;
@@ -1402,7 +1403,7 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
         r.out = r.S > 1 ? (float*)workspace : dw;
         hipStream_t s = kpx_stream(stream);
         const dim3 grid((unsigned)(r.S * KH * KW * r.ct * r.kt));
-        if (bm == 128 && getenv("KPX_WGRAD_4W")) hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, r);
+        if (bm == 128 && kpx_env()->wgrad_4w) hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, r);
         else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<128, 128, 2, 4>), grid, dim3(512), 0, s, r);
         else hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, r);
         int rc = kpx_launch_status();

@@ -5,6 +5,7 @@
 // the KW*Cin floats of a filter row are contiguous in NHWC, so k runs over (row, kk < KW*Cin) and the A operand of pixel (y, x) is
 // patch[(y + r) * PWC + x * Cin + kk].  4 wavefronts x 2 M-tiles of 32 pixels (two output rows) x Cout/32 N-tiles.
 #include "kpx_common.h"
+#include "kpx_env.h"
 
 struct RgbGeom {
     const float* x; const float* w; const float* bias; float* y;
@@ -95,7 +96,7 @@ static std::atomic<unsigned long long> rgb_attr_mask{0};
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW,
                                                                   const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
                                                                   int pad_t, int pad_l, int act, hipStream_t s) {
-    if (Cin > 4 || Cout > 64 || KH > 7 || KW > 7 || getenv("KPX_NO_RGB")) return -2;
+    if (Cin > 4 || Cout > 64 || KH > 7 || KW > 7 || kpx_env()->no_rgb) return -2;
     RgbGeom g{};
     g.x = x; g.w = w; g.bias = bias; g.y = y;
     g.N = N; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
@@ -223,7 +224,7 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_dgrad(const fl
                                                                     float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, hipStream_t s) {
     const bool k3 = KH == 3 && KW == 3 && stride == 1, k4 = KH == 4 && KW == 4 && stride == 2;
     if (!(k3 || k4) || (Cin != 3 && Cin != 4) || Cout % 16 || lddy % 4 || (((uintptr_t)dy) & 15) || (((uintptr_t)w) & 15) || pad_t < 0 || pad_l < 0 ||
-        pad_t >= KH || pad_l >= KW || getenv("KPX_NO_RGB"))
+        pad_t >= KH || pad_l >= KW || kpx_env()->no_rgb)
         return -2;
     // every input pixel's taps must land inside the 18-pixel patch: true for Ho = ceil-type SAME / explicit pads of this path (checked per launch)
     RgbDgradGeom g{};
@@ -244,7 +245,7 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_few_fwd(const floa
                                                                   const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
                                                                   int stride, int pad_t, int pad_l, int act, hipStream_t s) {
     if (KH != 3 || KW != 3 || stride != 1 || (Cout != 3 && Cout != 4) || Cin % 16 || ldx % 4 || (((uintptr_t)x) & 15) || (((uintptr_t)w) & 15) ||
-        pad_t < 0 || pad_l < 0 || pad_t > 2 || pad_l > 2 || Ho != Hi + 2 * pad_t - 2 || Wo != Wi + 2 * pad_l - 2 || getenv("KPX_NO_RGB"))
+        pad_t < 0 || pad_l < 0 || pad_t > 2 || pad_l > 2 || Ho != Hi + 2 * pad_t - 2 || Wo != Wi + 2 * pad_l - 2 || kpx_env()->no_rgb)
         return -2;
     RgbDgradGeom g{};
     g.dy = x; g.w = w; g.dx = y; g.bias = bias; g.act = act;

@@ -13,6 +13,7 @@
 // entry point (kpx_wino_filter_transform[_batch]_f32): constant filters (VGG19) are transformed once, trainable ones once per
 // optimiser update in ONE launch, instead of once per convolution call.
 #include "kpx_common.h"
+#include "kpx_env.h"
 #include <stdlib.h>
 #include <type_traits>
 #include <atomic>
@@ -394,10 +395,10 @@ static std::atomic<unsigned long long> wino_attr_mask{0};
 
 // shape / alignment eligibility (stride-1 3x3 SAME only); K = channels of the gathered tensor, Nn = produced channels
 extern "C" int kpx_conv3x3_wino_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
-    if (getenv("KPX_NO_WINO") || N <= 0 || K <= 0 || Nn <= 0) return 0;       // (read per call: bench.py flips it to time the direct kernel)
+    if (kpx_env()->no_wino || N <= 0 || K <= 0 || Nn <= 0) return 0;       // (bench.py flips KPX_NO_WINO and calls kpx_reload_env() to time the direct kernel)
     // K is padded to a multiple of 8 (the pad channels must exist in the row: ldin >= Kp) and Nn to a multiple of 32
     const bool shape = (H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8 && N % 4 == 0);      // 8x8 images are packed four to a workgroup
-    static const int kmin = getenv("KPX_WINO_KMIN") ? atoi(getenv("KPX_WINO_KMIN")) : 4, nmin = getenv("KPX_WINO_NMIN") ? atoi(getenv("KPX_WINO_NMIN")) : 4;
+    const int kmin = kpx_env()->wino_kmin, nmin = kpx_env()->wino_nmin;
     const bool kfit = ldin >= ((K + 7) & ~7) || K == 4;          // K = 4: only the lower 16-B half of the chunk is ever loaded
     return shape && K >= kmin && Nn >= nmin && (K >= 16 || K == 4 || K == 8) && kfit && (ldin % 4 == 0) && (((uintptr_t)in_ptr) & 15) == 0;
 }
@@ -511,9 +512,9 @@ static int wino_launch(const float* in, int N, int H, int W, int K, int ldin, co
     g.tiles_y = g.pack ? 1 : H / 16; g.tiles_x = g.pack ? 1 : W / 16; g.nt = g.Np / 32;
     const unsigned blocks = (unsigned)((size_t)(g.pack ? N / 4 : N) * g.tiles_y * g.tiles_x * g.nt);
     // 64 output channels per workgroup when that still fills the 256 CUs, else 32
-    static const int force_ct = getenv("KPX_WINO_CT") ? atoi(getenv("KPX_WINO_CT")) : 0;
+    const int force_ct = kpx_env()->wino_ct;
     const bool wide = (force_ct ? force_ct == 2 : (blocks / 2 >= 256)) && g.Np % 64 == 0;
-    static const int stagger = getenv("KPX_WINO_STAGGER") ? atoi(getenv("KPX_WINO_STAGGER")) : 1;
+    const int stagger = kpx_env()->wino_stagger;
     g.stagger = stagger;
     const int st = !tile_stats ? 0 : (mask_y ? 2 : 1);
 #define W2_GO(M, S) hipLaunchKernelGGL((conv_wino_v2_kernel<M, S>), dim3(M == 2 ? blocks / 2 : blocks), dim3(512), w2_lds_bytes(M), s, g)
@@ -719,13 +720,13 @@ static inline int ww_tile(int C) { return (C % 64 == 0 || C > 96) ? 2 : 1; }
 
 // splits for the Winograd wgrad (0 = shape not handled): ~256 workgroups (one per CU; measured best of 128..1024), >= 8 chunks per split, slabs <= 128 MB
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
-    if (getenv("KPX_NO_WINO") || getenv("KPX_NO_WINO_WGRAD")) return 0;
-    static const int comin = getenv("KPX_WW_COMIN") ? atoi(getenv("KPX_WW_COMIN")) : 4;
+    if (kpx_env()->no_wino || kpx_env()->no_wino_wgrad) return 0;
+    const int comin = kpx_env()->ww_comin;
     if (H % 4 || W % 8 || Cout % 4 || Cin < 32 || Cout < comin) return 0;         // (a Cin that is not a multiple of 4 needs ldx >= Cin rounded up, checked by the caller)
     const int ti = ww_tile(Cin), to = ww_tile(Cout);
     if (ti == 1 && to == 1) return 0;                     // 32 x 32 blocks: too few MFMAs per barrier, the direct kernels do better
     const long tc = (long)N * (H / 4) * (W / 8), tiles = (long)((Cin + 32 * ti - 1) / (32 * ti)) * ((Cout + 32 * to - 1) / (32 * to));
-    static const long target = getenv("KPX_WW_TARGET") ? atol(getenv("KPX_WW_TARGET")) : 256;
+    const long target = kpx_env()->ww_target;
     long S = (target + tiles - 1) / tiles;
     if (S > tc / 8) S = tc / 8;
     const long cap = (128L << 20) / ((long)9 * Cin * Cout * 4);

@@ -25,6 +25,7 @@
 //     (tile, 4 couts), applies A^T . A to the three point rows of the pass and keeps its 16 output pixels in registers between them;
 //   * STATS: per-strip batch-norm sums from the epilogue; PACK: two 16 x 16 images per workgroup.
 #include "kpx_common.h"
+#include "kpx_env.h"
 #include <stdlib.h>
 
 struct Wino43Geom {
@@ -465,7 +466,7 @@ static std::atomic<unsigned long long> w43_attr_mask{0};
 static inline int w43_lds_bytes() { return (W4_MAIN > W4_EPI ? W4_MAIN : W4_EPI) * 4; }
 
 extern "C" int kpx_conv3x3_wino43_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
-    if (getenv("KPX_NO_WINO43") || getenv("KPX_NO_WINO") || N <= 0) return 0;
+    if (kpx_env()->no_wino43 || kpx_env()->no_wino || N <= 0) return 0;
     const bool shape = (H % 16 == 0 && W % 32 == 0) || (H == 16 && W == 16 && N % 2 == 0);      // 16 x 16 images are packed two to a workgroup
     return shape && K >= 16 && Nn >= 33 && ldin >= ((K + 7) & ~7) && ldin % 4 == 0 && (((uintptr_t)in_ptr) & 15) == 0 &&
            (size_t)H * W * ldin * 8 < 0x7fffffffu;

@@ -10,6 +10,7 @@
 // linspace follows tf.linspace in fp32 (start + step*i, two roundings) via __fmul_rn/__fadd_rn so that hipcc's
 // default fp-contraction cannot fuse it.
 #include "kpx_common.h"
+#include "kpx_env.h"
 #include <stdlib.h>
 
 #define KP_RS 8   // rows per stripe in stage 1
@@ -301,11 +302,11 @@ extern "C" int kpx_gaussian_maps_fwd_f32(const float* mu, int B, int K, int H, i
             if (fill >= best) { best = fill; m = mm; wfix = wf; }
         }
         const int T = K * m, n4 = (int)(((size_t)H * W * K) >> 2);
-        static const int target = getenv("KPX_GAUSS_BLOCKS") ? atoi(getenv("KPX_GAUSS_BLOCKS")) : 768;
+        const int target = kpx_env()->gauss_blocks;
         int G = target / B; if (G < 1) G = 1;
         int iters = (n4 + T * G - 1) / (T * G); if (iters < 1) iters = 1;
         G = (n4 + T * iters - 1) / (T * iters);
-        static const int nt = getenv("KPX_GAUSS_NT") ? atoi(getenv("KPX_GAUSS_NT")) : 1;
+        const int nt = kpx_env()->gauss_nt;
         const dim3 grid((unsigned)G, (unsigned)B), block((unsigned)T);
         if (wfix) {
             if (nt) hipLaunchKernelGGL((gauss_fwd_reg_kernel<true, true>), grid, block, 0, s, mu, K, H, W, inv2, maps, iters);

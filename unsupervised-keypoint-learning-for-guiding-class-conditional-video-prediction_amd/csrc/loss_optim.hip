@@ -126,6 +126,43 @@ __global__ __launch_bounds__(256) void adam_tf_kernel(float* __restrict__ p, con
         p[i] = __fsub_rn(p[i], __fdiv_rn(__fmul_rn(mn, alpha), __fadd_rn(__fsqrt_rn(vn), eps)));
     }
 }
+// The same update with the step size read from DEVICE memory: a captured HIP graph replays the launch with frozen arguments, and alpha
+// (learning-rate decay, bias correction) is the one number of the step that changes between replays.
+__global__ __launch_bounds__(256) void adam_tf_dev_alpha_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                                float* __restrict__ v, size_t n, const float* __restrict__ alpha_dev,
+                                                                float omb1, float omb2, float eps, float gs) {
+    const float alpha = *alpha_dev;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 pp = reinterpret_cast<f32x4*>(p)[i], mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gr = gg[j] * gs;
+            mm[j] = __fadd_rn(mm[j], __fmul_rn(__fsub_rn(gr, mm[j]), omb1));
+            vv[j] = __fadd_rn(vv[j], __fmul_rn(__fsub_rn(__fmul_rn(gr, gr), vv[j]), omb2));
+            pp[j] = __fsub_rn(pp[j], __fdiv_rn(__fmul_rn(mm[j], alpha), __fadd_rn(__fsqrt_rn(vv[j]), eps)));
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pp; reinterpret_cast<f32x4*>(m)[i] = mm; reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gr = g[i] * gs;
+        const float mn = __fadd_rn(m[i], __fmul_rn(__fsub_rn(gr, m[i]), omb1));
+        const float vn = __fadd_rn(v[i], __fmul_rn(__fsub_rn(__fmul_rn(gr, gr), v[i]), omb2));
+        m[i] = mn; v[i] = vn;
+        p[i] = __fsub_rn(p[i], __fdiv_rn(__fmul_rn(mn, alpha), __fadd_rn(__fsqrt_rn(vn), eps)));
+    }
+}
+extern "C" int kpx_adam_tf_flat_dev_alpha_f32(float* p, const float* g, float* m, float* v, size_t n,
+                                              const float* alpha_dev, float beta1, float beta2, float eps, float gscale, void* stream) {
+    if (!p || !g || !m || !v || !alpha_dev || ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15)) return KPX_EINVAL;
+    if (n == 0) return 0;
+    size_t nb = (n / 4 + 255) / 256; if (nb < 1) nb = 1; if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(adam_tf_dev_alpha_kernel, dim3((unsigned)nb), dim3(256), 0, kpx_stream(stream), p, g, m, v, n, alpha_dev,
+                       1.0f - beta1, 1.0f - beta2, eps, gscale);
+    return kpx_launch_status();
+}
+
 extern "C" int kpx_adam_tf_flat_f32(float* p, const float* g, float* m, float* v, size_t n,
                                     float alpha, float beta1, float beta2, float eps, float gscale, void* stream) {
     if (!p || !g || !m || !v || ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15)) return KPX_EINVAL;

@@ -26,6 +26,11 @@ AUX_STREAM = os.environ.get('KPX_AUX_STREAM', '1') != '0'
 AUX_STREAM_FWD = os.environ.get('KPX_AUX_STREAM_FWD', '1') != '0'      # the image encoder (forward and backward) beside the key-point detector
 AUX_STREAM_ADV = os.environ.get('KPX_AUX_STREAM_ADV', '1') != '0'      # the G run's adversarial branch on that stream as well
 
+# The whole step -- ~700 launches on three streams -- as ONE HIP graph, captured from the second call on a given input shape and replayed
+# afterwards (KPX_GRAPH=0: every step is enqueued from Python).  Single-process steps on the shared batch only; see _train_step_graphed.
+GRAPH = os.environ.get('KPX_GRAPH', '1') != '0'
+GRAPH_WARMUP_STEPS = 1          # eager steps before the capture: they create every lazily allocated scratch buffer and kernel attribute
+
 log = logging.getLogger('kpx')
 
 
@@ -55,6 +60,11 @@ class DetectorTranslatorModel(BaseModel):
         self.beta1, self.beta2, self.adam_eps = np.float32(0.5), np.float32(0.999), np.float32(1e-8)
         self.beta_power = {'D': [np.float32(0.5), np.float32(0.999)], 'G': [np.float32(0.5), np.float32(0.999)]}
         self.last = {}
+        self._graphs = {}               # input shape -> captured step (graph, static inputs, outputs)
+        self._eager_steps = {}          # input shape -> eager steps taken so far
+        self._capturing = False
+        self._graph_failed = False
+        self._alpha_dev = None          # {'D','G'} -> [1] device tensors holding Adam's step size for the captured launches
 
     # ------------------------------------------------------------------------------------------------ build
     def build(self, inputs=None):
@@ -171,11 +181,23 @@ class DetectorTranslatorModel(BaseModel):
             pending.wait()                      # stream-level wait for the asynchronous all-reduce
         elif not exchanged:
             self.exchange_gradients(which)
-        b1p, b2p = self.beta_power[which]
-        alpha = np.float32(np.float32(lr) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p))
-        ops.adam_tf_flat_(bucket.params, bucket.grads, bucket.m, bucket.v, alpha, self.beta1, self.beta2, self.adam_eps,
-                          gscale=1.0 / self.world_size)
+        if self._capturing:
+            # a captured launch replays with frozen arguments: the step size lives in device memory and is refreshed before each replay
+            ops.adam_tf_flat_dev_alpha_(bucket.params, bucket.grads, bucket.m, bucket.v, self._alpha_dev[which], self.beta1, self.beta2,
+                                        self.adam_eps, gscale=1.0 / self.world_size)
+        else:
+            ops.adam_tf_flat_(bucket.params, bucket.grads, bucket.m, bucket.v, self._adam_alpha(which, lr), self.beta1, self.beta2, self.adam_eps,
+                              gscale=1.0 / self.world_size)
+            self._advance_beta_powers(which)
         self.store.touch(which)                 # the filters changed: their Winograd forms are re-derived before the next use
+
+    def _adam_alpha(self, which, lr):
+        """lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t) in fp32, like tf.train.AdamOptimizer._prepare / _apply_dense."""
+        b1p, b2p = self.beta_power[which]
+        return np.float32(np.float32(lr) * np.sqrt(np.float32(1) - b2p) / (np.float32(1) - b1p))
+
+    def _advance_beta_powers(self, which):
+        b1p, b2p = self.beta_power[which]
         self.beta_power[which] = [np.float32(b1p * self.beta1), np.float32(b2p * self.beta2)]
 
     # ------------------------------------------------------------------------------------------------ steps
@@ -186,9 +208,89 @@ class DetectorTranslatorModel(BaseModel):
         convention).  The reference's input node hands a NEW batch to each sess.run (train.py:46-50):
         pass that second batch as 'image_G' / 'future_image_G' and the G-run recomputes the forward on it, exactly like the
         reference's second sess.run (BN moving statistics then come from the G-run's batch only, :199-202)."""
+        start_time = time.time()
+        if self._graph_eligible(feed_dict):
+            self._train_step_graphed(feed_dict)
+        else:
+            self._train_step_eager(feed_dict)
+        if should_write_log:
+            vals = self.loss_values()
+            duration = time.time() - start_time
+            log.info('%s: step %d, loss_D = %.4f, loss_G = %.4f (%.1f examples/sec) %.3f sec/batch',
+                     datetime.now(), step, vals['loss_D'], vals['loss_G'], batch_size / float(duration), duration)
+
+    # ---- the step as a HIP graph ------------------------------------------------------------------------------------------
+    def _graph_eligible(self, feed_dict):
+        im = feed_dict['image']
+        return (GRAPH and not self._graph_failed and not self.distributed and 'image_G' not in feed_dict and self.device.type == 'cuda'
+                and im.is_cuda and im.dtype == torch.float32 and feed_dict['future_image'].shape == im.shape)
+
+    def _train_step_graphed(self, feed_dict):
+        """One train step through a captured HIP graph.
+
+        The step is ~700 kernel launches on three streams whose host side (Python, ctypes, the autograd tape) costs 11-18 ms -- as much as
+        the GPU needs for it.  Nothing in it depends on host values except the two Adam step sizes, so from the second call on an input
+        shape the whole step (forward, both backward passes on their streams, both fused Adam updates, the Winograd filter re-derivations)
+        is captured ONCE into a HIP graph and replayed: inputs are copied into the capture's static buffers, the two step sizes into two
+        device floats.  Every kernel, its arguments and the stream order are those of the eager step, so the result is bit-identical to it
+        (tests/test_model_gpu.py::test_graph_replay_is_bit_identical_to_the_eager_step).  Host state the step advances -- beta powers,
+        global_step -- is advanced here per replay.  A capture that fails (a runtime without the needed support) falls back to eager."""
+        im, fut = feed_dict['image'], feed_dict['future_image']
+        key = (tuple(im.shape), im.device.index)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if self._eager_steps.get(key, 0) < GRAPH_WARMUP_STEPS:
+                self._eager_steps[key] = self._eager_steps.get(key, 0) + 1
+                return self._train_step_eager(feed_dict)
+            ent = self._capture_step(key, im, fut)
+            if ent is None:
+                return self._train_step_eager(feed_dict)
+        graph, static, outputs = ent
+        lr = self.current_lr()
+        ops.flat_copy_raw(im.contiguous().data_ptr(), static['image'].data_ptr(), im.numel())
+        ops.flat_copy_raw(fut.contiguous().data_ptr(), static['future_image'].data_ptr(), fut.numel())
+        for which in ('D', 'G'):
+            ops.fill_raw_(self._alpha_dev[which], float(self._adam_alpha(which, lr)))
+        graph.replay()
+        for which in ('D', 'G'):
+            self._advance_beta_powers(which)
+        self.global_step += 1
+        self.last = dict(outputs, lr=float(lr))
+
+    def _capture_step(self, key, im, fut):
+        dev = self.device
+        if self._alpha_dev is None:
+            self._alpha_dev = {w: torch.zeros(1, dtype=torch.float32, device=dev) for w in ('D', 'G')}
+        static = {'image': torch.empty_like(im, memory_format=torch.contiguous_format),
+                  'future_image': torch.empty_like(fut, memory_format=torch.contiguous_format)}
+        saved = (dict(self.beta_power), self.global_step, self.last)
+        bank = getattr(self.store, 'filter_bank', None)
+        if bank is not None:
+            bank.touch()                    # the capture must CONTAIN the re-derivation of the filter forms, whatever ran before it
+        graph = torch.cuda.CUDAGraph()
+        self._capturing = True
+        from . import _lib
+        calls0 = _lib.abi_calls[0]
+        try:
+            with torch.cuda.graph(graph):
+                self._train_step_eager(static)
+            outputs = {k: v for k, v in self.last.items() if k != 'lr'}
+            self._graph_launches = _lib.abi_calls[0] - calls0          # diagnostics: C-ABI launches recorded in the graph
+        except Exception as e:              # noqa: BLE001 -- whatever the runtime refuses: stay on the eager path
+            log.warning('HIP graph capture of the train step failed (%s: %s); continuing with eager launches', type(e).__name__, e)
+            self._graph_failed = True
+            torch.cuda.synchronize(dev)
+            return None
+        finally:
+            self._capturing = False
+            self.beta_power, self.global_step, self.last = dict(saved[0]), saved[1], saved[2]      # nothing has executed yet
+        ent = self._graphs[key] = (graph, static, outputs)
+        return ent
+
+    def _train_step_eager(self, feed_dict):
+        """The step enqueued launch by launch (also the function a capture records)."""
         im, future_im = feed_dict['image'], feed_dict['future_image']
         separate = 'image_G' in feed_dict
-        start_time = time.time()
         lr = self.current_lr()
         with variables.as_default(self.store):
             # ---- D run (:93)
@@ -253,11 +355,6 @@ class DetectorTranslatorModel(BaseModel):
         self.global_step += 1                                             # incremented by the G optimiser (:201-202)
         self.last = dict(d_losses=d_losses.detach(), recon=recon.detach(), adv=adv.detach(), lr=float(lr),
                          fwd={k: v.detach() for k, v in fwd.items()})
-        if should_write_log:
-            vals = self.loss_values()
-            duration = time.time() - start_time
-            log.info('%s: step %d, loss_D = %.4f, loss_G = %.4f (%.1f examples/sec) %.3f sec/batch',
-                     datetime.now(), step, vals['loss_D'], vals['loss_G'], batch_size / float(duration), duration)
 
     def loss_values(self):
         """Host copies of the last step's scalars (synchronises)."""

@@ -928,6 +928,14 @@ def adam_tf_flat_(p, g, m, v, alpha, beta1, beta2, eps, gscale=1.0):
                                    float(alpha), float(beta1), float(beta2), float(eps), float(gscale), _stream()), 'kpx_adam_tf_flat_f32')
 
 
+def adam_tf_flat_dev_alpha_(p, g, m, v, alpha_dev, beta1, beta2, eps, gscale=1.0):
+    """The same update with the step size in device memory (a [1] fp32 tensor): the form a captured HIP graph replays."""
+    for t in (p, g, m, v, alpha_dev):
+        _require_gpu(t)
+    check(lib.kpx_adam_tf_flat_dev_alpha_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), alpha_dev.data_ptr(),
+                                             float(beta1), float(beta2), float(eps), float(gscale), _stream()), 'kpx_adam_tf_flat_dev_alpha_f32')
+
+
 # ----------------------------------------------------------------------------------------------- rollout (forward only)
 def dense(x, w, b, act=ACT_NONE):
     """act(x @ w + b) for x [B,In], w [In,Out]: a 1x1 convolution over a [B,1,1,In] tensor on the implicit-GEMM kernel
