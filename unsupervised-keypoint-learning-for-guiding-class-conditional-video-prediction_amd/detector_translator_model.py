@@ -310,7 +310,10 @@ class DetectorTranslatorModel(BaseModel):
             with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
                 d_losses = self._loss_D(final_d, future_im)
                 ops.begin_backward()
-                torch.autograd.backward([d_losses], [self._e0])
+                # on the auxiliary stream the update continues right here (exchange, Adam), so its weight gradients run inline on this
+                # stream: a side stream forked from a forked stream must never be joined back into it (ops: stream discipline)
+                with (ops.inline_wgrad() if aux is not None else contextlib.nullcontext()):
+                    torch.autograd.backward([d_losses], [self._e0])
                 pending = self.exchange_gradients('D', async_op=True)      # overlaps the VGG forward below
                 if aux is not None:
                     self._apply_adam('D', lr, pending=pending, exchanged=True)
@@ -350,7 +353,9 @@ class DetectorTranslatorModel(BaseModel):
                 ops.begin_backward()
                 torch.autograd.backward([recon, adv], [self._one, self._e0])
             if self.device.type == 'cuda' and getattr(self, '_aux', None) is not None:
-                torch.cuda.current_stream(self.device).wait_stream(self._aux)      # backward nodes recorded on the auxiliary stream ran there
+                # backward nodes recorded on the auxiliary stream ran there (their weight gradients on the side stream forked from it):
+                # the main stream joins the auxiliary stream here and every side stream in exchange_gradients('G') (ops: stream discipline)
+                torch.cuda.current_stream(self.device).wait_stream(self._aux)
             self._apply_adam('G', lr)
         self.global_step += 1                                             # incremented by the G optimiser (:201-202)
         self.last = dict(d_losses=d_losses.detach(), recon=recon.detach(), adv=adv.detach(), lr=float(lr),

@@ -89,18 +89,46 @@ FUSE_BN_STATS = _os.environ.get('KPX_FUSE_BN_STATS', '1') != '0'     # batch sta
 # 31.3 ms without it: the reduction passes it removes ran concurrently with the weight-gradient stream, while the longer
 # epilogue sits on the MFMA-bound critical path
 FUSE_BN_BWD = _os.environ.get('KPX_FUSE_BN_BWD', '0') != '0'
-_side_streams = {}
-_side_dirty = set()
-_side_keep = []          # tensors read by kernels on the side stream: kept alive until join_side_stream() (cheaper than
+# where a layer's weight gradient forks from its stream: 'after' its data gradient has been enqueued, 'before' it, or 'capture' (default):
+# before it while the step is being captured into a HIP graph, after it in eager mode -- measured on MI355X at B=32: eager 26.57 ms (after) /
+# 27.22 ms (before); graph replay 27.44 ms (after) / 26.96 ms (before)
+FORK_BEFORE_DGRAD = _os.environ.get('KPX_FORK_BEFORE_DGRAD', 'capture')
+_side_streams = {}       # (device, raw handle of the stream the weight gradients were forked from) -> side stream
+_side_dirty = {}         # the same keys -> True while un-joined kernels are pending on that side stream
+_side_keep = []          # tensors read by kernels on a side stream: kept alive until join_side_stream() (cheaper than
                          # Tensor.record_stream, whose pending events the caching allocator polls on every allocation)
 
 
-def _side_stream(device):
-    st = _side_streams.get(device)
+# Stream discipline (it is what makes the step capturable into a HIP graph, and it is harmless in eager mode):
+#   * one side stream PER ORIGIN stream: backward nodes on the main stream fork side(main), nodes of a branch that ran on the auxiliary
+#     stream fork side(aux) -- the fork graph is a tree  main -> {aux -> {side(aux)}, side(main)};
+#   * EVERY join goes into the main stream; a forked stream never waits for a stream forked from itself.  The HIP runtime under torch 2.10
+#     re-parents any non-origin stream that waits on a captured event, so a fork from aux that is later joined back INTO aux makes the two
+#     streams each other's "parallel capture stream" and hipStreamEndCapture recurses until the stack overflows (found with rocgdb; the
+#     pattern is legal HIP).  Where a branch on the auxiliary stream needs its weight gradients before it continues (the discriminator
+#     update: backward -> Adam on that stream), they are launched inline on that stream: ``inline_wgrad()``.
+_inline_wgrad = [False]
+
+
+class inline_wgrad:
+    """Context: weight / bias gradients of the backward nodes inside run on the node's own stream instead of a side stream."""
+
+    def __enter__(self):
+        self.old, _inline_wgrad[0] = _inline_wgrad[0], True
+
+    def __exit__(self, *exc):
+        _inline_wgrad[0] = self.old
+        return False
+
+
+def _side_stream(device, origin):
+    """The weight-gradient stream forked from ``origin`` (raw stream handle)."""
+    key = (device, origin)
+    st = _side_streams.get(key)
     if st is None:
         st = torch.cuda.Stream(device=device)
-        _side_streams[device] = st
-    return st
+        _side_streams[key] = st
+    return key, st
 
 
 # Gradients are written (not accumulated) into the flat bucket.  If one variable is used by several ops inside one backward
@@ -136,15 +164,18 @@ def normalize_device(device):
 
 
 def join_side_stream(device=None):
-    """Make the current stream wait for every weight-gradient kernel launched on the side stream."""
+    """Make the current stream wait for the weight-gradient kernels launched on the side streams of ``device`` (all devices if None).
+    Call it on the MAIN stream (see the stream discipline above)."""
     if device is not None:
         device = normalize_device(device)
-    for dev in list(_side_dirty):
-        if device is None or dev == device:
-            torch.cuda.current_stream(dev).wait_stream(_side_streams[dev])
-            _side_dirty.discard(dev)
+    for key in list(_side_dirty):
+        dev, origin = key
+        if device is not None and dev != device:
+            continue
+        torch.cuda.current_stream(dev).wait_stream(_side_streams[key])
+        del _side_dirty[key]
     if not _side_dirty:
-        _side_keep.clear()       # the current stream is now ordered after every side kernel: the blocks may be recycled
+        _side_keep.clear()       # every side kernel is now ordered before something the consumers wait for: the blocks may be recycled
 
 
 # ----------------------------------------------------------------------------------------------- compute dtype
@@ -488,6 +519,19 @@ class Conv2dFn(torch.autograd.Function):
             act_bwd_raw(dy, y, dz, act)
             dy = dz
         dx = dw = db = None
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        # side stream only when the gradient goes straight into the flat bucket (nobody on the main stream reads it
+        # before join_side_stream())
+        side = (SIDE_WGRAD and not _inline_wgrad[0] and (want_w or want_b) and (not want_w or ctx.w_grad_out is not None)
+                and (not want_b or ctx.b_grad_out is not None))
+        fork = None
+        if side and (FORK_BEFORE_DGRAD == 'before' or (FORK_BEFORE_DGRAD == 'capture' and torch.cuda.is_current_stream_capturing())):
+            # The weight gradient needs dy and x, not dx: the fork point is recorded BEFORE the data gradient is launched, so the two run
+            # side by side -- and, in a captured graph, the data-gradient chain stays the first successor of its predecessor (the graph
+            # runtime continues a queue along the first successor; forking after the data gradient made the chain hop queues per layer).
+            fork = torch.cuda.Event()
+            fork.record(torch.cuda.current_stream(x.device))
         if ctx.needs_input_grad[0]:
             cx = x.shape[3]
             dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
@@ -497,17 +541,15 @@ class Conv2dFn(torch.autograd.Function):
                                 bn_src=(x, ctx.bn_src[0]) if ctx.bn_src is not None else None)
             if st is not None:
                 _pending_bwd_stats[dx.data_ptr()] = (st[0], st[1], ctx.bn_src[1])
-        want_w = ctx.needs_input_grad[1]
-        want_b = ctx.has_bias and ctx.needs_input_grad[2]
-        # side stream only when the gradient goes straight into the flat bucket (nobody on the main stream reads it
-        # before join_side_stream())
-        side = SIDE_WGRAD and (want_w or want_b) and (not want_w or ctx.w_grad_out is not None) and (not want_b or ctx.b_grad_out is not None)
         if side:
-            main = torch.cuda.current_stream(x.device)
-            st = _side_stream(x.device)
-            st.wait_stream(main)                         # dy (and x) are ready once the main stream reaches this point
+            main = torch.cuda.current_stream(x.device)   # the stream this backward node runs on (= its forward's stream)
+            skey, st = _side_stream(x.device, main.cuda_stream)
+            if fork is not None:
+                st.wait_event(fork)                      # dy (and x) were ready when the fork point was recorded
+            else:
+                st.wait_stream(main)                     # ... or wait for everything enqueued so far, the data gradient included
             _side_keep.append((dy, x))                   # keep the allocator from recycling them under the side kernels
-            _side_dirty.add(x.device)
+            _side_dirty[skey] = True
             stream_ctx = torch.cuda.stream(st)
         else:
             import contextlib
