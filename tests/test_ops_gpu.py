@@ -637,3 +637,50 @@ def test_vgg_feature_gradient_in_one_pass_equals_the_four_pass_chain(kpx, dev, b
         want = dl
     want = torch.where(fg[b:] > 0, want, torch.zeros_like(want))
     assert torch.equal(got, want)
+
+
+GEMM3_CASES = [  # n, h, w, cin, cout, k, stride, pad, act
+    (4, 34, 34, 128, 256, 4, 2, 1, 2),      # img_discr conv_2 geometry
+    (8, 65, 65, 64, 128, 4, 2, 1, 2),       # img_discr conv_1: SAME split (1, 2)
+    (16, 6, 6, 1024, 2048, 4, 2, 1, 2),     # img_discr conv_5: small M, K = 16384 (split-K slabs + reduce)
+    (4, 64, 64, 64, 128, 3, 2, 0, 0),       # encoder conv_5: 3x3 stride 2, SAME pad (0, 1)
+    (2, 32, 32, 32, 64, 3, 2, 0, 1),        # encoder conv_3, 64 produced channels (BN = 64 tiles)
+    (2, 64, 64, 16, 16, 1, 1, 0, 0),        # 1x1, half a K chunk, 16 produced channels
+    (3, 17, 13, 40, 72, 3, 2, 0, 2),        # ragged: K = 40 (a partial chunk), 72 couts (masked tile columns), odd image sizes
+    (2, 20, 20, 24, 20, 3, 1, 1, 0),        # explicit pad on a stride-1 3x3 (not the Winograd geometry), 20 couts
+]
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,k,s,pad,act', GEMM3_CASES)
+def test_gemm3_bf16x3_is_fp32_equivalent_against_float64(kpx, dev, n, h, w, cin, cout, k, s, pad, act):
+    """csrc/conv_gemm3.hip: forward and data gradient on the bf16 matrix pipe with every fp32 operand split exactly into three bf16 terms.
+    Admissible in the fp32 configuration only if it is as close to a FLOAT64 convolution as the fp32-MFMA kernel it replaces: both run
+    here on the same inputs (KPX_NO_GEMM3 flips the library back), and the bf16x3 error may not exceed 1.5x the fp32 kernel's (+1e-7)."""
+    from kpx_amd._lib import lib
+    rs = np.random.RandomState(cin + 3 * cout + k)
+    x = rs.randn(n, h, w, cin).astype(np.float32)
+    wt = (rs.randn(k, k, cin, cout) / np.sqrt(k * k * cin)).astype(np.float32)
+    b = rs.randn(cout).astype(np.float32)
+    x64 = torch.from_numpy(x).double().requires_grad_(True); w64 = torch.from_numpy(wt).double()
+    z64 = R.conv(x64, w64, torch.from_numpy(b).double(), s, pad)
+    gy = rs.randn(*z64.shape).astype(np.float32)
+    z64.backward(torch.from_numpy(gy).double())
+    errs = {}
+    for mode in ('gemm3', 'fp32'):
+        if mode == 'fp32':
+            os.environ['KPX_NO_GEMM3'] = '1'
+        lib.kpx_reload_env()
+        try:
+            xg = torch.from_numpy(x).to(dev).requires_grad_(True); wg = torch.from_numpy(wt).to(dev); bg = torch.from_numpy(b).to(dev)
+            zg = kpx.ops.conv2d(xg, wg, bg, stride=s, pad=pad, act=0)
+            zg.backward(torch.from_numpy(gy).to(dev))
+            errs[mode] = (rel_l2(t2n(zg), t2n(z64)), rel_l2(t2n(xg.grad), t2n(x64.grad)))
+        finally:
+            os.environ.pop('KPX_NO_GEMM3', None)
+            lib.kpx_reload_env()
+    print('conv %s: rel-L2 vs float64 fwd %.2e (fp32 MFMA %.2e), dgrad %.2e (fp32 MFMA %.2e)'
+          % ((n, h, w, cin, cout, k, s), errs['gemm3'][0], errs['fp32'][0], errs['gemm3'][1], errs['fp32'][1]))
+    for i in (0, 1):
+        assert errs['gemm3'][i] <= 1.5 * errs['fp32'][i] + 1e-7, (i, errs)
+        assert errs['gemm3'][i] < 2e-6
+    assert errs['gemm3'] != errs['fp32']                  # the two kernels really are different code paths

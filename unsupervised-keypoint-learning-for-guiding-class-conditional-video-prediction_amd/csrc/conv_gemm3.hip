@@ -1,0 +1,398 @@
+// fp32-equivalent implicit-GEMM convolution on the bf16 matrix pipe of gfx950 (MI355X): forward and data gradient of the layers the
+// Winograd kernels cannot take (strided, 4x4, 1x1: the discriminator, the encoders' stride-2 layers, the key-point head), through the same
+// geometry (conv_geom.h) and the same C entry points as the fp32 kernel of conv_igemm.hip (kpx_conv2d_fwd_f32 / kpx_conv2d_dgrad_f32).
+//
+// Arithmetic.  Every fp32 operand is split EXACTLY into three bf16 terms while its tile is staged in LDS:
+//     a = a0 + a1 + a2,   a0 = trunc16(a),  a1 = trunc16(a - a0),  a2 = a - a0 - a1
+// (a - a0 has at most 16 significant bits and a - a0 - a1 at most 8, so both subtractions are exact and a2 is a bf16 number: no bit of
+// the fp32 value is lost).  The product a*b = sum_ij ai*bj is accumulated with the six terms of weight >= 2^-16,
+//     a0*b0 + (a0*b1 + a1*b0) + (a1*b1 + a0*b2 + a2*b0),
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; each bf16 x bf16 product is exact in fp32.  The dropped terms (a1*b2, a2*b1, a2*b2)
+// are below 2^-23 |a*b| -- smaller than the rounding of one fp32 accumulation.  Measured against a float64 convolution the result is as
+// close as the v_mfma_f32_32x32x2_f32 kernel's (tests/test_ops_gpu.py::test_gemm3_*): this is the fp32 configuration's arithmetic, not the
+// bf16 mode.  Six bf16 MFMAs cost 6 x 32 = 192 cycles per 32x32x16 block against 8 x 64 = 512 for the fp32 MFMA, and -- unlike the fp32
+// MFMA, which holds its SIMD's issue port -- the bf16 MFMA lets the splitting VALU work and the LDS traffic issue beside it.
+// TERMS = 1 keeps only a0*b0: the bf16 configuration's arithmetic (BASELINE configs[2]) from the same kernel.
+//
+// One workgroup = 8 wavefronts (WM x WN) = BM x BN outputs as 32x32 accumulators; K chunks of 32 channels.
+// LDS per stage: TERMS planes of A [BM][32] bf16 and of B [BN][32] bf16 (k contiguous: one ds_read_b128 = one MFMA operand of a lane) at a
+// row pitch of 80 bytes (conflict-free reads and writes, see G3_PITCH).
+#include "conv_geom.h"
+#include "kpx_env.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned g3_bits(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ float g3_float(unsigned v) { return __builtin_bit_cast(float, v); }
+// {hi16(b), hi16(a)}: two truncated bf16 values in one dword, a in the low half
+__device__ __forceinline__ unsigned g3_pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// exact three-way split of two floats; p[t] = packed (term t of a, term t of b)
+template <int TERMS>
+__device__ __forceinline__ void g3_split2(float a, float b, unsigned* p) {
+    const unsigned ua = g3_bits(a), ub = g3_bits(b);
+    p[0] = g3_pack_hi(ua, ub);
+    if (TERMS > 1) {
+        const float ra = a - g3_float(ua & 0xffff0000u), rb = b - g3_float(ub & 0xffff0000u);
+        const unsigned va = g3_bits(ra), vb = g3_bits(rb);
+        p[1] = g3_pack_hi(va, vb);
+        if (TERMS > 2) {
+            const float sa = ra - g3_float(va & 0xffff0000u), sb = rb - g3_float(vb & 0xffff0000u);
+            p[2] = g3_pack_hi(g3_bits(sa), g3_bits(sb));
+        }
+    }
+}
+
+template <int V> struct g3_ic { static constexpr int value = V; };
+
+#define G3_PITCH 80            // bytes of one LDS row (32 bf16 + 16 pad): 80 = 5 x 16 and 5 is odd, so sixteen consecutive rows start in sixteen
+                               // different 16-B slots of the 256-B bank window -- ds_read_b128 fragment reads, the 8-lane ds_write_b128 groups and
+                               // the 16-lane ds_write_b64 groups of the transposing B store are all conflict-free without an XOR swizzle
+#define G3_OOB 0x7ffffff0      // voffset beyond any buffer: the load returns zeros (out-of-image taps, channel tails, chunks past the end)
+
+template <int BM, int BN, int WM, int WN, bool BT, int TERMS>
+__global__ __launch_bounds__(WM * WN * 64) void conv_gemm3_kernel(const ConvGeom g) {
+    constexpr int NT = WM * WN * 64, BK = 32;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int APL = BM * G3_PITCH, BPL = BN * G3_PITCH;        // bytes of one bf16 plane
+    constexpr int ASZ = TERMS * APL, BSZ = TERMS * BPL;            // bytes of one stage
+    static_assert(TM >= 1 && TN >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile shape");
+    static_assert(NT == BM * 4, "one A unit (row, 8-channel octet) per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [2 stages][A planes] [2 stages][B planes]
+    unsigned char* const Asm = smem;
+    unsigned char* const Bsm = smem + 2 * ASZ;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const ConvClass k = g.cls[blockIdx.y];
+    const int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    if (L >= k.mt * g.nt) return;
+    const int m0 = (L / g.nt) * BM, n0 = (L % g.nt) * BN;
+    const int HW = k.Ha * k.Wa;
+    const int wrow = wm * TM * 32, wcol = wn * TN * 32;
+
+    // Operands are fetched through buffer descriptors: an invalid unit (tap outside the image, channel tail, tile row / column past the
+    // tensor, chunk past the end of the K loop) simply carries an out-of-range offset and reads as zeros -- the chunk body has no branch.
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0,
+                                            (int)((size_t)g.N * g.Hi * g.Wi * g.ldx * 4), 0x00020000);
+    const size_t w_bytes = (size_t)g.KW * ((size_t)k.wr0 + (size_t)(k.Tr > 0 ? k.Tr - 1 : 0) * g.wrs + 1) * g.wts * 4;     // up to the last filter row this class reads
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w), 0, (int)(w_bytes < 0x7fffffffu ? w_bytes : 0x7fffffffu), 0x00020000);
+
+    // ---- loop-invariant per-thread state
+    const int oct = t & 3;                              // 8-channel octet of the 32-channel chunk
+    int a_voff, a_st;
+    unsigned a_vr = 0, a_vq = 0;
+    {
+        const int row = t >> 2;
+        const int m = m0 + row;
+        const bool ok = m < k.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / HW, rem = mm - n * HW, a = rem / k.Wa, b = rem - a * k.Wa;
+        const int ih0 = a * g.isy + k.iy0, iw0 = b * g.isx + k.ix0;
+        a_voff = ((n * g.Hi * g.Wi + ih0 * g.Wi + iw0) * g.ldx + oct * 8) * 4;
+        for (int r = 0; r < k.Tr; ++r) if (ok && (unsigned)(ih0 + r * g.ity) < (unsigned)g.Hi) a_vr |= 1u << r;
+        for (int q = 0; q < k.Tq; ++q) if ((unsigned)(iw0 + q * g.itx) < (unsigned)g.Wi) a_vq |= 1u << q;
+        a_st = row * G3_PITCH + oct * 16;
+    }
+    // every thread owns exactly ONE B unit as well (no guard, no branch in the chunk body):
+    //   weights read k-contiguous (dgrad): KU = 32 BN / NT consecutive k of one n row (8 for BN = 128, 4 for BN = 64);
+    //   weights read n-contiguous (forward): 2 k x CW n, CW = 16 BN / NT (4 / 2), transposed in registers -- each n becomes one bf16 pair.
+    constexpr int KU = 32 * BN / NT, CW = 16 * BN / NT;
+    static_assert((KU == 8 || KU == 4) && (CW == 4 || CW == 2), "B unit shape");
+    int b_voff, b_st, b_k;                             // b_k: first gathered channel of the unit within a chunk
+    bool b_ok;
+    if (BT) {
+        const int ku = t % (32 / KU), nn = t / (32 / KU), n = n0 + nn;
+        b_ok = n < g.Cout;
+        b_voff = (n * g.ldw + ku * KU) * 4;
+        b_st = nn * G3_PITCH + ku * KU * 2;
+        b_k = ku * KU;
+    } else {
+        const int kp = t & 15, nq = t >> 4, n = n0 + nq * CW;                     // sixteen k pairs x BN / CW column groups
+        b_ok = n < g.Cout;
+        b_voff = ((kp * 2) * g.ldw + n) * 4;
+        b_st = (nq * CW) * G3_PITCH + kp * 4;
+        b_k = kp * 2;
+    }
+    int a_rd[TM], b_rd[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_rd[i] = (wrow + i * 32 + li) * G3_PITCH + lh * 16;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_rd[j] = (wcol + j * 32 + li) * G3_PITCH + lh * 16;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nck = (g.Cin + BK - 1) / BK;
+    int nchunks = k.Tr * k.Tq * nck;
+    int tr = 0, tq = 0, c0 = 0;
+    if (g.ksplit > 1) {
+        const int cps = (nchunks + g.ksplit - 1) / g.ksplit;
+        const int cb = blockIdx.z * cps, ce = min(nchunks, cb + cps);
+        const int tap0 = cb / nck;
+        c0 = (cb - tap0 * nck) * BK; tr = tap0 / k.Tq; tq = tap0 - tr * k.Tq;
+        nchunks = ce > cb ? ce - cb : 0;
+    }
+    int left = nchunks;                                 // chunks not yet loaded
+
+    f32x4 ra[2], rb[2];                                 // (the narrow B units fill only part of rb)
+    auto load_chunk = [&]() {                           // registers <- the next chunk in K order (zeros once the K loop is exhausted)
+        const int a_off = (((tr * g.ity) * g.Wi + tq * g.itx) * g.ldx + c0) * 4;          // wave-uniform byte offsets
+        const int tap = (k.wr0 + tr * g.wrs) * g.KW + (k.wq0 + tq * g.wqs);
+        const int b_off = (tap * g.wts + (BT ? c0 : c0 * g.ldw)) * 4;
+        const bool live = left > 0;
+        const bool va = live & ((((a_vr >> tr) & (a_vq >> tq)) & 1u) != 0) & (c0 + oct * 8 < g.Cin);       // (bitwise: no short-circuit branches)
+        const int av = va ? a_voff + a_off : G3_OOB;
+        ra[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, av, 0, 0));
+        ra[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, av + 16, 0, 0));
+        if (BT) {
+            const bool vb = live & b_ok & (c0 + b_k < g.Cin);
+            const int bv = vb ? b_voff + b_off : G3_OOB;
+            rb[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv, 0, 0));
+            if (KU == 8) rb[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv + 16, 0, 0));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool vb = live & b_ok & (c0 + b_k + j < g.Cin);
+                const int bv = vb ? b_voff + b_off + j * g.ldw * 4 : G3_OOB;
+                if (CW == 4) rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv, 0, 0));
+                else {
+                    // (two dword loads: hipcc of ROCm 7.2 lowers __builtin_amdgcn_raw_buffer_load_b64 to ONE buffer_load_dword and
+                    //  hands back its value twice -- found with the 64-cout forward parity cases)
+                    rb[j][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, bv, 0, 0));
+                    rb[j][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, bv + 4, 0, 0));
+                }
+            }
+        }
+        --left;
+        c0 += BK;
+        const bool wrap = c0 >= g.Cin;
+        c0 = wrap ? 0 : c0;
+        tq += wrap ? 1 : 0;
+        const bool wrapq = tq == k.Tq;
+        tq = wrapq ? 0 : tq;
+        tr += wrapq ? 1 : 0;
+    };
+    // split the staged fp32 units into their bf16 terms and write the planes of one stage
+    auto store_a = [&](int buf) {
+        unsigned char* const Ab = Asm + buf * ASZ + a_st;
+        unsigned p[4][3];
+        g3_split2<TERMS>(ra[0][0], ra[0][1], p[0]); g3_split2<TERMS>(ra[0][2], ra[0][3], p[1]);
+        g3_split2<TERMS>(ra[1][0], ra[1][1], p[2]); g3_split2<TERMS>(ra[1][2], ra[1][3], p[3]);
+#pragma unroll
+        for (int tm = 0; tm < TERMS; ++tm) *reinterpret_cast<u32x4*>(Ab + tm * APL) = u32x4{p[0][tm], p[1][tm], p[2][tm], p[3][tm]};
+    };
+    auto store_b = [&](int buf) {
+        unsigned char* const Bb = Bsm + buf * BSZ + b_st;
+        if (BT) {
+            unsigned p[4][3];
+            g3_split2<TERMS>(rb[0][0], rb[0][1], p[0]); g3_split2<TERMS>(rb[0][2], rb[0][3], p[1]);
+            if (KU == 8) {
+                g3_split2<TERMS>(rb[1][0], rb[1][1], p[2]); g3_split2<TERMS>(rb[1][2], rb[1][3], p[3]);
+#pragma unroll
+                for (int tm = 0; tm < TERMS; ++tm) *reinterpret_cast<u32x4*>(Bb + tm * BPL) = u32x4{p[0][tm], p[1][tm], p[2][tm], p[3][tm]};
+            } else {
+#pragma unroll
+                for (int tm = 0; tm < TERMS; ++tm) *reinterpret_cast<u32x2*>(Bb + tm * BPL) = u32x2{p[0][tm], p[1][tm]};
+            }
+        } else {
+            // rb[j][c] = w[k = 2 kp + j][n = nq*CW + c]: column c becomes one bf16 pair (4 bytes) of LDS row nq*CW + c
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                unsigned p[3];
+                g3_split2<TERMS>(rb[0][c], rb[1][c], p);
+#pragma unroll
+                for (int tm = 0; tm < TERMS; ++tm) *reinterpret_cast<unsigned*>(Bb + tm * BPL + c * G3_PITCH) = p[tm];
+            }
+        }
+    };
+
+    struct Frag { bf16x8 a[TM][TERMS], b[TN][TERMS]; };
+    auto read_frag = [&](int buf, int s, Frag& f) {      // k16 step s of the chunk: bytes 32 s + 16 lh of the row
+        const unsigned char* const Ab = Asm + buf * ASZ + s * 32;
+        const unsigned char* const Bb = Bsm + buf * BSZ + s * 32;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int tm = 0; tm < TERMS; ++tm) f.a[i][tm] = *reinterpret_cast<const bf16x8*>(Ab + tm * APL + a_rd[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int tm = 0; tm < TERMS; ++tm) f.b[j][tm] = *reinterpret_cast<const bf16x8*>(Bb + tm * BPL + b_rd[j]);
+    };
+    auto mfma_frag = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                if (TERMS > 2) {                          // smallest terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][1], c, 0, 0, 0);
+                }
+                if (TERMS > 1) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][1], c, 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][0], c, 0, 0, 0);
+            }
+    };
+    // Two chunks of prefetch distance, no branch in the body: while chunk c is multiplied, the registers loaded during chunk c-1 (chunk
+    // c+1's operands) are split and written to the other LDS stage -- the A unit beside the first k16 step's MFMAs, the B unit beside the
+    // second's -- and the loads of chunk c+2 are issued as soon as their registers are free.  The sched_group_barrier pattern spreads the
+    // ~6 VALU per MFMA of the splitting evenly between the MFMAs (two wavefronts share a SIMD: each gets the matrix pipe every 64 cycles).
+    constexpr int NMF = TM * TN * (TERMS == 3 ? 6 : TERMS == 2 ? 3 : 1);          // MFMAs per k16 step
+    auto chunk = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+        Frag f0, f1;
+        read_frag(buf, 0, f0);
+        read_frag(buf, 1, f1);
+        mfma_frag(f0);
+        store_a(buf ^ 1);
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (44 + NMF - 1) / NMF, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, TERMS, 0);
+        mfma_frag(f1);
+        store_b(buf ^ 1);
+        constexpr int BV = BT ? (KU == 8 ? 44 : 22) : 11 * CW, BW = BT ? TERMS : CW * TERMS;        // VALU / LDS stores of the B unit
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (BV + NMF - 1) / NMF, 0);
+            if (q >= NMF - BW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        load_chunk();
+        __syncthreads();
+    };
+
+    load_chunk();
+    store_a(0); store_b(0);
+    load_chunk();
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ch += 2) {            // (an odd chunk count multiplies one stage of zeros at the end)
+        chunk(g3_ic<0>{});
+        chunk(g3_ic<1>{});
+    }
+
+    // ---- epilogue (as conv_igemm_kernel): the output pixel of every tile row goes through LDS
+    int* rowpix = reinterpret_cast<int*>(smem);
+    if (t < BM) {
+        const int m = m0 + t;
+        int pix = -1;
+        if (m < k.M) {
+            const int n = m / HW, rem = m - n * HW, a = rem / k.Wa, b = rem - a * k.Wa;
+            pix = (n * g.Ho + a * g.osy + k.oy0) * g.Wo + b * g.osx + k.ox0;
+        }
+        rowpix[t] = pix;
+    }
+    __syncthreads();
+    if (g.ksplit > 1) {                                  // raw partial sums; bias / activation happen in splitk_reduce_kernel
+        float* wsl = g.ws + (size_t)blockIdx.z * g.ws_slab;
+#pragma unroll
+        for (int n = 0; n < TN; ++n) {
+            const int col = n0 + wcol + n * 32 + li;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pix = rowpix[wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+                    if (col < g.Cout && pix >= 0) wsl[(size_t)pix * g.Cout + col] = acc[i][n][r];
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int n = 0; n < TN; ++n) {
+        const int col = n0 + wcol + n * 32 + li;
+        const bool cok = col < g.Cout;
+        const float bv = (cok && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix = rowpix[wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh];
+                if (cok && pix >= 0) {
+                    float v = acc[i][n][r] + bv;
+                    if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
+                    else if (g.act == KPX_ACT_TANH) v = tanhf(v);
+                    g.y[(size_t)pix * g.ldy + col] = v;
+                }
+            }
+        }
+    }
+}
+
+static std::atomic<unsigned long long> g3_attr_mask{0};
+
+// wavefront grids: 128 x 128 tiles as 2 x 4 wavefronts of 64 x 32, 128 x 64 tiles as 4 x 2 of 32 x 32 (two wavefronts per SIMD: one
+// wavefront's operand splitting / LDS traffic issues beside the other's MFMAs)
+template <int BN> struct g3_waves { static constexpr int wm = BN == 128 ? 2 : 4, wn = BN == 128 ? 4 : 2; };
+template <int BM, int BN, bool BT, int TERMS>
+static int g3_launch_one(const ConvGeom& g, dim3 grid, hipStream_t s) {
+    constexpr int lds = 2 * TERMS * (BM + BN) * G3_PITCH;
+    hipLaunchKernelGGL((conv_gemm3_kernel<BM, BN, g3_waves<BN>::wm, g3_waves<BN>::wn, BT, TERMS>), grid, dim3(512), lds, s, g);
+    return kpx_launch_status();
+}
+template <int BM, int BN, bool BT, int TERMS>
+static hipError_t g3_set_attr() {
+    constexpr int lds = 2 * TERMS * (BM + BN) * G3_PITCH;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm3_kernel<BM, BN, g3_waves<BN>::wm, g3_waves<BN>::wn, BT, TERMS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
+// Shapes the bf16x3 kernel takes (everything else stays on conv_igemm_kernel): 16-B aligned operands, the gathered channel count a
+// multiple of 8 (one LDS unit = 8 channels of one pixel), produced channels a multiple of 4, no row-merged taps.
+extern "C" __attribute__((visibility("hidden"))) int kpx_gemm3_eligible(const ConvGeom* g) {
+    const KpxEnv* e = kpx_env();
+    if (e->no_gemm3 || g->merge || !g->vecA || !g->vecB) return 0;
+    if (g->Cin % 8 != 0 || g->Cin < 16 || g->Cout % 4 != 0 || g->Cout < 16 || g->ldx % 4 != 0 || g->ldw % 4 != 0) return 0;
+    return 1;
+}
+
+// Launch the bf16x3 (TERMS = 3; 1 = plain bf16) gather convolution for a geometry prepared by kpx_conv2d_fwd_f32 / kpx_conv2d_dgrad_f32
+// (classes, split-K slice count and workspace already decided).  bt: weights read transposed (dgrad).
+extern "C" __attribute__((visibility("hidden"))) int kpx_gemm3_launch(ConvGeom g, int bt, int terms, hipStream_t s) {
+    if (kpx_first_use_on_device(&g3_attr_mask)) {
+        hipError_t e = g3_set_attr<128, 128, false, 3>();
+        if (e == hipSuccess) e = g3_set_attr<128, 128, true, 3>();
+        if (e == hipSuccess) e = g3_set_attr<128, 64, false, 3>();
+        if (e == hipSuccess) e = g3_set_attr<128, 64, true, 3>();
+        if (e == hipSuccess) e = g3_set_attr<128, 128, false, 1>();
+        if (e == hipSuccess) e = g3_set_attr<128, 128, true, 1>();
+        if (e == hipSuccess) e = g3_set_attr<128, 64, false, 1>();
+        if (e == hipSuccess) e = g3_set_attr<128, 64, true, 1>();
+        if (e != hipSuccess) return -(int)e;
+    }
+    if (g.ncls <= 0) { g.ncls = 1; g.cls[0] = ConvClass{g.Ha, g.Wa, g.oy0, g.ox0, g.Tr, g.Tq, g.iy0, g.ix0, g.wr0, g.wq0, 0, 0}; }
+    g.M = 0;
+    for (int i = 0; i < g.ncls; ++i) { g.cls[i].M = g.N * g.cls[i].Ha * g.cls[i].Wa; if (g.cls[i].M > g.M) g.M = g.cls[i].M; }
+    if (g.M <= 0 || g.Cout <= 0) return 0;
+    const int BM = 128, BN = g.Cout > 64 ? 128 : 64;
+    g.nt = (g.Cout + BN - 1) / BN;
+    int mtmax = 0;
+    for (int i = 0; i < g.ncls; ++i) { g.cls[i].mt = (g.cls[i].M + BM - 1) / BM; if (g.cls[i].mt > mtmax) mtmax = g.cls[i].mt; }
+    g.mt = mtmax;
+    const dim3 grid((unsigned)(g.mt * g.nt), (unsigned)g.ncls, (unsigned)(g.ksplit > 1 ? g.ksplit : 1));
+#define G3_GO(bn, btv, tv) return g3_launch_one<128, bn, btv, tv>(g, grid, s)
+    if (terms == 1) {
+        if (BN == 128) { if (bt) G3_GO(128, true, 1); else G3_GO(128, false, 1); }
+        else { if (bt) G3_GO(64, true, 1); else G3_GO(64, false, 1); }
+    }
+    if (BN == 128) { if (bt) G3_GO(128, true, 3); else G3_GO(128, false, 3); }
+    if (bt) G3_GO(64, true, 3);
+    G3_GO(64, false, 3);
+#undef G3_GO
+}

@@ -1,0 +1,28 @@
+// Geometry of the "gather convolution" shared by the fp32 implicit-GEMM kernels (conv_igemm.hip) and the bf16x3 kernels (conv_gemm3.hip):
+//   out[n, a*osy+oy0, b*osx+ox0, j] = act( bias[j] + sum_{tr,tq,c} in[n, a*isy+tr*ity+iy0, b*isx+tq*itx+ix0, c] * B[tap(tr,tq)][c][j] )
+// forward: in = x, B = HWIO weights; dgrad: in = dy, B = the same weights read transposed, one class per stride parity of dx pixels.
+#pragma once
+#include "kpx_common.h"
+
+// per stride-parity class of output pixels (dgrad of a strided conv); forward has exactly one class
+struct ConvClass { int Ha, Wa, oy0, ox0, Tr, Tq, iy0, ix0, wr0, wq0, M, mt; };
+
+struct ConvGeom {
+    const float* x; float* y; const float* w; const float* bias;
+    int N, Hi, Wi, Cin, ldx;
+    int Ho, Wo, Cout, ldy;
+    int Ha, Wa;
+    int osy, oy0, osx, ox0;
+    int isy, iy0, isx, ix0;
+    int Tr, Tq, ity, itx;
+    int wr0, wrs, wq0, wqs, KW;
+    int wts, ldw;
+    int act, vecA, vecB;
+    int M, mt, nt;
+    ConvClass cls[4]; int ncls;   // blockIdx.y selects the class
+    int ksplit; float* ws;        // split-K: blockIdx.z owns an equal slice of the K chunks; raw partials go to ws[z][pixel][Cout]
+    size_t ws_slab;               // floats per split slab = N*Ho*Wo*Cout
+    int merge;      // >0: row-merged taps for tiny Cin (= original Cin): the KW*Cin floats of one filter row are
+                    // contiguous in NHWC, so they are treated as one tap with KW*Cin channels (per-element x bounds)
+};
+

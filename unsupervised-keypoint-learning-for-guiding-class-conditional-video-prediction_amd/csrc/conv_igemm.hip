@@ -18,27 +18,7 @@
 #include <stdlib.h>
 #include <stdio.h>
 
-// per stride-parity class of output pixels (dgrad of a strided conv); forward has exactly one class
-struct ConvClass { int Ha, Wa, oy0, ox0, Tr, Tq, iy0, ix0, wr0, wq0, M, mt; };
-
-struct ConvGeom {
-    const float* x; float* y; const float* w; const float* bias;
-    int N, Hi, Wi, Cin, ldx;
-    int Ho, Wo, Cout, ldy;
-    int Ha, Wa;
-    int osy, oy0, osx, ox0;
-    int isy, iy0, isx, ix0;
-    int Tr, Tq, ity, itx;
-    int wr0, wrs, wq0, wqs, KW;
-    int wts, ldw;
-    int act, vecA, vecB;
-    int M, mt, nt;
-    ConvClass cls[4]; int ncls;   // blockIdx.y selects the class
-    int ksplit; float* ws;        // split-K: blockIdx.z owns an equal slice of the K chunks; raw partials go to ws[z][pixel][Cout]
-    size_t ws_slab;               // floats per split slab = N*Ho*Wo*Cout
-    int merge;      // >0: row-merged taps for tiny Cin (= original Cin): the KW*Cin floats of one filter row are
-                    // contiguous in NHWC, so they are treated as one tap with KW*Cin channels (per-element x bounds)
-};
+#include "conv_geom.h"
 
 // Tile geometry: BM x BN outputs per workgroup, WM x WN wavefronts each owning (BM/WM) x (BN/WN) as 32x32 MFMA
 // accumulators, K chunks of 32 channels.  LDS (double buffered): A [BM][32] with the 16-B slot index XOR-swizzled by
@@ -47,7 +27,7 @@ struct ConvGeom {
 // column index is XORed with ((k>>2)&7)<<2 so the scalar transposing writes spread over all banks.
 // 16 zero bytes in the code object: invalid (out-of-image / out-of-range) 16-B units are loaded from here, so the
 // TAIL=false kernels need no per-element select between the load and the LDS write.
-__device__ __attribute__((aligned(16))) float kpx_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) float kpx_zero16[4] = {0.f, 0.f, 0.f, 0.f};          // (each translation unit that needs it has its own)
 
 template <int V> struct kpx_ic { static constexpr int value = V; };
 
@@ -445,8 +425,21 @@ static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
     return kpx_launch_status();
 }
 
+// conv_gemm3.hip: the same gather convolution on the bf16 matrix pipe with fp32 operands split into three bf16 terms (fp32-equivalent)
+extern "C" __attribute__((visibility("hidden"))) int kpx_gemm3_eligible(const ConvGeom* g);
+extern "C" __attribute__((visibility("hidden"))) int kpx_gemm3_launch(ConvGeom g, int bt, int terms, hipStream_t s);
+
 template <bool BT>
 static int launch_gather_conv(const ConvGeom& g, hipStream_t s) {
+    if (kpx_gemm3_eligible(&g)) {
+        int rc = kpx_gemm3_launch(g, BT ? 1 : 0, kpx_env()->gemm3_terms, s);
+        if (rc || g.ksplit <= 1) return rc;
+        const size_t npix = (size_t)g.N * g.Ho * g.Wo;
+        size_t nb = (npix * (g.Cout / 4) + 255) / 256; if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)g.ws, g.ws_slab, g.ksplit, npix, g.Cout,
+                           g.bias, g.act, g.y, g.ldy);
+        return kpx_launch_status();
+    }
     if (g.merge) return launch_gather_conv_v<false, false, true, true>(g, s);
     if (g.vecA && g.vecB) {
         if (g.Cin % 4 == 0 && g.Cout % 4 == 0) return launch_gather_conv_v<BT, true, false, false>(g, s);
