@@ -8,7 +8,7 @@ dev = torch.device('cuda:0')
 def rel(a, b):
     a = a.astype(np.float64); b = b.astype(np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
-for (n, h, w, cin, cout, k, s, pad) in [(2,16,16,32,64,3,2,0), (2,16,16,32,128,3,2,0), (2,16,16,64,64,3,2,0), (2,16,16,32,64,1,1,0), (2,16,16,32,32,1,1,0), (2,16,16,32,128,1,1,0), (2, 32, 32, 16, 15, 1, 1, 0), (4,34,34,128,256,4,2,1), (2,16,16,32,64,4,2,1)]:
+for (n, h, w, cin, cout, k, s, pad) in [(4,17,17,64,128,4,2,1), (4,10,10,128,256,4,2,1), (4,6,6,256,512,4,2,1), (4,4,4,512,1024,4,2,1), (4,3,3,1024,2048,4,2,1), (2,3,3,1024,2048,4,2,1), (4,65,65,64,128,4,2,1),(4,34,34,128,256,4,2,1),(4,18,18,256,512,4,2,1),(4,10,10,512,1024,4,2,1),(4,6,6,1024,2048,4,2,1), (4,16,16,32,64,3,2,0), (4,8,8,64,128,3,2,0), (4,4,4,128,256,3,2,0)]:
     rs = np.random.RandomState(1)
     x = rs.randn(n, h, w, cin).astype(np.float32); wt = (rs.randn(k, k, cin, cout) / np.sqrt(k*k*cin)).astype(np.float32)
     xg = torch.from_numpy(x).to(dev).requires_grad_(True); wg = torch.from_numpy(wt).to(dev)

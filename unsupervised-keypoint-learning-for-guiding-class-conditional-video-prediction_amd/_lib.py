@@ -13,7 +13,7 @@ import torch  # noqa: F401  -- MUST precede the CDLL below: PyTorch-ROCm ships i
 #                library's libamdhip64 dependency resolves to the runtime that is already in the process.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libkpx_hip.so')
+LIB_PATH = os.environ.get('KPX_LIB') or os.path.join(_HERE, 'libkpx_hip.so')      # (KPX_LIB: a diagnostic build of the same library)
 
 
 class KpxError(RuntimeError):

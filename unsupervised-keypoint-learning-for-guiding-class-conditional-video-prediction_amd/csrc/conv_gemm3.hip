@@ -53,16 +53,22 @@ template <int V> struct g3_ic { static constexpr int value = V; };
 #define G3_OOB 0x7ffffff0      // voffset beyond any buffer: the load returns zeros (out-of-image taps, channel tails, chunks past the end)
 
 template <int BM, int BN, int WM, int WN, bool BT, int TERMS>
-__global__ __launch_bounds__(WM * WN * 64) void conv_gemm3_kernel(const ConvGeom g) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3_kernel(const ConvGeom g) {
     constexpr int NT = WM * WN * 64, BK = 32;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int APL = BM * G3_PITCH, BPL = BN * G3_PITCH;        // bytes of one bf16 plane
-    constexpr int ASZ = TERMS * APL, BSZ = TERMS * BPL;            // bytes of one stage
-    static_assert(TM >= 1 && TN >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile shape");
-    static_assert(NT == BM * 4, "one A unit (row, 8-channel octet) per thread");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [2 stages][A planes] [2 stages][B planes]
+    constexpr int ASZ = TERMS * APL;
+    // staging units, RA / RB per thread (no guards, no branches in the chunk body):
+    //   A: (row, 8-channel octet);  B read k-contiguous (dgrad): KU consecutive k of one n row;  B read n-contiguous (forward): 2 k x CW n,
+    //   transposed in registers -- each n becomes one bf16 pair.
+    constexpr int RA = BM * 4 / NT;
+    constexpr int KU = BN * 4 >= NT ? 8 : 4, CW = BN * 4 >= NT ? 4 : 2;
+    constexpr int RB = BT ? BN * 32 / KU / NT : 16 * BN / CW / NT;
+    static_assert(TM >= 1 && TN >= 1 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && RA >= 1 && RB >= 1, "tile shape");
+    static_assert(RA * NT == BM * 4 && RB * NT == (BT ? BN * 32 / KU : 16 * BN / CW), "whole units per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // [A planes][B planes] (one stage)
     unsigned char* const Asm = smem;
-    unsigned char* const Bsm = smem + 2 * ASZ;
+    unsigned char* const Bsm = smem + ASZ;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 31, lh = lane >> 5;
@@ -82,40 +88,43 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm3_kernel(const ConvGeom
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w), 0, (int)(w_bytes < 0x7fffffffu ? w_bytes : 0x7fffffffu), 0x00020000);
 
     // ---- loop-invariant per-thread state
-    const int oct = t & 3;                              // 8-channel octet of the 32-channel chunk
-    int a_voff, a_st;
-    unsigned a_vr = 0, a_vq = 0;
-    {
-        const int row = t >> 2;
+    int a_voff[RA], a_st[RA], a_k[RA];
+    unsigned a_vm[RA];                                  // bit tr * Tq + tq: the tap lies inside the image for this unit's pixel (<= 32 taps)
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int u = t + NT * i, oct = u & 3, row = u >> 2;
         const int m = m0 + row;
         const bool ok = m < k.M;
         const int mm = ok ? m : 0;
         const int n = mm / HW, rem = mm - n * HW, a = rem / k.Wa, b = rem - a * k.Wa;
         const int ih0 = a * g.isy + k.iy0, iw0 = b * g.isx + k.ix0;
-        a_voff = ((n * g.Hi * g.Wi + ih0 * g.Wi + iw0) * g.ldx + oct * 8) * 4;
-        for (int r = 0; r < k.Tr; ++r) if (ok && (unsigned)(ih0 + r * g.ity) < (unsigned)g.Hi) a_vr |= 1u << r;
-        for (int q = 0; q < k.Tq; ++q) if ((unsigned)(iw0 + q * g.itx) < (unsigned)g.Wi) a_vq |= 1u << q;
-        a_st = row * G3_PITCH + oct * 16;
+        a_voff[i] = ((n * g.Hi * g.Wi + ih0 * g.Wi + iw0) * g.ldx + oct * 8) * 4;
+        unsigned vm = 0;
+        for (int r = 0; r < k.Tr; ++r)
+            for (int q = 0; q < k.Tq; ++q)
+                if (ok && (unsigned)(ih0 + r * g.ity) < (unsigned)g.Hi && (unsigned)(iw0 + q * g.itx) < (unsigned)g.Wi) vm |= 1u << (r * k.Tq + q);
+        a_vm[i] = vm;
+        a_st[i] = row * G3_PITCH + oct * 16;
+        a_k[i] = oct * 8;
     }
-    // every thread owns exactly ONE B unit as well (no guard, no branch in the chunk body):
-    //   weights read k-contiguous (dgrad): KU = 32 BN / NT consecutive k of one n row (8 for BN = 128, 4 for BN = 64);
-    //   weights read n-contiguous (forward): 2 k x CW n, CW = 16 BN / NT (4 / 2), transposed in registers -- each n becomes one bf16 pair.
-    constexpr int KU = 32 * BN / NT, CW = 16 * BN / NT;
-    static_assert((KU == 8 || KU == 4) && (CW == 4 || CW == 2), "B unit shape");
-    int b_voff, b_st, b_k;                             // b_k: first gathered channel of the unit within a chunk
-    bool b_ok;
-    if (BT) {
-        const int ku = t % (32 / KU), nn = t / (32 / KU), n = n0 + nn;
-        b_ok = n < g.Cout;
-        b_voff = (n * g.ldw + ku * KU) * 4;
-        b_st = nn * G3_PITCH + ku * KU * 2;
-        b_k = ku * KU;
-    } else {
-        const int kp = t & 15, nq = t >> 4, n = n0 + nq * CW;                     // sixteen k pairs x BN / CW column groups
-        b_ok = n < g.Cout;
-        b_voff = ((kp * 2) * g.ldw + n) * 4;
-        b_st = (nq * CW) * G3_PITCH + kp * 4;
-        b_k = kp * 2;
+    int b_voff[RB], b_st[RB], b_k[RB];                 // b_k: first gathered channel of the unit within a chunk
+    bool b_ok[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int u = t + NT * i;
+        if (BT) {
+            const int ku = u % (32 / KU), nn = u / (32 / KU), n = n0 + nn;
+            b_ok[i] = n < g.Cout;
+            b_voff[i] = (n * g.ldw + ku * KU) * 4;
+            b_st[i] = nn * G3_PITCH + ku * KU * 2;
+            b_k[i] = ku * KU;
+        } else {
+            const int kp = u & 15, nq = u >> 4, n = n0 + nq * CW;                 // sixteen k pairs x BN / CW column groups
+            b_ok[i] = n < g.Cout;
+            b_voff[i] = ((kp * 2) * g.ldw + n) * 4;
+            b_st[i] = (nq * CW) * G3_PITCH + kp * 4;
+            b_k[i] = kp * 2;
+        }
     }
     int a_rd[TM], b_rd[TN];
 #pragma unroll
@@ -143,32 +152,39 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm3_kernel(const ConvGeom
     }
     int left = nchunks;                                 // chunks not yet loaded
 
-    f32x4 ra[2], rb[2];                                 // (the narrow B units fill only part of rb)
+    f32x4 ra[RA][2], rb[RB][2];                         // (the narrow B units fill only part of rb)
     auto load_chunk = [&]() {                           // registers <- the next chunk in K order (zeros once the K loop is exhausted)
         const int a_off = (((tr * g.ity) * g.Wi + tq * g.itx) * g.ldx + c0) * 4;          // wave-uniform byte offsets
+        const int tapbit = tr * k.Tq + tq;
         const int tap = (k.wr0 + tr * g.wrs) * g.KW + (k.wq0 + tq * g.wqs);
         const int b_off = (tap * g.wts + (BT ? c0 : c0 * g.ldw)) * 4;
         const bool live = left > 0;
-        const bool va = live & ((((a_vr >> tr) & (a_vq >> tq)) & 1u) != 0) & (c0 + oct * 8 < g.Cin);       // (bitwise: no short-circuit branches)
-        const int av = va ? a_voff + a_off : G3_OOB;
-        ra[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, av, 0, 0));
-        ra[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, av + 16, 0, 0));
-        if (BT) {
-            const bool vb = live & b_ok & (c0 + b_k < g.Cin);
-            const int bv = vb ? b_voff + b_off : G3_OOB;
-            rb[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv, 0, 0));
-            if (KU == 8) rb[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv + 16, 0, 0));
-        } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool vb = live & b_ok & (c0 + b_k + j < g.Cin);
-                const int bv = vb ? b_voff + b_off + j * g.ldw * 4 : G3_OOB;
-                if (CW == 4) rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv, 0, 0));
-                else {
-                    // (two dword loads: hipcc of ROCm 7.2 lowers __builtin_amdgcn_raw_buffer_load_b64 to ONE buffer_load_dword and
-                    //  hands back its value twice -- found with the 64-cout forward parity cases)
-                    rb[j][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, bv, 0, 0));
-                    rb[j][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, bv + 4, 0, 0));
+        for (int i = 0; i < RA; ++i) {
+            const bool va = live & (((a_vm[i] >> tapbit) & 1u) != 0) & (c0 + a_k[i] < g.Cin);       // (bitwise: no short-circuit branches)
+            const int av = va ? a_voff[i] + a_off : G3_OOB;
+            ra[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, av, 0, 0));
+            ra[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, av + 16, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            if (BT) {
+                const bool vb = live & b_ok[i] & (c0 + b_k[i] < g.Cin);
+                const int bv = vb ? b_voff[i] + b_off : G3_OOB;
+                rb[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv, 0, 0));
+                if (KU == 8) rb[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv + 16, 0, 0));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool vb = live & b_ok[i] & (c0 + b_k[i] + j < g.Cin);
+                    const int bv = vb ? b_voff[i] + b_off + j * g.ldw * 4 : G3_OOB;
+                    if (CW == 4) rb[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv, 0, 0));
+                    else {
+                        // (two dword loads: hipcc of ROCm 7.2 lowers __builtin_amdgcn_raw_buffer_load_b64 to ONE buffer_load_dword and
+                        //  hands back its value twice -- found with the 64-cout forward parity cases)
+                        rb[i][j][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, bv, 0, 0));
+                        rb[i][j][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_b, bv + 4, 0, 0));
+                    }
                 }
             }
         }
@@ -181,44 +197,48 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm3_kernel(const ConvGeom
         tq = wrapq ? 0 : tq;
         tr += wrapq ? 1 : 0;
     };
-    // split the staged fp32 units into their bf16 terms and write the planes of one stage
-    auto store_a = [&](int buf) {
-        unsigned char* const Ab = Asm + buf * ASZ + a_st;
-        unsigned p[4][3];
-        g3_split2<TERMS>(ra[0][0], ra[0][1], p[0]); g3_split2<TERMS>(ra[0][2], ra[0][3], p[1]);
-        g3_split2<TERMS>(ra[1][0], ra[1][1], p[2]); g3_split2<TERMS>(ra[1][2], ra[1][3], p[3]);
+    // split the staged fp32 units into their bf16 terms and write the planes
+    auto store_ab = [&]() {
 #pragma unroll
-        for (int tm = 0; tm < TERMS; ++tm) *reinterpret_cast<u32x4*>(Ab + tm * APL) = u32x4{p[0][tm], p[1][tm], p[2][tm], p[3][tm]};
-    };
-    auto store_b = [&](int buf) {
-        unsigned char* const Bb = Bsm + buf * BSZ + b_st;
-        if (BT) {
+        for (int i = 0; i < RA; ++i) {
+            unsigned char* const Ab = Asm + a_st[i];
             unsigned p[4][3];
-            g3_split2<TERMS>(rb[0][0], rb[0][1], p[0]); g3_split2<TERMS>(rb[0][2], rb[0][3], p[1]);
-            if (KU == 8) {
-                g3_split2<TERMS>(rb[1][0], rb[1][1], p[2]); g3_split2<TERMS>(rb[1][2], rb[1][3], p[3]);
+            g3_split2<TERMS>(ra[i][0][0], ra[i][0][1], p[0]); g3_split2<TERMS>(ra[i][0][2], ra[i][0][3], p[1]);
+            g3_split2<TERMS>(ra[i][1][0], ra[i][1][1], p[2]); g3_split2<TERMS>(ra[i][1][2], ra[i][1][3], p[3]);
 #pragma unroll
-                for (int tm = 0; tm < TERMS; ++tm) *reinterpret_cast<u32x4*>(Bb + tm * BPL) = u32x4{p[0][tm], p[1][tm], p[2][tm], p[3][tm]};
+            for (int tm = 0; tm < TERMS; ++tm) *reinterpret_cast<u32x4*>(Ab + tm * APL) = u32x4{p[0][tm], p[1][tm], p[2][tm], p[3][tm]};
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            unsigned char* const Bb = Bsm + b_st[i];
+            if (BT) {
+                unsigned p[4][3];
+                g3_split2<TERMS>(rb[i][0][0], rb[i][0][1], p[0]); g3_split2<TERMS>(rb[i][0][2], rb[i][0][3], p[1]);
+                if (KU == 8) {
+                    g3_split2<TERMS>(rb[i][1][0], rb[i][1][1], p[2]); g3_split2<TERMS>(rb[i][1][2], rb[i][1][3], p[3]);
+#pragma unroll
+                    for (int tm = 0; tm < TERMS; ++tm) *reinterpret_cast<u32x4*>(Bb + tm * BPL) = u32x4{p[0][tm], p[1][tm], p[2][tm], p[3][tm]};
+                } else {
+#pragma unroll
+                    for (int tm = 0; tm < TERMS; ++tm) *reinterpret_cast<u32x2*>(Bb + tm * BPL) = u32x2{p[0][tm], p[1][tm]};
+                }
             } else {
+                // rb[i][j][c] = w[k = 2 kp + j][n = nq*CW + c]: column c becomes one bf16 pair (4 bytes) of LDS row nq*CW + c
 #pragma unroll
-                for (int tm = 0; tm < TERMS; ++tm) *reinterpret_cast<u32x2*>(Bb + tm * BPL) = u32x2{p[0][tm], p[1][tm]};
-            }
-        } else {
-            // rb[j][c] = w[k = 2 kp + j][n = nq*CW + c]: column c becomes one bf16 pair (4 bytes) of LDS row nq*CW + c
+                for (int c = 0; c < CW; ++c) {
+                    unsigned p[3];
+                    g3_split2<TERMS>(rb[i][0][c], rb[i][1][c], p);
 #pragma unroll
-            for (int c = 0; c < CW; ++c) {
-                unsigned p[3];
-                g3_split2<TERMS>(rb[0][c], rb[1][c], p);
-#pragma unroll
-                for (int tm = 0; tm < TERMS; ++tm) *reinterpret_cast<unsigned*>(Bb + tm * BPL + c * G3_PITCH) = p[tm];
+                    for (int tm = 0; tm < TERMS; ++tm) *reinterpret_cast<unsigned*>(Bb + tm * BPL + c * G3_PITCH) = p[tm];
+                }
             }
         }
     };
 
     struct Frag { bf16x8 a[TM][TERMS], b[TN][TERMS]; };
-    auto read_frag = [&](int buf, int s, Frag& f) {      // k16 step s of the chunk: bytes 32 s + 16 lh of the row
-        const unsigned char* const Ab = Asm + buf * ASZ + s * 32;
-        const unsigned char* const Bb = Bsm + buf * BSZ + s * 32;
+    auto read_frag = [&](int s, Frag& f) {               // k16 step s of the chunk: bytes 32 s + 16 lh of the row
+        const unsigned char* const Ab = Asm + s * 32;
+        const unsigned char* const Bb = Bsm + s * 32;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -246,45 +266,27 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm3_kernel(const ConvGeom
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][0], c, 0, 0, 0);
             }
     };
-    // Two chunks of prefetch distance, no branch in the body: while chunk c is multiplied, the registers loaded during chunk c-1 (chunk
-    // c+1's operands) are split and written to the other LDS stage -- the A unit beside the first k16 step's MFMAs, the B unit beside the
-    // second's -- and the loads of chunk c+2 are issued as soon as their registers are free.  The sched_group_barrier pattern spreads the
-    // ~6 VALU per MFMA of the splitting evenly between the MFMAs (two wavefronts share a SIMD: each gets the matrix pipe every 64 cycles).
-    constexpr int NMF = TM * TN * (TERMS == 3 ? 6 : TERMS == 2 ? 3 : 1);          // MFMAs per k16 step
-    auto chunk = [&](auto bufc) {
-        constexpr int buf = decltype(bufc)::value;
-        Frag f0, f1;
-        read_frag(buf, 0, f0);
-        read_frag(buf, 1, f1);
-        mfma_frag(f0);
-        store_a(buf ^ 1);
-#pragma unroll
-        for (int q = 0; q < NMF; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, (44 + NMF - 1) / NMF, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x200, TERMS, 0);
-        mfma_frag(f1);
-        store_b(buf ^ 1);
-        constexpr int BV = BT ? (KU == 8 ? 44 : 22) : 11 * CW, BW = BT ? TERMS : CW * TERMS;        // VALU / LDS stores of the B unit
-#pragma unroll
-        for (int q = 0; q < NMF; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, (BV + NMF - 1) / NMF, 0);
-            if (q >= NMF - BW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-        load_chunk();
+    // ONE LDS stage, TWO workgroups per CU.  Measured on MI355X (img_discr/conv_2, N = 64, 90 us of pure MFMA time at the clock the chip
+    // held): fragment reads + MFMAs alone 130 us, + operand split and LDS stores 154 us, + global loads 175 us -- the phases of a chunk ADD
+    // on a SIMD instead of overlapping, whatever the software pipelining inside the workgroup (double-buffered LDS, barrier in mid-chunk,
+    // two register sets, pinned instruction order: all within 3 %; removing 8 of the 11 split VALU per pair: -5 %).  Two independent
+    // workgroups per CU (one 60 KB LDS stage each, <= 128 VGPRs) fill each other's barrier / store phases: -5..10 %.
+    auto chunk = [&]() {
+        Frag f;
+        read_frag(0, f);
+        load_chunk();                                    // registers <- next chunk: lands under this chunk's MFMAs
+        mfma_frag(f);
+        read_frag(1, f);
+        mfma_frag(f);
+        __syncthreads();                                 // every wavefront has read the stage
+        store_ab();
         __syncthreads();
     };
 
     load_chunk();
-    store_a(0); store_b(0);
-    load_chunk();
+    store_ab();
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ch += 2) {            // (an odd chunk count multiplies one stage of zeros at the end)
-        chunk(g3_ic<0>{});
-        chunk(g3_ic<1>{});
-    }
+    for (int ch = 0; ch < nchunks; ++ch) chunk();
 
     // ---- epilogue (as conv_igemm_kernel): the output pixel of every tile row goes through LDS
     int* rowpix = reinterpret_cast<int*>(smem);
@@ -337,18 +339,19 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_gemm3_kernel(const ConvGeom
 
 static std::atomic<unsigned long long> g3_attr_mask{0};
 
-// wavefront grids: 128 x 128 tiles as 2 x 4 wavefronts of 64 x 32, 128 x 64 tiles as 4 x 2 of 32 x 32 (two wavefronts per SIMD: one
-// wavefront's operand splitting / LDS traffic issues beside the other's MFMAs)
+// wavefront grids (8 wavefronts per workgroup, two workgroups per CU): 128 x 128 tiles as 2 x 4 wavefronts of 64 x 32, 128 x 64 tiles as 4 x 2
+// of 32 x 32.  (Measured alternatives, img_discr layers at N = 64, forward / data gradient per step: 4 wavefronts of 64 x 64: 1.98 / 1.49 ms;
+// this: 1.82 / 1.34 ms; one double-buffered workgroup per CU: 1.89 / 1.50 ms; the fp32-MFMA kernel: 2.75 / 1.99 ms.)
 template <int BN> struct g3_waves { static constexpr int wm = BN == 128 ? 2 : 4, wn = BN == 128 ? 4 : 2; };
 template <int BM, int BN, bool BT, int TERMS>
 static int g3_launch_one(const ConvGeom& g, dim3 grid, hipStream_t s) {
-    constexpr int lds = 2 * TERMS * (BM + BN) * G3_PITCH;
-    hipLaunchKernelGGL((conv_gemm3_kernel<BM, BN, g3_waves<BN>::wm, g3_waves<BN>::wn, BT, TERMS>), grid, dim3(512), lds, s, g);
+    constexpr int lds = TERMS * (BM + BN) * G3_PITCH;
+    hipLaunchKernelGGL((conv_gemm3_kernel<BM, BN, g3_waves<BN>::wm, g3_waves<BN>::wn, BT, TERMS>), grid, dim3(g3_waves<BN>::wm * g3_waves<BN>::wn * 64), lds, s, g);
     return kpx_launch_status();
 }
 template <int BM, int BN, bool BT, int TERMS>
 static hipError_t g3_set_attr() {
-    constexpr int lds = 2 * TERMS * (BM + BN) * G3_PITCH;
+    constexpr int lds = TERMS * (BM + BN) * G3_PITCH;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm3_kernel<BM, BN, g3_waves<BN>::wm, g3_waves<BN>::wn, BT, TERMS>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
