@@ -661,7 +661,7 @@ def test_gemm3_bf16x3_is_fp32_equivalent_against_float64(kpx, dev, n, h, w, cin,
     x = rs.randn(n, h, w, cin).astype(np.float32)
     wt = (rs.randn(k, k, cin, cout) / np.sqrt(k * k * cin)).astype(np.float32)
     b = rs.randn(cout).astype(np.float32)
-    x64 = torch.from_numpy(x).double().requires_grad_(True); w64 = torch.from_numpy(wt).double()
+    x64 = torch.from_numpy(x).double().requires_grad_(True); w64 = torch.from_numpy(wt).double().requires_grad_(True)
     z64 = R.conv(x64, w64, torch.from_numpy(b).double(), s, pad)
     gy = rs.randn(*z64.shape).astype(np.float32)
     z64.backward(torch.from_numpy(gy).double())
@@ -671,16 +671,17 @@ def test_gemm3_bf16x3_is_fp32_equivalent_against_float64(kpx, dev, n, h, w, cin,
             os.environ['KPX_NO_GEMM3'] = '1'
         lib.kpx_reload_env()
         try:
-            xg = torch.from_numpy(x).to(dev).requires_grad_(True); wg = torch.from_numpy(wt).to(dev); bg = torch.from_numpy(b).to(dev)
+            xg = torch.from_numpy(x).to(dev).requires_grad_(True); wg = torch.from_numpy(wt).to(dev).requires_grad_(True); bg = torch.from_numpy(b).to(dev)
             zg = kpx.ops.conv2d(xg, wg, bg, stride=s, pad=pad, act=0)
             zg.backward(torch.from_numpy(gy).to(dev))
-            errs[mode] = (rel_l2(t2n(zg), t2n(z64)), rel_l2(t2n(xg.grad), t2n(x64.grad)))
+            kpx.ops.join_side_stream()
+            errs[mode] = (rel_l2(t2n(zg), t2n(z64)), rel_l2(t2n(xg.grad), t2n(x64.grad)), rel_l2(t2n(wg.grad), t2n(w64.grad)))
         finally:
             os.environ.pop('KPX_NO_GEMM3', None)
             lib.kpx_reload_env()
-    print('conv %s: rel-L2 vs float64 fwd %.2e (fp32 MFMA %.2e), dgrad %.2e (fp32 MFMA %.2e)'
-          % ((n, h, w, cin, cout, k, s), errs['gemm3'][0], errs['fp32'][0], errs['gemm3'][1], errs['fp32'][1]))
-    for i in (0, 1):
+    print('conv %s: rel-L2 vs float64 fwd %.2e (fp32 MFMA %.2e), dgrad %.2e (fp32 MFMA %.2e), wgrad %.2e (fp32 MFMA %.2e)'
+          % ((n, h, w, cin, cout, k, s), errs['gemm3'][0], errs['fp32'][0], errs['gemm3'][1], errs['fp32'][1], errs['gemm3'][2], errs['fp32'][2]))
+    for i in (0, 1, 2):
         assert errs['gemm3'][i] <= 1.5 * errs['fp32'][i] + 1e-7, (i, errs)
         assert errs['gemm3'][i] < 2e-6
-    assert errs['gemm3'] != errs['fp32']                  # the two kernels really are different code paths
+    assert errs['gemm3'][:2] != errs['fp32'][:2]          # the two kernels really are different code paths

@@ -399,3 +399,188 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_gemm3_launch(ConvGeom g
     G3_GO(64, false, 3);
 #undef G3_GO
 }
+
+// ------------------------------------------------------------------------------------------------------------------------ weight gradient
+// dw[tap][c][k] = sum_p x[p shifted by tap][c] * dy[p][k] on the same bf16x3 arithmetic: M = Cin, N = Cout, K = output pixels.  Both
+// operands are pixel-major in HBM (channels contiguous) while an MFMA fragment wants 8 consecutive K = pixels per lane, so BOTH are staged
+// like the forward kernel's n-contiguous weights: a unit = 2 pixels x 4 channels (two 16-B loads), transposed in registers -- each channel
+// becomes one bf16 pair per term, written to LDS row `channel` of the operand's plane (pitch G3_PITCH: conflict-free).  Workgroup =
+// (split, tap, Cin tile, Cout tile) as in conv_wgrad_kernel (conv_igemm.hip), partial slabs reduced in fixed order by wgrad_reduce_kernel.
+template <int BM, int WM, int WN, int TERMS>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad3_kernel(const WgradGeom g) {
+    constexpr int NT = WM * WN * 64, BKP = 32, BN = BM;
+    constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+    constexpr int APL = BM * G3_PITCH, BPL = BN * G3_PITCH;
+    constexpr int ASZ = TERMS * APL;
+    static_assert(NT == 16 * (BM / 4), "one A unit and one B unit (2 pixels x 4 channels) per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Asm = smem;
+    unsigned char* const Bsm = smem + ASZ;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    const int taps = g.KH * g.KW;
+    const int kti = L % g.kt; L /= g.kt;
+    const int cti = L % g.ct; L /= g.ct;
+    const int tap = L % taps; L /= taps;
+    const int split = L;
+    const int r = tap / g.KW, q = tap - r * g.KW;
+    const int cbase = cti * BM, kbase = kti * BN;
+    const int pbeg = split * g.pps;
+    const int pend = min(g.P, pbeg + g.pps);
+    const int wrow = wm * TM * 32, wcol = wn * TN * 32;
+
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, (int)((size_t)g.N * g.Hi * g.Wi * g.ldx * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dy), 0, (int)((size_t)g.P * g.lddy * 4), 0x00020000);
+
+    // this thread's unit: pixel pair kp of the 32-pixel chunk, channel quad cq (kp fastest: conflict-free ds_write_b32 at pitch 80)
+    const int kp = t & 15, cq = t >> 4;
+    const int ac = cbase + cq * 4, bc = kbase + cq * 4;
+    const bool a_cok = ac < g.Cin, b_cok = bc < g.Cout;            // (Cin, Cout multiples of 4: a quad is all in or all out)
+    const int a_st = (cq * 4) * G3_PITCH + kp * 4, b_st = a_st;
+    // pixel coordinates of the unit's two pixels, advanced by 32 pixels per chunk
+    int pn[2], pho[2], pwo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = pbeg + 2 * kp + j;
+        pn[j] = p / (g.Ho * g.Wo);
+        const int rem = p - pn[j] * g.Ho * g.Wo;
+        pho[j] = rem / g.Wo;
+        pwo[j] = rem - pho[j] * g.Wo;
+    }
+    int p0 = pbeg + 2 * kp;
+
+    int a_rd[TM], b_rd[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a_rd[i] = (wrow + i * 32 + li) * G3_PITCH + lh * 16;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_rd[j] = (wcol + j * 32 + li) * G3_PITCH + lh * 16;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[2], rb[2];
+    auto load_chunk = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ih = pho[j] * g.stride + r - g.pad_t, iw = pwo[j] * g.stride + q - g.pad_l;
+            const bool va = a_cok & (p0 + j < pend) & ((unsigned)ih < (unsigned)g.Hi) & ((unsigned)iw < (unsigned)g.Wi);
+            const int av = va ? (((pn[j] * g.Hi + ih) * g.Wi + iw) * g.ldx + ac) * 4 : G3_OOB;
+            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, av, 0, 0));
+            const bool vb = b_cok & (p0 + j < pend);
+            const int bv = vb ? ((p0 + j) * g.lddy + bc) * 4 : G3_OOB;
+            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv, 0, 0));
+            // advance this pixel by one chunk (32 pixels): at most a few row wraps for narrow images
+            pwo[j] += BKP;
+            while (pwo[j] >= g.Wo) {
+                pwo[j] -= g.Wo;
+                if (++pho[j] == g.Ho) { pho[j] = 0; ++pn[j]; }
+            }
+        }
+        p0 += BKP;
+    };
+    auto store_ab = [&]() {
+        unsigned char* const Ab = Asm + a_st;
+        unsigned char* const Bb = Bsm + b_st;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned pa[3], pb[3];
+            g3_split2<TERMS>(ra[0][c], ra[1][c], pa);
+            g3_split2<TERMS>(rb[0][c], rb[1][c], pb);
+#pragma unroll
+            for (int tm = 0; tm < TERMS; ++tm) {
+                *reinterpret_cast<unsigned*>(Ab + tm * APL + c * G3_PITCH) = pa[tm];
+                *reinterpret_cast<unsigned*>(Bb + tm * BPL + c * G3_PITCH) = pb[tm];
+            }
+        }
+    };
+    struct Frag { bf16x8 a[TM][TERMS], b[TN][TERMS]; };
+    auto read_frag = [&](int s, Frag& f) {
+        const unsigned char* const Ab = Asm + s * 32;
+        const unsigned char* const Bb = Bsm + s * 32;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int tm = 0; tm < TERMS; ++tm) f.a[i][tm] = *reinterpret_cast<const bf16x8*>(Ab + tm * APL + a_rd[i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int tm = 0; tm < TERMS; ++tm) f.b[j][tm] = *reinterpret_cast<const bf16x8*>(Bb + tm * BPL + b_rd[j]);
+    };
+    auto mfma_frag = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                f32x16 c = acc[i][j];
+                if (TERMS > 2) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][2], f.b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][1], c, 0, 0, 0);
+                }
+                if (TERMS > 1) {
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][1], f.b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][1], c, 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[i][0], f.b[j][0], c, 0, 0, 0);
+            }
+    };
+
+    const int nchunks = pend > pbeg ? (pend - pbeg + BKP - 1) / BKP : 0;
+    load_chunk();
+    store_ab();
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        Frag f;
+        read_frag(0, f);
+        load_chunk();                                    // next chunk (zeros past the end of the split: p >= pend)
+        mfma_frag(f);
+        read_frag(1, f);
+        mfma_frag(f);
+        __syncthreads();
+        store_ab();
+        __syncthreads();
+    }
+
+    float* out = g.out + (size_t)split * g.slab + (size_t)tap * g.Cin * g.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int k = kbase + wcol + j * 32 + li;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = cbase + wrow + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (c < g.Cin && k < g.Cout) out[(size_t)c * g.Cout + k] = acc[i][j][e];
+            }
+    }
+}
+
+extern "C" __attribute__((visibility("hidden"))) int kpx_wgrad3_eligible(const WgradGeom* g) {
+    const KpxEnv* e = kpx_env();
+    if (e->no_gemm3 || e->no_wgrad3 || g->merge || !g->vecA || !g->vecB) return 0;
+    if (g->Cin % 4 != 0 || g->Cout % 4 != 0 || g->Cin < 16 || g->Cout < 16) return 0;
+    if ((size_t)g->N * g->Hi * g->Wi * g->ldx * 4 >= 0x7fffffffu || (size_t)g->P * g->lddy * 4 >= 0x7fffffffu) return 0;     // 32-bit buffer offsets
+    return 1;
+}
+// bm: the square channel tile conv_igemm.hip planned the grid for (128 or 64); the grid is g.S * taps * g.ct * g.kt workgroups.
+extern "C" __attribute__((visibility("hidden"))) int kpx_wgrad3_launch(WgradGeom g, int bm, int terms, hipStream_t s) {
+    const dim3 grid((unsigned)(g.S * g.KH * g.KW * g.ct * g.kt));
+    if (bm == 128) {
+        constexpr int lds = 3 * 256 * G3_PITCH;
+        if (terms == 1) hipLaunchKernelGGL((conv_wgrad3_kernel<128, 2, 4, 1>), grid, dim3(512), lds / 3, s, g);
+        else hipLaunchKernelGGL((conv_wgrad3_kernel<128, 2, 4, 3>), grid, dim3(512), lds, s, g);
+    } else {
+        constexpr int lds = 3 * 128 * G3_PITCH;
+        if (terms == 1) hipLaunchKernelGGL((conv_wgrad3_kernel<64, 2, 2, 1>), grid, dim3(256), lds / 3, s, g);
+        else hipLaunchKernelGGL((conv_wgrad3_kernel<64, 2, 2, 3>), grid, dim3(256), lds, s, g);
+    }
+    return kpx_launch_status();
+}

@@ -26,3 +26,17 @@ struct ConvGeom {
                     // contiguous in NHWC, so they are treated as one tap with KW*Cin channels (per-element x bounds)
 };
 
+
+// Weight gradient dw[tap][c][k] = sum_p x[p shifted by tap][c] * dy[p][k]: GEMM with M = Cin, N = Cout, K = pixels, split over workgroups
+// along K (fixed-order reduction of the partial slabs afterwards: bitwise reproducible, no float atomics).
+struct WgradGeom {
+    const float* x; const float* dy; float* out;
+    int N, Hi, Wi, Cin, ldx;
+    int Ho, Wo, Cout, lddy;
+    int KH, KW, stride, pad_t, pad_l;
+    int P, S, pps;          // pixels, splits, pixels per split (multiple of 16)
+    int ct, kt;             // channel tiles
+    int vecA, vecB;
+    int merge;              // >0: row-merged taps (see ConvGeom::merge); Cin/KW below are the merged values
+    size_t slab;            // floats per slab = KH*KW*Cin*Cout
+};

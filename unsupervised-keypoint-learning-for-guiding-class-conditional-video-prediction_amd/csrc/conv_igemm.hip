@@ -428,6 +428,8 @@ static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
 // conv_gemm3.hip: the same gather convolution on the bf16 matrix pipe with fp32 operands split into three bf16 terms (fp32-equivalent)
 extern "C" __attribute__((visibility("hidden"))) int kpx_gemm3_eligible(const ConvGeom* g);
 extern "C" __attribute__((visibility("hidden"))) int kpx_gemm3_launch(ConvGeom g, int bt, int terms, hipStream_t s);
+extern "C" __attribute__((visibility("hidden"))) int kpx_wgrad3_eligible(const WgradGeom* g);
+extern "C" __attribute__((visibility("hidden"))) int kpx_wgrad3_launch(WgradGeom g, int bm, int terms, hipStream_t s);
 
 template <bool BT>
 static int launch_gather_conv(const ConvGeom& g, hipStream_t s) {
@@ -645,17 +647,6 @@ extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int 
 // and the MFMA operands are ds_read_b32 (32 consecutive channels per half-wave, conflict-free).
 // The pixel range is split over blocks (split-K); partial slabs are summed by wgrad_reduce_kernel in a
 // fixed order, so the result is bitwise reproducible (no float atomics).
-struct WgradGeom {
-    const float* x; const float* dy; float* out;
-    int N, Hi, Wi, Cin, ldx;
-    int Ho, Wo, Cout, lddy;
-    int KH, KW, stride, pad_t, pad_l;
-    int P, S, pps;          // pixels, splits, pixels per split (multiple of 16)
-    int ct, kt;             // channel tiles
-    int vecA, vecB;
-    int merge;              // >0: row-merged taps (see ConvGeom::merge); Cin/KW below are the merged values
-    size_t slab;            // floats per slab = KH*KW*Cin*Cout
-};
 
 template <int BMc, int BNk, int WM, int WN, bool VEC, bool MERGE>
 __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_kernel(const WgradGeom g) {
@@ -1308,7 +1299,11 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     if (!x || !dy || !dw || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || lddy < Cout)
         return KPX_EINVAL;
-    if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && ldx % 4 == 0 && lddy % 4 == 0 &&
+    // KPX_WGRAD3_FIRST (tuning): 1 = the bf16x3 kernel (conv_gemm3.hip) ahead of the specialised fp32 kernels below except the Winograd
+    // weight gradient; 2 = ahead of that one too.  Default 0: only where the generic fp32 kernel would run.
+    const int g3_first = (kpx_env()->no_gemm3 || kpx_env()->no_wgrad3 || Cin % 4 || Cout % 4 || Cin < 16 || Cout < 16 || ldx % 4 || lddy % 4 ||
+                          !aligned16(x) || !aligned16(dy)) ? 0 : kpx_env()->wgrad3_first;
+    if (g3_first < 2 && KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && ldx % 4 == 0 && lddy % 4 == 0 &&
         ldx >= ((Cin + 3) & ~3) && aligned16(x) && aligned16(dy)) {
         const int Sw = kpx_wino_wgrad_splits(N, Hi, Wi, Cin, Cout);
         const size_t slab = (size_t)9 * Cin * Cout;
@@ -1322,7 +1317,7 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     }
     {
         int S2, cpb;
-        if (stride == 1 && ldx == Cin && lddy % 4 == 0 && aligned16(dy) && wgrad_rows_merged_plan(N, Ho, Wo, Cin, Cout, KH, KW, &S2, &cpb)) {
+        if (!g3_first && stride == 1 && ldx == Cin && lddy % 4 == 0 && aligned16(dy) && wgrad_rows_merged_plan(N, Ho, Wo, Cin, Cout, KH, KW, &S2, &cpb)) {
             WgradRowsGeom r{};
             r.x = x; r.dy = dy;
             r.N = N; r.Hi = Hi; r.Wi = Wi; r.Cin = Cin; r.ldx = ldx;
@@ -1343,7 +1338,7 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     {
         int S2, cpb, CT;
         const bool vec = (ldx % 4 == 0) && (lddy % 4 == 0) && (Cin % 4 == 0) && aligned16(x) && aligned16(dy);
-        if (stride == 1 && vec && wgrad_rows_plan(N, Ho, Wo, Cin, Cout, KH, KW, &S2, &cpb, &CT)) {
+        if (!g3_first && stride == 1 && vec && wgrad_rows_plan(N, Ho, Wo, Cin, Cout, KH, KW, &S2, &cpb, &CT)) {
             WgradRowsGeom r{};
             r.x = x; r.dy = dy;
             r.N = N; r.Hi = Hi; r.Wi = Wi; r.Cin = Cin; r.ldx = ldx;
@@ -1382,7 +1377,10 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     g.ct = (Cin + bm - 1) / bm; g.kt = (Cout + bn - 1) / bn;
     g.vecA = (ldx % 4 == 0) && aligned16(x);
     g.vecB = (lddy % 4 == 0) && aligned16(dy);
-    if (!kpx_env()->no_wtaprows && g.vecA && g.vecB && Cin % 4 == 0 && Cout % 4 == 0 && Wo % 32 == 0 && !wgrad_merge(Cin, ldx, KW)) {
+    // (strided layers: the bf16x3 kernel below beats the fp32 tap-rows kernel -- encoder conv_3 at N = 64: 0.152 vs 0.198 ms; the stride-1
+    //  layers that reach this point are faster on tap-rows / rows, and the 3x3 stride-1 layers on the Winograd weight gradient)
+    const bool g3_strided = stride > 1 && g.vecA && g.vecB && kpx_wgrad3_eligible(&g);
+    if (!g3_first && !g3_strided && !kpx_env()->no_wtaprows && g.vecA && g.vecB && Cin % 4 == 0 && Cout % 4 == 0 && Wo % 32 == 0 && !wgrad_merge(Cin, ldx, KW)) {
         // chunk-aligned split: same S as the generic plan, but in units of 32-pixel row chunks
         WgradTapGeom r{};
         r.x = x; r.dy = dy;
@@ -1412,6 +1410,12 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     hipStream_t s = kpx_stream(stream);
     const dim3 grid((unsigned)(g.S * taps * g.ct * g.kt));
     const bool vec = g.vecA && g.vecB && !g.merge;
+    if (vec && kpx_wgrad3_eligible(&g)) {                // bf16x3 (fp32-equivalent) weight gradient on the bf16 matrix pipe (conv_gemm3.hip)
+        int rc = kpx_wgrad3_launch(g, bm, kpx_env()->gemm3_terms, s);
+        if (rc) return rc;
+        if (g.S > 1) { launch_wgrad_reduce((const float*)workspace, dw, g.slab, g.S, s); rc = kpx_launch_status(); }
+        return rc;
+    }
     if (g.merge) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 2, 2, false, true>), grid, dim3(256), 0, s, g);
     else if (bm == 128 && vec) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 4, true, false>), grid, dim3(512), 0, s, g);
     else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 2, 4, false, false>), grid, dim3(512), 0, s, g);

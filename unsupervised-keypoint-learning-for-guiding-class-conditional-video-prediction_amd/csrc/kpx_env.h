@@ -13,7 +13,7 @@ struct KpxEnv {
     int ww_comin; long ww_target;
     int bf16_wide;
     int gauss_blocks, gauss_nt;
-    int no_gemm3, gemm3_terms;  // bf16x3 implicit-GEMM family (conv_gemm3.hip)
+    int no_gemm3, no_wgrad3, wgrad3_first, gemm3_terms;  // bf16x3 implicit-GEMM family (conv_gemm3.hip)
 };
 
 extern "C" __attribute__((visibility("hidden"))) const KpxEnv* kpx_env();

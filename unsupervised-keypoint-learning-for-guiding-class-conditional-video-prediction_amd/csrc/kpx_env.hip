@@ -40,6 +40,8 @@ static void env_parse(KpxEnv* e) {
     e->gauss_blocks = (int)env_long("KPX_GAUSS_BLOCKS", 768);
     e->gauss_nt = (int)env_long("KPX_GAUSS_NT", 1);
     e->no_gemm3 = env_flag("KPX_NO_GEMM3");
+    e->no_wgrad3 = env_flag("KPX_NO_WGRAD3");
+    e->wgrad3_first = (int)env_long("KPX_WGRAD3_FIRST", 0);
     e->gemm3_terms = (int)env_long("KPX_GEMM3_TERMS", 3);
 }
 
