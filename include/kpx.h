@@ -172,6 +172,20 @@ int kpx_bn_stats_from_tiles_f32(const float* tile_stats, size_t tile0, size_t nt
                                 float* mean, float* invstd, float* var_biased,
                                 float* moving_mean, float* moving_var, float decay, void* stream);
 /* invstd[c] = rsqrt(moving_var[c]+eps) for inference-mode BN (models/keypoint_model.py:48-50). */
+/* Train-mode batch norm of `groups` weight-sharing calls batched along N (the two pose_encoder calls of a pair, reference
+ * detector_translator_model.py:166-167, each with batch statistics of its own; layers.py:13-14): x = [groups][P pixels][C], one launch per
+ * phase for all groups.  Forward: statistics per group -- from tile_stats (per-tile sums of a convolution epilogue, tiles_per_group tiles per
+ * group, or NULL: a reduction pass over x) -- mean / invstd [groups][C] (outputs, kept for the backward), moving statistics updated once per
+ * group IN ORDER, then y = act(gamma * (x - mean) * invstd + beta).  Backward: dx, and dgamma / dbeta summed over the groups in order
+ * (accumulate != 0: added to what the destinations hold).  Bitwise identical to `groups` calls of kpx_bn_stats(_from_tiles)_f32 +
+ * kpx_bn_apply_f32 / of kpx_bn_bwd_f32.  scratch: kpx_bn_train_scratch_bytes(C, groups) bytes. */
+size_t kpx_bn_train_scratch_bytes(int C, int groups);
+int kpx_bn_train_fwd_f32(const float* x, size_t P, int groups, int C, int ldx, const float* tile_stats, size_t tiles_per_group,
+                         float eps, const float* gamma, const float* beta, float* mean, float* invstd,
+                         float* moving_mean, float* moving_var, float decay, float* y, int ldy, int act, void* scratch, void* stream);
+int kpx_bn_train_bwd_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int groups, int C,
+                         const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                         float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* scratch, void* stream);
 int kpx_bn_invstd_f32(const float* var, int C, float eps, float* invstd, void* stream);
 /* step 2: y = act((x-mean)*invstd*gamma + beta), act in {NONE, RELU} (tf.nn.relu networks/__init__.py:12...). */
 int kpx_bn_apply_f32(const float* x, size_t P, int C, int ldx, const float* mean, const float* invstd,

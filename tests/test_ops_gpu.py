@@ -685,3 +685,54 @@ def test_gemm3_bf16x3_is_fp32_equivalent_against_float64(kpx, dev, n, h, w, cin,
         assert errs['gemm3'][i] <= 1.5 * errs['fp32'][i] + 1e-7, (i, errs)
         assert errs['gemm3'][i] < 2e-6
     assert errs['gemm3'][:2] != errs['fp32'][:2]          # the two kernels really are different code paths
+
+
+@pytest.mark.parametrize('n,h,w,c,groups,with_tiles', [(4, 16, 16, 32, 2, False), (6, 8, 8, 20, 3, False), (4, 32, 32, 64, 2, True), (2, 16, 16, 6, 1, False)])
+def test_batched_batch_norm_equals_one_call_per_group_bit_for_bit(kpx, dev, n, h, w, c, groups, with_tiles):
+    """kpx_bn_train_fwd_f32 / kpx_bn_train_bwd_f32 (all weight-sharing calls of a batch in one launch per phase, a finalize workgroup per
+    channel looping over the groups) against `groups` calls of the single-group entries: same partial sums in the same order, so every
+    output -- y, mean, invstd, the moving statistics after the in-order updates, dx, dgamma, dbeta -- must be identical bit for bit."""
+    from kpx_amd._lib import lib, check
+    from kpx_amd import ops
+    rs = np.random.RandomState(c + groups)
+    x = torch.from_numpy(rs.randn(n, h, w, c).astype(np.float32)).to(dev)
+    dy = torch.from_numpy(rs.randn(n, h, w, c).astype(np.float32)).to(dev)
+    gamma = torch.from_numpy((rs.rand(c) + 0.5).astype(np.float32)).to(dev); beta = torch.from_numpy(rs.randn(c).astype(np.float32)).to(dev)
+    ng, pix, st = n // groups, (n // groups) * h * w, ops._stream()
+    slab = None
+    if with_tiles:                                         # per-tile sums as a convolution epilogue would deliver them: 16x16-pixel tiles
+        tiles = x.reshape(n, h // 16, 16, w // 16, 16, c).permute(0, 1, 3, 2, 4, 5).reshape(-1, 256, c)
+        slab = torch.stack([tiles.sum(1), (tiles * tiles).sum(1)], dim=1).contiguous()
+        tpi = (h // 16) * (w // 16)
+    out = {}
+    for mode in ('per_group', 'batched'):
+        mm, mv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        mean, invstd = torch.empty(groups, c, device=dev), torch.empty(groups, c, device=dev)
+        y, dx = torch.empty_like(x), torch.empty_like(x)
+        dg, db = torch.full((c,), 7.0, device=dev), torch.full((c,), -3.0, device=dev)
+        if mode == 'per_group':
+            sc = ops.scratch.reduce(c, dev)
+            for g in range(groups):
+                xg, yg = x[g * ng:(g + 1) * ng], y[g * ng:(g + 1) * ng]
+                if slab is not None:
+                    check(lib.kpx_bn_stats_from_tiles_f32(slab.data_ptr(), g * ng * tpi, ng * tpi, 256, c, 1e-5, mean[g].data_ptr(), invstd[g].data_ptr(), None,
+                                                          mm.data_ptr(), mv.data_ptr(), 0.999, st), 'stats_from_tiles')
+                else:
+                    check(lib.kpx_bn_stats_f32(xg.data_ptr(), pix, c, c, 1e-5, mean[g].data_ptr(), invstd[g].data_ptr(), None, mm.data_ptr(), mv.data_ptr(), 0.999,
+                                               sc.data_ptr(), st), 'stats')
+                check(lib.kpx_bn_apply_f32(xg.data_ptr(), pix, c, c, mean[g].data_ptr(), invstd[g].data_ptr(), gamma.data_ptr(), beta.data_ptr(), yg.data_ptr(), c, 1, st), 'apply')
+            for g in range(groups):
+                sl = slice(g * ng, (g + 1) * ng)
+                check(lib.kpx_bn_bwd_f32(dy[sl].data_ptr(), c, x[sl].data_ptr(), c, pix, c, mean[g].data_ptr(), invstd[g].data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1,
+                                         dx[sl].data_ptr(), c, dg.data_ptr(), db.data_ptr(), 1, sc.data_ptr(), st), 'bwd')
+        else:
+            sc = ops.scratch.get('bn_test', lib.kpx_bn_train_scratch_bytes(c, groups), dev)
+            check(lib.kpx_bn_train_fwd_f32(x.data_ptr(), pix, groups, c, c, slab.data_ptr() if slab is not None else None, ng * tpi if slab is not None else 0, 1e-5,
+                                           gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), invstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), 0.999,
+                                           y.data_ptr(), c, 1, sc.data_ptr(), st), 'train_fwd')
+            check(lib.kpx_bn_train_bwd_f32(dy.data_ptr(), c, x.data_ptr(), c, pix, groups, c, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1,
+                                           dx.data_ptr(), c, dg.data_ptr(), db.data_ptr(), 1, sc.data_ptr(), st), 'train_bwd')
+        torch.cuda.synchronize()
+        out[mode] = [t2n(t).copy() for t in (y, mean, invstd, mm, mv, dx, dg, db)]
+    for a, b, name in zip(out['per_group'], out['batched'], ('y', 'mean', 'invstd', 'moving_mean', 'moving_var', 'dx', 'dgamma', 'dbeta')):
+        assert np.array_equal(a, b), name

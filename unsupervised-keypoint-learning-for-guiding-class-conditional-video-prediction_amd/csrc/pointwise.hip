@@ -100,6 +100,9 @@ struct RedArgs {
     size_t P; int C;
     const float* mean; const float* invstd; const float* gamma; const float* beta; int act;
     double* part;       // [gridDim.x][2][C]
+    // blockIdx.z = group g of a batched launch (weight-sharing calls with statistics of their own): x, dy advance by P pixels, mean /
+    // invstd by C, the partials by part_gstride doubles per group (all 0 / unused for the plain single-group entries)
+    size_t part_gstride;
 };
 
 template <int MODE, bool VEC>
@@ -112,6 +115,9 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const RedArgs a) {
     const int cgl = t % Gb, prow = t / Gb;
     const int cg = blockIdx.y * Gb + cgl;
     const bool active = prow < PPB && cg < G;
+    const int grp = blockIdx.z;
+    const float* const gx = a.x + (size_t)grp * a.P * a.ldx;
+    const float* const gdy = MODE == 2 ? a.dy + (size_t)grp * a.P * a.lddy : nullptr;
     double s0[W], s1[W];
 #pragma unroll
     for (int j = 0; j < W; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const RedArgs a) {
 #pragma unroll
         for (int j = 0; j < W; ++j) {
             const int c = cg * W + j;
-            mu[j] = a.mean[c]; is[j] = a.invstd[c]; ga[j] = a.gamma[c]; be[j] = a.beta[c];
+            mu[j] = a.mean[grp * a.C + c]; is[j] = a.invstd[grp * a.C + c]; ga[j] = a.gamma[c]; be[j] = a.beta[c];
         }
     }
     if (active) {
@@ -134,17 +140,17 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const RedArgs a) {
                 const size_t p = p0 + u * step;
                 const bool in = p < a.P;
                 if (VEC) {
-                    const f32x4 v = in ? *reinterpret_cast<const f32x4*>(a.x + p * a.ldx + cg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 v = in ? *reinterpret_cast<const f32x4*>(gx + p * a.ldx + cg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < W; ++j) xv[u][j] = v[j];
                     if (MODE == 2) {
-                        const f32x4 d = in ? *reinterpret_cast<const f32x4*>(a.dy + p * a.lddy + cg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        const f32x4 d = in ? *reinterpret_cast<const f32x4*>(gdy + p * a.lddy + cg * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int j = 0; j < W; ++j) gv[u][j] = d[j];
                     }
                 } else {
-                    xv[u][0] = a.x[p * a.ldx + cg];
-                    if (MODE == 2) gv[u][0] = a.dy[p * a.lddy + cg];
+                    xv[u][0] = gx[p * a.ldx + cg];
+                    if (MODE == 2) gv[u][0] = gdy[p * a.lddy + cg];
                 }
             }
 #pragma unroll
@@ -174,13 +180,14 @@ __global__ __launch_bounds__(256) void chan_reduce_kernel(const RedArgs a) {
             double r0 = 0.0, r1 = 0.0;
             for (int pr = 0; pr < PPB; ++pr) { r0 += sm[0][(pr * Gb + t) * W + j]; r1 += sm[1][(pr * Gb + t) * W + j]; }
             const int c = (blockIdx.y * Gb + t) * W + j;
-            a.part[((size_t)blockIdx.x * 2 + 0) * a.C + c] = r0;
-            a.part[((size_t)blockIdx.x * 2 + 1) * a.C + c] = r1;
+            double* const gp = a.part + (size_t)grp * a.part_gstride;
+            gp[((size_t)blockIdx.x * 2 + 0) * a.C + c] = r0;
+            gp[((size_t)blockIdx.x * 2 + 1) * a.C + c] = r1;
         }
     }
 }
 
-static int launch_chan_reduce(int mode, RedArgs a, int* nb_out, hipStream_t s) {
+static int launch_chan_reduce(int mode, RedArgs a, int* nb_out, hipStream_t s, int groups = 1) {
     const bool vec = (a.C % 4 == 0) && (a.ldx % 4 == 0) && (((uintptr_t)a.x) & 15) == 0 &&
                      (mode != 2 || ((a.lddy % 4 == 0) && (((uintptr_t)a.dy) & 15) == 0));
     const int G = vec ? a.C / 4 : a.C;
@@ -190,7 +197,7 @@ static int launch_chan_reduce(int mode, RedArgs a, int* nb_out, hipStream_t s) {
     if (nb < 1) nb = 1;
     if (nb > KPX_RED_BLOCKS) nb = KPX_RED_BLOCKS;
     *nb_out = (int)nb;
-    const dim3 grid((unsigned)nb, (unsigned)((G + Gb - 1) / Gb)), block(256);
+    const dim3 grid((unsigned)nb, (unsigned)((G + Gb - 1) / Gb), (unsigned)groups), block(256);
 #define KPX_RED(M) \
     do { if (vec) hipLaunchKernelGGL((chan_reduce_kernel<M, true>), grid, block, 0, s, a); \
          else hipLaunchKernelGGL((chan_reduce_kernel<M, false>), grid, block, 0, s, a); } while (0)
@@ -383,6 +390,8 @@ __global__ __launch_bounds__(256) void bn_apply_strip_kernel(const float* __rest
     const int t = threadIdx.x, cgl = t % Gb, prow = t / Gb;
     const int cg = blockIdx.y * Gb + cgl;
     if (prow >= PPB || cg >= G) return;
+    // blockIdx.z = group of a batched launch: P pixels and C statistics further on (gridDim.z = 1 for the plain entry)
+    x += (size_t)blockIdx.z * P * ldx; y += (size_t)blockIdx.z * P * ldy; mean += blockIdx.z * C; invstd += blockIdx.z * C;
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cg * 4), is = *reinterpret_cast<const f32x4*>(invstd + cg * 4);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + cg * 4), be = *reinterpret_cast<const f32x4*>(beta + cg * 4);
     const size_t step = (size_t)gridDim.x * PPB;
@@ -413,6 +422,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_strip_kernel(const float* __
     const int t = threadIdx.x, cgl = t % Gb, prow = t / Gb;
     const int cg = blockIdx.y * Gb + cgl;
     if (prow >= PPB || cg >= G) return;
+    dy += (size_t)blockIdx.z * P * lddy; x += (size_t)blockIdx.z * P * ldx; dx += (size_t)blockIdx.z * P * lddx;       // group of a batched launch
+    mean += blockIdx.z * C; invstd += blockIdx.z * C; sums += blockIdx.z * 2 * C;
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cg * 4), is = *reinterpret_cast<const f32x4*>(invstd + cg * 4);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + cg * 4), be = *reinterpret_cast<const f32x4*>(beta + cg * 4);
     const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + cg * 4), s1 = *reinterpret_cast<const f32x4*>(sums + C + cg * 4);
@@ -443,12 +454,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_strip_kernel(const float* __
         }
     }
 }
-static inline dim3 strip_grid(size_t P, int C) {
+static inline dim3 strip_grid(size_t P, int C, int groups = 1) {
     const int G = C >> 2, Gb = G < 256 ? G : 256, PPB = 256 / Gb;
     size_t nb = (P + (size_t)PPB * 4 - 1) / ((size_t)PPB * 4);
     if (nb < 1) nb = 1;
     if (nb > KPX_MAX_BLOCKS) nb = KPX_MAX_BLOCKS;
-    return dim3((unsigned)nb, (unsigned)((G + Gb - 1) / Gb));
+    return dim3((unsigned)nb, (unsigned)((G + Gb - 1) / Gb), (unsigned)groups);
 }
 
 extern "C" int kpx_bn_apply_f32(const float* x, size_t P, int C, int ldx, const float* mean, const float* invstd,
@@ -543,6 +554,140 @@ extern "C" int kpx_bn_bwd_from_tiles_f32(const float* dy, int lddy, const float*
     if (vec) hipLaunchKernelGGL(bn_bwd_apply_strip_kernel, strip_grid(P, C), dim3(256), 0, s, dy, lddy, x, ldx, P, C, mean, invstd, gamma, beta, act, sums, inv_count, dx, lddx);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(P * C)), dim3(256), 0, s, dy, lddy, x, ldx, P, C, mean, invstd, gamma, beta, act, sums, inv_count, dx, lddx);
     return kpx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------ batched batch norm
+// The weight-sharing calls of the path (the two pose_encoder calls of one pair, reference detector_translator_model.py:166-167) run as ONE
+// batch with `groups` sets of statistics: consecutive groups of P pixels, mean / invstd [groups][C], moving statistics updated once per
+// group IN ORDER, gamma / beta gradients summed over the groups in order.  One launch per phase for all groups (blockIdx.z), one finalize
+// workgroup per channel looping over the groups -- the same partial sums in the same order as `groups` separate calls: same bits.
+__global__ __launch_bounds__(256) void bn_stats_finalize_groups_kernel(const double* part, size_t part_gstride, int nb, const float* __restrict__ ts, size_t tiles_per_group,
+                                                                      int groups, int C, double count, float eps, float* mean, float* invstd,
+                                                                      float* mm, float* mv, float decay) {
+    const int c = blockIdx.x;
+    __shared__ double sm[2][4];
+    for (int g = 0; g < groups; ++g) {
+        double a0 = 0.0, a1 = 0.0;
+        if (ts) {                                          // per-tile sums from a convolution epilogue (floats)
+            const size_t t0 = (size_t)g * tiles_per_group;
+            for (size_t b = threadIdx.x; b < tiles_per_group; b += 256) {
+                a0 += (double)ts[((t0 + b) * 2) * C + c];
+                a1 += (double)ts[((t0 + b) * 2 + 1) * C + c];
+            }
+        } else {                                           // block partials of chan_reduce_kernel<1> (doubles)
+            const double* gp = part + (size_t)g * part_gstride;
+            for (int b = threadIdx.x; b < nb; b += 256) {
+                a0 += gp[((size_t)b * 2) * C + c];
+                a1 += gp[((size_t)b * 2 + 1) * C + c];
+            }
+        }
+        a0 = kpx_wave_sum_d(a0);
+        a1 = kpx_wave_sum_d(a1);
+        __syncthreads();                                   // (sm is reused per group)
+        if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a0; sm[1][threadIdx.x >> 6] = a1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double s = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]), q = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
+            const double m = s / count;
+            double v = q / count - m * m;
+            if (v < 0.0) v = 0.0;
+            const float mf = (float)m, vf = (float)v;
+            mean[g * C + c] = mf;
+            invstd[g * C + c] = 1.0f / sqrtf(vf + eps);
+            if (mm && mv) {
+                const float one_minus = 1.0f - decay;
+                const float unb = (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+                mm[c] = mm[c] - (mm[c] - mf) * one_minus;
+                mv[c] = mv[c] - (mv[c] - unb) * one_minus;
+            }
+        }
+    }
+}
+extern "C" int kpx_bn_train_fwd_f32(const float* x, size_t P, int groups, int C, int ldx, const float* tile_stats, size_t tiles_per_group,
+                                    float eps, const float* gamma, const float* beta, float* mean, float* invstd,
+                                    float* moving_mean, float* moving_var, float decay, float* y, int ldy, int act, void* scratch, void* stream) {
+    if (!x || !y || !gamma || !beta || !mean || !invstd || !scratch || groups <= 0 || groups > 65535 || C <= 0 || ldx < C || ldy < C || act < 0 || act > 1 || P == 0)
+        return KPX_EINVAL;
+    hipStream_t s = kpx_stream(stream);
+    const size_t gstride = (size_t)KPX_RED_BLOCKS * 2 * C;
+    int nb = 0;
+    if (!tile_stats) {
+        RedArgs a{}; a.x = x; a.ldx = ldx; a.P = P; a.C = C; a.part = (double*)scratch; a.part_gstride = gstride;
+        int rc = launch_chan_reduce(1, a, &nb, s, groups);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(bn_stats_finalize_groups_kernel, dim3(C), dim3(256), 0, s, (const double*)scratch, gstride, nb, tile_stats, tiles_per_group,
+                       groups, C, (double)P, eps, mean, invstd, moving_mean, moving_var, decay);
+    int rc = kpx_launch_status();
+    if (rc) return rc;
+    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0;
+    if (vec) {
+        hipLaunchKernelGGL(bn_apply_strip_kernel, strip_grid(P, C, groups), dim3(256), 0, s, x, P, C, ldx, mean, invstd, gamma, beta, y, ldy, act);
+        return kpx_launch_status();
+    }
+    for (int g = 0; g < groups; ++g) {
+        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(grid_for(P * C)), dim3(256), 0, s, x + (size_t)g * P * ldx, P, C, ldx, mean + g * C, invstd + g * C,
+                           gamma, beta, y + (size_t)g * P * ldy, ldy, act);
+        if ((rc = kpx_launch_status())) return rc;
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_groups_kernel(const double* part, size_t part_gstride, int nb, int groups, int C,
+                                                                    float* dgamma, float* dbeta, float* sums, int accumulate) {
+    const int c = blockIdx.x;
+    __shared__ double sm[2][4];
+    for (int g = 0; g < groups; ++g) {
+        const double* gp = part + (size_t)g * part_gstride;
+        double a0 = 0.0, a1 = 0.0;
+        for (int b = threadIdx.x; b < nb; b += 256) {
+            a0 += gp[((size_t)b * 2) * C + c];
+            a1 += gp[((size_t)b * 2 + 1) * C + c];
+        }
+        a0 = kpx_wave_sum_d(a0);
+        a1 = kpx_wave_sum_d(a1);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a0; sm[1][threadIdx.x >> 6] = a1; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const double s = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]), q = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
+            if (accumulate || g > 0) { dbeta[c] += (float)s; dgamma[c] += (float)q; } else { dbeta[c] = (float)s; dgamma[c] = (float)q; }
+            sums[(size_t)g * 2 * C + c] = (float)s; sums[(size_t)g * 2 * C + C + c] = (float)q;
+        }
+    }
+}
+extern "C" int kpx_bn_train_bwd_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int groups, int C,
+                                    const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                                    float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* scratch, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !scratch || groups <= 0 || groups > 65535 || C <= 0 ||
+        ldx < C || lddy < C || lddx < C || act < 0 || act > 1 || P == 0)
+        return KPX_EINVAL;
+    hipStream_t s = kpx_stream(stream);
+    const size_t gstride = (size_t)KPX_RED_BLOCKS * 2 * C;
+    RedArgs a{}; a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.P = P; a.C = C;
+    a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.act = act; a.part = (double*)scratch; a.part_gstride = gstride;
+    int nb; int rc = launch_chan_reduce(2, a, &nb, s, groups);
+    if (rc) return rc;
+    float* sums = reinterpret_cast<float*>((double*)scratch + (size_t)groups * gstride);          // [groups][2][C] behind the partials
+    hipLaunchKernelGGL(bn_bwd_finalize_groups_kernel, dim3(C), dim3(256), 0, s, (const double*)scratch, gstride, nb, groups, C, dgamma, dbeta, sums, accumulate);
+    if ((rc = kpx_launch_status())) return rc;
+    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
+    const float inv_count = (float)(1.0 / (double)P);
+    if (vec) {
+        hipLaunchKernelGGL(bn_bwd_apply_strip_kernel, strip_grid(P, C, groups), dim3(256), 0, s, dy, lddy, x, ldx, P, C, mean, invstd, gamma, beta, act, sums, inv_count, dx, lddx);
+        return kpx_launch_status();
+    }
+    for (int g = 0; g < groups; ++g) {
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(P * C)), dim3(256), 0, s, dy + (size_t)g * P * lddy, lddy, x + (size_t)g * P * ldx, ldx, P, C,
+                           mean + g * C, invstd + g * C, gamma, beta, act, sums + (size_t)g * 2 * C, inv_count, dx + (size_t)g * P * lddx, lddx);
+        if ((rc = kpx_launch_status())) return rc;
+    }
+    return 0;
+}
+// scratch of the two entries above: per group the partials of kpx_chan_reduce_scratch_bytes + 2 C floats
+extern "C" size_t kpx_bn_train_scratch_bytes(int C, int groups) {
+    const size_t c = (size_t)(C > 0 ? C : 1), g = (size_t)(groups > 0 ? groups : 1);
+    return g * ((size_t)KPX_RED_BLOCKS * 2 * c * sizeof(double) + ((2 * c * sizeof(float) + 15) & ~(size_t)15));
 }
 
 // ------------------------------------------------------------------------------------------ bilinear x2 (legacy TF sampling)

@@ -609,27 +609,23 @@ class BatchNormFn(torch.autograd.Function):
         assert n % groups == 0
         y = torch.empty_like(x)
         dev = x.device
-        sc = scratch.reduce(c, dev)
         if train:
+            # all `groups` weight-sharing calls in one launch per phase (statistics finalize + apply; + one reduction pass when the
+            # producing convolution's epilogue did not deliver the per-tile sums)
             mean = torch.empty((groups, c), dtype=torch.float32, device=dev)
             invstd = torch.empty((groups, c), dtype=torch.float32, device=dev)
             ng = n // groups
             pix = ng * h * w
-            for g in range(groups):
-                xg, yg = x[g * ng:(g + 1) * ng], y[g * ng:(g + 1) * ng]
-                mmp = moving_mean.data_ptr() if update_moving else None
-                mvp = moving_var.data_ptr() if update_moving else None
-                if tile_stats is not None:               # sums from the producing convolution's epilogue: no pass over x
-                    slab, tpi = tile_stats
-                    fused_bn_uses['stats_from_conv_epilogue'] += 1
-                    check(lib.kpx_bn_stats_from_tiles_f32(slab.data_ptr(), g * ng * tpi, ng * tpi, (h * w) // tpi, c, BN_EPS,
-                                                          mean[g].data_ptr(), invstd[g].data_ptr(), None, mmp, mvp, BN_DECAY, _stream()),
-                          'kpx_bn_stats_from_tiles_f32')
-                else:
-                    check(lib.kpx_bn_stats_f32(xg.data_ptr(), pix, c, c, BN_EPS, mean[g].data_ptr(), invstd[g].data_ptr(), None,
-                                               mmp, mvp, BN_DECAY, sc.data_ptr(), _stream()), 'kpx_bn_stats_f32')
-                check(lib.kpx_bn_apply_f32(xg.data_ptr(), pix, c, c, mean[g].data_ptr(), invstd[g].data_ptr(),
-                                           gamma.data_ptr(), beta.data_ptr(), yg.data_ptr(), c, act, _stream()), 'kpx_bn_apply_f32')
+            sc = scratch.get('bn%d' % groups, lib.kpx_bn_train_scratch_bytes(c, groups), dev)
+            slab_ptr, tpg = None, 0
+            if tile_stats is not None:                   # sums from the producing convolution's epilogue: no pass over x
+                slab, tpi = tile_stats
+                fused_bn_uses['stats_from_conv_epilogue'] += groups
+                slab_ptr, tpg = slab.data_ptr(), ng * tpi
+            check(lib.kpx_bn_train_fwd_f32(x.data_ptr(), pix, groups, c, c, slab_ptr, tpg, BN_EPS, gamma.data_ptr(), beta.data_ptr(),
+                                           mean.data_ptr(), invstd.data_ptr(), moving_mean.data_ptr() if update_moving else None,
+                                           moving_var.data_ptr() if update_moving else None, BN_DECAY, y.data_ptr(), c, act, sc.data_ptr(), _stream()),
+                  'kpx_bn_train_fwd_f32')
         else:
             mean = moving_mean.reshape(1, c)
             invstd = torch.empty((1, c), dtype=torch.float32, device=dev)
@@ -659,10 +655,17 @@ class BatchNormFn(torch.autograd.Function):
         if ctx.g_grad_out is not None:
             fresh = _claim_grad(ctx.g_grad_out)
             _claim_grad(ctx.b_grad_out)
-        sc = scratch.reduce(c, dev)
         ent = _pending_bwd_stats.pop(dy.data_ptr(), None)        # sums reduced by the epilogue of the dgrad kernel that produced dy
         if ent is not None and (ent[2] != ctx.bn_id or ctx.act != ACT_RELU or tuple(ent[0].shape) != (n * ent[1] * 2 * c,)):
             ent = None
+        if ent is None:                                          # reduction, finalize, apply: one launch each for all groups
+            sc = scratch.get('bn%d' % groups, lib.kpx_bn_train_scratch_bytes(c, groups), dev)
+            check(lib.kpx_bn_train_bwd_f32(dy.data_ptr(), c, x.data_ptr(), c, pix, groups, c, mean.data_ptr(), invstd.data_ptr(),
+                                           gamma.data_ptr(), beta.data_ptr(), ctx.act, dx.data_ptr(), c, dg.data_ptr(), db.data_ptr(),
+                                           0 if fresh else 1, sc.data_ptr(), _stream()), 'kpx_bn_train_bwd_f32')
+            return (dx, None if ctx.g_grad_out is not None else dg, None if ctx.b_grad_out is not None else db,
+                    None, None, None, None, None, None, None, None, None, None)
+        sc = scratch.reduce(c, dev)
         for g in range(groups):
             sl = slice(g * ng, (g + 1) * ng)
             acc = 0 if (g == 0 and fresh) else 1        # later groups (and a variable already written this epoch) accumulate in the finalize kernel
