@@ -329,6 +329,7 @@ def main():
                          'data gradient of the 3x3 stride-1 layers on the bf16 matrix pipe (fp32 tensors, accumulate, master weights, BN '
                          'statistics, weight gradients); a SEPARATE configuration, never the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true', help='skip the kernel microbenchmarks after the timed steps (clean per-step rocprofv3 kernel statistics)')
     ap.add_argument('--roofline-only', action='store_true', help='only the two kernel microbenchmarks (used for the rocprofv3 cross-check)')
     args = ap.parse_args()
 
@@ -437,7 +438,7 @@ def main():
                                % (1, getattr(model, '_graph_launches', 0))) if graphed else 'eager: every kernel enqueued from Python',
                'host_abi_calls_per_step': round(calls_per_step, 1),
                'loss_D': round(losses['loss_D'], 5), 'loss_G': round(losses['loss_G'], 5)}
-        if world == 1:
+        if world == 1 and not args.no_roofline:
             kops.set_compute_dtype('f32')
             if args.dtype == 'bf16':
                 out['roofline_bf16_conv'] = roofline_conv_bf16(dev)

@@ -1,0 +1,70 @@
+#!/bin/bash
+# Round-3 profile collection, run on the GPU box from the repo root:   bash profiles/collect_r03.sh
+# Writes raw rocprofv3 output under gpurun_out/r03/ and the summaries that are committed under profiles/ (names r03_*).
+cd /tmp && export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:-/root/repo}" || exit 1
+O=gpurun_out/r03; mkdir -p $O
+if [ "$1" != "post" ]; then
+HEAD=$(cat .git_head 2>/dev/null || echo unknown)
+# 1. the bench lines (headline c1 with graph replay and eager, c3, c4)
+python3 bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err
+KPX_GRAPH=0 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_eager.json 2>/dev/null
+python3 bench.py --config c3 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_c3.json 2>/dev/null
+python3 bench.py --config c4 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_c4.json 2>/dev/null
+# 2. per-kernel statistics of the step alone (13 profiled steps, eager launches: one trace record per kernel either way)
+KPX_GRAPH=0 rocprofv3 --kernel-trace --stats -d $O/step -o s --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_profiled.json 2>/dev/null
+KPX_GRAPH=0 rocprofv3 --kernel-trace --stats -d $O/step_c3 -o s --output-format csv -- python3 bench.py --config c3 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $O/bench_c3_profiled.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d $O/step_c4 -o s --output-format csv -- python3 bench.py --config c4 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_c4_profiled.json 2>/dev/null
+# 3. the roofline micro-benchmarks alone (kernel averages must agree with the bench line's avg_launch_ms)
+rocprofv3 --kernel-trace --stats -d $O/roof -o s --output-format csv -- python3 bench.py --roofline-only > $O/roofline_only.json 2>/dev/null
+# 4. PMC, separate passes (FETCH_SIZE and WRITE_SIZE do not fit one pass; never with --stats / sys-trace)
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
+  d=$O/pmc_$(echo $c | tr ' ' '_' | cut -c1-24)
+  rocprofv3 --pmc $c --kernel-trace -d $d -o p --output-format csv -- python3 bench.py --roofline-only > /dev/null 2>&1
+done
+# (gpurun merges only gpurun_out/ back: run this post-processing step again in the build container -- `bash profiles/collect_r03.sh post` --
+#  to copy the summaries into profiles/)
+fi
+python3 - <<'PY'
+import csv, glob, collections, json, shutil, os, subprocess
+O = 'gpurun_out/r03'
+def cp(pattern, dst):
+    f = glob.glob(pattern, recursive=True)
+    if f: shutil.copy(f[0], 'profiles/' + dst)
+cp(O + '/step/**/*kernel_stats.csv', 'r03_step_kernel_stats.csv')
+cp(O + '/step_c3/**/*kernel_stats.csv', 'r03_step_c3_kernel_stats.csv')
+cp(O + '/step_c4/**/*kernel_stats.csv', 'r03_step_c4_kernel_stats.csv')
+cp(O + '/roof/**/*kernel_stats.csv', 'r03_roofline_only_kernel_stats.csv')
+for f, dst in (('bench.json', 'r03_bench.json'), ('bench_eager.json', 'r03_bench_eager.json'), ('bench_c3.json', 'r03_bench_c3.json'), ('bench_c4.json', 'r03_bench_c4.json'),
+               ('roofline_only.json', 'r03_roofline_only.json')):
+    if os.path.exists(os.path.join(O, f)): shutil.copy(os.path.join(O, f), 'profiles/' + dst)
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in sorted(glob.glob(O + '/pmc_*/**/*counter_collection.csv', recursive=True)):
+    for r in csv.DictReader(open(f)):
+        for key, tag in (('conv_wino43_kernel<0, false>', 'wino43'), ('conv_wino_v2_kernel<2, 0>', 'wino'), ('gauss_fwd', 'render'), ('conv_igemm_kernel<128, 128', 'direct')):
+            if key in r['Kernel_Name']:
+                pmc[tag][r['Counter_Name']].append(float(r['Counter_Value']))
+mean = lambda v: sum(v) / len(v) if v else None
+out = {tag: dict({c: mean(v) for c, v in d.items()}, dispatches={c: len(v) for c, v in d.items()}) for tag, d in pmc.items()}
+json.dump(out, open(O + '/pmc_raw.json', 'w'), indent=1)
+for tag, name, alg, kernel in (('wino43', 'r03_wino43_pmc.json', 134807552, 'conv_wino43_kernel<0, false> F(4x4,3x3) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)'),
+                               ('wino', 'r03_wino_pmc.json', 134807552, 'conv_wino_v2_kernel<2, 0> fwd 3x3 s1 128->128 @64x64 B=32'),
+                               ('render', 'r03_render_pmc.json', 62922240, 'gauss_fwd_reg_kernel [64,128,128,15], nine rotating 62.9 MB outputs')):
+    d = out.get(tag, {})
+    if d.get('WRITE_SIZE') is None: continue
+    # guide: FETCH_SIZE is in KB and counts 64 B per 128-B request on gfx950 wide reads -> x2; WRITE_SIZE (KB) is exact for 16-B stores
+    fetch, write = (d.get('FETCH_SIZE') or 0) * 1024 * 2, d['WRITE_SIZE'] * 1024
+    json.dump(dict({k: v for k, v in d.items() if k != 'dispatches'}, kernel=kernel, dispatches=d['dispatches'],
+                   source='rocprofv3 --pmc, separate passes (profiles/collect_r03.sh), mean over the dispatches of `bench.py --roofline-only`',
+                   fetch_bytes_corrected=fetch, write_bytes=write, algorithmic_bytes=alg, traffic_bytes_per_launch=fetch + write),
+              open('profiles/' + name, 'w'), indent=1)
+for csvf, steps, dst in (('profiles/r03_step_kernel_stats.csv', 13, 'profiles/r03_step_breakdown.txt'), ('profiles/r03_step_c3_kernel_stats.csv', 13, 'profiles/r03_step_c3_breakdown.txt')):
+    if os.path.exists(csvf):
+        txt = subprocess.run(['python3', 'profiles/step_breakdown.py', csvf, str(steps)], capture_output=True, text=True).stdout
+        open(dst, 'w').write(txt); print(txt)
+PY
+for f in bench bench_eager bench_c3 bench_c4; do python3 -c "
+import json,sys
+try:
+    d=json.loads(open('$O/$f.json').read().strip().split(chr(10))[-1]); print('$f', d['value'], d['unit'], d['ms_per_step'], 'host', d.get('host_enqueue_ms_per_step'))
+except Exception as e: print('$f ERR', e)"; done
