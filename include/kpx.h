@@ -40,6 +40,13 @@ int kpx_abi_version(void);
  * launches.  Returns 0.  (No reference counterpart: TF-1.12 reads its TF_* switches the same way, once.) */
 int kpx_reload_env(void);
 
+/* Arithmetic of the bf16-matrix-pipe implicit-GEMM kernels behind kpx_conv2d_fwd_f32 / _dgrad_f32 / _wgrad_f32 (csrc/conv_gemm3.hip):
+ * terms = 3 (default): every fp32 operand is split exactly into three bf16 terms and six partial products are accumulated in fp32 --
+ * fp32-equivalent, the fp32 configuration; terms = 1: operands rounded (truncated) to bf16, one product -- the bf16 configuration
+ * (BASELINE configs[2]).  Process-wide; returns the previous value or KPX_EINVAL.  Replaces nothing in the reference (TF-1.12 has no
+ * such switch): it selects which of the two configurations the same entry points compute. */
+int kpx_set_gemm3_terms(int terms);
+
 /* ---- convolution: replaces tf.pad + tf.layers.conv2d(padding='same') (models/networks/layers.py:6-9)
  *      and tf.nn.conv2d + bias_add + relu (models/networks/vgg.py:51-54).
  *      y[n,oh,ow,:] = act( sum_{r,q,c} x[n, oh*stride + r - pad_t, ow*stride + q - pad_l, c] * w[r,q,c,:] + bias )

@@ -514,7 +514,9 @@ def test_conv3x3_bf16_fwd_dgrad_tolerance(kpx, dev, n, h, w, cin, cout, act):
         kpx.ops.set_compute_dtype('f32')
     assert 1e-4 < err_f < 8e-3, err_f            # > 1e-4: the bf16 kernel really ran (the fp32 kernels give ~2e-7)
     assert err_d < 8e-3, err_d
-    assert err_w < 1e-5, err_w                   # weight gradients stay on the fp32 kernels (activation mask taken from the bf16 forward)
+    # weight gradients: the Winograd kernel (>= 64-wide channel tiles) stays fp32; layers on the direct kernel take bf16 operands in this mode
+    # (conv_wgrad3, one bf16 term) and carry the mode's tolerance
+    assert err_w < 8e-3, err_w
     # the fp32 path on the same inputs is unaffected by the mode switch
     y32 = kpx.ops.conv2d(torch.from_numpy(x).to(dev), torch.from_numpy(wt).to(dev), torch.from_numpy(b).to(dev), stride=1, pad=0, act=0, cin=cin)
     assert rel_l2(t2n(y32), t2n(zo)) < 1e-5

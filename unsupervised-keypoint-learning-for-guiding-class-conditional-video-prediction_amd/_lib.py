@@ -32,6 +32,7 @@ P = c_void_p
 SIGNATURES = {
     'kpx_abi_version': (c_int, []),
     'kpx_reload_env': (c_int, []),
+    'kpx_set_gemm3_terms': (c_int, [c_int]),
     'kpx_conv2d_fwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P,
                                    P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),

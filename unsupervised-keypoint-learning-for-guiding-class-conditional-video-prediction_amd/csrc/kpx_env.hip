@@ -63,3 +63,13 @@ extern "C" int kpx_reload_env(void) {
     g_env_loaded.store(1, std::memory_order_release);
     return 0;
 }
+
+// Number of bf16 terms the conv_gemm3 / conv_wgrad3 kernels split each fp32 operand into: 3 = fp32-equivalent (the default, the fp32
+// configuration), 1 = plain bf16 operands (the bf16 configuration, BASELINE configs[2]).  Returns the previous value, or KPX_EINVAL.
+extern "C" int kpx_set_gemm3_terms(int terms) {
+    if (terms != 1 && terms != 3) return KPX_EINVAL;
+    KpxEnv* e = const_cast<KpxEnv*>(kpx_env());
+    const int old = e->gemm3_terms;
+    e->gemm3_terms = terms;
+    return old;
+}

@@ -189,6 +189,13 @@ def set_compute_dtype(name):
     if name not in ('f32', 'bf16'):
         raise ValueError("compute dtype must be 'f32' or 'bf16'")
     _compute_dtype[0] = name
+    # the implicit-GEMM kernels of the strided / 4x4 / 1x1 layers and the direct weight gradients: three bf16 terms per fp32 operand
+    # (fp32-equivalent) or one (bf16 operands, fp32 accumulation)
+    lib.kpx_set_gemm3_terms(1 if name == 'bf16' else 3)
+
+
+if _compute_dtype[0] == 'bf16':
+    lib.kpx_set_gemm3_terms(1)
 
 
 def compute_dtype():
