@@ -841,3 +841,36 @@ def test_graph_replay_is_bit_identical_to_the_eager_step(monkeypatch):
     assert set(eager) == set(graphed)
     for name in eager:
         assert np.array_equal(eager[name], graphed[name]), name
+
+
+def test_rollout_graph_replay_is_bit_identical_to_the_eager_rollout(monkeypatch):
+    """FinalModel.run from its second call on a batch shape replays ONE captured HIP graph (final_model.GRAPH): on new inputs / a new latent the
+    replayed rollout must equal the launch-by-launch rollout bit for bit."""
+    import kpx_amd
+    import kpx_amd.final_model as fmod
+    dev = torch.device('cuda:0')
+    res, k, b, cells, vdim = 32, 3, 2, (64, 64), 8
+    cfg = {'model': {'n_pts': k, 'cell_info': list(cells), 'vae_dim': vdim, 'n_action': 9}, 'paths': {'log_dir': '/tmp/kpx_final'}}
+    arrays = {**R.init_variables(k, res=res, seed=77), **R.init_stage2_decoder(k, cell_info=cells, vae_dim=vdim, seed=78)}
+    arrays = {n: a for n, a in arrays.items() if not n.startswith('img_discr')}
+    rs = np.random.RandomState(9)
+    feeds = []
+    for i in range(3):
+        im, _ = R.synthetic_pair(b, res=res, seed0=50 + i, seed1=60 + i)
+        feeds.append((torch.from_numpy(im).to(dev), torch.from_numpy(np.eye(9, dtype=np.float32)[rs.randint(0, 9, size=b)]).to(dev),
+                      torch.from_numpy(rs.randn(b, vdim).astype(np.float32)).to(dev)))
+    outs = {}
+    for graph in (False, True):
+        monkeypatch.setattr(fmod, 'GRAPH', graph)
+        fm = kpx_amd.FinalModel(cfg, device=dev, image_size=res, frames_per_launch=32)
+        fm.build()
+        fm.store.load_numpy(arrays, strict=True)
+        outs[graph] = []
+        for im, act, z in feeds:
+            o = fm.run(None, {'image': im, 'action_code': act}, z=z)
+            outs[graph].append({k_: o[k_].cpu().numpy().copy() for k_ in ('pred_im_seq', 'mask', 'fut_pt_raw', 'first_pt')})
+        if graph:
+            assert len(fm._graphs) == 1 and not fm._graph_failed
+    for i in range(3):
+        for k_ in outs[False][i]:
+            assert np.array_equal(outs[False][i][k_], outs[True][i][k_]), (i, k_)

@@ -4,6 +4,9 @@ detector -> stage-2 vae_decoder (z ~ N(0,1), 32 LSTM steps) -> translator on B*3
 Only the tensors evaluate.py saves are produced; the colourised key-point visualisations (utils/model.py:13-46, unseeded
 ``random``) are out of scope.  ``z`` can be injected for deterministic parity tests (the reference draws it unseeded, :71).
 """
+import logging
+import os
+
 import torch
 
 from . import model_utils, networks, ops, variables
@@ -12,6 +15,11 @@ from .variables import Sym
 
 N_FUTURE_FRAMES = 32          # reference :11
 IMAGE_SIZE = 128              # reference :12
+# The rollout is ~1 500 small launches per call (32 LSTM steps, eight translator slabs): from the second call on a batch shape it is replayed
+# as ONE captured HIP graph (KPX_GRAPH=0: enqueue every launch from Python).  The returned tensors then live in the graph's buffers and are
+# overwritten by the next run() of the same shape -- evaluate.py consumes them before it calls run() again.
+GRAPH = os.environ.get('KPX_GRAPH', '1') != '0'
+log = logging.getLogger('kpx')
 
 
 class FinalModel(BaseModel):
@@ -30,6 +38,7 @@ class FinalModel(BaseModel):
         self.frames_per_launch = frames_per_launch      # translator slab size (B*32 frames are processed in slabs)
         self.device = ops.normalize_device(device)
         self.store = variables.VariableStore(device=self.device, seed=seed)
+        self._graphs, self._eager_runs, self._graph_failed = {}, {}, False
 
     def build(self, inputs=None):
         r, k, b = self.image_size, self.n_points, 2
@@ -43,7 +52,44 @@ class FinalModel(BaseModel):
 
     def run(self, sess, feed_dict, z=None):
         """reference run (:124-125).  feed_dict: {'image': [B,H,W,3] in [-1,1], 'action_code': [B,n_action] one-hot,
-        optional 'real_im_seq', 'real_seq'}."""
+        optional 'real_im_seq', 'real_seq'}.  z: the VAE latent [B, vae_dim]; drawn from N(0,1) when not given (:71)."""
+        im, act = feed_dict['image'], feed_dict['action_code']
+        if not (GRAPH and not self._graph_failed and im.is_cuda and im.dtype == torch.float32):
+            return self._run_eager(feed_dict, z)
+        if z is None:
+            z = torch.randn((im.shape[0], self.vae_dim), dtype=torch.float32, device=im.device)              # :71 (drawn outside the graph)
+        key = (tuple(im.shape), tuple(act.shape), im.device.index)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if self._eager_runs.get(key, 0) < 1:                     # one eager run first: it creates every lazily allocated buffer / attribute
+                self._eager_runs[key] = 1
+                return self._run_eager(feed_dict, z)
+            static = {'image': torch.empty_like(im, memory_format=torch.contiguous_format), 'action_code': torch.empty_like(act, memory_format=torch.contiguous_format),
+                      'z': torch.empty_like(z, memory_format=torch.contiguous_format)}
+            for k_, v in (('image', im), ('action_code', act), ('z', z)):
+                static[k_].copy_(v)
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    out = self._run_eager({'image': static['image'], 'action_code': static['action_code']}, static['z'])
+            except Exception as e:          # noqa: BLE001 -- whatever the runtime refuses: stay on the eager path
+                log.warning('HIP graph capture of the rollout failed (%s: %s); continuing with eager launches', type(e).__name__, e)
+                self._graph_failed = True
+                torch.cuda.synchronize(im.device)
+                return self._run_eager(feed_dict, z)
+            ent = self._graphs[key] = (graph, static, out)
+        graph, static, out = ent
+        for k_, v in (('image', im), ('action_code', act), ('z', z)):
+            v = v.contiguous()
+            ops.flat_copy_raw(v.data_ptr(), static[k_].data_ptr(), v.numel())
+        graph.replay()
+        res = dict(out)
+        res['im'] = im
+        res['real_im_seq'] = feed_dict.get('real_im_seq')
+        return res
+
+    def _run_eager(self, feed_dict, z=None):
+        """The rollout enqueued launch by launch (also the function a capture records)."""
         im = feed_dict['image'].contiguous()
         act = feed_dict['action_code'].contiguous()
         b, r, k, t = im.shape[0], self.image_size, self.n_points, N_FUTURE_FRAMES
