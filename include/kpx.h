@@ -193,6 +193,12 @@ int kpx_bn_train_fwd_f32(const float* x, size_t P, int groups, int C, int ldx, c
 int kpx_bn_train_bwd_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int groups, int C,
                          const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
                          float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* scratch, void* stream);
+/* Inference-mode batch norm folded into the convolution in front of it (is_training = False: reference keypoint_model.py:48-50,
+ * final_model.py:62,68,95): w_out[r][c] = w[r][c] * s[c], b_out[c] = (bias[c] - moving_mean[c]) * s[c] + beta[c] with
+ * s = gamma * rsqrt(moving_var + eps); w = [rows = kh*kw*Cin][C] (HWIO), bias may be NULL.  conv(x, w_out) + b_out followed by ReLU then
+ * equals relu(batch_norm(conv(x, w) + bias)) up to fp32 rounding, without the pass over the activation. */
+int kpx_bn_fold_conv_f32(const float* w, const float* bias, size_t rows, int C, const float* gamma, const float* beta,
+                         const float* moving_mean, const float* moving_var, float eps, float* w_out, float* b_out, void* stream);
 int kpx_bn_invstd_f32(const float* var, int C, float eps, float* invstd, void* stream);
 /* step 2: y = act((x-mean)*invstd*gamma + beta), act in {NONE, RELU} (tf.nn.relu networks/__init__.py:12...). */
 int kpx_bn_apply_f32(const float* x, size_t P, int C, int ldx, const float* mean, const float* invstd,

@@ -828,7 +828,7 @@ def test_graph_replay_is_bit_identical_to_the_eager_step(monkeypatch):
             im, fut = R.synthetic_pair(b, res=res, seed0=50 + step, seed1=60 + step)
             model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, step, b)
             losses.append(list(model.loss_values().values()))
-            if step == 2:
+            if step >= 2:                      # (an eager evaluation pass after EVERY later step: it must see the weights the replay just wrote)
                 im2, fut2 = R.synthetic_pair(b, res=res, seed0=70, seed1=71)
                 losses.append(list(model.test_step(None, {'image': torch.from_numpy(im2).to(dev), 'future_image': torch.from_numpy(fut2).to(dev)}, 0, 0, b)[:2]))
         out = model.store.export_numpy(include_slots=True)

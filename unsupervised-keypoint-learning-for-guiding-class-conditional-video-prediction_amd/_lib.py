@@ -71,6 +71,7 @@ SIGNATURES = {
     'kpx_chan_sum_f32': (c_int, [P, c_size_t, c_int, c_int, P, P, P]),
     'kpx_bn_stats_f32': (c_int, [P, c_size_t, c_int, c_int, c_float, P, P, P, P, P, c_float, P, P]),
     'kpx_bn_invstd_f32': (c_int, [P, c_int, c_float, P, P]),
+    'kpx_bn_fold_conv_f32': (c_int, [P, P, c_size_t, c_int, P, P, P, P, c_float, P, P, P]),
     'kpx_bn_train_scratch_bytes': (c_size_t, [c_int, c_int]),
     'kpx_bn_train_fwd_f32': (c_int, [P, c_size_t, c_int, c_int, c_int, P, c_size_t, c_float, P, P, P, P, P, P, c_float, P, c_int, c_int, P, P]),
     'kpx_bn_train_bwd_f32': (c_int, [P, c_int, P, c_int, c_size_t, c_int, c_int, P, P, P, P, c_int, P, c_int, P, P, c_int, P, P]),

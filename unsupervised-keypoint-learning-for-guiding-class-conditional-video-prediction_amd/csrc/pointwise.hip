@@ -556,6 +556,30 @@ extern "C" int kpx_bn_bwd_from_tiles_f32(const float* dy, int lddy, const float*
     return kpx_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------ inference: batch norm folded into the conv
+// relu(gamma * (conv(x, w) + b - mean) * rsqrt(var + eps) + beta) = relu(conv(x, w * s) + (b - mean) * s + beta), s = gamma * rsqrt(var + eps):
+// with the MOVING statistics (is_training = False: KeypointModel / FinalModel, reference keypoint_model.py:48-50, final_model.py:62,68,95) the
+// normalisation is a constant per-channel affine map, folded once per checkpoint into the filter and the bias -- the inference networks then
+// run conv + ReLU epilogue and never make the batch-norm pass over the activation.
+__global__ __launch_bounds__(256) void bn_fold_conv_kernel(const float* __restrict__ w, const float* __restrict__ bias, size_t rows, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mm,
+                                                          const float* __restrict__ mv, float eps, float* __restrict__ w_out, float* __restrict__ b_out) {
+    const size_t total = rows * (size_t)C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const float sc = gamma[c] * (1.0f / sqrtf(mv[c] + eps));
+        w_out[i] = w[i] * sc;
+        if (i < (size_t)C) b_out[c] = ((bias ? bias[c] : 0.f) - mm[c]) * sc + beta[c];
+    }
+}
+extern "C" int kpx_bn_fold_conv_f32(const float* w, const float* bias, size_t rows, int C, const float* gamma, const float* beta,
+                                    const float* moving_mean, const float* moving_var, float eps, float* w_out, float* b_out, void* stream) {
+    if (!w || !gamma || !beta || !moving_mean || !moving_var || !w_out || !b_out || rows == 0 || C <= 0) return KPX_EINVAL;
+    hipLaunchKernelGGL(bn_fold_conv_kernel, dim3(grid_for(rows * C)), dim3(256), 0, kpx_stream(stream), w, bias, rows, C, gamma, beta,
+                       moving_mean, moving_var, eps, w_out, b_out);
+    return kpx_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------ batched batch norm
 // The weight-sharing calls of the path (the two pose_encoder calls of one pair, reference detector_translator_model.py:166-167) run as ONE
 // batch with `groups` sets of statistics: consecutive groups of P pixels, mean / invstd [groups][C], moving statistics updated once per

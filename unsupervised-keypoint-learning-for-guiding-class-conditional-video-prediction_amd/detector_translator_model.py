@@ -254,6 +254,7 @@ class DetectorTranslatorModel(BaseModel):
         graph.replay()
         for which in ('D', 'G'):
             self._advance_beta_powers(which)
+            self.store.touch(which)         # host-side bookkeeping of the replayed Adam updates: derived filter forms are stale for eager code
         self.global_step += 1
         self.last = dict(outputs, lr=float(lr))
 

@@ -12,6 +12,8 @@ from .variables import Sym, default_store, is_sym
 
 ACT_NONE, ACT_RELU, ACT_LRELU = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LRELU
 EXACT_ZERO_BIAS_GRAD = True      # see conv_bn_relu
+import os as _os
+FOLD_BN_INFERENCE = _os.environ.get('KPX_FOLD_BN_INFERENCE', '1') != '0'      # see conv_bn_relu
 
 
 def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', act=ACT_NONE, cin=None, head31=False, bias_grad=True, bn_stats=False):
@@ -56,6 +58,17 @@ def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, 
     zero when a train-mode batch norm follows (the batch mean removes any per-channel constant), so it is not computed: the
     flat gradient bucket holds 0 there and Adam leaves those biases at their initial value.  The reference computes fp32
     rounding noise for them, which its Adam turns into a +-lr random walk that batch norm again cancels in the forward."""
+    if not train_mode and not is_sym(x) and FOLD_BN_INFERENCE and x.is_cuda and not torch.is_grad_enabled():
+        # inference (KeypointModel / FinalModel): the moving-statistics batch norm is a constant per-channel affine map -- folded into the
+        # filter and the bias once per checkpoint, so the layer is one conv with a ReLU epilogue and no pass over its activation
+        st = default_store()
+        with st.variable_scope(conv_scope), st.variable_scope('conv2d'):
+            kname, bname = st.scoped('kernel'), st.scoped('bias')
+        with st.variable_scope(bn_scope):
+            names = [st.scoped(n) for n in ('gamma', 'beta', 'moving_mean', 'moving_variance')]
+        if all(n in st.vars for n in [kname, bname] + names):
+            wf, bf = st.folded_conv_bn(kname, bname, names[0], names[1], names[2], names[3], ops.BN_EPS)
+            return ops.conv2d(x, wf, bf, stride=stride, pad=0, act=ACT_RELU, cin=cin)
     x = conv(x, channels, kernel=kernel, stride=stride, scope=conv_scope, cin=cin, bias_grad=not (EXACT_ZERO_BIAS_GRAD and train_mode),
              bn_stats=bool(train_mode))       # the conv epilogue delivers the batch statistics when it can
     return batch_norm(x, train_mode, scope=bn_scope, act=ACT_RELU, groups=groups, update_moving=update_moving)

@@ -151,11 +151,38 @@ class VariableStore:
         """Call after writing parameters behind torch's back (fused Adam kernel, restore): derived filter forms are refreshed lazily.
         ``bucket``: the flat bucket that was written ('G' / 'D' / ...); an update of a bucket none of whose filters has a derived form
         (the discriminator's) leaves the forms valid."""
+        self.drop_folded()                            # inference-folded filters (layers.conv_bn_relu) are functions of the parameters
         bank = getattr(self, 'filter_bank', None)
         if bank is not None:
             owners = getattr(self, '_bank_buckets', None)
             if bucket is None or owners is None or bucket in owners:
                 bank.touch()
+
+    def drop_folded(self):
+        """Forget the inference-mode (conv filter x batch-norm scale) products: a parameter or a moving statistic changed."""
+        folded = getattr(self, '_folded', None)
+        if folded:
+            from . import ops
+            for _, _, keys in folded.values():
+                ops.release_filters(keys)
+            folded.clear()
+
+    def folded_conv_bn(self, kname, bname, gamma, beta, mm, mv, eps):
+        """(w', b') with relu(conv(x, w') + b') = relu(batch_norm_inference(conv(x, w) + b)); computed once per parameter state
+        (kpx_bn_fold_conv_f32) and registered like a constant filter so that the Winograd kernels take it pre-transformed."""
+        folded = self.__dict__.setdefault('_folded', {})
+        ent = folded.get(kname)
+        if ent is None:
+            from . import ops
+            from ._lib import lib, check
+            w = self.vars[kname].detach()
+            wf, bf = torch.empty_like(w), torch.empty(w.shape[3], dtype=torch.float32, device=w.device)
+            b = self.vars[bname].detach() if bname is not None else None
+            check(lib.kpx_bn_fold_conv_f32(w.data_ptr(), b.data_ptr() if b is not None else None, w.numel() // w.shape[3], int(w.shape[3]),
+                                           self.vars[gamma].data_ptr(), self.vars[beta].data_ptr(), self.vars[mm].data_ptr(), self.vars[mv].data_ptr(),
+                                           float(eps), wf.data_ptr(), bf.data_ptr(), ops._stream()), 'kpx_bn_fold_conv_f32')
+            ent = folded[kname] = (wf, bf, ops.register_constant_filter(wf, kname))
+        return ent[0], ent[1]
 
     # ---- access ------------------------------------------------------------------------------------------------
     def __getitem__(self, name):
