@@ -394,8 +394,11 @@ def main():
     from kpx_amd import _lib as klib
     calls0 = klib.abi_calls[0]
     t0 = time.perf_counter()
+    per_call = []
     for i in range(args.steps):
+        tc = time.perf_counter()
         model.train_step(None, feed, args.warmup + i, args.batch)
+        per_call.append(time.perf_counter() - tc)
     t_enq = time.perf_counter() - t0          # host wall time to enqueue K steps: includes waiting on a full launch queue
     calls_per_step = (klib.abi_calls[0] - calls0) / max(args.steps, 1)
     graphed = bool(getattr(model, '_graphs', None)) and not getattr(model, '_graph_failed', False)
@@ -434,6 +437,9 @@ def main():
                'step_algorithmic_frac_of_f32_peak': round(2 * gmac * 1e9 * value / world / 157.3e12, 4),
                'n_ranks_seen': n_ranks_seen, 'dist_backend': backend if launched else None,
                'host_enqueue_ms_per_step': round(max(enq), 3), 'host_enqueue_ms_per_step_by_rank': [round(x, 3) for x in enq],
+               'host_enqueue_note': 'wall time of the K train_step() calls / K: includes blocking on a full launch queue (a graph replay call blocks once '
+                                    'a few replays are in flight); host_work_ms_per_step_min = the shortest single call = the host work of one step',
+               'host_work_ms_per_step_min': round(min(per_call) * 1e3, 3),
                'launch_mode': ('one HIP graph replay per step (captured after %d eager warm-up step(s); %d C-ABI kernel launches inside the graph)'
                                % (1, getattr(model, '_graph_launches', 0))) if graphed else 'eager: every kernel enqueued from Python',
                'host_abi_calls_per_step': round(calls_per_step, 1),

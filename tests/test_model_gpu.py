@@ -874,3 +874,62 @@ def test_rollout_graph_replay_is_bit_identical_to_the_eager_rollout(monkeypatch)
     for i in range(3):
         for k_ in outs[False][i]:
             assert np.array_equal(outs[False][i][k_], outs[True][i][k_]), (i, k_)
+
+
+def smooth_pair(bsz, res, seed):
+    """Structured synthetic frames: five coloured Gaussian blobs on a linear-gradient background, the blobs displaced between the two
+    frames of a pair -- images with the low-frequency content of real frames (uniform noise makes the loss gradient chaotic)."""
+    yy, xx = np.meshgrid(np.linspace(-1, 1, res), np.linspace(-1, 1, res), indexing='ij')
+    ims = []
+    for shift in (0.0, 0.15):
+        im = np.zeros((bsz, res, res, 3), np.float32)
+        for i in range(bsz):
+            rs_i = np.random.RandomState(seed * 1000 + i)
+            base = 0.3 * xx * rs_i.uniform(-1, 1) + 0.3 * yy * rs_i.uniform(-1, 1)
+            img = np.stack([base + 0.1 * c for c in range(3)], -1)
+            for j in range(5):
+                cx, cy = rs_i.uniform(-0.6, 0.6, 2)
+                col = rs_i.uniform(-1, 1, 3)
+                g = np.exp(-(((xx - cx - shift * (j % 2)) ** 2 + (yy - cy - shift * ((j + 1) % 2)) ** 2) / 0.03))
+                img = img + g[..., None] * col
+            im[i] = np.clip(img, -1, 1)
+        ims.append(im)
+    return ims[0], ims[1]
+
+
+def test_bf16_configuration_tracks_the_fp32_configuration_on_structured_frames():
+    """BASELINE configs[2] arithmetic against the fp32 configuration of the same HIP path on STRUCTURED inputs (smooth frames with moving
+    blobs, 128x128, K=15, B=8, full-width VGG19), three train steps from the seeded initial state.  On uniform-noise frames the generator
+    gradient is chaotic (cosine ~0.6 between ANY two roundings); here it is meaningful: the first step's generator gradient must point the
+    same way (cosine >= 0.95 overall, >= 0.97 on the translator -- measured 0.964 / 0.982) and the losses of all three steps must agree to
+    1 % (measured 1e-4 .. 3e-3) although the weights separate by +-lr per step."""
+    from kpx_amd import ops
+    dev = torch.device('cuda:0')
+    res, k, b = 128, 15, 8
+
+    def run(dtype):
+        ops.set_compute_dtype(dtype)
+        try:
+            m = make_model(res, k, b, dev, width_div=1)
+            out = []
+            for s in range(3):
+                im, fut = smooth_pair(b, res, 100 + s)
+                m.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, s, b)
+                out.append((m.loss_values(), {n: m.store.grad(n).cpu().numpy().astype(np.float64) for n in m.store.buckets['G'].entries if n.endswith('kernel')}))
+        finally:
+            ops.set_compute_dtype('f32')
+        return out
+    f32, bf16 = run('f32'), run('bf16')
+    for s in range(3):
+        for key in ('loss_G', 'loss_D', 'loss_G_recon'):
+            assert abs(bf16[s][0][key] - f32[s][0][key]) <= 1e-2 * abs(f32[s][0][key]), (s, key, bf16[s][0][key], f32[s][0][key])
+
+    def cosine(names):
+        dot = sum(float((bf16[0][1][n] * f32[0][1][n]).sum()) for n in names)
+        return dot / (sum(float((bf16[0][1][n] ** 2).sum()) for n in names) * sum(float((f32[0][1][n] ** 2).sum()) for n in names)) ** 0.5
+    names = list(f32[0][1])
+    c_all, c_tr = cosine(names), cosine([n for n in names if n.startswith('translator')])
+    print('bf16 vs fp32 configuration, structured frames: generator-gradient cosine %.4f (translator %.4f); loss_G %s vs %s'
+          % (c_all, c_tr, [round(x[0]['loss_G'], 4) for x in bf16], [round(x[0]['loss_G'], 4) for x in f32]))
+    assert c_all >= 0.95 and c_tr >= 0.97, (c_all, c_tr)
+    assert max(float(np.abs(bf16[0][1][n] - f32[0][1][n]).max()) for n in names) > 0          # the bf16 kernels really ran

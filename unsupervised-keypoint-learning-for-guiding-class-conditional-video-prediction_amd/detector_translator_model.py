@@ -327,21 +327,17 @@ class DetectorTranslatorModel(BaseModel):
             if aux is not None and AUX_STREAM_ADV:
                 # Two-stream G loss: the gradient of each term with respect to the generated frame is taken separately -- the VGG19
                 # data-gradient chain on the main stream straight after the VGG19 forward, without waiting for the discriminator update --
-                # and the generator is walked once with their sum.  On one GPU the adversarial branch (discriminator forward with the
-                # UPDATED weights + its data gradients) runs on the auxiliary stream behind that update, beside the VGG19 chain: both are
-                # half-batch launches that underfill the chip.  Data-parallel, the discriminator's 179 MB all-reduce sits between its
-                # backward and its Adam step: there the adversarial branch runs on the main stream AFTER the join, so that the exchange has
-                # the whole VGG19 forward + backward (~5 ms) to hide under instead of lengthening the auxiliary chain.
+                # and the generator is walked once with their sum.  The adversarial branch (discriminator forward with the UPDATED weights +
+                # its data gradients) runs on the auxiliary stream behind that update, beside the VGG19 chain: both are half-batch launches
+                # that underfill the chip.  Data-parallel, the discriminator's 179 MB all-reduce sits between its backward and its Adam step
+                # on that same stream: auxiliary chain = D forward + backward (~3.7 ms) + exchange + Adam + adversarial branch (~1.5 ms)
+                # against ~5.3 ms of VGG19 forward + data gradients on the main stream -- never later than with the branch moved behind the
+                # join on the main stream (round 2's choice, which cost +1.35 ms = 5.5 % on the 1-rank RCCL run: 25.87 vs 24.52 ms).
                 g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
-                if not self.distributed:
-                    with torch.cuda.stream(aux):
-                        adv = self._loss_G_adv(final)
-                        g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
-                    torch.cuda.current_stream(self.device).wait_stream(aux)
-                else:
-                    torch.cuda.current_stream(self.device).wait_stream(aux)
+                with torch.cuda.stream(aux):
                     adv = self._loss_G_adv(final)
                     g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
+                torch.cuda.current_stream(self.device).wait_stream(aux)
                 ops.begin_backward()
                 final.backward(g_recon + g_adv)
             else:
