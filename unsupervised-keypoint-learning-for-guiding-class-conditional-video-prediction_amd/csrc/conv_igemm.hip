@@ -960,32 +960,60 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_wgrad_tap_rows_kernel(const
     }
 }
 
-// dw[i] = sum_s ws[s][i] in a fixed order: a workgroup owns 64 consecutive elements, its 4 wavefronts stride over the
-// slabs (256 contiguous bytes per slab and wave -> coalesced), 8 loads in flight per lane, then a 4-way LDS combine.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                           size_t n, int S) {
-    const int e = threadIdx.x & 63, sg = threadIdx.x >> 6;
-    const size_t i = (size_t)blockIdx.x * 64 + e;
-    float acc = 0.f;
-    if (i < n) {
-        int k = sg;
-        for (; k + 28 < S; k += 32) {
-            float v[8];
+// dw[i] = sum_s ws[s][i] in a fixed order.  Two shapes of the same sum:
+//  * few slabs (S <= 16: the discriminator's large filters, 8-34 M elements): a thread owns four consecutive elements (16-B accesses) and walks
+//    the slabs in order with all loads of a group of eight in flight -- the 64-elements-per-workgroup form below moved 168 MB at 1.5 TB/s;
+//  * many slabs: a workgroup owns 256 consecutive elements (four per lane), its 4 wavefronts stride over the slabs (1 KB per slab and wave),
+//    8 loads in flight per lane, then a 4-way LDS combine in fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_few_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n4, size_t n, int S) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(ws + i * 4);
+        int k = 1;
+        for (; k + 7 < S; k += 8) {
+            f32x4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = ws[(size_t)(k + 4 * j) * n + i];
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(ws + (size_t)(k + j) * n + i * 4);
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc += v[j];
         }
-        for (; k < S; k += 4) acc += ws[(size_t)k * n + i];
+        for (; k < S; ++k) acc += *reinterpret_cast<const f32x4*>(ws + (size_t)k * n + i * 4);
+        *reinterpret_cast<f32x4*>(dw + i * 4) = acc;
     }
-    __shared__ float sm[4][64];
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t n, int S) {
+    constexpr int W = VEC ? 4 : 1;
+    typedef float vecw __attribute__((ext_vector_type(W)));
+    const int e = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const size_t i = ((size_t)blockIdx.x * 64 + e) * W;
+    vecw acc = 0.f;
+    if (i < n) {
+        int k = sg;
+        for (; k + 28 < S; k += 32) {
+            vecw v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const vecw*>(ws + (size_t)(k + 4 * j) * n + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += v[j];
+        }
+        for (; k < S; k += 4) acc += *reinterpret_cast<const vecw*>(ws + (size_t)k * n + i);
+    }
+    __shared__ vecw sm[4][64];
     sm[sg][e] = acc;
     __syncthreads();
-    if (sg == 0 && i < n) dw[i] = (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
+    if (sg == 0 && i < n) *reinterpret_cast<vecw*>(dw + i) = (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
 }
 
 static inline void launch_wgrad_reduce(const float* ws, float* dw, size_t n, int S, hipStream_t s) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, ws, dw, n, S);
+    const bool vec = n % 4 == 0 && (((uintptr_t)ws | (uintptr_t)dw) & 15) == 0;
+    if (vec && S <= 16) {
+        size_t nb = (n / 4 + 255) / 256; if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(wgrad_reduce_few_kernel, dim3((unsigned)nb), dim3(256), 0, s, ws, dw, n / 4, n, S);
+    } else if (vec) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, s, ws, dw, n, S);
+    } else {
+        hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, ws, dw, n, S);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ wgrad, small channel counts

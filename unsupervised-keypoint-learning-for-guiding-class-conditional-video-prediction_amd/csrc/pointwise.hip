@@ -585,44 +585,52 @@ extern "C" int kpx_bn_fold_conv_f32(const float* w, const float* bias, size_t ro
 // batch with `groups` sets of statistics: consecutive groups of P pixels, mean / invstd [groups][C], moving statistics updated once per
 // group IN ORDER, gamma / beta gradients summed over the groups in order.  One launch per phase for all groups (blockIdx.z), one finalize
 // workgroup per channel looping over the groups -- the same partial sums in the same order as `groups` separate calls: same bits.
-__global__ __launch_bounds__(256) void bn_stats_finalize_groups_kernel(const double* part, size_t part_gstride, int nb, const float* __restrict__ ts, size_t tiles_per_group,
-                                                                      int groups, int C, double count, float eps, float* mean, float* invstd,
-                                                                      float* mm, float* mv, float decay) {
-    const int c = blockIdx.x;
-    __shared__ double sm[2][4];
-    for (int g = 0; g < groups; ++g) {
+// (up to four groups side by side: segment sg = threadIdx.x / 256 of a 256 x min(groups, 4)-thread workgroup sums group g0 + sg exactly as the
+//  single-group kernels do -- thread t of the segment takes partials t, t + 256, ..; shuffle tree per wavefront; the four wave sums in LDS
+//  order -- and thread 0 then finishes the groups IN ORDER: the moving statistics / gradient sums see the same numbers in the same order)
+__global__ __launch_bounds__(1024) void bn_stats_finalize_groups_kernel(const double* part, size_t part_gstride, int nb, const float* __restrict__ ts, size_t tiles_per_group,
+                                                                       int groups, int C, double count, float eps, float* mean, float* invstd,
+                                                                       float* mm, float* mv, float decay) {
+    const int c = blockIdx.x, sg = threadIdx.x >> 8, t = threadIdx.x & 255, nseg = blockDim.x >> 8;
+    __shared__ double sm[4][2][4];
+    for (int g0 = 0; g0 < groups; g0 += nseg) {
+        const int g = g0 + sg;
         double a0 = 0.0, a1 = 0.0;
-        if (ts) {                                          // per-tile sums from a convolution epilogue (floats)
-            const size_t t0 = (size_t)g * tiles_per_group;
-            for (size_t b = threadIdx.x; b < tiles_per_group; b += 256) {
-                a0 += (double)ts[((t0 + b) * 2) * C + c];
-                a1 += (double)ts[((t0 + b) * 2 + 1) * C + c];
-            }
-        } else {                                           // block partials of chan_reduce_kernel<1> (doubles)
-            const double* gp = part + (size_t)g * part_gstride;
-            for (int b = threadIdx.x; b < nb; b += 256) {
-                a0 += gp[((size_t)b * 2) * C + c];
-                a1 += gp[((size_t)b * 2 + 1) * C + c];
+        if (g < groups) {
+            if (ts) {                                      // per-tile sums from a convolution epilogue (floats)
+                const size_t t0 = (size_t)g * tiles_per_group;
+                for (size_t b = t; b < tiles_per_group; b += 256) {
+                    a0 += (double)ts[((t0 + b) * 2) * C + c];
+                    a1 += (double)ts[((t0 + b) * 2 + 1) * C + c];
+                }
+            } else {                                       // block partials of chan_reduce_kernel<1> (doubles)
+                const double* gp = part + (size_t)g * part_gstride;
+                for (int b = t; b < nb; b += 256) {
+                    a0 += gp[((size_t)b * 2) * C + c];
+                    a1 += gp[((size_t)b * 2 + 1) * C + c];
+                }
             }
         }
         a0 = kpx_wave_sum_d(a0);
         a1 = kpx_wave_sum_d(a1);
-        __syncthreads();                                   // (sm is reused per group)
-        if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a0; sm[1][threadIdx.x >> 6] = a1; }
+        __syncthreads();                                   // (sm is reused per batch of groups)
+        if ((t & 63) == 0) { sm[sg][0][t >> 6] = a0; sm[sg][1][t >> 6] = a1; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            const double s = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]), q = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
-            const double m = s / count;
-            double v = q / count - m * m;
-            if (v < 0.0) v = 0.0;
-            const float mf = (float)m, vf = (float)v;
-            mean[g * C + c] = mf;
-            invstd[g * C + c] = 1.0f / sqrtf(vf + eps);
-            if (mm && mv) {
-                const float one_minus = 1.0f - decay;
-                const float unb = (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0)));
-                mm[c] = mm[c] - (mm[c] - mf) * one_minus;
-                mv[c] = mv[c] - (mv[c] - unb) * one_minus;
+            for (int j = 0; j < nseg && g0 + j < groups; ++j) {
+                const double s = (sm[j][0][0] + sm[j][0][1]) + (sm[j][0][2] + sm[j][0][3]), q = (sm[j][1][0] + sm[j][1][1]) + (sm[j][1][2] + sm[j][1][3]);
+                const double m = s / count;
+                double v = q / count - m * m;
+                if (v < 0.0) v = 0.0;
+                const float mf = (float)m, vf = (float)v;
+                mean[(g0 + j) * C + c] = mf;
+                invstd[(g0 + j) * C + c] = 1.0f / sqrtf(vf + eps);
+                if (mm && mv) {
+                    const float one_minus = 1.0f - decay;
+                    const float unb = (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+                    mm[c] = mm[c] - (mm[c] - mf) * one_minus;
+                    mv[c] = mv[c] - (mv[c] - unb) * one_minus;
+                }
             }
         }
     }
@@ -640,7 +648,7 @@ extern "C" int kpx_bn_train_fwd_f32(const float* x, size_t P, int groups, int C,
         int rc = launch_chan_reduce(1, a, &nb, s, groups);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(bn_stats_finalize_groups_kernel, dim3(C), dim3(256), 0, s, (const double*)scratch, gstride, nb, tile_stats, tiles_per_group,
+    hipLaunchKernelGGL(bn_stats_finalize_groups_kernel, dim3(C), dim3(256 * (groups < 4 ? groups : 4)), 0, s, (const double*)scratch, gstride, nb, tile_stats, tiles_per_group,
                        groups, C, (double)P, eps, mean, invstd, moving_mean, moving_var, decay);
     int rc = kpx_launch_status();
     if (rc) return rc;
@@ -657,26 +665,31 @@ extern "C" int kpx_bn_train_fwd_f32(const float* x, size_t P, int groups, int C,
     return 0;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_groups_kernel(const double* part, size_t part_gstride, int nb, int groups, int C,
-                                                                    float* dgamma, float* dbeta, float* sums, int accumulate) {
-    const int c = blockIdx.x;
-    __shared__ double sm[2][4];
-    for (int g = 0; g < groups; ++g) {
-        const double* gp = part + (size_t)g * part_gstride;
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_groups_kernel(const double* part, size_t part_gstride, int nb, int groups, int C,
+                                                                     float* dgamma, float* dbeta, float* sums, int accumulate) {
+    const int c = blockIdx.x, sg = threadIdx.x >> 8, t = threadIdx.x & 255, nseg = blockDim.x >> 8;
+    __shared__ double sm[4][2][4];
+    for (int g0 = 0; g0 < groups; g0 += nseg) {
+        const int g = g0 + sg;
         double a0 = 0.0, a1 = 0.0;
-        for (int b = threadIdx.x; b < nb; b += 256) {
-            a0 += gp[((size_t)b * 2) * C + c];
-            a1 += gp[((size_t)b * 2 + 1) * C + c];
+        if (g < groups) {
+            const double* gp = part + (size_t)g * part_gstride;
+            for (int b = t; b < nb; b += 256) {
+                a0 += gp[((size_t)b * 2) * C + c];
+                a1 += gp[((size_t)b * 2 + 1) * C + c];
+            }
         }
         a0 = kpx_wave_sum_d(a0);
         a1 = kpx_wave_sum_d(a1);
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a0; sm[1][threadIdx.x >> 6] = a1; }
+        if ((t & 63) == 0) { sm[sg][0][t >> 6] = a0; sm[sg][1][t >> 6] = a1; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            const double s = (sm[0][0] + sm[0][1]) + (sm[0][2] + sm[0][3]), q = (sm[1][0] + sm[1][1]) + (sm[1][2] + sm[1][3]);
-            if (accumulate || g > 0) { dbeta[c] += (float)s; dgamma[c] += (float)q; } else { dbeta[c] = (float)s; dgamma[c] = (float)q; }
-            sums[(size_t)g * 2 * C + c] = (float)s; sums[(size_t)g * 2 * C + C + c] = (float)q;
+            for (int j = 0; j < nseg && g0 + j < groups; ++j) {
+                const double s = (sm[j][0][0] + sm[j][0][1]) + (sm[j][0][2] + sm[j][0][3]), q = (sm[j][1][0] + sm[j][1][1]) + (sm[j][1][2] + sm[j][1][3]);
+                if (accumulate || g0 + j > 0) { dbeta[c] += (float)s; dgamma[c] += (float)q; } else { dbeta[c] = (float)s; dgamma[c] = (float)q; }
+                sums[(size_t)(g0 + j) * 2 * C + c] = (float)s; sums[(size_t)(g0 + j) * 2 * C + C + c] = (float)q;
+            }
         }
     }
 }
@@ -693,7 +706,7 @@ extern "C" int kpx_bn_train_bwd_f32(const float* dy, int lddy, const float* x, i
     int nb; int rc = launch_chan_reduce(2, a, &nb, s, groups);
     if (rc) return rc;
     float* sums = reinterpret_cast<float*>((double*)scratch + (size_t)groups * gstride);          // [groups][2][C] behind the partials
-    hipLaunchKernelGGL(bn_bwd_finalize_groups_kernel, dim3(C), dim3(256), 0, s, (const double*)scratch, gstride, nb, groups, C, dgamma, dbeta, sums, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_groups_kernel, dim3(C), dim3(256 * (groups < 4 ? groups : 4)), 0, s, (const double*)scratch, gstride, nb, groups, C, dgamma, dbeta, sums, accumulate);
     if ((rc = kpx_launch_status())) return rc;
     const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
     const float inv_count = (float)(1.0 / (double)P);
