@@ -74,7 +74,7 @@ def _time_conv_3_1(dev, pretransformed=False, name='translator/conv_3_1'):
     return ms, 2.0 * 603979776 * n
 
 
-def _rocprof_avg_ms(kernel_substr, csv_name='r02_roofline_only_kernel_stats.csv'):
+def _rocprof_avg_ms(kernel_substr, csv_name='r03_roofline_only_kernel_stats.csv'):
     """Average kernel duration from the committed rocprofv3 --kernel-trace --stats summary of `bench.py --roofline-only` (same command, same
     kernels): the live HIP-event figure includes the launch-to-launch gap (~1.5-3 us), which matters for a 12 us kernel."""
     import csv
@@ -96,7 +96,7 @@ def _pmc_traffic(name):
         return None, None
 
 
-WINO43_PMC, WINO_PMC, DIRECT_PMC, RENDER_PMC = 'r02_wino43_pmc.json', 'r02_wino_pmc.json', 'r01_conv_pmc.json', 'r02_render_pmc.json'
+WINO43_PMC, WINO_PMC, DIRECT_PMC, RENDER_PMC = 'r03_wino43_pmc.json', 'r03_wino_pmc.json', 'r01_conv_pmc.json', 'r03_render_pmc.json'
 
 
 def _roofline_wino(dev, name, kernel_substr, kernel_desc, reduction, pmc):
@@ -161,6 +161,25 @@ def roofline_conv_bf16(dev):
             'achieved': round(nbytes / (ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(nbytes / (ms * 1e-3) / 8e12, 4),
             'traffic': None, 'avg_launch_ms': round(ms, 4), 'bytes_per_launch': nbytes,
             'mfma_tflops_bf16': round(flops / (ms * 1e-3) / 1e12, 1), 'mfma_frac_of_bf16_peak': round(flops / (ms * 1e-3) / 2.5e15, 4)}
+
+
+def roofline_conv_bf16x3(dev):
+    """The fp32-equivalent bf16x3 implicit-GEMM kernel (csrc/conv_gemm3.hip) on the discriminator's conv_3 (4x4 stride 2, 256 -> 512 at
+    18x18 -> 10x10, N = 64 = real + generated halves of a batch of 32): six bf16 MFMAs per 32x32x16 block, so the matrix-pipe bound is the
+    bf16 peak / 6 = 417 TFLOP/s of fp32-equivalent work; `frac` is against that, `frac_of_fp32_mfma_peak` against the 157.3 TF a
+    v_mfma_f32_32x32x2_f32 kernel is bound by (the kernel this one replaced reached 0.59 of it on this layer)."""
+    from kpx_amd import ops
+    n, h, ci, co = 2 * BATCH, 18, 256, 512
+    x = torch.randn(n, h, h, ci, device=dev)
+    w = torch.randn(4, 4, ci, co, device=dev) * 0.02
+    b = torch.zeros(co, device=dev)
+    y = torch.empty(n, 10, 10, co, device=dev)
+    ms = time_kernel(lambda: ops.conv_fwd_raw(x, ci, ci, w, b, y, co, 2, 2, 2, 2), iters=50, warm=10)
+    flops = 2.0 * n * 10 * 10 * co * 16 * ci
+    ach = flops / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': 'conv_gemm3_kernel<128,128,2,4,false,3> (+ split-K slab reduce) fwd 4x4 s2 256->512 @18x18 N=64 (img_discr conv_3), bf16x3 = fp32-equivalent',
+            'achieved': round(ach, 2), 'peak': 416.7, 'unit': 'TFLOP/s (fp32-equivalent; bf16 dense peak 2500 / 6 products)', 'frac': round(ach / 416.7, 4),
+            'frac_of_fp32_mfma_peak': round(ach / 157.3, 4), 'traffic': None, 'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops}
 
 
 def roofline_render(dev, res=RES, k_pts=K_PTS, batch=BATCH):
@@ -369,7 +388,7 @@ def main():
         return bench_rollout(args, conf, dev, rank, world, launched, backend)
     if args.roofline_only:
         kops.set_compute_dtype('f32')
-        print(json.dumps({'roofline': roofline_conv(dev), 'roofline_wino_f23': roofline_conv_f23(dev), 'roofline_direct_conv': roofline_conv_direct(dev),
+        print(json.dumps({'roofline': roofline_conv(dev), 'roofline_wino_f23': roofline_conv_f23(dev), 'roofline_direct_conv': roofline_conv_direct(dev), 'roofline_bf16x3_conv': roofline_conv_bf16x3(dev),
                           'roofline_hbm_render': roofline_render(dev), 'roofline_bf16_conv': roofline_conv_bf16(dev)}), flush=True)
         return
     cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': args.batch},
@@ -451,6 +470,7 @@ def main():
             out['roofline'] = roofline_conv(dev)
             out['roofline_wino_f23'] = roofline_conv_f23(dev)
             out['roofline_direct_conv'] = roofline_conv_direct(dev)
+            out['roofline_bf16x3_conv'] = roofline_conv_bf16x3(dev)
             out['roofline_hbm_render'] = roofline_render(dev, RES, K_PTS, args.batch)
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline()
