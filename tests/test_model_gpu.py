@@ -933,3 +933,23 @@ def test_bf16_configuration_tracks_the_fp32_configuration_on_structured_frames()
           % (c_all, c_tr, [round(x[0]['loss_G'], 4) for x in bf16], [round(x[0]['loss_G'], 4) for x in f32]))
     assert c_all >= 0.95 and c_tr >= 0.97, (c_all, c_tr)
     assert max(float(np.abs(bf16[0][1][n] - f32[0][1][n]).max()) for n in names) > 0          # the bf16 kernels really ran
+
+
+def test_assign_invalidates_the_cached_winograd_filter_forms():
+    """the pre-transformed Winograd filters are cached per store version.  A parameter written through VariableStore.assign()
+    (or followed by touch()) must show in the next forward; the forward after an in-place write WITHOUT touch() is the documented stale
+    case (``VariableStore.__getitem__`` is read access)."""
+    dev = torch.device('cuda:0')
+    res, k, b = 32, 3, 2
+    model = make_model(res, k, b, dev)
+    im, fut = R.synthetic_pair(b, res=res, seed0=1, seed1=2)
+    x, y = torch.from_numpy(im).to(dev), torch.from_numpy(fut).to(dev)
+    name = 'translator/conv_1_1/conv2d/kernel'                       # a 3x3 stride-1 layer on the Winograd kernels
+    base = model.forward(x, y, with_vis_maps=False)['final_output'].cpu().numpy().copy()
+    w = model.store[name].detach().cpu().numpy().copy()
+    model.store.assign(name, w * 1.5)
+    changed = model.forward(x, y, with_vis_maps=False)['final_output'].cpu().numpy().copy()
+    assert np.abs(changed - base).max() > 1e-4                       # the new filter is in use
+    model.store.assign(name, w)
+    back = model.forward(x, y, with_vis_maps=False)['final_output'].cpu().numpy()
+    assert np.array_equal(back, base)                                # and restoring it restores the output bit for bit

@@ -186,7 +186,17 @@ class VariableStore:
 
     # ---- access ------------------------------------------------------------------------------------------------
     def __getitem__(self, name):
+        """READ access to a variable.  The tensor is a view of the flat bucket; derived forms of the filters (Winograd U, inference-folded
+        filters) are cached per store version, so a parameter must not be written through this view behind the store's back: write with
+        ``assign`` (or call ``touch`` after a bulk write such as the fused Adam kernel / ``load_numpy`` do)."""
         return self.vars[name]
+
+    def assign(self, name, value):
+        """Write one variable (tf.assign): copies ``value`` into the bucket view and invalidates every derived filter form."""
+        v = self.vars[name]
+        with torch.no_grad():
+            v.copy_(torch.as_tensor(value, dtype=torch.float32).to(v.device).reshape(v.shape))
+        self.touch()
 
     def grad(self, name):
         return self.grad_views.get(name)
