@@ -210,15 +210,24 @@ def write_table(path, items):
     separator between its last key and the next block's first key, the short successor of the last key for the final block."""
     with open(path, 'wb') as f:
         index, block, pending = [], [], None            # pending = (last key of the flushed block, its handle)
+        est = 0                                         # running BlockBuilder::CurrentSizeEstimate(): entry bytes so far (restart array added below)
         for k, v in items:
             if pending is not None:
                 index.append((_short_separator(pending[0], k), pending[1]))
                 pending = None
+            # size of this entry as _build_block will encode it (shared-prefix compression against the previous key, none at a restart point)
+            shared = 0
+            if len(block) % RESTART_INTERVAL != 0:
+                last = block[-1][0]
+                while shared < min(len(last), len(k)) and last[shared] == k[shared]:
+                    shared += 1
+            est += len(_varint(shared)) + len(_varint(len(k) - shared)) + len(_varint(len(v))) + (len(k) - shared) + len(v)
             block.append((k, v))
-            if len(_build_block(block, RESTART_INTERVAL)) >= BLOCK_SIZE:
+            n_restarts = (len(block) + RESTART_INTERVAL - 1) // RESTART_INTERVAL
+            if est + 4 * n_restarts + 4 >= BLOCK_SIZE:                  # = len(_build_block(block)) without re-encoding the block per key
                 h = _emit_block(f, _build_block(block, RESTART_INTERVAL))
                 pending = (block[-1][0], _varint(h[0]) + _varint(h[1]))
-                block = []
+                block, est = [], 0
         if block:
             h = _emit_block(f, _build_block(block, RESTART_INTERVAL))
             pending = (block[-1][0], _varint(h[0]) + _varint(h[1]))
