@@ -87,6 +87,14 @@ def _rocprof_avg_ms(kernel_substr, csv_name='r03_roofline_only_kernel_stats.csv'
     return None, None
 
 
+def _profile_stamp():
+    """Commit the committed rocprofv3 summaries under profiles/ were collected at (profiles/r03_commit.txt, written by collect_r03.sh)."""
+    try:
+        return open(os.path.join(ROOT, 'profiles', 'r03_commit.txt')).read().strip()
+    except OSError:
+        return None
+
+
 def _pmc_traffic(name):
     """HBM bytes per launch from a committed rocprofv3 PMC summary of this same kernel / shape (profiles/<name>); the
     counters cannot be collected inside a normal bench run, so the JSON line names the file they come from."""
@@ -105,7 +113,9 @@ def _roofline_wino(dev, name, kernel_substr, kernel_desc, reduction, pmc):
     ach = alg / reduction
     traffic, src = _pmc_traffic(pmc)
     rp_ms, rp_src = _rocprof_avg_ms(kernel_substr)
-    return {'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'frac_at_rocprof_avg': round(flops / reduction / (rp_ms * 1e-3) / 157.3e12, 4) if rp_ms else None,
+    return {'committed_profile': {'note': 'from files committed under profiles/, NOT measured in this run', 'collected_at_commit': _profile_stamp(),
+                                  'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'traffic_source': src,
+                                  'frac_at_rocprof_avg': round(flops / reduction / (rp_ms * 1e-3) / 157.3e12, 4) if rp_ms else None},
             'bound': 'mfma', 'kernel': kernel_desc,
             'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4),
             'traffic': traffic, 'traffic_source': src, 'avg_launch_ms': round(ms, 4),
@@ -204,7 +214,9 @@ def roofline_render(dev, res=RES, k_pts=K_PTS, batch=BATCH):
     ach = nbytes / (ms * 1e-3) / 1e9
     traffic, src = _pmc_traffic(RENDER_PMC) if (res, k_pts, batch) == (128, 15, 32) else (None, None)
     rp_ms, rp_src = _rocprof_avg_ms('gauss_fwd_reg_kernel') if (res, k_pts, batch) == (128, 15, 32) else (None, None)
-    return {'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'frac_at_rocprof_avg': round(nbytes / (rp_ms * 1e-3) / 8e12, 4) if rp_ms else None,
+    return {'committed_profile': {'note': 'from files committed under profiles/, NOT measured in this run', 'collected_at_commit': _profile_stamp(),
+                                  'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'traffic_source': src,
+                                  'frac_at_rocprof_avg': round(nbytes / (rp_ms * 1e-3) / 8e12, 4) if rp_ms else None},
             'avg_launch_ms_note': 'HIP events over back-to-back launches include the launch-to-launch gap of this 12 us kernel',
             'bound': 'hbm', 'kernel': 'gauss_fwd kernel [%d,%d,%d,%d] (current+future maps of %d pairs), %d rotating outputs' % (b, RES, RES, K_PTS, batch, len(outs)), 'achieved': round(ach, 1),
             'peak': 8000.0, 'unit': 'GB/s', 'frac': round(ach / 8000.0, 4), 'traffic': traffic, 'traffic_source': src,

@@ -31,6 +31,7 @@ O = 'gpurun_out/r03'
 def cp(pattern, dst):
     f = glob.glob(pattern, recursive=True)
     if f: shutil.copy(f[0], 'profiles/' + dst)
+if os.path.exists('.git_head'): shutil.copy('.git_head', 'profiles/r03_commit.txt')
 cp(O + '/step/**/*kernel_stats.csv', 'r03_step_kernel_stats.csv')
 cp(O + '/step_c3/**/*kernel_stats.csv', 'r03_step_c3_kernel_stats.csv')
 cp(O + '/step_c4/**/*kernel_stats.csv', 'r03_step_c4_kernel_stats.csv')

@@ -7,12 +7,9 @@ try:
 except Exception as e: print('$name ERR', e)
 PY
 }
-run eager KPX_GRAPH=0
-run graph KPX_GRAPH=1
-run graph_forkafter KPX_GRAPH=1 KPX_FORK_BEFORE_DGRAD=after
-run graph_q2 DEBUG_HIP_FORCE_GRAPH_QUEUES=2
-run graph_q3 DEBUG_HIP_FORCE_GRAPH_QUEUES=3
-run graph_q6 DEBUG_HIP_FORCE_GRAPH_QUEUES=6
-run graph_noadv KPX_AUX_STREAM_ADV=0
-run graph_nofwd KPX_AUX_STREAM_FWD=0
-run eager2 KPX_GRAPH=0
+for i in 1 2; do
+run eager_vggaux KPX_GRAPH=0 KPX_VGG_ON_AUX=1
+run eager_daux KPX_GRAPH=0 KPX_VGG_ON_AUX=0
+run graph_vggaux KPX_GRAPH=1 KPX_VGG_ON_AUX=1
+run graph_daux KPX_GRAPH=1 KPX_VGG_ON_AUX=0
+done

@@ -24,7 +24,10 @@ from .vgg import Vgg19
 # the discriminator update on an auxiliary HIP stream beside the VGG19 forward of the G run (KPX_AUX_STREAM=0: one stream)
 AUX_STREAM = os.environ.get('KPX_AUX_STREAM', '1') != '0'
 AUX_STREAM_FWD = os.environ.get('KPX_AUX_STREAM_FWD', '1') != '0'      # the image encoder (forward and backward) beside the key-point detector
-AUX_STREAM_ADV = os.environ.get('KPX_AUX_STREAM_ADV', '1') != '0'      # the G run's adversarial branch on that stream as well
+AUX_STREAM_ADV = os.environ.get('KPX_AUX_STREAM_ADV', '1') != '0'
+# which half of the middle of the step runs on the auxiliary stream: the discriminator update (default) or the perceptual VGG19 chain
+# (KPX_VGG_ON_AUX=1; lets the update's weight gradients use a side stream under graph capture, but measured +0.9 ms: 25.1-25.5 vs 24.2-24.7 ms)
+VGG_ON_AUX = os.environ.get('KPX_VGG_ON_AUX', '0') != '0'      # the G run's adversarial branch on that stream as well
 
 # The whole step -- ~700 launches on three streams -- as ONE HIP graph, captured from the second call on a given input shape and replayed
 # afterwards (KPX_GRAPH=0: every step is enqueued from Python).  Single-process steps on the shared batch only; see _train_step_graphed.
@@ -301,54 +304,72 @@ class DetectorTranslatorModel(BaseModel):
             else:
                 fwd = self._define_forward_pass(im, future_im)
                 final_d = fwd['final_output'].detach()
-            # The whole discriminator update (forward on real + fake, backward, exchange, Adam) is independent of the perceptual half of
-            # the G run (VGG19 on fake + real): with one shared batch it runs on an auxiliary stream beside it.  (With a separate G
-            # batch the generator forward below re-derives every Winograd filter form, the discriminator's included, so the D update
-            # must be complete first: no overlap there.)
+            # The whole discriminator update (forward on real + fake, backward, exchange, Adam) and the G run's adversarial branch behind it
+            # (discriminator forward with the UPDATED weights + its data gradients) are independent of the perceptual half of the G run (VGG19
+            # on fake + real, forward and data gradients): with one shared batch the two halves run side by side, the gradient of each G-loss
+            # term with respect to the generated frame is taken separately and the generator is walked once with their sum.  (With a separate
+            # G batch the generator forward below re-derives every Winograd filter form, the discriminator's included, so the D update must be
+            # complete first: no overlap there.)
             aux = self._aux_stream() if (AUX_STREAM and not separate and self.device.type == 'cuda') else None
-            if aux is not None:
-                aux.wait_stream(torch.cuda.current_stream(self.device))
-            with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
+            if aux is not None and AUX_STREAM_ADV and VGG_ON_AUX:
+                # WHICH half goes to the auxiliary stream is decided by the stream discipline (ops.py): the discriminator update needs its weight
+                # gradients back before Adam, and a side stream may only be joined into the MAIN stream -- so the update stays on the main
+                # stream (weight gradients on side(main), as everywhere) and the perceptual half, whose VGG19 weights are constants (no weight
+                # gradients, nothing to fork), moves to the auxiliary stream.  MEASURED SLOWER than the default below (eager 25.1-25.5 vs 24.2 ms,
+                # replayed 25.4 vs 24.7 ms, same box, alternating runs): the large VGG19 launches then share the chip with the update AND its
+                # weight-gradient stream.  Kept behind KPX_VGG_ON_AUX=1 for A/B.
+                main = torch.cuda.current_stream(self.device)
+                final = fwd['final_output']
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    recon = self._loss_G_recon(final, future_im)
+                    g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
                 d_losses = self._loss_D(final_d, future_im)
                 ops.begin_backward()
-                # on the auxiliary stream the update continues right here (exchange, Adam), so its weight gradients run inline on this
-                # stream: a side stream forked from a forked stream must never be joined back into it (ops: stream discipline)
-                with (ops.inline_wgrad() if aux is not None else contextlib.nullcontext()):
-                    torch.autograd.backward([d_losses], [self._e0])
-                pending = self.exchange_gradients('D', async_op=True)      # overlaps the VGG forward below
-                if aux is not None:
-                    self._apply_adam('D', lr, pending=pending, exchanged=True)
-            # ---- G run (:94): the perceptual forward does not involve the discriminator, so it runs first ...
-            if separate:
-                im, future_im = feed_dict['image_G'], feed_dict['future_image_G']
-                fwd = self._define_forward_pass(im, future_im)
-            final = fwd['final_output']
-            recon = self._loss_G_recon(final, future_im)
-            if aux is not None and AUX_STREAM_ADV:
-                # Two-stream G loss: the gradient of each term with respect to the generated frame is taken separately -- the VGG19
-                # data-gradient chain on the main stream straight after the VGG19 forward, without waiting for the discriminator update --
-                # and the generator is walked once with their sum.  The adversarial branch (discriminator forward with the UPDATED weights +
-                # its data gradients) runs on the auxiliary stream behind that update, beside the VGG19 chain: both are half-batch launches
-                # that underfill the chip.  Data-parallel, the discriminator's 179 MB all-reduce sits between its backward and its Adam step
-                # on that same stream: auxiliary chain = D forward + backward (~3.7 ms) + exchange + Adam + adversarial branch (~1.5 ms)
-                # against ~5.3 ms of VGG19 forward + data gradients on the main stream -- never later than with the branch moved behind the
-                # join on the main stream (round 2's choice, which cost +1.35 ms = 5.5 % on the 1-rank RCCL run: 25.87 vs 24.52 ms).
-                g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
-                with torch.cuda.stream(aux):
-                    adv = self._loss_G_adv(final)
-                    g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
-                torch.cuda.current_stream(self.device).wait_stream(aux)
+                torch.autograd.backward([d_losses], [self._e0])
+                pending = self.exchange_gradients('D', async_op=True)      # (data-parallel: the exchange runs beside the VGG19 chain)
+                self._apply_adam('D', lr, pending=pending, exchanged=True)
+                adv = self._loss_G_adv(final)                              # sees the UPDATED discriminator, like the reference's second sess.run
+                g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
+                main.wait_stream(aux)
                 ops.begin_backward()
                 final.backward(g_recon + g_adv)
             else:
                 if aux is not None:
+                    aux.wait_stream(torch.cuda.current_stream(self.device))
+                with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
+                    d_losses = self._loss_D(final_d, future_im)
+                    ops.begin_backward()
+                    # on the auxiliary stream the update continues right here (exchange, Adam), so its weight gradients run inline on this
+                    # stream: a side stream forked from a forked stream must never be joined back into it (ops: stream discipline)
+                    with (ops.inline_wgrad() if aux is not None else contextlib.nullcontext()):
+                        torch.autograd.backward([d_losses], [self._e0])
+                    pending = self.exchange_gradients('D', async_op=True)
+                    if aux is not None:
+                        self._apply_adam('D', lr, pending=pending, exchanged=True)
+                # ---- G run (:94): the perceptual forward does not involve the discriminator, so it runs first ...
+                if separate:
+                    im, future_im = feed_dict['image_G'], feed_dict['future_image_G']
+                    fwd = self._define_forward_pass(im, future_im)
+                final = fwd['final_output']
+                recon = self._loss_G_recon(final, future_im)
+                if aux is not None and AUX_STREAM_ADV:         # (KPX_VGG_ON_AUX=0: round 3's first structure, kept for A/B)
+                    g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
+                    with torch.cuda.stream(aux):
+                        adv = self._loss_G_adv(final)
+                        g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
                     torch.cuda.current_stream(self.device).wait_stream(aux)
+                    ops.begin_backward()
+                    final.backward(g_recon + g_adv)
                 else:
-                    self._apply_adam('D', lr, pending=pending, exchanged=True)
-                # ... and the adversarial term sees the UPDATED discriminator, exactly as the reference's second sess.run
-                adv = self._loss_G_adv(final)
-                ops.begin_backward()
-                torch.autograd.backward([recon, adv], [self._one, self._e0])
+                    if aux is not None:
+                        torch.cuda.current_stream(self.device).wait_stream(aux)
+                    else:
+                        self._apply_adam('D', lr, pending=pending, exchanged=True)
+                    # ... and the adversarial term sees the UPDATED discriminator, exactly as the reference's second sess.run
+                    adv = self._loss_G_adv(final)
+                    ops.begin_backward()
+                    torch.autograd.backward([recon, adv], [self._one, self._e0])
             if self.device.type == 'cuda' and getattr(self, '_aux', None) is not None:
                 # backward nodes recorded on the auxiliary stream ran there (their weight gradients on the side stream forked from it):
                 # the main stream joins the auxiliary stream here and every side stream in exchange_gradients('G') (ops: stream discipline)
