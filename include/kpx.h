@@ -226,6 +226,19 @@ int kpx_keypoint_head_fwd_f32(const float* logits, int B, int H, int W, int K,
 int kpx_keypoint_head_bwd_f32(const float* dmu, const float* mu, const float* prob_y, const float* prob_x,
                               int B, int H, int W, int K, float* dlogits, void* stream);
 
+/* ---- 1x1 head + key-point head in one: layers.conv(x, n_pts, kernel=1) followed by the two get_coord calls
+ * (models/networks/__init__.py:54,68-72; utils/model.py:63-70).  The axis means commute with the 1x1 projection, so the logits
+ * [B,H,W,K] are never formed.  x [B,H,W,C] contiguous (C % 4 == 0), wk [C,K] (the HWIO 1x1 filter), bias [K] or NULL.
+ * Forward also returns the row / column sums of x (xs_y [B,H,C], xs_x [B,W,C]) that the backward needs.
+ * Backward: dx [B,H,W,C] (or NULL), dw [C,K] and db [K] (each may be NULL; accumulate != 0 adds into them).
+ * scratch: kpx_keypoint_head_proj_scratch_bytes(B,H,W,C,K) for either direction. */
+size_t kpx_keypoint_head_proj_scratch_bytes(int B, int H, int W, int C, int K);
+int kpx_keypoint_head_proj_fwd_f32(const float* x, const float* wk, const float* bias, int B, int H, int W, int C, int K,
+                                   float* mu, float* prob_y, float* prob_x, float* xs_y, float* xs_x, void* scratch, void* stream);
+int kpx_keypoint_head_proj_bwd_f32(const float* dmu, const float* mu, const float* prob_y, const float* prob_x,
+                                   const float* xs_y, const float* xs_x, const float* wk, int B, int H, int W, int C, int K,
+                                   float* dx, float* dw, float* db, int accumulate, void* scratch, void* stream);
+
 /* ---- Gaussian heat-map render: model_utils.get_gaussian_maps (utils/model.py:49-60).
  * mu [B,K,2] (x,y) -> maps [B,H,W,K] written with pixel stride ldy (NHWC directly; no BKHW transpose pass). */
 int kpx_gaussian_maps_fwd_f32(const float* mu, int B, int K, int H, int W, double inv_std, float* maps, int ldy, void* stream);

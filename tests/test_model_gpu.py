@@ -947,7 +947,7 @@ def test_assign_invalidates_the_cached_winograd_filter_forms():
     name = 'translator/conv_1_1/conv2d/kernel'                       # a 3x3 stride-1 layer on the Winograd kernels
     base = model.forward(x, y, with_vis_maps=False)['final_output'].cpu().numpy().copy()
     w = model.store[name].detach().cpu().numpy().copy()
-    model.store.assign(name, w * 1.5)
+    model.store.assign(name, np.ascontiguousarray(w[::-1, ::-1]))    # (a rescaled filter would be undone by the batch norm behind it)
     changed = model.forward(x, y, with_vis_maps=False)['final_output'].cpu().numpy().copy()
     assert np.abs(changed - base).max() > 1e-4                       # the new filter is in use
     model.store.assign(name, w)

@@ -222,6 +222,48 @@ def test_keypoint_head_fwd_bwd(kpx, dev, shape, scale):
     assert rel_l2(t2n(xg.grad), t2n(xo.grad)) < 1e-4
 
 
+@pytest.mark.parametrize('shape,k,scale', [((4, 128, 128, 16), 15, 1.0), ((1, 24, 40, 8), 5, 3.0), ((3, 32, 32, 32), 40, 0.5)])
+def test_keypoint_head_folded_1x1_matches_conv_then_head(kpx, dev, shape, k, scale):
+    """pose_encoder's 1x1 head + get_coord x2 as one op that never forms the logits (reference networks/__init__.py:54,68-72):
+    key-points, profiles and all three gradients against the restatement run on conv-then-head, and against the unfused HIP pair."""
+    rs = np.random.RandomState(shape[1] + k)
+    c = shape[3]
+    x = np.maximum(rs.randn(*shape), 0).astype(np.float32)                 # the head's input is a ReLU output
+    w = (rs.randn(1, 1, c, k) * scale / np.sqrt(c)).astype(np.float32)
+    bias = rs.randn(k).astype(np.float32)
+    xo = torch.from_numpy(x).double().requires_grad_(True)
+    wo = torch.from_numpy(w).double().requires_grad_(True)
+    bo = torch.from_numpy(bias).double().requires_grad_(True)
+    lo = xo @ wo[0, 0] + bo
+    gy, pyo = R.get_coord(lo, 2, shape[1]); gx, pxo = R.get_coord(lo, 1, shape[2])
+    muo = torch.stack([gx, gy], dim=2)
+    gm = rs.randn(*muo.shape).astype(np.float32)
+    muo.backward(torch.from_numpy(gm).double())
+    xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+    wg = torch.from_numpy(w).to(dev).requires_grad_(True)
+    bg = torch.from_numpy(bias).to(dev).requires_grad_(True)
+    mug, py, px = kpx.ops.keypoint_head_proj(xg, wg, bg)
+    np.testing.assert_allclose(t2n(mug), t2n(muo), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(t2n(py), t2n(pyo), atol=1e-7, rtol=2e-5)
+    np.testing.assert_allclose(t2n(px), t2n(pxo), atol=1e-7, rtol=2e-5)
+    mug.backward(torch.from_numpy(gm).to(dev))
+    assert rel_l2(t2n(xg.grad), t2n(xo.grad)) < 1e-4
+    assert rel_l2(t2n(wg.grad), t2n(wo.grad)) < 1e-4
+    # d(loss)/d(bias) is analytically zero (a per-channel constant cancels in both softmaxes): both sides hold rounding noise only
+    assert np.abs(t2n(bo.grad)).max() < 1e-9
+    assert np.abs(t2n(bg.grad)).max() < 1e-5 * max(1.0, np.abs(t2n(wg.grad)).max())
+    # the unfused HIP pair (1x1 conv, then the head on the materialised logits) agrees to fp32 rounding
+    xu = torch.from_numpy(x).to(dev).requires_grad_(True)
+    wu = torch.from_numpy(w).to(dev).requires_grad_(True)
+    bu = torch.from_numpy(bias).to(dev).requires_grad_(True)
+    muu, _, _ = kpx.ops.keypoint_head(kpx.ops.conv2d(xu, wu, bu, stride=1))
+    muu.backward(torch.from_numpy(gm).to(dev))
+    kpx.ops.join_side_stream(dev)
+    np.testing.assert_allclose(t2n(mug), t2n(muu), atol=2e-6, rtol=0)
+    assert rel_l2(t2n(xg.grad), t2n(xu.grad)) < 1e-5
+    assert rel_l2(t2n(wg.grad), t2n(wu.grad)) < 1e-5
+
+
 def test_keypoint_head_and_renderer_match_reference_golden(kpx, dev, golden_dir):
     ref = np.load(os.path.join(golden_dir, 'model_utils_ref.npz'))
     for tag in ('a', 'b'):

@@ -83,6 +83,9 @@ SIGNATURES = {
     'kpx_keypoint_head_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'kpx_keypoint_head_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P]),
     'kpx_keypoint_head_bwd_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    'kpx_keypoint_head_proj_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'kpx_keypoint_head_proj_fwd_f32': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
+    'kpx_keypoint_head_proj_bwd_f32': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P]),
     'kpx_gaussian_maps_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_double, P, c_int, P]),
     'kpx_gaussian_maps_bwd_f32': (c_int, [P, c_int, P, c_int, c_int, c_int, c_int, c_double, P, P]),
     'kpx_head_blend_fwd_f32': (c_int, [P, P, c_size_t, P, P, P, P]),

@@ -158,6 +158,220 @@ extern "C" int kpx_keypoint_head_bwd_f32(const float* dmu, const float* mu, cons
     return kpx_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------ 1x1 head folded into the key-point head
+// pose_encoder ends in a 1x1 convolution C -> K (networks/__init__.py:54) whose output, the logits [B,H,W,K], is consumed ONLY by the two
+// axis means of get_coord (utils/model.py:63-70).  Both are linear, so they commute:
+//   mean_w(x W + b)[b,h,k] = (sum_w x[b,h,w,:]) W[:,k] / W_ + b[k]
+// and the logits are never formed: stage 1 runs on the C-channel activation x itself, the [C,K] projection is applied to the H + W profile
+// rows of each image.  The backward is separable for the same reason:
+//   dlogits[b,h,w,k] = dRow[b,h,k]/W_ + dCol[b,w,k]/H_                      (kp_bwd_kernel above)
+//   dx[b,h,w,c]      = R[b,h,c] + Cc[b,w,c],   R = (dRow/W_) W^T, Cc = (dCol/H_) W^T            -> one write pass, nothing read
+//   dW[c,k]          = sum_{b,h} xs_y[b,h,c] dRow[b,h,k]/W_ + sum_{b,w} xs_x[b,w,c] dCol[b,w,k]/H_  (xs_* = the forward's row / column sums)
+//   db[k]            = sum_{b,h} dRow[b,h,k] + sum_{b,w} dCol[b,w,k]            (analytically 0: softmax ignores a per-channel constant)
+// Against conv + head this removes the logits write + two reads, the dlogits write + three reads and the 1x1 weight-gradient pass.
+// Rounding differs from the unfused order only in where the fp32 sums are taken (sum over pixels first, project second).
+
+// grid (B, 2): axis 1 -> y profile (rows, from xs_y), axis 0 -> x profile (columns: stripe partials are summed here and kept as xs_x)
+__global__ __launch_bounds__(256) void kp_proj_stage2_kernel(const float* __restrict__ xs_y, const float* __restrict__ colpart,
+                                                             float* __restrict__ xs_x, const float* __restrict__ wk,
+                                                             const float* __restrict__ bias, int H, int W, int C, int K, int nstripes,
+                                                             float* __restrict__ mu, float* __restrict__ prob_y, float* __restrict__ prob_x) {
+    extern __shared__ float kp_sm[];            // [n][C] profile sums, then [C][K] weights
+    const int b = blockIdx.x, axis = blockIdx.y;
+    const int n = axis ? H : W, other = axis ? W : H;
+    float* S = kp_sm;
+    float* wl = kp_sm + (size_t)n * C;
+    const int nC = n * C, WC = W * C;
+    for (int e = threadIdx.x; e < nC; e += 256) {
+        float s;
+        if (axis) s = xs_y[(size_t)b * nC + e];
+        else {
+            s = 0.f;
+            for (int st = 0; st < nstripes; ++st) s += colpart[((size_t)b * nstripes + st) * WC + e];
+            xs_x[(size_t)b * nC + e] = s;
+        }
+        S[e] = s;
+    }
+    for (int e = threadIdx.x; e < C * K; e += 256) wl[e] = wk[e];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float inv_other = (float)other;
+    for (int k = wave; k < K; k += 4) {
+        const float bk = bias ? bias[k] : 0.f;
+        float v[8];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = lane + 64 * j;
+            float m = -INFINITY;
+            if (i < n) {
+                float d = 0.f;
+                for (int c = 0; c < C; ++c) d = fmaf(S[i * C + c], wl[c * K + k], d);
+                m = d / inv_other + bk;
+            }
+            v[j] = m;
+            mx = fmaxf(mx, m);
+        }
+        mx = kpx_wave_max(mx);
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = lane + 64 * j;
+            v[j] = (i < n) ? expf(v[j] - mx) : 0.f;
+            se += v[j];
+        }
+        se = kpx_wave_sum(se);
+        const float inv = 1.0f / se;
+        float ex = 0.f;
+        float* pout = axis ? prob_y : prob_x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = lane + 64 * j;
+            if (i < n) {
+                const float p = v[j] * inv;
+                pout[((size_t)b * n + i) * K + k] = p;
+                ex += p * kpx_linspace(i, n);
+            }
+        }
+        ex = kpx_wave_sum(ex);
+        if (lane == 0) mu[((size_t)b * K + k) * 2 + axis] = ex;
+    }
+}
+
+static bool kp_proj_dims_ok(int B, int H, int W, int C, int K) {
+    const int n = H > W ? H : W;
+    return B > 0 && H >= 2 && W >= 2 && H <= 512 && W <= 512 && C > 0 && C <= 256 && K > 0 && K <= 64 && (C % 4) == 0 &&
+           ((size_t)n * C + (size_t)C * K) * sizeof(float) <= 64 * 1024 && ((size_t)n * K + (size_t)C * K) * sizeof(float) <= 64 * 1024;
+}
+
+extern "C" size_t kpx_keypoint_head_proj_scratch_bytes(int B, int H, int W, int C, int K) {
+    const size_t nstripes = (size_t)(H + KP_RS - 1) / KP_RS;
+    const size_t fwd = (size_t)B * nstripes * W * C;                                   // stripe column sums
+    const size_t bwd = (size_t)B * (H + W) * C + (size_t)B * 2 * ((size_t)C * K + K);  // R, Cc, per-(image, axis) dW / db partials
+    return (fwd > bwd ? fwd : bwd) * sizeof(float);
+}
+
+extern "C" int kpx_keypoint_head_proj_fwd_f32(const float* x, const float* wk, const float* bias, int B, int H, int W, int C, int K,
+                                              float* mu, float* prob_y, float* prob_x, float* xs_y, float* xs_x, void* scratch, void* stream) {
+    if (!x || !wk || !mu || !prob_y || !prob_x || !xs_y || !xs_x || !scratch || !kp_proj_dims_ok(B, H, W, C, K)) return KPX_EINVAL;
+    hipStream_t s = kpx_stream(stream);
+    const int nstripes = (H + KP_RS - 1) / KP_RS;
+    float* colpart = (float*)scratch;
+    hipLaunchKernelGGL(kp_stage1_kernel, dim3(B, nstripes), dim3(256), 0, s, x, H, W, C, xs_y, colpart, nstripes);
+    int rc = kpx_launch_status();
+    if (rc) return rc;
+    const int n = H > W ? H : W;
+    hipLaunchKernelGGL(kp_proj_stage2_kernel, dim3(B, 2), dim3(256), ((size_t)n * C + (size_t)C * K) * sizeof(float), s,
+                       (const float*)xs_y, (const float*)colpart, xs_x, wk, bias, H, W, C, K, nstripes, mu, prob_y, prob_x);
+    return kpx_launch_status();
+}
+
+// grid (B, 2): d[i,k] = dmu * p * (lin - mu) / other;  RC[b,i,c] = sum_k d[i,k] W[c,k];  partial dW[c,k] = sum_i xs[b,i,c] d[i,k];
+// partial db[k] = other * sum_i d[i,k]
+__global__ __launch_bounds__(256) void kp_proj_bwd_small_kernel(const float* __restrict__ dmu, const float* __restrict__ mu,
+                                                                const float* __restrict__ prob_y, const float* __restrict__ prob_x,
+                                                                const float* __restrict__ xs_y, const float* __restrict__ xs_x,
+                                                                const float* __restrict__ wk, int H, int W, int C, int K,
+                                                                float* __restrict__ Rb, float* __restrict__ Cb, float* __restrict__ part) {
+    extern __shared__ float kp_sm[];            // [n][K] d, then [C][K] weights
+    const int b = blockIdx.x, axis = blockIdx.y, B = gridDim.x;
+    const int n = axis ? H : W, other = axis ? W : H;
+    float* d = kp_sm;
+    float* wl = kp_sm + (size_t)n * K;
+    const float* p = axis ? prob_y : prob_x;
+    const float io = 1.0f / (float)other;
+    for (int e = threadIdx.x; e < n * K; e += 256) {
+        const int i = e / K, k = e - i * K;
+        const size_t bk = ((size_t)b * K + k) * 2 + axis;
+        d[e] = dmu[bk] * p[(size_t)b * n * K + e] * (kpx_linspace(i, n) - mu[bk]) * io;
+    }
+    for (int e = threadIdx.x; e < C * K; e += 256) wl[e] = wk[e];
+    __syncthreads();
+    float* out = axis ? Rb + (size_t)b * H * C : Cb + (size_t)b * W * C;
+    for (int e = threadIdx.x; e < n * C; e += 256) {
+        const int i = e / C, c = e - i * C;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s = fmaf(d[i * K + k], wl[c * K + k], s);
+        out[e] = s;
+    }
+    const float* xs = (axis ? xs_y : xs_x) + (size_t)b * n * C;
+    float* pp = part + ((size_t)b * 2 + axis) * ((size_t)C * K + K);
+    for (int e = threadIdx.x; e < C * K + K; e += 256) {
+        float s = 0.f;
+        if (e < C * K) {
+            const int c = e / K, k = e - c * K;
+            for (int i = 0; i < n; ++i) s = fmaf(xs[i * C + c], d[i * K + k], s);
+        } else {
+            const int k = e - C * K;
+            for (int i = 0; i < n; ++i) s += d[i * K + k];
+            s *= (float)other;
+        }
+        pp[e] = s;
+    }
+    (void)B;
+}
+
+// dW / db = sum over the 2B partial rows, in order (deterministic); accumulate != 0 adds into the destination
+__global__ __launch_bounds__(256) void kp_proj_bwd_reduce_kernel(const float* __restrict__ part, int rows, int CK, int K,
+                                                                 float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= CK + K) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += part[(size_t)r * (CK + K) + e];
+    if (e < CK) { if (dw) dw[e] = accumulate ? dw[e] + s : s; }
+    else if (db) db[e - CK] = accumulate ? db[e - CK] + s : s;
+}
+
+// dx[b,h,w,:] = R[b,h,:] + Cc[b,w,:]: pure write stream, 16 B per lane.  grid (slabs of rows, B); a thread owns one (w, channel quad)
+// column for the whole slab when W*C/4 is a multiple of the block size (the Cc term stays in registers).
+__global__ __launch_bounds__(256) void kp_proj_dx_kernel(const float* __restrict__ Rb, const float* __restrict__ Cb, int H, int W, int C,
+                                                         int rows_per_block, float* __restrict__ dx) {
+    const int b = blockIdx.y, h0 = blockIdx.x * rows_per_block;
+    const int cq = C >> 2, rowq = W * cq;            // float4 per image row
+    const float4* R4 = (const float4*)(Rb + (size_t)b * H * C);
+    const float4* C4 = (const float4*)(Cb + (size_t)b * W * C);
+    float4* out = (float4*)(dx + (size_t)b * H * W * C);
+    for (int q0 = threadIdx.x; q0 < rowq; q0 += 256) {
+        const float4 cc = C4[q0];
+        const int c4 = q0 % cq;
+        for (int r = 0; r < rows_per_block; ++r) {
+            const int h = h0 + r;
+            if (h >= H) break;
+            const float4 rr = R4[h * cq + c4];
+            float4 o;
+            o.x = rr.x + cc.x; o.y = rr.y + cc.y; o.z = rr.z + cc.z; o.w = rr.w + cc.w;
+            out[(size_t)h * rowq + q0] = o;
+        }
+    }
+}
+
+extern "C" int kpx_keypoint_head_proj_bwd_f32(const float* dmu, const float* mu, const float* prob_y, const float* prob_x,
+                                              const float* xs_y, const float* xs_x, const float* wk, int B, int H, int W, int C, int K,
+                                              float* dx, float* dw, float* db, int accumulate, void* scratch, void* stream) {
+    if (!dmu || !mu || !prob_y || !prob_x || !xs_y || !xs_x || !wk || !scratch || !kp_proj_dims_ok(B, H, W, C, K)) return KPX_EINVAL;
+    hipStream_t s = kpx_stream(stream);
+    float* Rb = (float*)scratch;
+    float* Cb = Rb + (size_t)B * H * C;
+    float* part = Cb + (size_t)B * W * C;
+    const int n = H > W ? H : W;
+    hipLaunchKernelGGL(kp_proj_bwd_small_kernel, dim3(B, 2), dim3(256), ((size_t)n * K + (size_t)C * K) * sizeof(float), s,
+                       dmu, mu, prob_y, prob_x, xs_y, xs_x, wk, H, W, C, K, Rb, Cb, part);
+    int rc = kpx_launch_status();
+    if (rc) return rc;
+    if (dw || db) {
+        hipLaunchKernelGGL(kp_proj_bwd_reduce_kernel, dim3((C * K + K + 255) / 256), dim3(256), 0, s, (const float*)part, 2 * B, C * K, K,
+                           dw, db, accumulate);
+        rc = kpx_launch_status();
+        if (rc) return rc;
+    }
+    if (dx) {
+        const int rpb = 8;
+        hipLaunchKernelGGL(kp_proj_dx_kernel, dim3((H + rpb - 1) / rpb, B), dim3(256), 0, s, (const float*)Rb, (const float*)Cb, H, W, C, rpb, dx);
+        rc = kpx_launch_status();
+    }
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------ Gaussian maps
 // ONE definition of a heat-map element for every renderer and for the backward: the reference's rounding sequence
 // square(y - mu_y) + square(x - mu_x), times float32(inv_std**2), negate, exp (utils/model.py:56-59); exp is the hardware

@@ -103,8 +103,10 @@ class DetectorTranslatorModel(BaseModel):
             embeddings = networks.image_encoder(im, train, update_moving=update_moving)
         # :166-167 -- the two weight-sharing pose_encoder calls as one batched launch, BN statistics per call
         both = Sym(2 * b, *im.shape[1:]) if sym else ops.concat_batch(im, future_im)
-        pts, logits = networks.pose_encoder(both, self.n_points, train, final_res=self.image_size, bn_groups=2,
-                                            return_logits=True, update_moving=update_moving)
+        # (the reference also fetches the head's logits here and never uses them: not requesting them lets the 1x1 head fold into
+        # the key-point head, networks.FUSE_KEYPOINT_HEAD)
+        pts = networks.pose_encoder(both, self.n_points, train, final_res=self.image_size, bn_groups=2,
+                                    update_moving=update_moving)
         if sym:
             joint = Sym(b, self.heat_size, self.heat_size, (embeddings[-2].shape[-1] + 2 * self.n_points + 3) // 4 * 4)
             cur_pt = fut_pt = None

@@ -34,6 +34,24 @@ def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', 
     return ops.conv2d(x, w_, b_, stride=stride, pad=pad, act=act, cin=cin, w_grad_out=wg, b_grad_out=bg, bias_grad=bias_grad, bn_stats=bn_stats)
 
 
+def conv1x1_keypoints(x, channels, scope='conv_0'):
+    """layers.conv(x, channels, kernel=1, stride=1) followed by the separable-softmax key-point head (reference networks/__init__.py:54,
+    68-72) as one op: same variables as ``conv`` (<scope>/conv2d/{kernel,bias}), the logits are never materialised (ops.KeypointHeadProjFn).
+    Returns (mu [B,K,2] as (x,y), prob_y [B,H,K], prob_x [B,W,K])."""
+    st = default_store()
+    channels = int(channels)
+    cin_ = int(x.shape[-1])
+    with st.variable_scope(scope), st.variable_scope('conv2d'):
+        kname = st.get_variable('kernel', (1, 1, cin_, channels), 'kernel')
+        bname = st.get_variable('bias', (channels,), 'zeros')
+    if is_sym(x):
+        n, h, w, _ = x.shape
+        return Sym(n, channels, 2), Sym(n, h, channels), Sym(n, w, channels)
+    w_, wg = st.param(kname)
+    b_, bg = st.param(bname)
+    return ops.keypoint_head_proj(x, w_, b_, w_grad_out=wg, b_grad_out=bg)
+
+
 def batch_norm(x, train_mode, scope='batch_norm', act=ACT_NONE, groups=1, update_moving=True):
     """reference layers.batch_norm (layers.py:13-14): contrib batch_norm(eps=1e-5, center, scale, is_training)."""
     st = default_store()

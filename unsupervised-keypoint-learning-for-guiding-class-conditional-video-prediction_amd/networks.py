@@ -8,7 +8,13 @@ batch-norm statistics per call.
 from . import layers, ops
 from . import model_utils
 from .layers import ACT_LRELU, ACT_NONE
+import os as _os
+
 from .variables import Sym, default_store, is_sym
+
+# pose_encoder's 1x1 head and the two get_coord reductions as ONE op that never writes the [B,H,W,K] logits (ops.KeypointHeadProjFn);
+# KPX_FUSE_KP_HEAD=0 keeps the conv + head pair (also used whenever the caller asks for the logits)
+FUSE_KEYPOINT_HEAD = _os.environ.get('KPX_FUSE_KP_HEAD', '1') != '0'
 
 
 def _upsample_concat(x, skip):
@@ -54,6 +60,10 @@ def pose_encoder(x, n_pts, train_mode, final_res=128, filters=128, bn_groups=1, 
             x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % conv_id, 'b_norm_%d_0' % conv_id, bn_groups, update_moving=update_moving)
             x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id, bn_groups, update_moving=update_moving)
             if size == final_res:
+                if FUSE_KEYPOINT_HEAD and not return_logits and (is_sym(x) or (x.is_cuda and x.shape[-1] % 4 == 0)):
+                    # 1x1 head (:54) + get_coord x2 (:68-71) as one op: the logits are consumed by the two axis means only
+                    gauss_mu, _, _ = layers.conv1x1_keypoints(x, n_pts)
+                    return gauss_mu
                 x = layers.conv(x, n_pts, kernel=1, stride=1)        # default scope 'conv_0' (:54)
                 break
             x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1), bn_groups, update_moving=update_moving)

@@ -833,6 +833,68 @@ def keypoint_head(logits):
     return KeypointHeadFn.apply(logits)
 
 
+class KeypointHeadProjFn(torch.autograd.Function):
+    """layers.conv(x, n_pts, kernel=1) + get_coord x2 + stack with the logits never formed (reference networks/__init__.py:54,68-72;
+    utils/model.py:63-70): the axis means commute with the 1x1 projection.  x [B,H,W,C], w [1,1,C,K], b [K] -> mu [B,K,2] (x,y)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, w_grad_out, b_grad_out):
+        _require_gpu(x)
+        x = x.contiguous()
+        bsz, h, wd, c = x.shape
+        k = w.shape[3]
+        dev = x.device
+        mu = torch.empty((bsz, k, 2), dtype=torch.float32, device=dev)
+        py = torch.empty((bsz, h, k), dtype=torch.float32, device=dev)
+        px = torch.empty((bsz, wd, k), dtype=torch.float32, device=dev)
+        xs_y = torch.empty((bsz, h, c), dtype=torch.float32, device=dev)
+        xs_x = torch.empty((bsz, wd, c), dtype=torch.float32, device=dev)
+        sc = scratch.get('kpproj', lib.kpx_keypoint_head_proj_scratch_bytes(bsz, h, wd, c, k), dev)
+        check(lib.kpx_keypoint_head_proj_fwd_f32(x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, bsz, h, wd, c, k,
+                                                 mu.data_ptr(), py.data_ptr(), px.data_ptr(), xs_y.data_ptr(), xs_x.data_ptr(),
+                                                 sc.data_ptr(), _stream()), 'kpx_keypoint_head_proj_fwd_f32')
+        ctx.dims = (bsz, h, wd, c, k)
+        ctx.has_bias = b is not None
+        ctx.w_grad_out, ctx.b_grad_out = w_grad_out, b_grad_out
+        ctx.save_for_backward(mu, py, px, xs_y, xs_x, w)
+        ctx.mark_non_differentiable(py, px)
+        return mu, py, px
+
+    @staticmethod
+    def backward(ctx, dmu, _dpy, _dpx):
+        mu, py, px, xs_y, xs_x, w = ctx.saved_tensors
+        bsz, h, wd, c, k = ctx.dims
+        dev = dmu.device
+        dmu = dmu.contiguous()
+        dx = torch.empty((bsz, h, wd, c), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        want_w = ctx.needs_input_grad[1]
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        # both parameter gradients leave one launch: they go straight into the flat bucket only when both slots are fresh
+        direct = (want_w and ctx.w_grad_out is not None and (not want_b or ctx.b_grad_out is not None))
+        if direct:
+            fresh_w = _claim_grad(ctx.w_grad_out)
+            fresh_b = _claim_grad(ctx.b_grad_out) if want_b else fresh_w
+            assert fresh_w == fresh_b, 'kernel and bias of one 1x1 head are always used together'
+            dw_buf, db_buf, acc = ctx.w_grad_out, (ctx.b_grad_out if want_b else None), 0 if fresh_w else 1
+        else:
+            dw_buf = torch.empty_like(w) if want_w else None
+            db_buf = torch.empty(k, dtype=torch.float32, device=dev) if want_b else None
+            acc = 0
+        sc = scratch.get('kpproj', lib.kpx_keypoint_head_proj_scratch_bytes(bsz, h, wd, c, k), dev)
+        check(lib.kpx_keypoint_head_proj_bwd_f32(dmu.data_ptr(), mu.data_ptr(), py.data_ptr(), px.data_ptr(), xs_y.data_ptr(), xs_x.data_ptr(),
+                                                 w.data_ptr(), bsz, h, wd, c, k, dx.data_ptr() if dx is not None else None,
+                                                 dw_buf.data_ptr() if dw_buf is not None else None,
+                                                 db_buf.data_ptr() if db_buf is not None else None, acc, sc.data_ptr(), _stream()),
+              'kpx_keypoint_head_proj_bwd_f32')
+        if direct:
+            return dx, None, None, None, None
+        return dx, dw_buf, db_buf, None, None
+
+
+def keypoint_head_proj(x, w, b=None, w_grad_out=None, b_grad_out=None):
+    return KeypointHeadProjFn.apply(x, w, b, w_grad_out, b_grad_out)
+
+
 class GaussianMapsFn(torch.autograd.Function):
     """get_gaussian_maps (reference utils/model.py:49-60): [B,K,2] -> [B,H,W,K]."""
 
