@@ -222,6 +222,35 @@ def test_keypoint_head_fwd_bwd(kpx, dev, shape, scale):
     assert rel_l2(t2n(xg.grad), t2n(xo.grad)) < 1e-4
 
 
+def test_cached_winograd_forms_die_with_their_filter(kpx, dev):
+    """The pre-transformed filter cache is keyed by the filter's address.  A constant (VGG19 / inference-folded) filter that is freed
+    without release_filters() must not serve its stale form to an unrelated filter that the allocator later places at the same address
+    (seen as a wrong forward in a full test run: a dead store's folded filters, then a test tensor in the same block)."""
+    rs = np.random.RandomState(77)
+    x = rs.randn(2, 16, 16, 32).astype(np.float32)
+    w_old = torch.from_numpy((rs.randn(3, 3, 32, 64) / 17.0).astype(np.float32)).to(dev)
+    kpx.ops.register_constant_filter(w_old, 'stale/kernel')
+    ptr = w_old.data_ptr()
+    del w_old                                                     # owner gone, keys never released
+    wn = (rs.randn(3, 3, 32, 64) / 17.0).astype(np.float32)
+    w_new = torch.from_numpy(wn).to(dev)
+    if w_new.data_ptr() != ptr:
+        pytest.skip('the allocator did not reuse the block')
+    y = kpx.ops.conv2d(torch.from_numpy(x).to(dev), w_new, None, stride=1)
+    yo = R.conv(torch.from_numpy(x), torch.from_numpy(wn), None, 1, 0)
+    assert rel_l2(t2n(y), t2n(yo)) < 1e-5
+    # ... and a same-address filter of another shape is never matched either
+    del w_new, y
+    w_live = torch.from_numpy(wn).to(dev)
+    kpx.ops.register_constant_filter(w_live, 'live/kernel')
+    w_view = w_live.view(-1)[:3 * 3 * 16 * 128].view(3, 3, 16, 128)          # same address, different (Cin, Cout)
+    x16 = rs.randn(2, 16, 16, 16).astype(np.float32)
+    y = kpx.ops.conv2d(torch.from_numpy(x16).to(dev), w_view, None, stride=1)
+    yo = R.conv(torch.from_numpy(x16), w_view.cpu(), None, 1, 0)
+    assert rel_l2(t2n(y), t2n(yo)) < 1e-5
+    kpx.ops.release_filters([(w_live.data_ptr(), 0), (w_live.data_ptr(), 1)])
+
+
 @pytest.mark.parametrize('shape,k,scale', [((4, 128, 128, 16), 15, 1.0), ((1, 24, 40, 8), 5, 3.0), ((3, 32, 32, 32), 40, 0.5)])
 def test_keypoint_head_folded_1x1_matches_conv_then_head(kpx, dev, shape, k, scale):
     """pose_encoder's 1x1 head + get_coord x2 as one op that never forms the logits (reference networks/__init__.py:54,68-72):

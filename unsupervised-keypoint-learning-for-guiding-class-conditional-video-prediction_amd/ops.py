@@ -222,8 +222,23 @@ def _bf16_conv(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad):
 import ctypes as _ctypes
 import struct as _struct
 
-_wino_u = {}          # (filter data_ptr, dgrad) -> (U tensor, owning FilterBank or None)
+_wino_u = {}          # (filter data_ptr, dgrad) -> (U tensor, owning FilterBank or None, weak reference to the filter tensor, (Cin, Cout))
 _wino43_u = {}        # the same for the F(4x4,3x3) form of the filters whose layers may use it
+import weakref as _weakref
+
+
+def _cached_u(table, w, dgrad):
+    """The cached transform of filter ``w``, or None.  The key is the filter's ADDRESS, so an entry is only trusted while the tensor it
+    was made from is alive (a bank keeps its filters alive itself; a constant / folded filter is tracked by a weak reference) and has this
+    shape -- the allocator hands a freed filter's address to unrelated tensors."""
+    key = (w.data_ptr(), 1 if dgrad else 0)
+    ent = table.get(key)
+    if ent is None:
+        return None
+    if (ent[2] is not None and ent[2]() is None) or ent[3] != (int(w.shape[2]), int(w.shape[3])):
+        table.pop(key, None)
+        return None
+    return ent
 conv_kernel_uses = {'wino43': 0}      # diagnostics / tests: launches of the F(4x4,3x3) kernel
 
 # F(4x4,3x3) (csrc/conv_wino43.hip) does 2.25x fewer multiplies than F(2x2,3x3) at ~6x its rounding error (2-3e-6 rel-L2 per layer, still
@@ -264,12 +279,12 @@ class FilterBank:
             for dgrad in (0, 1):
                 u = self.arena[off:off + n]
                 off += n
-                _wino_u[(w.data_ptr(), dgrad)] = (u, self)
+                _wino_u[(w.data_ptr(), dgrad)] = (u, self, None, (int(w.shape[2]), int(w.shape[3])))
                 table += _struct.pack('<QQiiii', w.data_ptr(), u.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, 0)
                 if wt[dgrad]:
                     u = self.arena[off:off + n43]
                     off += n43
-                    _wino43_u[(w.data_ptr(), dgrad)] = (u, self)
+                    _wino43_u[(w.data_ptr(), dgrad)] = (u, self, None, (int(w.shape[2]), int(w.shape[3])))
                     table43 += _struct.pack('<QQiiii', w.data_ptr(), u.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, 0)
         self.n_desc = 2 * len(self.filters)
         self.table = torch.frombuffer(bytearray(table), dtype=torch.uint8).to(device)
@@ -300,12 +315,12 @@ def register_constant_filter(w, name=''):
     for dgrad in (0, 1):
         u = torch.empty(n, dtype=torch.float32, device=w.device)
         check(lib.kpx_wino_filter_transform_f32(w.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, u.data_ptr(), _stream()), 'kpx_wino_filter_transform_f32')
-        _wino_u[(w.data_ptr(), dgrad)] = (u, None)
+        _wino_u[(w.data_ptr(), dgrad)] = (u, None, _weakref.ref(w), (int(w.shape[2]), int(w.shape[3])))
         keys.append((w.data_ptr(), dgrad))
         if _wino43_wanted(name, int(w.shape[2]), int(w.shape[3]), dgrad):
             u = torch.empty(lib.kpx_wino43_u_bytes(int(w.shape[2]), int(w.shape[3])) // 4, dtype=torch.float32, device=w.device)
             check(lib.kpx_wino43_filter_transform_f32(w.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, u.data_ptr(), _stream()), 'kpx_wino43_filter_transform_f32')
-            _wino43_u[(w.data_ptr(), dgrad)] = (u, None)
+            _wino43_u[(w.data_ptr(), dgrad)] = (u, None, _weakref.ref(w), (int(w.shape[2]), int(w.shape[3])))
     return keys
 
 
@@ -319,17 +334,17 @@ def release_filters(keys):
 def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, want_stats=False, bn_src=None):
     """Run the fused Winograd kernel on a cached U; False when there is none for this filter or the shape is not eligible.
     want_stats: also have the epilogue write the per-tile batch-norm sums of the output; returns (slab, tiles per image) then."""
-    ent = _wino_u.get((w.data_ptr(), 1 if dgrad else 0))
+    ent = _cached_u(_wino_u, w, dgrad)
     if ent is None:
         return False
     n, h, wd = inp.shape[0], inp.shape[1], inp.shape[2]
     if not lib.kpx_conv3x3_wino_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr()):
         return False
-    u, bank = ent
+    u, bank = ent[0], ent[1]
     if bank is not None:
         bank.ensure_fresh()
     bptr = bias.data_ptr() if bias is not None else None
-    ent43 = _wino43_u.get((w.data_ptr(), 1 if dgrad else 0)) if WINO43 else None
+    ent43 = _cached_u(_wino43_u, w, dgrad) if WINO43 else None
     tiles = lib.kpx_conv3x3_wino43_stats_tiles(n, h, wd) if want_stats else 1      # 0: no statistics from this kernel for the shape (16 x 16)
     # one F(4x4,3x3) workgroup covers 16 x 32 pixels x 64 channels and lives alone on its CU: below ~half a chip of them the
     # F(2x2,3x3) kernel's twice as many, half as large workgroups finish sooner (measured: 128 workgroups 0.187 vs 0.158 ms)
@@ -368,7 +383,7 @@ def conv3x3_wino43_ex(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, mask=
     """The F(4x4,3x3) kernel with VGG19's epilogue options: ``mask`` -- zero the output where mask <= 0 (ReLU backward of the tensor the
     data gradient belongs to), ``pool_out`` -- also write the 2x2 max-pool of the activated output.  True if it ran; False when the
     layer / launch is not one the kernel takes (the caller then uses the plain path and the separate kernels)."""
-    ent43 = _wino43_u.get((w.data_ptr(), 1 if dgrad else 0)) if WINO43 else None
+    ent43 = _cached_u(_wino43_u, w, dgrad) if WINO43 else None
     if ent43 is None or nn % 64:
         return False
     n, h, wd = inp.shape[0], inp.shape[1], inp.shape[2]
