@@ -229,7 +229,7 @@ import weakref as _weakref
 
 def _cached_u(table, w, dgrad):
     """The cached transform of filter ``w``, or None.  The key is the filter's ADDRESS, so an entry is only trusted while the tensor it
-    was made from is alive (a bank keeps its filters alive itself; a constant / folded filter is tracked by a weak reference) and has this
+    was made from is allocated (a bank keeps its filters alive itself; a constant / folded filter is tracked by a weak reference to its storage) and has this
     shape -- the allocator hands a freed filter's address to unrelated tensors."""
     key = (w.data_ptr(), 1 if dgrad else 0)
     ent = table.get(key)
@@ -315,12 +315,12 @@ def register_constant_filter(w, name=''):
     for dgrad in (0, 1):
         u = torch.empty(n, dtype=torch.float32, device=w.device)
         check(lib.kpx_wino_filter_transform_f32(w.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, u.data_ptr(), _stream()), 'kpx_wino_filter_transform_f32')
-        _wino_u[(w.data_ptr(), dgrad)] = (u, None, _weakref.ref(w), (int(w.shape[2]), int(w.shape[3])))
+        _wino_u[(w.data_ptr(), dgrad)] = (u, None, _weakref.ref(w.untyped_storage()), (int(w.shape[2]), int(w.shape[3])))
         keys.append((w.data_ptr(), dgrad))
         if _wino43_wanted(name, int(w.shape[2]), int(w.shape[3]), dgrad):
             u = torch.empty(lib.kpx_wino43_u_bytes(int(w.shape[2]), int(w.shape[3])) // 4, dtype=torch.float32, device=w.device)
             check(lib.kpx_wino43_filter_transform_f32(w.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, u.data_ptr(), _stream()), 'kpx_wino43_filter_transform_f32')
-            _wino43_u[(w.data_ptr(), dgrad)] = (u, None, _weakref.ref(w), (int(w.shape[2]), int(w.shape[3])))
+            _wino43_u[(w.data_ptr(), dgrad)] = (u, None, _weakref.ref(w.untyped_storage()), (int(w.shape[2]), int(w.shape[3])))
     return keys
 
 
