@@ -436,15 +436,17 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     enq = [t_enq / args.steps * 1e3]
+    ms_by_rank = [dt / args.steps * 1e3]
     n_ranks_seen = 1
     if launched:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
         n_ranks_seen = torch.distributed.get_world_size()
-        e = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
-        torch.distributed.all_gather(e, torch.tensor(enq, dtype=torch.float64, device=dev))
-        enq = [float(x.item()) for x in e]
+        e = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+        torch.distributed.all_gather(e, torch.tensor([enq[0], ms_by_rank[0]], dtype=torch.float64, device=dev))
+        enq = [float(x[0].item()) for x in e]
+        ms_by_rank = [float(x[1].item()) for x in e]          # each rank's own clock around its K steps; `ms_per_step` is their maximum
+        dt = float(t.item())
     losses = model.loss_values()
     assert np.isfinite(losses['loss_D']) and np.isfinite(losses['loss_G']), losses
 
@@ -467,6 +469,7 @@ def main():
                'step_tflops': round(2 * gmac * 1e9 * value / 1e12, 2),
                'step_algorithmic_frac_of_f32_peak': round(2 * gmac * 1e9 * value / world / 157.3e12, 4),
                'n_ranks_seen': n_ranks_seen, 'dist_backend': backend if launched else None,
+               'ms_per_step_by_rank': [round(x, 3) for x in ms_by_rank],
                'host_enqueue_ms_per_step': round(max(enq), 3), 'host_enqueue_ms_per_step_by_rank': [round(x, 3) for x in enq],
                'host_enqueue_note': 'wall time of the K train_step() calls / K: includes blocking on a full launch queue (a graph replay call blocks once '
                                     'a few replays are in flight); host_work_ms_per_step_min = the shortest single call = the host work of one step',

@@ -121,6 +121,50 @@ def test_data_parallel_gradient_exchange_two_gloo_ranks():
         assert out == {'D': True, 'G': True, 'alias': True}, (rank, out)
 
 
+def _dp_bf16_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), KPX_DP_BF16='D')
+    import torch.distributed
+    sys.path.insert(0, REPO)
+    torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+    m = build_cpu_model(n_pts=3, res=32)
+    out = {}
+    for which in ('D', 'G'):
+        b = m.store.buckets[which]
+        local = [torch.sin(torch.arange(b.grads.numel(), dtype=torch.float32) * 0.37 + r) * (r + 1.5) for r in range(world)]
+        b.grads.copy_(local[rank])
+        work = m.exchange_gradients(which, async_op=(which == 'D'))
+        if work is not None:
+            work.wait()
+        if which == 'D':     # the flagged bucket: every rank's gradient rounded to bf16, summed in bf16, widened back
+            want = local[0].to(torch.bfloat16)
+            for r in range(1, world):
+                want = want + local[r].to(torch.bfloat16)
+            out[which] = bool(torch.equal(b.grads, want.float())) and b.grads.dtype == torch.float32
+            out['D_close_to_fp32_sum'] = bool(torch.allclose(b.grads, sum(local), rtol=2e-2, atol=2e-2))
+        else:                # the other bucket keeps the exact fp32 exchange
+            out[which] = bool(torch.equal(b.grads, local[0] + local[1]))
+    q.put((rank, out))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_bf16_exchange_flag_two_gloo_ranks():
+    """KPX_DP_BF16=D (off by default): the discriminator's flat gradient bucket crosses the links as bf16, the generator's stays fp32."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out in results:
+        assert out == {'D': True, 'D_close_to_fp32_sum': True, 'G': True}, (rank, out)
+
+
 def test_f43_layer_policy_follows_the_float64_arbiter_findings():
     """Which layers may run the F(4x4,3x3) kernel is host logic (ops.WINO43_EXCLUDE_*): data gradients everywhere, forward only on VGG19
     and the translator's 64x64 / 128x128 layers; the key-point detector, the image encoder and the translator's 32x32 layers keep

@@ -32,6 +32,23 @@ VGG_ON_AUX = os.environ.get('KPX_VGG_ON_AUX', '0') != '0'      # the G run's adv
 # The whole step -- ~700 launches on three streams -- as ONE HIP graph, captured from the second call on a given input shape and replayed
 # afterwards (KPX_GRAPH=0: every step is enqueued from Python).  Single-process steps on the shared batch only; see _train_step_graphed.
 GRAPH = os.environ.get('KPX_GRAPH', '1') != '0'
+# Data parallel, optional: exchange the named flat gradient buckets as bf16 (half the bytes on xGMI; the 178.9 MB discriminator bucket is the
+# candidate).  OFF by default -- it rounds every gradient element to 8 mantissa bits before the sum, which the fp32 configuration must not do;
+# e.g. KPX_DP_BF16=D.  Parameters, Adam moments and the local gradients stay fp32.
+DP_BF16_BUCKETS = tuple(b for b in os.environ.get('KPX_DP_BF16', '').split(',') if b)
+
+
+class _Bf16Exchange:
+    """Handle of a bf16 gradient exchange: ``wait()`` orders the collective before the caller's stream and widens the sums back into the
+    fp32 gradient buffer (the same interface as the work handle of an asynchronous all-reduce)."""
+
+    def __init__(self, work, buf, grads):
+        self.work, self.buf, self.grads = work, buf, grads
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        self.grads.copy_(self.buf)
 GRAPH_WARMUP_STEPS = 1          # eager steps before the capture: they create every lazily allocated scratch buffer and kernel attribute
 
 log = logging.getLogger('kpx')
@@ -169,6 +186,18 @@ class DetectorTranslatorModel(BaseModel):
         bucket = self.store.buckets[which]
         ops.join_side_stream(self.device)       # weight gradients are written on the side stream
         if self.distributed:
+            if which in DP_BF16_BUCKETS:
+                bufs = self.__dict__.setdefault('_bf16_exchange_bufs', {})
+                buf = bufs.get(which)
+                if buf is None:
+                    buf = bufs[which] = torch.empty(bucket.grads.numel(), dtype=torch.bfloat16, device=bucket.grads.device)
+                buf.copy_(bucket.grads)              # round to nearest even, like every fp32 -> bf16 conversion on this path
+                work = torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=self.process_group, async_op=async_op)
+                handle = _Bf16Exchange(work if async_op else None, buf, bucket.grads)
+                if async_op:
+                    return handle
+                handle.wait()
+                return None
             work = torch.distributed.all_reduce(bucket.grads, op=torch.distributed.ReduceOp.SUM, group=self.process_group,
                                                 async_op=async_op)
             return work if async_op else None
