@@ -71,7 +71,7 @@ def timeit(fn, iters=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--batch', type=int, default=32)
-    ap.add_argument('--filter', default='')
+    ap.add_argument('--filter', default='', help='comma-separated substrings of layer names')
     ap.add_argument('--unregistered', action='store_true', help='3x3 layers through the plain C entry (filter transformed inside the call, F(2x2,3x3) only)')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -79,7 +79,7 @@ def main():
     flops_tot = 0.0
     print('%-36s %5s %4s %5s %5s k s | %9s %6s | %9s %6s | %9s %6s' % ('layer', 'N', 'H', 'Cin', 'Cout', 'fwd ms', 'TF', 'dgrad ms', 'TF', 'wgrad ms', 'TF'))
     for (name, n, h, ci, co, k, s, pad, ld, wf, wd, ww) in layers(args.batch):
-        if args.filter and args.filter not in name:
+        if args.filter and not any(f in name for f in args.filter.split(',')):
             continue
         x = torch.randn(n, h, h, ld, device=dev)
         w = torch.randn(k, k, ci, co, device=dev) * 0.05

@@ -76,6 +76,13 @@ CONV_CASES = [
     (64, 32, 32, 24, 64, 3, 1, 0, 2),      # 64-cout Winograd workgroups with a 3-chunk K loop (only the un-pipelined tail iterations run)
     (128, 8, 8, 64, 512, 3, 1, 0, 0),      # 64-cout Winograd workgroups on packed 8x8 images (VGG conv5 at a large batch)
     (8, 64, 64, 64, 40, 3, 1, 0, 0),       # 32-cout Winograd workgroups (Np = 64 but too few blocks), couts 40..63 masked, 8-chunk pipelined loop
+    # tiny-filter weight gradients (conv_wsmall.hip: the whole filter gradient in one workgroup's 16x16 MFMA accumulators); (4,128,128,3,32,7)
+    # and (8,64,64,64,4,3) above are its 7x7 image-input and 64 -> 4 head variants
+    (2, 128, 128, 16, 16, 3, 1, 0, 1),     # pose conv_7_1 shape: 16 -> 16 at full resolution, nine 16-row blocks on three wavefronts
+    (3, 100, 120, 16, 12, 3, 1, 0, 0),     # same variant, ragged: 25 x 2 tiles with a 56-column tail, 12 of 16 output channels
+    (3, 104, 120, 3, 24, 7, 1, 0, 0),      # 7x7 image-input variant, ragged tiles, 24 of 32 output channels, 147 of 160 rows
+    (8, 128, 128, 3, 64, 4, 2, 1, 2),      # img_discr conv_0: 4x4 stride 2 with the explicit pad, 65 x 65 outputs (one padded quad per row)
+    (5, 96, 72, 64, 4, 3, 1, 0, 0),        # 64 -> 4 head variant on a non-square image (tile tails in both directions)
 ]
 
 

@@ -521,6 +521,9 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_few_fwd(const floa
                                                                   const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
                                                                   int stride, int pad_t, int pad_l, int act, hipStream_t s);
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N, int H, int W, int Cin, int Cout);
+extern "C" __attribute__((visibility("hidden"))) int kpx_wsmall_splits(int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride);
+extern "C" __attribute__((visibility("hidden"))) int kpx_wsmall_launch(const float* x, int N, int Hi, int Wi, int Cin, int ldx, const float* dy, int Ho, int Wo, int Cout, int lddy,
+                                                                   int KH, int KW, int stride, int pad_t, int pad_l, float* slabs, int S, hipStream_t s);
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad3x3(const float* x, int N, int H, int W, int Cin, int ldx, const float* dy, int Cout, int lddy,
                                                                    float* slabs, int S, hipStream_t s);
 static inline size_t wino_ws_bytes(int Cin, int Cout) {          // U[16][K padded to 8][Nn padded to 32] for either direction
@@ -1308,6 +1311,11 @@ extern "C" size_t kpx_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Ci
         const size_t nw = (size_t)Sw * 9 * Cin * Cout * 4;
         if (Sw > 1 && nw > need) need = nw;
     }
+    for (int st = 1; st <= 2; ++st) {             // tiny-filter family (conv_wsmall.hip); the stride is unknown here: both
+        const int Ss = kpx_wsmall_splits(N, Ho * st, Wo * st, Cin, Ho, Wo, Cout, KH, KW, st);
+        const size_t ns = (size_t)Ss * KH * KW * Cin * Cout * 4;
+        if (Ss > 1 && ns > need) need = ns;
+    }
     int S2, cpb, CT;
     if (wgrad_rows_plan(N, Ho, Wo, Cin, Cout, KH, KW, &S2, &cpb, &CT)) {
         const size_t n2 = (size_t)S2 * KH * KW * Cin * Cout * 4;
@@ -1327,6 +1335,19 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     if (!x || !dy || !dw || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || lddy < Cout)
         return KPX_EINVAL;
+    {   // tiny filters over very many pixels (image-input layers, 16 -> 16 at full resolution, the 64 -> 4 head): conv_wsmall.hip
+        // (16-B staging units: dy always, x when it has a multiple of 4 channels)
+        const bool units_ok = Cout % 4 == 0 && lddy % 4 == 0 && aligned16(dy) && (Cin % 4 != 0 || (ldx % 4 == 0 && aligned16(x)));
+        const int Ss = units_ok ? kpx_wsmall_splits(N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride) : 0;
+        const size_t slab = (size_t)KH * KW * Cin * Cout;
+        if (Ss >= 1 && (Ss == 1 || (workspace && workspace_bytes >= (size_t)Ss * slab * 4))) {
+            hipStream_t s = kpx_stream(stream);
+            int rc = kpx_wsmall_launch(x, N, Hi, Wi, Cin, ldx, dy, Ho, Wo, Cout, lddy, KH, KW, stride, pad_t, pad_l, Ss > 1 ? (float*)workspace : dw, Ss, s);
+            if (rc) return rc;
+            if (Ss > 1) { launch_wgrad_reduce((const float*)workspace, dw, slab, Ss, s); rc = kpx_launch_status(); }
+            return rc;
+        }
+    }
     // KPX_WGRAD3_FIRST (tuning): 1 = the bf16x3 kernel (conv_gemm3.hip) ahead of the specialised fp32 kernels below except the Winograd
     // weight gradient; 2 = ahead of that one too.  Default 0: only where the generic fp32 kernel would run.
     const int g3_first = (kpx_env()->no_gemm3 || kpx_env()->no_wgrad3 || Cin % 4 || Cout % 4 || Cin < 16 || Cout < 16 || ldx % 4 || lddy % 4 ||
