@@ -71,9 +71,13 @@ class DetectorTranslatorModel(BaseModel):
         self.device = ops.normalize_device(device)
         self.global_step = int(global_step or 0)
         self.process_group = process_group
-        # a process group (even of one rank, e.g. `torch.distributed.run --nproc-per-node 1`) means: exchange through it
-        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
-        self.world_size = torch.distributed.get_world_size(process_group) if self.distributed else 1
+        # a process group of more than one rank means: exchange through it.  A group of ONE rank (`torch.distributed.run --nproc-per-node 1`)
+        # has nothing to exchange -- a sum over one rank is the identity -- and runs the plain single-GPU step (graph replay included);
+        # KPX_DP_FORCE_EXCHANGE=1 keeps the two collectives in, which is how the cost of the RCCL path alone is measured on one GPU
+        # (+1.6 ms per step)
+        in_group = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.world_size = torch.distributed.get_world_size(process_group) if in_group else 1
+        self.distributed = in_group and (self.world_size > 1 or os.environ.get('KPX_DP_FORCE_EXCHANGE', '0') != '0')
         self.store = variables.VariableStore(device=self.device, seed=seed)
         self.vgg = vgg
         # Adam state (two optimisers, reference :198 and :201): fp32 beta powers like TF's beta{1,2}_power variables
