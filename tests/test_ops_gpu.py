@@ -83,6 +83,8 @@ CONV_CASES = [
     (3, 104, 120, 3, 24, 7, 1, 0, 0),      # 7x7 image-input variant, ragged tiles, 24 of 32 output channels, 147 of 160 rows
     (8, 128, 128, 3, 64, 4, 2, 1, 2),      # img_discr conv_0: 4x4 stride 2 with the explicit pad, 65 x 65 outputs (one padded quad per row)
     (5, 96, 72, 64, 4, 3, 1, 0, 0),        # 64 -> 4 head variant on a non-square image (tile tails in both directions)
+    (2, 128, 128, 32, 32, 3, 1, 0, 1),     # 32 -> 32 variant (encoder conv_2): 18 row blocks x 2 column blocks on six wavefronts
+    (5, 100, 72, 32, 24, 3, 1, 0, 0),      # same, ragged tiles, 24 of 32 output channels
 ]
 
 

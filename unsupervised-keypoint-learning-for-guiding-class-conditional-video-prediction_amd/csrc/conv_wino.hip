@@ -727,7 +727,8 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N
     if (ti == 1 && to == 1) return 0;                     // 32 x 32 blocks: too few MFMAs per barrier, the direct kernels do better
     const long tc = (long)N * (H / 4) * (W / 8), tiles = (long)((Cin + 32 * ti - 1) / (32 * ti)) * ((Cout + 32 * to - 1) / (32 * to));
     const long target = kpx_env()->ww_target;
-    long S = (target + tiles - 1) / tiles;
+    long S = target / tiles;                              // floor: tiles * S workgroups must fit ONE round of the chip (158 -> 256 channels: 12 tiles,
+    if (S < 1) S = 1;                                     // 22 splits = 264 workgroups ran as two rounds, 0.309 ms; 21 splits = 252: one round)
     if (S > tc / 8) S = tc / 8;
     const long cap = (128L << 20) / ((long)9 * Cin * Cout * 4);
     if (S > cap) S = cap;

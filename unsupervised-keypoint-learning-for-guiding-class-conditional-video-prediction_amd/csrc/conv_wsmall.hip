@@ -173,13 +173,15 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_small_kernel(const Wsma
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------------
-// variant: 0 = none; 1 = Cin 16, 3x3, Cout <= 16; 2 = Cin 3, 7x7, Cout <= 32; 3 = Cin 3, 4x4, Cout <= 64; 4 = Cin 64, 3x3, Cout <= 16
+// variant: 0 = none; 1 = Cin 16, 3x3, Cout <= 16; 2 = Cin 3, 7x7, Cout <= 32; 3 = Cin 3, 4x4 stride 2, Cout <= 64; 4 = Cin 64, 3x3, Cout <= 16;
+// 5 = Cin 32, 3x3, Cout <= 32
 static int wsmall_variant(int Cin, int Cout, int KH, int KW, int stride) {
     if (kpx_env()->no_wsmall) return 0;
     if (Cin == 16 && KH == 3 && KW == 3 && stride == 1 && Cout <= 16) return 1;
     if (Cin == 3 && KH == 7 && KW == 7 && stride == 1 && Cout <= 32) return 2;
     if (Cin == 3 && KH == 4 && KW == 4 && stride == 2 && Cout <= 64) return 3;
     if (Cin == 64 && KH == 3 && KW == 3 && stride == 1 && Cout <= kpx_env()->wsmall_c64_max) return 4;
+    if (Cin == 32 && KH == 3 && KW == 3 && stride == 1 && Cout <= 32 && !kpx_env()->no_wsmall32) return 5;
     return 0;
 }
 
@@ -192,6 +194,7 @@ static void wsmall_geom(int variant, int N, int Hi, int Wi, int ldx, int Ho, int
         case 1: th = 4; tw = 64; nb = 1; waves = 3; break;
         case 2: th = 2; tw = 64; nb = 2; waves = 5; break;      // (4 rows per tile measured slower: 0.195 vs 0.174 ms at N = 64)
         case 3: th = 2; tw = 68; nb = 4; waves = 3; break;
+        case 5: th = 2; tw = 64; nb = 2; waves = 6; break;
         default: th = 4; tw = 32; nb = 1; waves = 4; break;
     }
     if (th > Ho) th = Ho;                                 // (the tile width is compile-time: columns beyond Wo are staged as zeros)
@@ -235,11 +238,13 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wsmall_launch(const flo
 #define WS_K2 conv_wgrad_small_kernel<3, 7, 1, 64, 2, 2, 5, 6, 4, false, true>
 #define WS_K3 conv_wgrad_small_kernel<3, 4, 2, 68, 1, 4, 3, 13, 12, false, true>
 #define WS_K4 conv_wgrad_small_kernel<64, 3, 1, 32, 9, 1, 4, 13, 2, true, true>
+#define WS_K5 conv_wgrad_small_kernel<32, 3, 1, 64, 3, 2, 6, 6, 3, true, true>
     if (kpx_first_use_on_device(&attr_mask)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(WS_K1), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(WS_K2), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(WS_K3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(WS_K4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(WS_K5), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return -(int)e;
     }
     const dim3 grid((unsigned)((g.total_tiles + g.tpb - 1) / g.tpb));
@@ -248,6 +253,7 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wsmall_launch(const flo
         case 1: hipLaunchKernelGGL(WS_K1, grid, dim3(threads), lds, s, g); break;
         case 2: hipLaunchKernelGGL(WS_K2, grid, dim3(threads), lds, s, g); break;
         case 3: hipLaunchKernelGGL(WS_K3, grid, dim3(threads), lds, s, g); break;
+        case 5: hipLaunchKernelGGL(WS_K5, grid, dim3(threads), lds, s, g); break;
         default: hipLaunchKernelGGL(WS_K4, grid, dim3(threads), lds, s, g); break;
     }
     return kpx_launch_status();

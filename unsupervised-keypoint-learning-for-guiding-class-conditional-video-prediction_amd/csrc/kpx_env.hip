@@ -44,6 +44,7 @@ static void env_parse(KpxEnv* e) {
     e->wgrad3_first = (int)env_long("KPX_WGRAD3_FIRST", 0);
     e->gemm3_terms = (int)env_long("KPX_GEMM3_TERMS", 3);
     e->no_wsmall = env_flag("KPX_NO_WSMALL");
+    e->no_wsmall32 = env_flag("KPX_NO_WSMALL32");
     e->wsmall_c64_max = (int)env_long("KPX_WSMALL_C64_MAX", 4);
 }
 
