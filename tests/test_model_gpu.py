@@ -411,20 +411,20 @@ def test_final_model_rollout_matches_oracle():
 F43_LAUNCHES_PER_STEP = {'configs0': 17 + 36, 'configs3': 18 + 36}
 
 
-@pytest.mark.parametrize('force_f43', [False, True], ids=['bench_policy', 'f43_on_every_policy_layer'])
+@pytest.mark.parametrize('force_f43', [False, True], ids=['f23_for_launches_up_to_128_workgroups', 'bench_policy_f43_on_every_policy_layer'])
 def test_configs0_train_step_128_k15_b4_matches_oracle(monkeypatch, force_f43):
     """BASELINE configs[0]: Penn 128x128 K=15, batch 4, full-width VGG19 (synthetic weights): one complete train step
     (D update + G update) against the CPU restatement -- all six loss terms, key-points, frame, and the norm-weighted
     aggregate of every generator / discriminator kernel gradient.
 
-    ``force_f43``: at B=4 most policy layers launch <= 128 workgroups and fall back to F(2x2,3x3); the benchmark (B=32) runs them on
-    F(4x4,3x3).  With the threshold at 0 every policy layer takes the F(4x4,3x3) kernel here too -- the kernel selection of the bench
-    under the same float64-arbitrated bounds -- and the launch counter must show it."""
+    ``force_f43``: with ops.WINO43_MIN_WORKGROUPS = 0 (the default since the threshold was measured inside the step: 23.8 vs 24.1 ms at
+    B=32) every policy layer takes the F(4x4,3x3) kernel -- the kernel selection of the bench under the float64-arbitrated bounds -- and the
+    launch counter must show it.  The other variant sets the threshold to 128 workgroups (round 2's policy): at B=4 most policy layers then
+    fall back to F(2x2,3x3), which keeps that path covered at model level."""
     from kpx_amd import ops
     dev = torch.device('cuda:0')
     res, k, b = 128, 15, 4
-    if force_f43:
-        monkeypatch.setattr(ops, 'WINO43_MIN_WORKGROUPS', 0)
+    monkeypatch.setattr(ops, 'WINO43_MIN_WORKGROUPS', 0 if force_f43 else 128)
     model = make_model(res, k, b, dev, width_div=1)
     used = ops.conv_kernel_uses['wino43']
     im, fut, want, want64 = oracle_first_step(res, k, b, 1)
@@ -573,12 +573,14 @@ def test_against_the_reference_graph_fixture(golden_dir):
             dp = projection(n, g) - wantp[i]
             pnum += dp ** 2
             # (the head biases are sums over every pixel of terms of both signs -- 1 and 3 numbers whose projection also scales with the
-            # drawn direction's few elements: 4x the bound of a filter)
+            # drawn direction's few elements: 8x the bound of a filter.  Measured for the 1-element mask bias: under 0.20 of its value with the
+            # small launches on F(2x2,3x3), 0.22 with every policy layer on F(4x4,3x3), the default since round 3; a sign error is 2.0)
             if step == 0:                     # (step 1 starts from weights the two fp32 implementations have separated: aggregate only)
-                assert abs(dp) <= (4 if n.endswith('/bias') else 1) * 5e-2 * want[i][0] + 1e-7, (step, n, dp, want[i][0])
+                assert abs(dp) <= (8 if n.endswith('/bias') else 1) * 5e-2 * want[i][0] + 1e-7, (step, n, dp, want[i][0])
         pagg = (pnum / sum(w_[0] ** 2 for w_ in want)) ** 0.5
         print('reference-graph fixture step %d: generator-gradient projections off by %.2e of the gradient norm (aggregate)' % (step, pagg))
-        # (measured at step 0: 1.9e-2 with the fp32-MFMA kernels on the encoder's stride-2 layers, 2.5e-2 with the bf16x3 kernels -- the
+        # (measured at step 0: 1.9e-2 with the fp32-MFMA kernels on the encoder's stride-2 layers, 2.5e-2 with the bf16x3 kernels, 2.9e-2 with
+        #  every policy layer on F(4x4,3x3) -- the
         #  K = 3 key-point softmax of this fixture amplifies either rounding; a flipped or permuted gradient of one variable is caught by
         #  the per-variable bound above, 5 % of that variable's norm)
         # Step 1 is reported, not asserted: it starts from weights that two fp32 implementations have separated by +-lr on every element with
@@ -608,7 +610,7 @@ def test_against_the_reference_graph_fixture(golden_dir):
     assert abs(lg - float(ref['test_loss_G'])) <= 5e-3 * max(1.0, abs(float(ref['test_loss_G'])))
 
 
-@pytest.mark.parametrize('force_f43', [False, True], ids=['bench_policy', 'f43_on_every_policy_layer'])
+@pytest.mark.parametrize('force_f43', [False, True], ids=['f23_for_launches_up_to_128_workgroups', 'bench_policy_f43_on_every_policy_layer'])
 def test_configs3_train_step_256_k40_matches_oracle(monkeypatch, force_f43):
     """BASELINE configs[3]: 256x256, K=40 (SURVEY 8d generalisation of the literals: final_res = H, low-res maps H/4), one complete
     train step at B=2, width/4 VGG19: six loss terms, key-points, frame, and the float64-arbitrated gradient bound -- with the
@@ -616,8 +618,7 @@ def test_configs3_train_step_256_k40_matches_oracle(monkeypatch, force_f43):
     from kpx_amd import ops
     dev = torch.device('cuda:0')
     res, k, b = 256, 40, 2
-    if force_f43:
-        monkeypatch.setattr(ops, 'WINO43_MIN_WORKGROUPS', 0)
+    monkeypatch.setattr(ops, 'WINO43_MIN_WORKGROUPS', 0 if force_f43 else 128)
     model = make_model(res, k, b, dev, width_div=4)
     im, fut, want, want64 = oracle_first_step(res, k, b, 4, seed0=11, seed1=12)
     used = ops.conv_kernel_uses['wino43']
@@ -641,7 +642,7 @@ def test_configs3_train_step_256_k40_matches_oracle(monkeypatch, force_f43):
 
 def test_configs1_train_step_at_the_bench_batch_32_matches_oracle():
     """BASELINE configs[1] = THE benchmarked configuration (128x128, K=15, B=32, full-width VGG19, every kernel-selection policy at its
-    default: at this batch the translator / VGG19 layers launch 512-2048 F(4x4,3x3) workgroups): one complete train step against the fp32
+    default: every policy layer on F(4x4,3x3), the translator / VGG19 layers with 512-2048 workgroups): one complete train step against the fp32
     CPU restatement -- six loss terms, key-points, generated frame, crude / mask heads, and the norm-weighted aggregate of every kernel
     gradient (fp32 oracle as the reference here: the float64 arbiter at B=32 would need ~40 GB of host memory)."""
     from kpx_amd import ops
@@ -651,7 +652,10 @@ def test_configs1_train_step_at_the_bench_batch_32_matches_oracle():
     im, fut, want, _ = oracle_first_step(res, k, b, 1, with_f64=False)
     used = ops.conv_kernel_uses['wino43']
     model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, 0, b)
-    if ops.WINO43 and ops.WINO43_MIN_WORKGROUPS == 128:
+    if ops.WINO43 and ops.WINO43_MIN_WORKGROUPS == 0:
+        # every policy layer: forward 6 translator + 11 VGG19; data gradients 11 VGG19 + 10 translator + 13 key-point detector + 2 image encoder
+        assert ops.conv_kernel_uses['wino43'] - used == F43_LAUNCHES_PER_STEP['configs0'], ops.conv_kernel_uses['wino43'] - used
+    elif ops.WINO43 and ops.WINO43_MIN_WORKGROUPS == 128:
         # F(4x4,3x3) launches of more than 128 workgroups at B=32: forward 6 translator + 11 VGG19 (N=64); data gradients 6 VGG19 (N=32:
         # conv4_* are 16x16 -> 16 image pairs x 8 blocks = 128, conv3_1 produces 128 channels -> 128) + 10 translator + 5 key-point
         # detector (N=64: encoder conv_4 / conv_6, conv_3_0, conv_5_0, conv_7_0) + 1 image encoder (conv_4)

@@ -251,7 +251,10 @@ conv_kernel_uses = {'wino43': 0}      # diagnostics / tests: launches of the F(4
 #     float64 gradient as the fp32 oracle's own.
 WINO43 = _os.environ.get('KPX_WINO43', '1') != '0'
 WINO43_EXCLUDE_FWD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_FWD', 'pose_encoder,image_encoder,translator/conv_1,translator/conv_2').split(',') if p)
-WINO43_MIN_WORKGROUPS = int(_os.environ.get('KPX_WINO43_MIN_WGS', '128'))
+# launches of at most this many F(4x4,3x3) workgroups stay on F(2x2,3x3).  Round 2 set 128 from a kernel measured ALONE (128 workgroups: 0.187 vs
+# 0.158 ms -- one F(4x4) workgroup owns its CU); inside the step, where the other streams fill the idle CUs, F(4x4,3x3) wins on those layers too:
+# 23.73-23.83 ms per step at 0 / 32 / 64 against 24.01-24.16 at 128 (three repetitions each, B=32) -- so no threshold
+WINO43_MIN_WORKGROUPS = int(_os.environ.get('KPX_WINO43_MIN_WGS', '0'))
 WINO43_EXCLUDE_DGRAD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_DGRAD', '').split(',') if p)
 
 
@@ -346,8 +349,7 @@ def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, wa
     bptr = bias.data_ptr() if bias is not None else None
     ent43 = _cached_u(_wino43_u, w, dgrad) if WINO43 else None
     tiles = lib.kpx_conv3x3_wino43_stats_tiles(n, h, wd) if want_stats else 1      # 0: no statistics from this kernel for the shape (16 x 16)
-    # one F(4x4,3x3) workgroup covers 16 x 32 pixels x 64 channels and lives alone on its CU: below ~half a chip of them the
-    # F(2x2,3x3) kernel's twice as many, half as large workgroups finish sooner (measured: 128 workgroups 0.187 vs 0.158 ms)
+    # (WINO43_MIN_WORKGROUPS: see its definition -- 0 by default)
     wgs43 = (n // 2 if wd == 16 else n * (h // 16) * (wd // 32)) * ((nn + 63) // 64)
     if (ent43 is not None and bn_src is None and tiles and wgs43 > WINO43_MIN_WORKGROUPS
             and lib.kpx_conv3x3_wino43_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr())):
