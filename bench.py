@@ -141,18 +141,21 @@ def roofline_conv_f23(dev):
 
 
 def roofline_conv_direct(dev):
-    """The direct implicit-GEMM kernel on the same layer (what strided / 4x4 / odd-channel layers run): KPX_NO_WINO=1."""
+    """The fp32-MFMA direct implicit-GEMM kernel on the same layer (the fallback of the bf16x3 kernels: odd-channel / tiny-channel shapes):
+    KPX_NO_WINO=1 and KPX_NO_GEMM3=1 (without the second switch the layer runs fp32-equivalent on the bf16 pipe and is not bound by this peak)."""
     from kpx_amd._lib import lib
     os.environ['KPX_NO_WINO'] = '1'
+    os.environ['KPX_NO_GEMM3'] = '1'
     lib.kpx_reload_env()                    # the switches are parsed once; re-read them for this leg only
     try:
         ms, flops = _time_conv_3_1(dev)
     finally:
         del os.environ['KPX_NO_WINO']
+        del os.environ['KPX_NO_GEMM3']
         lib.kpx_reload_env()
     ach = flops / (ms * 1e-3) / 1e12
     traffic, src = _pmc_traffic(DIRECT_PMC)
-    return {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,128,2,4> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1, KPX_NO_WINO=1)',
+    return {'bound': 'mfma', 'kernel': 'conv_igemm_kernel<128,128,2,4> fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1, KPX_NO_WINO=1 KPX_NO_GEMM3=1)',
             'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4),
             'traffic': traffic, 'traffic_source': src, 'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops}
 
