@@ -104,7 +104,8 @@ def _pmc_traffic(name):
         return None, None
 
 
-WINO43_PMC, WINO_PMC, DIRECT_PMC, RENDER_PMC = 'r03_wino43_pmc.json', 'r03_wino_pmc.json', 'r01_conv_pmc.json', 'r03_render_pmc.json'
+WINO43_PMC, WINO_PMC, DIRECT_PMC, RENDER_PMC = 'r03_wino43_pmc.json', 'r03_wino_pmc.json', 'r03_direct_pmc.json', 'r03_render_pmc.json'
+GEMM3_PMC, BF16_PMC = 'r03_gemm3_pmc.json', 'r03_bf16_pmc.json'
 
 
 def _roofline_wino(dev, name, kernel_substr, kernel_desc, reduction, pmc):
@@ -172,7 +173,7 @@ def roofline_conv_bf16(dev):
     nbytes = 2 * BATCH * 64 * 64 * 128 * 4 + 9 * 128 * 128 * 4
     return {'bound': 'hbm', 'kernel': 'conv3x3_bf16_wide_kernel<4> (16x32 pixels x 128 couts per workgroup; + weight prepare) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
             'achieved': round(nbytes / (ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(nbytes / (ms * 1e-3) / 8e12, 4),
-            'traffic': None, 'avg_launch_ms': round(ms, 4), 'bytes_per_launch': nbytes,
+            'traffic': _pmc_traffic(BF16_PMC)[0], 'traffic_source': _pmc_traffic(BF16_PMC)[1], 'avg_launch_ms': round(ms, 4), 'bytes_per_launch': nbytes,
             'mfma_tflops_bf16': round(flops / (ms * 1e-3) / 1e12, 1), 'mfma_frac_of_bf16_peak': round(flops / (ms * 1e-3) / 2.5e15, 4)}
 
 
@@ -192,7 +193,9 @@ def roofline_conv_bf16x3(dev):
     ach = flops / (ms * 1e-3) / 1e12
     return {'bound': 'mfma', 'kernel': 'conv_gemm3_kernel<128,128,2,4,false,3> (+ split-K slab reduce) fwd 4x4 s2 256->512 @18x18 N=64 (img_discr conv_3), bf16x3 = fp32-equivalent',
             'achieved': round(ach, 2), 'peak': 416.7, 'unit': 'TFLOP/s (fp32-equivalent; bf16 dense peak 2500 / 6 products)', 'frac': round(ach / 416.7, 4),
-            'frac_of_fp32_mfma_peak': round(ach / 157.3, 4), 'traffic': None, 'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops}
+            'frac_of_fp32_mfma_peak': round(ach / 157.3, 4), 'traffic': _pmc_traffic(GEMM3_PMC)[0], 'traffic_source': _pmc_traffic(GEMM3_PMC)[1],
+            'traffic_note': 'HBM bytes of the conv kernel alone (its split-K slabs included, their reduce kernel not)',
+            'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops}
 
 
 def roofline_render(dev, res=RES, k_pts=K_PTS, batch=BATCH):
