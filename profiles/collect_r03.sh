@@ -70,6 +70,8 @@ for csvf, steps, dst in (('profiles/r03_step_kernel_stats.csv', 13, 'profiles/r0
         txt = subprocess.run(['python3', 'profiles/step_breakdown.py', csvf, str(steps)], capture_output=True, text=True).stdout
         open(dst, 'w').write(txt); print(txt)
 PY
+# how the streams overlap inside a step (needs the raw kernel trace, which stays under gpurun_out/)
+[ -f $O/step/s_kernel_trace.csv ] && python3 profiles/overlap.py $O/step/s_kernel_trace.csv 13 > profiles/r03_step_overlap.txt
 for f in bench bench_eager bench_c3 bench_c4; do python3 -c "
 import json,sys
 try:
