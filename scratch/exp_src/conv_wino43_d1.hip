@@ -1,3 +1,6 @@
+// TIMING-ONLY DIAGNOSTIC of csrc/conv_wino43.hip: the multiply phase issues three v_mfma_f32_32x32x16_bf16 per 8-channel chunk and
+// block on re-interpreted fp32 bits -- the same instruction / fragment traffic a bf16x3 version would have, NUMERICALLY MEANINGLESS.  Never linked
+// into libkpx_hip.so; built by hand into a scratch library selected with KPX_LIB (d1: fragments double-buffered, 42 spills; d2: single-buffered).
 // Fused Winograd F(4x4, 3x3) convolution for gfx950 (fp32, v_mfma_f32_32x32x2_f32): 36 multiplies per 4x4 output tile instead of 144,
 // i.e. 4x fewer MFMAs than the direct kernel and 1.78x fewer than F(2x2,3x3) (conv_wino.hip), for the large 3x3 stride-1 SAME layers
 // of the translator, VGG19 and the image encoder (reference models/networks/__init__.py:13,22,80-97, models/networks/vgg.py:51).
