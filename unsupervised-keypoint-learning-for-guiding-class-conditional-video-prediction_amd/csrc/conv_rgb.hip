@@ -11,83 +11,107 @@ struct RgbGeom {
     const float* x; const float* w; const float* bias; float* y;
     int N, Hi, Wi, Cin, Ho, Wo, Cout, ldy;
     int KH, KW, pad_t, pad_l, act;
-    int tiles_y, tiles_x;
+    int tiles_y, tiles_x, total_tiles, tpb;
     int PH, PWC, KWC, KWCp;          // patch rows, floats per patch row (+ slack), floats per filter row, padded to even
 };
 
+// Persistent workgroups: the filter is staged ONCE per workgroup, which then walks a contiguous range of 16x16 tiles.  On gfx950 nothing
+// overlaps an fp32 MFMA on its SIMD, and a tile is only 60-154 MFMAs per wavefront, so the instructions around them decide the
+// speed: the first version spent 1 700-2 000 VALU per wavefront and tile (per-element index divisions while staging the filter and the patch,
+// 64 stores with their own bounds / address arithmetic) against 3 840-9 900 MFMA cycles -- PMC: matrix pipe busy 18-40 %.  Here the patch is
+// staged by rows (one division-free row per wavefront and trip), and the epilogue works from one base pointer with a tile-uniform fast path.
 template <int NT>
 __global__ __launch_bounds__(256) void conv_rgb_kernel(const RgbGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch = smem;                                   // [PH][PWC] (+4 zero floats)
     float* Ws = smem + ((g.PH * g.PWC + 4 + 3) & ~3);      // [KH][KWCp][32*NT]
     constexpr int NC = 32 * NT;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
-    int L = blockIdx.x;
-    const int bx = L % g.tiles_x; L /= g.tiles_x;
-    const int by = L % g.tiles_y;
-    const int n = L / g.tiles_y;
-    const int oy0 = by * 16, ox0 = bx * 16;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lh = lane >> 5;
 
-    // ---- stage the patch (zero outside the image) and the filter (zero pad row when KW*Cin is odd)
-    const int iy0 = oy0 - g.pad_t, ixc0 = (ox0 - g.pad_l) * g.Cin, rowlen = g.Wi * g.Cin;
-    for (int i = t; i < g.PH * g.PWC + 4; i += 256) {
-        const int pr = i / g.PWC, pc = i - pr * g.PWC;
-        const int iy = iy0 + pr, ic = ixc0 + pc;
-        float v = 0.f;
-        if (pr < g.PH && (unsigned)iy < (unsigned)g.Hi && (unsigned)ic < (unsigned)rowlen) v = g.x[((size_t)n * g.Hi + iy) * rowlen + ic];
-        patch[i] = v;
+    // ---- the filter, once: thread t owns column nn = t % NC and walks the (row, kk) pairs with a stride of 256 / NC (no divisions per element)
+    {
+        const int nn = t & (NC - 1), j0 = t / NC, jstep = 256 / NC;
+        int r = 0, kk = j0;
+        while (kk >= g.KWCp) { kk -= g.KWCp; ++r; }
+        for (; r < g.KH; ) {
+            Ws[(r * g.KWCp + kk) * NC + nn] = (kk < g.KWC && nn < g.Cout) ? g.w[((size_t)r * g.KWC + kk) * g.Cout + nn] : 0.f;
+            kk += jstep;
+            while (kk >= g.KWCp) { kk -= g.KWCp; ++r; }
+        }
+        if (t < 4) patch[g.PH * g.PWC + t] = 0.f;           // the slack the last pixel's padded k reads
     }
-    for (int i = t; i < g.KH * g.KWCp * NC; i += 256) {
-        const int nn = i % NC, kk = (i / NC) % g.KWCp, r = i / (NC * g.KWCp);
-        Ws[i] = (kk < g.KWC && nn < g.Cout) ? g.w[((size_t)r * g.KWC + kk) * g.Cout + nn] : 0.f;
-    }
-    __syncthreads();
-
-    f32x16 acc[2][NT];
+    float bv[NT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = (g.bias && nt * 32 + li < g.Cout) ? g.bias[nt * 32 + li] : 0.f;
+    const int rowlen = g.Wi * g.Cin;
     // lane's pixel inside M-tile mt: row 2*mt + li/16, column li%16
     const int a0 = (2 * (2 * wave) + (li >> 4)) * g.PWC + (li & 15) * g.Cin + lh;
     const int a1 = a0 + 2 * g.PWC;
     const int b0 = lh * NC + li;
     const int ks = g.KWCp >> 1;
-    for (int r = 0; r < g.KH; ++r) {
-        const float* pa = patch + r * g.PWC;
-        const float* pb = Ws + r * g.KWCp * NC + b0;
-        for (int s = 0; s < ks; ++s) {
-            const float va0 = pa[a0 + 2 * s], va1 = pa[a1 + 2 * s];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float vb = pb[2 * s * NC + nt * 32];
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, vb, acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, vb, acc[1][nt], 0, 0, 0);
+    const float lo = g.act == KPX_ACT_RELU ? 0.f : -__builtin_inff();
+    const float slope = g.act == KPX_ACT_LRELU ? 0.01f : 1.f;
+
+    for (int tile = blockIdx.x * g.tpb, tend = min(tile + g.tpb, g.total_tiles); tile < tend; ++tile) {
+        int L = tile;
+        const int bx = L % g.tiles_x; L /= g.tiles_x;
+        const int by = L % g.tiles_y;
+        const int n = L / g.tiles_y;
+        const int oy0 = by * 16, ox0 = bx * 16;
+        // ---- stage the patch (zero outside the image): wavefront w takes patch rows w, w + 4, ..
+        const int iy0 = oy0 - g.pad_t, ixc0 = (ox0 - g.pad_l) * g.Cin;
+        __syncthreads();                                   // the previous tile's reads (and, first, the filter) are done
+        for (int pr = wave; pr < g.PH; pr += 4) {
+            const int iy = iy0 + pr;
+            const bool rowok = (unsigned)iy < (unsigned)g.Hi;
+            const float* src = g.x + ((size_t)n * g.Hi + (rowok ? iy : 0)) * rowlen;
+            for (int pc = lane; pc < g.PWC; pc += 64) {
+                const int ic = ixc0 + pc;
+                patch[pr * g.PWC + pc] = (rowok && (unsigned)ic < (unsigned)rowlen) ? src[ic] : 0.f;
             }
         }
-    }
+        __syncthreads();
+
+        f32x16 acc[2][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int c = nt * 32 + li;
-            if (c >= g.Cout) continue;
-            const float bv = g.bias ? g.bias[c] : 0.f;
+            for (int b = 0; b < NT; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;           // pixel of the 32-pixel M-tile
-                const int oy = oy0 + 2 * (2 * wave + mt) + (m >> 4), ox = ox0 + (m & 15);
-                if (oy < g.Ho && ox < g.Wo) {
-                    float v = acc[mt][nt][r] + bv;
-                    if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
-                    else if (g.act == KPX_ACT_TANH) v = tanhf(v);
-                    g.y[(((size_t)n * g.Ho + oy) * g.Wo + ox) * g.ldy + c] = v;
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int r = 0; r < g.KH; ++r) {
+            const float* pa = patch + r * g.PWC;
+            const float* pb = Ws + r * g.KWCp * NC + b0;
+            for (int s = 0; s < ks; ++s) {
+                const float va0 = pa[a0 + 2 * s], va1 = pa[a1 + 2 * s];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float vb = pb[2 * s * NC + nt * 32];
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, vb, acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, vb, acc[1][nt], 0, 0, 0);
                 }
             }
         }
+        // ---- epilogue: accumulator register r of M-tile mt is output row 2 * (2 * wave + mt) + (r >> 3), column ((r >> 2) & 1) * 8 + 4 * lh + (r & 3)
+        const bool full = oy0 + 16 <= g.Ho && ox0 + 16 <= g.Wo;            // tile-uniform
+        float* const ybase = g.y + (((size_t)n * g.Ho + oy0 + 4 * wave) * g.Wo + ox0 + 4 * lh) * g.ldy + li;
+        const size_t rstep = (size_t)g.Wo * g.ldy;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (nt * 32 + li >= g.Cout) continue;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 2 * mt + (r >> 3), col = ((r >> 2) & 1) * 8 + (r & 3);      // relative to (oy0 + 4 wave, ox0 + 4 lh)
+                    float v = acc[mt][nt][r] + bv[nt];
+                    if (g.act == KPX_ACT_TANH) v = tanhf(v);
+                    else { v = fmaxf(v, lo); v = v > 0.f ? v : v * slope; }
+                    if (full || (oy0 + 4 * wave + row < g.Ho && ox0 + 4 * lh + col < g.Wo))
+                        ybase[row * rstep + (size_t)col * g.ldy + nt * 32] = v;
+                }
+        }
+    }
 }
 
 static std::atomic<unsigned long long> rgb_attr_mask{0};
@@ -112,7 +136,12 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const floa
         if (e != hipSuccess) return -(int)e;
     }
     if (lds > 98304) return -2;
-    const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x);
+    g.total_tiles = N * g.tiles_y * g.tiles_x;
+    // persistent workgroups: as many as are resident at once (LDS-limited, at most 8 of 4 wavefronts per CU), a contiguous range of tiles each
+    int per_cu = (int)((160 * 1024) / (lds + 256)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+    int want = 256 * per_cu; if (want > g.total_tiles) want = g.total_tiles;
+    g.tpb = (g.total_tiles + want - 1) / want;
+    const unsigned blocks = (unsigned)((g.total_tiles + g.tpb - 1) / g.tpb);
     if (nt == 1) hipLaunchKernelGGL(conv_rgb_kernel<1>, dim3(blocks), dim3(256), lds, s, g);
     else hipLaunchKernelGGL(conv_rgb_kernel<2>, dim3(blocks), dim3(256), lds, s, g);
     return kpx_launch_status();
