@@ -78,6 +78,7 @@ CONV_CASES = [
     (8, 64, 64, 64, 40, 3, 1, 0, 0),       # 32-cout Winograd workgroups (Np = 64 but too few blocks), couts 40..63 masked, 8-chunk pipelined loop
     (3, 100, 72, 3, 64, 3, 1, 0, 1),       # image-input forward kernel (VGG conv1_1 shape), persistent workgroups over ragged 16x16 tiles, relu
     (2, 50, 70, 3, 24, 7, 1, 1, 2),        # same, 7x7 with an explicit pad, 24 of 32 output channels, lrelu
+    (3, 70, 54, 3, 64, 4, 2, 1, 2),        # same kernel at stride 2 (img_discr conv_0: 4x4, explicit pad 1, 36 x 28 outputs), lrelu
     # tiny-filter weight gradients (conv_wsmall.hip: the whole filter gradient in one workgroup's 16x16 MFMA accumulators); (4,128,128,3,32,7)
     # and (8,64,64,64,4,3) above are its 7x7 image-input and 64 -> 4 head variants
     (2, 128, 128, 16, 16, 3, 1, 0, 1),     # pose conv_7_1 shape: 16 -> 16 at full resolution, nine 16-row blocks on three wavefronts

@@ -511,7 +511,7 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const floa
 // conv_rgb.hip: LDS-resident first-layer kernel (Cin <= 4, stride 1)
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW,
                                                                   const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
-                                                                  int pad_t, int pad_l, int act, hipStream_t s);
+                                                                  int stride, int pad_t, int pad_l, int act, hipStream_t s);
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
                                                                     float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, hipStream_t s);
 extern "C" int kpx_conv3x3_c16_eligible(int N, int H, int W, int K, int Nn, int ldin, int ldout, const void* in_ptr);
@@ -563,8 +563,8 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && act != KPX_ACT_TANH && aligned16(w) &&
         workspace && workspace_bytes >= wino_ws_bytes(Cin, Cout) && kpx_wino_eligible(N, Hi, Wi, Cin, Cout, ldx, x))
         return kpx_wino_conv3x3(x, N, Hi, Wi, Cin, ldx, w, Cin, Cout, 0, bias, act, y, Cout, ldy, (float*)workspace, kpx_stream(stream));
-    if (Cin <= 4 && ldx == Cin && stride == 1 && Cout <= 64 && Ho * Wo >= 256) {       // image-input layers: patch + filter resident in LDS
-        const int rc = kpx_conv_rgb_fwd(x, N, Hi, Wi, Cin, w, KH, KW, bias, y, Ho, Wo, Cout, ldy, pad_t, pad_l, act, kpx_stream(stream));
+    if (Cin <= 4 && ldx == Cin && stride <= 2 && Cout <= 64 && Ho * Wo >= 256) {       // image-input layers (stride 2: img_discr conv_0): patch + filter resident in LDS
+        const int rc = kpx_conv_rgb_fwd(x, N, Hi, Wi, Cin, w, KH, KW, bias, y, Ho, Wo, Cout, ldy, stride, pad_t, pad_l, act, kpx_stream(stream));
         if (rc != -2) return rc;
     }
     ConvGeom g{};

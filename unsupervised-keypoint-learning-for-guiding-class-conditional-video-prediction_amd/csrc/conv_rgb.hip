@@ -10,7 +10,7 @@
 struct RgbGeom {
     const float* x; const float* w; const float* bias; float* y;
     int N, Hi, Wi, Cin, Ho, Wo, Cout, ldy;
-    int KH, KW, pad_t, pad_l, act;
+    int KH, KW, pad_t, pad_l, act, stride;
     int tiles_y, tiles_x, total_tiles, tpb;
     int PH, PWC, KWC, KWCp;          // patch rows, floats per patch row (+ slack), floats per filter row, padded to even
 };
@@ -45,8 +45,8 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const RgbGeom g) {
     for (int nt = 0; nt < NT; ++nt) bv[nt] = (g.bias && nt * 32 + li < g.Cout) ? g.bias[nt * 32 + li] : 0.f;
     const int rowlen = g.Wi * g.Cin;
     // lane's pixel inside M-tile mt: row 2*mt + li/16, column li%16
-    const int a0 = (2 * (2 * wave) + (li >> 4)) * g.PWC + (li & 15) * g.Cin + lh;
-    const int a1 = a0 + 2 * g.PWC;
+    const int a0 = g.stride * (2 * (2 * wave) + (li >> 4)) * g.PWC + g.stride * (li & 15) * g.Cin + lh;
+    const int a1 = a0 + 2 * g.stride * g.PWC;
     const int b0 = lh * NC + li;
     const int ks = g.KWCp >> 1;
     const float lo = g.act == KPX_ACT_RELU ? 0.f : -__builtin_inff();
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const RgbGeom g) {
         const int n = L / g.tiles_y;
         const int oy0 = by * 16, ox0 = bx * 16;
         // ---- stage the patch (zero outside the image): wavefront w takes patch rows w, w + 4, ..
-        const int iy0 = oy0 - g.pad_t, ixc0 = (ox0 - g.pad_l) * g.Cin;
+        const int iy0 = oy0 * g.stride - g.pad_t, ixc0 = (ox0 * g.stride - g.pad_l) * g.Cin;
         __syncthreads();                                   // the previous tile's reads (and, first, the filter) are done
         for (int pr = wave; pr < g.PH; pr += 4) {
             const int iy = iy0 + pr;
@@ -116,18 +116,18 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const RgbGeom g) {
 
 static std::atomic<unsigned long long> rgb_attr_mask{0};
 
-// stride-1 convolutions of a dense (ldx == Cin) image with Cin <= 4 and Cout <= 64; returns -2 when the shape is not handled
+// stride-1 / stride-2 convolutions of a dense (ldx == Cin) image with Cin <= 4 and Cout <= 64; returns -2 when the shape is not handled
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW,
                                                                   const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
-                                                                  int pad_t, int pad_l, int act, hipStream_t s) {
-    if (Cin > 4 || Cout > 64 || KH > 7 || KW > 7 || kpx_env()->no_rgb) return -2;
+                                                                  int stride, int pad_t, int pad_l, int act, hipStream_t s) {
+    if (Cin > 4 || Cout > 64 || KH > 7 || KW > 7 || stride < 1 || stride > 2 || kpx_env()->no_rgb) return -2;
     RgbGeom g{};
     g.x = x; g.w = w; g.bias = bias; g.y = y;
     g.N = N; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
-    g.KH = KH; g.KW = KW; g.pad_t = pad_t; g.pad_l = pad_l; g.act = act;
+    g.KH = KH; g.KW = KW; g.pad_t = pad_t; g.pad_l = pad_l; g.act = act; g.stride = stride;
     g.tiles_y = (Ho + 15) / 16; g.tiles_x = (Wo + 15) / 16;
     g.KWC = KW * Cin; g.KWCp = (g.KWC + 1) & ~1;
-    g.PH = 15 + KH; g.PWC = (15 + KW) * Cin + 1;          // +1: the padded k of the last pixel stays inside the row
+    g.PH = 15 * stride + KH; g.PWC = (15 * stride + KW) * Cin + 1;          // +1: the padded k of the last pixel stays inside the row
     const int nt = Cout <= 32 ? 1 : 2;
     const size_t lds = ((size_t)((g.PH * g.PWC + 4 + 3) & ~3) + (size_t)KH * g.KWCp * 32 * nt) * 4;
     if (kpx_first_use_on_device(&rgb_attr_mask)) {
