@@ -390,6 +390,14 @@ class DetectorTranslatorModel(BaseModel):
                 recon = self._loss_G_recon(final, future_im)
                 if aux is not None and AUX_STREAM_ADV:         # (KPX_VGG_ON_AUX=0: round 3's first structure, kept for A/B)
                     g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
+                    # CROSS-STREAM LIFETIME INVARIANT (no record_stream anywhere in this step): a tensor that crosses main <-> aux is produced
+                    # BEFORE the fork whose wait_stream orders it and stays referenced from Python until AFTER the join that orders its last
+                    # reader, so the caching allocator never recycles it under a kernel of the other stream:
+                    #   main -> aux: `final`, `final_d`, `future_im` predate aux.wait_stream(main) above (the fork of the discriminator update) and
+                    #                are locals of this frame until the join below;
+                    #   aux -> main: `g_adv`, `d_losses`, `adv` are read on main only after main.wait_stream(aux) below.
+                    # No fresh aux.wait_stream(main) here on purpose: it would order the adversarial branch behind the VGG19 chain just enqueued
+                    # on main (g_recon) and serialise the two halves; `final` is already ordered by the earlier fork.
                     with torch.cuda.stream(aux):
                         adv = self._loss_G_adv(final)
                         g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
