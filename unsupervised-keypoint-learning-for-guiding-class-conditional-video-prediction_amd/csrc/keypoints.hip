@@ -187,8 +187,17 @@ __global__ __launch_bounds__(256) void kp_proj_stage2_kernel(const float* __rest
         if (axis) s = xs_y[(size_t)b * nC + e];
         else {
             s = 0.f;
-            for (int st = 0; st < nstripes; ++st) s += colpart[((size_t)b * nstripes + st) * WC + e];
-            xs_x[(size_t)b * nC + e] = s;
+            const float* cp = colpart + (size_t)b * nstripes * WC + e;
+            int st = 0;
+            for (; st + 7 < nstripes; st += 8) {               // eight stripe loads in flight (the plain loop was a chain of dependent L2 loads)
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = cp[(size_t)(st + j) * WC];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[j];
+            }
+            for (; st < nstripes; ++st) s += cp[(size_t)st * WC];
+            if (blockIdx.z == 0) xs_x[(size_t)b * nC + e] = s;
         }
         S[e] = s;
     }
@@ -196,7 +205,8 @@ __global__ __launch_bounds__(256) void kp_proj_stage2_kernel(const float* __rest
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const float inv_other = (float)other;
-    for (int k = wave; k < K; k += 4) {
+    // blockIdx.z splits the K profiles of this (image, axis): workgroup z takes k = 4 z + wave, 4 (z + gridDim.z) + wave, ..
+    for (int k = blockIdx.z * 4 + wave; k < K; k += 4 * gridDim.z) {
         const float bk = bias ? bias[k] : 0.f;
         float v[8];
         float mx = -INFINITY;
@@ -261,7 +271,8 @@ extern "C" int kpx_keypoint_head_proj_fwd_f32(const float* x, const float* wk, c
     int rc = kpx_launch_status();
     if (rc) return rc;
     const int n = H > W ? H : W;
-    hipLaunchKernelGGL(kp_proj_stage2_kernel, dim3(B, 2), dim3(256), ((size_t)n * C + (size_t)C * K) * sizeof(float), s,
+    const int kz = (K + 3) / 4 < 4 ? (K + 3) / 4 : 4;          // 128 workgroups alone (B = 64) left the chip idle: 45 us -> split the K profiles 4 ways
+    hipLaunchKernelGGL(kp_proj_stage2_kernel, dim3(B, 2, kz), dim3(256), ((size_t)n * C + (size_t)C * K) * sizeof(float), s,
                        (const float*)xs_y, (const float*)colpart, xs_x, wk, bias, H, W, C, K, nstripes, mu, prob_y, prob_x);
     return kpx_launch_status();
 }
@@ -300,7 +311,15 @@ __global__ __launch_bounds__(256) void kp_proj_bwd_small_kernel(const float* __r
         float s = 0.f;
         if (e < C * K) {
             const int c = e / K, k = e - c * K;
-            for (int i = 0; i < n; ++i) s = fmaf(xs[i * C + c], d[i * K + k], s);
+            int i = 0;
+            for (; i + 7 < n; i += 8) {                      // eight row / column sums of x in flight per thread
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = xs[(i + j) * C + c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s = fmaf(v[j], d[(i + j) * K + k], s);
+            }
+            for (; i < n; ++i) s = fmaf(xs[i * C + c], d[i * K + k], s);
         } else {
             const int k = e - C * K;
             for (int i = 0; i < n; ++i) s += d[i * K + k];
@@ -311,15 +330,31 @@ __global__ __launch_bounds__(256) void kp_proj_bwd_small_kernel(const float* __r
     (void)B;
 }
 
-// dW / db = sum over the 2B partial rows, in order (deterministic); accumulate != 0 adds into the destination
+// dW / db = sum over the 2B partial rows in a fixed order (deterministic): segment sg = threadIdx.x / 64 of a 256-thread workgroup sums rows
+// sg, sg + 4, .. of 64 elements, the four segment sums are combined in LDS order; accumulate != 0 adds into the destination
+// (one thread per element walking all 128 rows was a 30 us chain of dependent L2 loads)
 __global__ __launch_bounds__(256) void kp_proj_bwd_reduce_kernel(const float* __restrict__ part, int rows, int CK, int K,
                                                                  float* __restrict__ dw, float* __restrict__ db, int accumulate) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= CK + K) return;
+    const int el = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
+    const int n = CK + K;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += part[(size_t)r * (CK + K) + e];
-    if (e < CK) { if (dw) dw[e] = accumulate ? dw[e] + s : s; }
-    else if (db) db[e - CK] = accumulate ? db[e - CK] + s : s;
+    if (e < n) {
+        int r = sg;
+        for (; r + 12 < rows; r += 16) {
+            const float v0 = part[(size_t)r * n + e], v1 = part[(size_t)(r + 4) * n + e], v2 = part[(size_t)(r + 8) * n + e], v3 = part[(size_t)(r + 12) * n + e];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; r < rows; r += 4) s += part[(size_t)r * n + e];
+    }
+    __shared__ float sm[4][64];
+    sm[sg][el] = s;
+    __syncthreads();
+    if (sg == 0 && e < n) {
+        const float tot = (sm[0][el] + sm[1][el]) + (sm[2][el] + sm[3][el]);
+        if (e < CK) { if (dw) dw[e] = accumulate ? dw[e] + tot : tot; }
+        else if (db) db[e - CK] = accumulate ? db[e - CK] + tot : tot;
+    }
 }
 
 // dx[b,h,w,:] = R[b,h,:] + Cc[b,w,:]: pure write stream, 16 B per lane.  grid (slabs of rows, B); a thread owns one (w, channel quad)
@@ -359,7 +394,7 @@ extern "C" int kpx_keypoint_head_proj_bwd_f32(const float* dmu, const float* mu,
     int rc = kpx_launch_status();
     if (rc) return rc;
     if (dw || db) {
-        hipLaunchKernelGGL(kp_proj_bwd_reduce_kernel, dim3((C * K + K + 255) / 256), dim3(256), 0, s, (const float*)part, 2 * B, C * K, K,
+        hipLaunchKernelGGL(kp_proj_bwd_reduce_kernel, dim3((C * K + K + 63) / 64), dim3(256), 0, s, (const float*)part, 2 * B, C * K, K,
                            dw, db, accumulate);
         rc = kpx_launch_status();
         if (rc) return rc;
