@@ -255,12 +255,13 @@ WINO43_EXCLUDE_FWD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_FWD', 
 # 0.158 ms -- one F(4x4) workgroup owns its CU); inside the step, where the other streams fill the idle CUs, F(4x4,3x3) wins on those layers too:
 # 23.73-23.83 ms per step at 0 / 32 / 64 against 24.01-24.16 at 128 (three repetitions each, B=32) -- so no threshold
 WINO43_MIN_WORKGROUPS = int(_os.environ.get('KPX_WINO43_MIN_WGS', '0'))
+WINO43_NMIN = int(_os.environ.get('KPX_WINO43_NMIN', '33'))      # produced channels from which a layer takes the 64-cout F(4x4,3x3) workgroups
 WINO43_EXCLUDE_DGRAD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_DGRAD', '').split(',') if p)
 
 
 def _wino43_wanted(name, cin, cout, dgrad):
     k, nn = (cout, cin) if dgrad else (cin, cout)
-    return WINO43 and k >= 16 and nn >= 33 and not any(name.startswith(p) for p in (WINO43_EXCLUDE_DGRAD if dgrad else WINO43_EXCLUDE_FWD))
+    return WINO43 and k >= 16 and nn >= WINO43_NMIN and not any(name.startswith(p) for p in (WINO43_EXCLUDE_DGRAD if dgrad else WINO43_EXCLUDE_FWD))
 
 
 class FilterBank:
