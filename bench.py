@@ -58,15 +58,15 @@ def time_kernel(fn, iters, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def _time_conv_3_1(dev, pretransformed=False, name='translator/conv_3_1'):
-    """name: the filter's variable name, which selects F(4x4,3x3) or F(2x2,3x3) exactly as in the train step (ops.WINO43_EXCLUDE_*)."""
+def _time_conv_3_1(dev, pretransformed=False, name='translator/conv_3_1', f43_fwd=True):
+    """f43_fwd: the layer attribute that selects F(4x4,3x3) or F(2x2,3x3) in the forward direction exactly as in the train step (ops.WINO43)."""
     from kpx_amd import ops
     n, h, c = BATCH, 64, 128
     x = torch.randn(n, h, h, c, device=dev)
     w = torch.randn(3, 3, c, c, device=dev) * 0.03
     b = torch.zeros(c, device=dev)
     y = torch.empty(n, h, h, c, device=dev)
-    keys = ops.register_constant_filter(w, name) if pretransformed else []     # the train step runs the kernel on filters transformed once per update
+    keys = ops.register_constant_filter(w, name, f43_fwd=f43_fwd) if pretransformed else []     # the train step runs the kernel on filters transformed once per update
     try:
         ms = time_kernel(lambda: ops.conv_fwd_raw(x, c, c, w, b, y, c, 1, 1, 1, 0), iters=100, warm=20)
     finally:
@@ -108,8 +108,8 @@ WINO43_PMC, WINO_PMC, DIRECT_PMC, RENDER_PMC = 'r03_wino43_pmc.json', 'r03_wino_
 GEMM3_PMC, BF16_PMC = 'r03_gemm3_pmc.json', 'r03_bf16_pmc.json'
 
 
-def _roofline_wino(dev, name, kernel_substr, kernel_desc, reduction, pmc):
-    ms, flops = _time_conv_3_1(dev, pretransformed=True, name=name)
+def _roofline_wino(dev, name, kernel_substr, kernel_desc, reduction, pmc, f43_fwd=True):
+    ms, flops = _time_conv_3_1(dev, pretransformed=True, name=name, f43_fwd=f43_fwd)
     alg = flops / (ms * 1e-3) / 1e12
     ach = alg / reduction
     traffic, src = _pmc_traffic(pmc)
@@ -138,7 +138,7 @@ def roofline_conv_f23(dev):
     """The F(2x2,3x3) kernel on the same layer shape (what the key-point detector, the image encoder and the translator's 32x32 layers
     run): executed FLOPs = algorithmic / 2.25."""
     return _roofline_wino(dev, 'pose_encoder/same_shape', 'conv_wino_v2_kernel<2, 0>',
-                          'conv_wino_v2_kernel<2, 0> F(2x2,3x3) fwd 3x3 s1 128->128 @64x64 B=32, filter pre-transformed', 2.25, WINO_PMC)
+                          'conv_wino_v2_kernel<2, 0> F(2x2,3x3) fwd 3x3 s1 128->128 @64x64 B=32, filter pre-transformed', 2.25, WINO_PMC, f43_fwd=False)
 
 
 def roofline_conv_direct(dev):
@@ -343,7 +343,7 @@ def bench_rollout(args, conf, dev, rank, world, launched, backend):
                            'algorithmic_gmac_per_frame': round(gmac_frame, 3)},
                 'step_tflops': round(2 * gmac_frame * 1e9 * frames / dt / 1e12, 2),
                 'step_algorithmic_frac_of_f32_peak': round(2 * gmac_frame * 1e9 * frames / dt / world / 157.3e12, 4),
-                'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 3), 'dist_backend': backend if launched else None}
+                'host_call_wall_ms_per_step': round(t_enq / args.steps * 1e3, 3), 'dist_backend': backend if launched else None}
         if world == 1:
             line['roofline'] = roofline_conv(dev)          # the translator's 3x3 layers dominate the rollout as they do the train step
         print(json.dumps(line), flush=True)
@@ -474,11 +474,13 @@ def main():
                           'algorithmic_gmac_per_pair': round(gmac, 2)},
                'step_tflops': round(2 * gmac * 1e9 * value / 1e12, 2),
                'step_algorithmic_frac_of_f32_peak': round(2 * gmac * 1e9 * value / world / 157.3e12, 4),
+               # the chip's fp32-EQUIVALENT ceiling is the six-product bf16x3 bound (2.5 PFLOP/s / 6 = 417 TFLOP/s), not the fp32-MFMA pipe
+               'step_algorithmic_frac_of_bf16x3_bound': round(2 * gmac * 1e9 * value / world / 416.7e12, 4),
                'n_ranks_seen': n_ranks_seen, 'dist_backend': backend if launched else None,
                'ms_per_step_by_rank': [round(x, 3) for x in ms_by_rank],
-               'host_enqueue_ms_per_step': round(max(enq), 3), 'host_enqueue_ms_per_step_by_rank': [round(x, 3) for x in enq],
-               'host_enqueue_note': 'wall time of the K train_step() calls / K: includes blocking on a full launch queue (a graph replay call blocks once '
-                                    'a few replays are in flight); host_work_ms_per_step_min = the shortest single call = the host work of one step',
+               'host_call_wall_ms_per_step': round(max(enq), 3), 'host_call_wall_ms_per_step_by_rank': [round(x, 3) for x in enq],
+               'host_note': 'host_call_wall = wall time of the K train_step() calls / K: mostly launch-queue BACK-PRESSURE (a graph replay call blocks once '
+                            'a few replays are in flight), not host work; host_work_ms_per_step_min = the shortest single call = the host work of one step',
                'host_work_ms_per_step_min': round(min(per_call) * 1e3, 3),
                'launch_mode': ('one HIP graph replay per step (captured after %d eager warm-up step(s); %d C-ABI kernel launches inside the graph)'
                                % (1, getattr(model, '_graph_launches', 0))) if graphed else 'eager: every kernel enqueued from Python',

@@ -96,9 +96,10 @@ def main():
         dw = torch.empty_like(w)
         flops = 2.0 * n * ho * ho * co * k * k * ci
         # the filter is registered under the layer's variable name, so that the 3x3 layers run on the kernel the train step picks for
-        # them (pre-transformed filters; F(4x4,3x3) or F(2x2,3x3) by ops.WINO43_EXCLUDE_* and the launch size)
+        # them (pre-transformed filters; F(4x4,3x3) or F(2x2,3x3) by the layer's f43_fwd attribute as networks.py declares it)
         vname = name.replace('pose/', 'pose_encoder/').replace('pose_encoder/enc/', 'pose_encoder/encoder/')
-        keys = ops.register_constant_filter(w, vname) if (k == 3 and not args.unregistered) else []
+        f43 = not vname.startswith(('pose_encoder', 'image_encoder', 'translator/conv_1', 'translator/conv_2'))
+        keys = ops.register_constant_filter(w, vname, f43_fwd=f43) if (k == 3 and not args.unregistered) else []
         used = ops.conv_kernel_uses['wino43']
         try:
             tf = timeit(lambda: ops.conv_fwd_raw(x, ld, ci, w, b, y, co, s, pad_t, pad_t, 0))

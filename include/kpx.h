@@ -40,12 +40,13 @@ int kpx_abi_version(void);
  * launches.  Returns 0.  (No reference counterpart: TF-1.12 reads its TF_* switches the same way, once.) */
 int kpx_reload_env(void);
 
-/* Arithmetic of the bf16-matrix-pipe implicit-GEMM kernels behind kpx_conv2d_fwd_f32 / _dgrad_f32 / _wgrad_f32 (csrc/conv_gemm3.hip):
- * terms = 3 (default): every fp32 operand is split exactly into three bf16 terms and six partial products are accumulated in fp32 --
- * fp32-equivalent, the fp32 configuration; terms = 1: operands rounded (truncated) to bf16, one product -- the bf16 configuration
- * (BASELINE configs[2]).  Process-wide; returns the previous value or KPX_EINVAL.  Replaces nothing in the reference (TF-1.12 has no
- * such switch): it selects which of the two configurations the same entry points compute. */
-int kpx_set_gemm3_terms(int terms);
+/* `arith` argument of kpx_conv2d_fwd_f32 / _dgrad_f32 / _wgrad_f32: the arithmetic of the layers those entries run on the bf16 matrix
+ * pipe (csrc/conv_gemm3.hip: strided / 4x4 / 1x1 layers and their weight gradients).  KPX_ARITH_F32: every fp32 operand is split exactly
+ * into three bf16 terms and six partial products are accumulated in fp32 -- fp32-equivalent, the fp32 configuration (the fp32-MFMA
+ * kernels the other shapes run on are unaffected by the argument).  KPX_ARITH_BF16: operands truncated to bf16, one product, fp32
+ * accumulation -- the bf16 configuration (BASELINE configs[2]).  Per call: two models of different configurations can share a process.
+ * No reference counterpart (TF-1.12 computes models/networks/layers.py:6-9 in the graph's one dtype). */
+enum { KPX_ARITH_F32 = 0, KPX_ARITH_BF16 = 1 };
 
 /* ---- convolution: replaces tf.pad + tf.layers.conv2d(padding='same') (models/networks/layers.py:6-9)
  *      and tf.nn.conv2d + bias_add + relu (models/networks/vgg.py:51-54).
@@ -58,7 +59,7 @@ size_t kpx_conv2d_fwd_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, 
 int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
                        const float* w_hwio, int KH, int KW, const float* bias,
                        float* y, int Ho, int Wo, int Cout, int ldy,
-                       int stride, int pad_t, int pad_l, int act,
+                       int stride, int pad_t, int pad_l, int act, int arith,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- fused Winograd F(2x2,3x3) path of the 3x3 stride-1 SAME convolution with PRE-TRANSFORMED filters (fp32 MFMA; same reference
@@ -106,7 +107,7 @@ size_t kpx_conv2d_dgrad_workspace_bytes(int N, int Hi, int Wi, int Cin, int Cout
 int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int Cout, int lddy,
                          const float* w_hwio, int KH, int KW,
                          float* dx, int Hi, int Wi, int Cin, int lddx,
-                         int stride, int pad_t, int pad_l,
+                         int stride, int pad_t, int pad_l, int arith,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* dw[r,q,c,k] = sum_{n,oh,ow} x[n, oh*s+r-pad_t, ow*s+q-pad_l, c] * dy[n,oh,ow,k].
@@ -114,7 +115,7 @@ int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int Cout, int l
 size_t kpx_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
 int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
                          const float* dy, int Ho, int Wo, int Cout, int lddy,
-                         float* dw_hwio, int KH, int KW, int stride, int pad_t, int pad_l,
+                         float* dw_hwio, int KH, int KW, int stride, int pad_t, int pad_l, int arith,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* dz = dy * act'(y) (y = the activated conv output; dz may alias dy): relu / leaky_relu(0.01) / tanh backward
@@ -233,6 +234,9 @@ int kpx_keypoint_head_bwd_f32(const float* dmu, const float* mu, const float* pr
  * Backward: dx [B,H,W,C] (or NULL), dw [C,K] and db [K] (each may be NULL; accumulate != 0 adds into them).
  * scratch: kpx_keypoint_head_proj_scratch_bytes(B,H,W,C,K) for either direction. */
 size_t kpx_keypoint_head_proj_scratch_bytes(int B, int H, int W, int C, int K);
+/* 1 when the folded operator takes the shape (C % 4 == 0, C <= 256, K <= 64, H, W in [2, 512], its profile rows within 64 KB of LDS);
+ * otherwise the caller runs kpx_conv2d_fwd_f32 (1x1) followed by kpx_keypoint_head_fwd_f32 -- the same reference call sites. */
+int kpx_keypoint_head_proj_eligible(int B, int H, int W, int C, int K);
 int kpx_keypoint_head_proj_fwd_f32(const float* x, const float* wk, const float* bias, int B, int H, int W, int C, int K,
                                    float* mu, float* prob_y, float* prob_x, float* xs_y, float* xs_x, void* scratch, void* stream);
 int kpx_keypoint_head_proj_bwd_f32(const float* dmu, const float* mu, const float* prob_y, const float* prob_x,

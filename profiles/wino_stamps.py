@@ -17,7 +17,7 @@ lib.kpx_conv2d_fwd_workspace_bytes.restype = ctypes.c_size_t
 lib.kpx_conv2d_fwd_workspace_bytes.argtypes = [ctypes.c_int] * 7
 lib.kpx_conv2d_fwd_f32.restype = ctypes.c_int
 lib.kpx_conv2d_fwd_f32.argtypes = [P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, ctypes.c_int, ctypes.c_int, P,
-                                   P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, ctypes.c_size_t, P]
+                                   P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, P, ctypes.c_size_t, P]
 lib.kpx_debug_wino_stamps.argtypes = [P]
 
 
@@ -36,7 +36,7 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
 
     def run():
-        rc = lib.kpx_conv2d_fwd_f32(x.data_ptr(), n, h, h, c, c, w.data_ptr(), 3, 3, b.data_ptr(), y.data_ptr(), h, h, c, c, 1, 1, 1, 0, ws.data_ptr(), nbytes, st)
+        rc = lib.kpx_conv2d_fwd_f32(x.data_ptr(), n, h, h, c, c, w.data_ptr(), 3, 3, b.data_ptr(), y.data_ptr(), h, h, c, c, 1, 1, 1, 0, 0, ws.data_ptr(), nbytes, st)
         assert rc == 0, rc
     for _ in range(200):                      # warm the clocks (DVFS) with back-to-back launches
         run()

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_bad_arguments_are_rejected_without_a_gpu():
     from kpx_amd._lib import lib
-    assert lib.kpx_conv2d_fwd_f32(None, 1, 8, 8, 4, 4, None, 3, 3, None, None, 8, 8, 4, 4, 1, 1, 1, 0, None, 0, None) == -1
+    assert lib.kpx_conv2d_fwd_f32(None, 1, 8, 8, 4, 4, None, 3, 3, None, None, 8, 8, 4, 4, 1, 1, 1, 0, 0, None, 0, None) == -1
     assert lib.kpx_bn_stats_f32(None, 10, 4, 4, 1e-5, None, None, None, None, None, 0.999, None, None) == -1
     assert lib.kpx_conv2d_wgrad_workspace_bytes(32, 128, 128, 64, 64, 3, 3) > 0
     assert lib.kpx_conv2d_wgrad_workspace_bytes(1, 4, 4, 1024, 2048, 4, 4) == 0

@@ -166,7 +166,7 @@ def test_data_parallel_bf16_exchange_flag_two_gloo_ranks():
 
 
 def test_f43_layer_policy_follows_the_float64_arbiter_findings():
-    """Which layers may run the F(4x4,3x3) kernel is host logic (ops.WINO43_EXCLUDE_*): data gradients everywhere, forward only on VGG19
+    """Which layers may run the F(4x4,3x3) kernel is host logic (a per-layer attribute declared in networks.py, ops.WINO43): data gradients everywhere, forward only on VGG19
     and the translator's 64x64 / 128x128 layers; the key-point detector, the image encoder and the translator's 32x32 layers keep
     F(2x2,3x3) in the forward direction.  Channel limits: K >= 16 gathered, more than 32 produced."""
     from kpx_amd import ops
@@ -177,9 +177,10 @@ def test_f43_layer_policy_follows_the_float64_arbiter_findings():
     for name, v in m.store.vars.items():
         if name.endswith('/kernel') and v.dim() == 4 and v.shape[0] == 3:
             cin, cout = int(v.shape[2]), int(v.shape[3])
-            if ops._wino43_wanted(name, cin, cout, 0):
+            f43 = m.store.layer_attrs[name]['f43_fwd']
+            if ops._wino43_wanted(name, cin, cout, 0, f43):
                 fwd.add(name.split('/conv2d')[0])
-            if ops._wino43_wanted(name, cin, cout, 1):
+            if ops._wino43_wanted(name, cin, cout, 1, f43):
                 dgrad.add(name.split('/conv2d')[0])
     assert fwd == {'translator/conv_%d_%d' % (i, j) for i in (3, 4, 5) for j in (0, 1)}
     assert not any(n.startswith(('pose_encoder', 'image_encoder', 'translator/conv_1', 'translator/conv_2', 'img_discr')) for n in fwd)
@@ -188,3 +189,6 @@ def test_f43_layer_policy_follows_the_float64_arbiter_findings():
     assert not any(n.startswith('translator/conv_6') for n in dgrad | fwd)          # the 4-channel head: K = 4 gathered in the gradient, 4 produced in the forward
     assert ops._wino43_wanted('vgg/conv3_2', 256, 256, 0) and ops._wino43_wanted('vgg/conv3_2', 256, 256, 1)
     assert not ops._wino43_wanted('vgg/conv1_1', 3, 64, 0)
+    # the attribute, not the name, decides: the same filter name with the attribute cleared stays off F(4x4,3x3) in the forward direction only
+    assert not ops._wino43_wanted('translator/conv_3_1/conv2d/kernel', 128, 128, 0, False) and ops._wino43_wanted('translator/conv_3_1/conv2d/kernel', 128, 128, 1, False)
+    assert ops._wino43_wanted('pose_encoder/renamed_scope/conv2d/kernel', 128, 128, 0, True)

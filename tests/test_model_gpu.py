@@ -880,6 +880,51 @@ def test_rollout_graph_replay_is_bit_identical_to_the_eager_rollout(monkeypatch)
             assert np.array_equal(outs[False][i][k_], outs[True][i][k_]), (i, k_)
 
 
+def test_rollout_graph_is_recaptured_after_the_parameters_change(monkeypatch):
+    """The captured rollout bakes in the addresses of the batch-norm-folded filters, which VariableStore.touch() releases: loading a second
+    checkpoint into the SAME FinalModel after the capture must drop the graph (store.version), and every later run -- the eager one, the
+    re-capture and its replays -- must equal the launch-by-launch rollout with the new parameters bit for bit."""
+    import kpx_amd
+    import kpx_amd.final_model as fmod
+    dev = torch.device('cuda:0')
+    res, k, b, cells, vdim = 32, 3, 2, (64, 64), 8
+    cfg = {'model': {'n_pts': k, 'cell_info': list(cells), 'vae_dim': vdim, 'n_action': 9}, 'paths': {'log_dir': '/tmp/kpx_final'}}
+
+    def checkpoint(seed):
+        arrays = {**R.init_variables(k, res=res, seed=seed), **R.init_stage2_decoder(k, cell_info=cells, vae_dim=vdim, seed=seed + 1)}
+        return {n: a for n, a in arrays.items() if not n.startswith('img_discr')}
+    rs = np.random.RandomState(11)
+    im, _ = R.synthetic_pair(b, res=res, seed0=70, seed1=71)
+    feed = {'image': torch.from_numpy(im).to(dev), 'action_code': torch.from_numpy(np.eye(9, dtype=np.float32)[rs.randint(0, 9, size=b)]).to(dev)}
+    z = torch.from_numpy(rs.randn(b, vdim).astype(np.float32)).to(dev)
+    keys = ('pred_im_seq', 'mask', 'fut_pt_raw', 'first_pt')
+    snap = lambda o: {k_: o[k_].cpu().numpy().copy() for k_ in keys}
+    want = {}
+    monkeypatch.setattr(fmod, 'GRAPH', False)
+    for seed in (77, 177):
+        fm = kpx_amd.FinalModel(cfg, device=dev, image_size=res, frames_per_launch=32)
+        fm.build()
+        fm.store.load_numpy(checkpoint(seed), strict=True)
+        want[seed] = snap(fm.run(None, feed, z=z))
+    assert not np.array_equal(want[77]['pred_im_seq'], want[177]['pred_im_seq'])
+    monkeypatch.setattr(fmod, 'GRAPH', True)
+    fm = kpx_amd.FinalModel(cfg, device=dev, image_size=res, frames_per_launch=32)
+    fm.build()
+    fm.store.load_numpy(checkpoint(77), strict=True)
+    for _ in range(3):                                  # eager, capture + replay, replay
+        got = snap(fm.run(None, feed, z=z))
+    assert len(fm._graphs) == 1
+    for k_ in keys:
+        assert np.array_equal(got[k_], want[77][k_]), k_
+    fm.store.load_numpy(checkpoint(177), strict=True)   # second checkpoint into the same model object
+    torch.empty(1 << 22, device=dev).fill_(float('nan'))   # recycle freed blocks with poison: a stale graph would read it
+    for i in range(3):
+        got = snap(fm.run(None, feed, z=z))
+        for k_ in keys:
+            assert np.array_equal(got[k_], want[177][k_]), (i, k_)
+    assert len(fm._graphs) == 1 and not fm._graph_failed
+
+
 def smooth_pair(bsz, res, seed):
     """Structured synthetic frames: five coloured Gaussian blobs on a linear-gradient background, the blobs displaced between the two
     frames of a pair -- images with the low-frequency content of real frames (uniform noise makes the loss gradient chaotic)."""

@@ -32,16 +32,15 @@ P = c_void_p
 SIGNATURES = {
     'kpx_abi_version': (c_int, []),
     'kpx_reload_env': (c_int, []),
-    'kpx_set_gemm3_terms': (c_int, [c_int]),
     'kpx_conv2d_fwd_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P,
-                                   P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+                                   P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'kpx_conv2d_dgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_dgrad_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int,
-                                     P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+                                     P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'kpx_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_wgrad_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int,
-                                     P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+                                     P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'kpx_wino_u_bytes': (c_size_t, [c_int, c_int]),
     'kpx_wino_filter_transform_f32': (c_int, [P, c_int, c_int, c_int, P, P]),
     'kpx_wino_filter_transform_batch_f32': (c_int, [P, c_int, P]),
@@ -84,6 +83,7 @@ SIGNATURES = {
     'kpx_keypoint_head_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P]),
     'kpx_keypoint_head_bwd_f32': (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P, P]),
     'kpx_keypoint_head_proj_scratch_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'kpx_keypoint_head_proj_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'kpx_keypoint_head_proj_fwd_f32': (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     'kpx_keypoint_head_proj_bwd_f32': (c_int, [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, P, P]),
     'kpx_gaussian_maps_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_double, P, c_int, P]),

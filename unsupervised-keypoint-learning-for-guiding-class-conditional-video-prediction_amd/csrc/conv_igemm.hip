@@ -434,7 +434,7 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wgrad3_launch(WgradGeom
 template <bool BT>
 static int launch_gather_conv(const ConvGeom& g, hipStream_t s) {
     if (kpx_gemm3_eligible(&g)) {
-        int rc = kpx_gemm3_launch(g, BT ? 1 : 0, kpx_env()->gemm3_terms, s);
+        int rc = kpx_gemm3_launch(g, BT ? 1 : 0, g.terms == 1 ? 1 : 3, s);
         if (rc || g.ksplit <= 1) return rc;
         const size_t npix = (size_t)g.N * g.Ho * g.Wo;
         size_t nb = (npix * (g.Cout / 4) + 255) / 256; if (nb > 2048) nb = 2048;
@@ -549,9 +549,9 @@ extern "C" size_t kpx_conv2d_dgrad_workspace_bytes(int N, int Hi, int Wi, int Ci
 extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
                                   const float* w, int KH, int KW, const float* bias,
                                   float* y, int Ho, int Wo, int Cout, int ldy,
-                                  int stride, int pad_t, int pad_l, int act, void* workspace, size_t workspace_bytes, void* stream) {
+                                  int stride, int pad_t, int pad_l, int act, int arith, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !w || !y || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
-        KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || ldy < Cout || act < 0 || act > 3)
+        KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || ldy < Cout || act < 0 || act > 3 || arith < 0 || arith > 1)
         return KPX_EINVAL;
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && act != KPX_ACT_TANH &&
         kpx_conv3x3_c16_eligible(N, Hi, Wi, Cin, Cout, ldx, ldy, x))                 // exactly 16 produced channels: 16x16x4 MFMA blocks (conv_c16.hip)
@@ -575,7 +575,7 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
     g.isy = stride; g.iy0 = -pad_t; g.isx = stride; g.ix0 = -pad_l;
     g.Tr = KH; g.Tq = KW; g.ity = 1; g.itx = 1;
     g.wr0 = 0; g.wrs = 1; g.wq0 = 0; g.wqs = 1; g.KW = KW;
-    g.wts = Cin * Cout; g.ldw = Cout; g.act = act;
+    g.wts = Cin * Cout; g.ldw = Cout; g.act = act; g.terms = arith == KPX_ARITH_BF16 ? 1 : 3;
     g.vecA = (ldx % 4 == 0) && aligned16(x);
     g.vecB = (Cout % 4 == 0) && aligned16(w);
     if (!(kpx_env()->no_merge_kh && kpx_env()->no_merge_kh == KH) && Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64) {      // image inputs (Cin = 3): merge each filter row
@@ -594,9 +594,9 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
 extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int Cout, int lddy,
                                     const float* w, int KH, int KW,
                                     float* dx, int Hi, int Wi, int Cin, int lddx,
-                                    int stride, int pad_t, int pad_l, void* workspace, size_t workspace_bytes, void* stream) {
+                                    int stride, int pad_t, int pad_l, int arith, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dy || !w || !dx || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
-        KH <= 0 || KW <= 0 || stride <= 0 || lddy < Cout || lddx < Cin)
+        KH <= 0 || KW <= 0 || stride <= 0 || lddy < Cout || lddx < Cin || arith < 0 || arith > 1)
         return KPX_EINVAL;
     if (stride > 2) return KPX_EINVAL;             // at most 4 parity classes per launch (the path has strides 1 and 2)
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi &&
@@ -616,7 +616,7 @@ extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int 
     g.osy = stride; g.osx = stride;
     g.isy = 1; g.ity = -1; g.isx = 1; g.itx = -1;
     g.wrs = stride; g.wqs = stride; g.KW = KW;
-    g.wts = Cin * Cout; g.ldw = Cout; g.act = KPX_ACT_NONE;
+    g.wts = Cin * Cout; g.ldw = Cout; g.act = KPX_ACT_NONE; g.terms = arith == KPX_ARITH_BF16 ? 1 : 3;
     g.vecA = (lddy % 4 == 0) && aligned16(dy);
     g.vecB = (Cout % 4 == 0) && aligned16(w);
     g.ncls = 0;
@@ -1330,10 +1330,10 @@ extern "C" size_t kpx_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Ci
 
 extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
                                     const float* dy, int Ho, int Wo, int Cout, int lddy,
-                                    float* dw, int KH, int KW, int stride, int pad_t, int pad_l,
+                                    float* dw, int KH, int KW, int stride, int pad_t, int pad_l, int arith,
                                     void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !dy || !dw || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
-        KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || lddy < Cout)
+        KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || lddy < Cout || arith < 0 || arith > 1)
         return KPX_EINVAL;
     {   // tiny filters over very many pixels (image-input layers, 16 -> 16 at full resolution, the 64 -> 4 head): conv_wsmall.hip
         // (16-B staging units: dy always, x when it has a multiple of 4 channels)
@@ -1426,6 +1426,7 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     g.ct = (Cin + bm - 1) / bm; g.kt = (Cout + bn - 1) / bn;
     g.vecA = (ldx % 4 == 0) && aligned16(x);
     g.vecB = (lddy % 4 == 0) && aligned16(dy);
+    g.terms = arith == KPX_ARITH_BF16 ? 1 : 3;
     // (strided layers: the bf16x3 kernel below beats the fp32 tap-rows kernel -- encoder conv_3 at N = 64: 0.152 vs 0.198 ms; the stride-1
     //  layers that reach this point are faster on tap-rows / rows, and the 3x3 stride-1 layers on the Winograd weight gradient)
     const bool g3_strided = stride > 1 && g.vecA && g.vecB && kpx_wgrad3_eligible(&g);
@@ -1460,7 +1461,7 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     const dim3 grid((unsigned)(g.S * taps * g.ct * g.kt));
     const bool vec = g.vecA && g.vecB && !g.merge;
     if (vec && kpx_wgrad3_eligible(&g)) {                // bf16x3 (fp32-equivalent) weight gradient on the bf16 matrix pipe (conv_gemm3.hip)
-        int rc = kpx_wgrad3_launch(g, bm, kpx_env()->gemm3_terms, s);
+        int rc = kpx_wgrad3_launch(g, bm, g.terms == 1 ? 1 : 3, s);
         if (rc) return rc;
         if (g.S > 1) { launch_wgrad_reduce((const float*)workspace, dw, g.slab, g.S, s); rc = kpx_launch_status(); }
         return rc;

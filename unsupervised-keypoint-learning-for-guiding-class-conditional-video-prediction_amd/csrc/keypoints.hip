@@ -254,6 +254,8 @@ static bool kp_proj_dims_ok(int B, int H, int W, int C, int K) {
            ((size_t)n * C + (size_t)C * K) * sizeof(float) <= 64 * 1024 && ((size_t)n * K + (size_t)C * K) * sizeof(float) <= 64 * 1024;
 }
 
+extern "C" int kpx_keypoint_head_proj_eligible(int B, int H, int W, int C, int K) { return kp_proj_dims_ok(B, H, W, C, K) ? 1 : 0; }
+
 extern "C" size_t kpx_keypoint_head_proj_scratch_bytes(int B, int H, int W, int C, int K) {
     const size_t nstripes = (size_t)(H + KP_RS - 1) / KP_RS;
     const size_t fwd = (size_t)B * nstripes * W * C;                                   // stripe column sums

@@ -42,7 +42,6 @@ static void env_parse(KpxEnv* e) {
     e->no_gemm3 = env_flag("KPX_NO_GEMM3");
     e->no_wgrad3 = env_flag("KPX_NO_WGRAD3");
     e->wgrad3_first = (int)env_long("KPX_WGRAD3_FIRST", 0);
-    e->gemm3_terms = (int)env_long("KPX_GEMM3_TERMS", 3);
     e->no_wsmall = env_flag("KPX_NO_WSMALL");
     e->no_wsmall32 = env_flag("KPX_NO_WSMALL32");
     e->wsmall_c64_max = (int)env_long("KPX_WSMALL_C64_MAX", 4);
@@ -65,14 +64,4 @@ extern "C" int kpx_reload_env(void) {
     env_parse(&g_env);
     g_env_loaded.store(1, std::memory_order_release);
     return 0;
-}
-
-// Number of bf16 terms the conv_gemm3 / conv_wgrad3 kernels split each fp32 operand into: 3 = fp32-equivalent (the default, the fp32
-// configuration), 1 = plain bf16 operands (the bf16 configuration, BASELINE configs[2]).  Returns the previous value, or KPX_EINVAL.
-extern "C" int kpx_set_gemm3_terms(int terms) {
-    if (terms != 1 && terms != 3) return KPX_EINVAL;
-    KpxEnv* e = const_cast<KpxEnv*>(kpx_env());
-    const int old = e->gemm3_terms;
-    e->gemm3_terms = terms;
-    return old;
 }

@@ -179,7 +179,7 @@ extern "C" int kpx_lstm_layer_fwd_f32(const float* x, int T, int B, int In, cons
         float* gs = gates + (size_t)s * B * 4 * U;
         int rc = kpx_copy_channels_f32(x + (size_t)s * B * In, In, xs, W, (size_t)B, In, stream);
         if (!rc) rc = kpx_copy_channels_f32(h_prev, U, xs + In, W, (size_t)B, U, stream);
-        if (!rc) rc = kpx_conv2d_fwd_f32(xs, B, 1, 1, W, W, kernel, 1, 1, bias, gs, 1, 1, 4 * U, 4 * U, 1, 0, 0, KPX_ACT_NONE, workspace, workspace_bytes, stream);
+        if (!rc) rc = kpx_conv2d_fwd_f32(xs, B, 1, 1, W, W, kernel, 1, 1, bias, gs, 1, 1, 4 * U, 4 * U, 1, 0, 0, KPX_ACT_NONE, KPX_ARITH_F32, workspace, workspace_bytes, stream);
         if (!rc) rc = kpx_lstm_pointwise_f32(gs, c_prev, 1.0f, cs + (size_t)s * B * U, hs + (size_t)s * B * U, B, U, stream);
         if (rc) return rc;
     }
@@ -208,7 +208,7 @@ extern "C" int kpx_lstm_layer_bwd_f32(const float* dhs, int T, int B, int In, co
                                                  dg, dc_out, B, U, stream);
         float* tmp = dc_in; dc_in = dc_out; dc_out = tmp;
         if (!rc && (s || dx)) {
-            rc = kpx_conv2d_dgrad_f32(dg, B, 1, 1, 4 * U, 4 * U, kernel, 1, 1, dxin, 1, 1, W, W, 1, 0, 0, workspace, workspace_bytes, stream);
+            rc = kpx_conv2d_dgrad_f32(dg, B, 1, 1, 4 * U, 4 * U, kernel, 1, 1, dxin, 1, 1, W, W, 1, 0, 0, KPX_ARITH_F32, workspace, workspace_bytes, stream);
             if (!rc && dx) rc = kpx_copy_channels_f32(dxin, W, dx + (size_t)s * B * In, In, (size_t)B, In, stream);
         }
         if (rc) return rc;

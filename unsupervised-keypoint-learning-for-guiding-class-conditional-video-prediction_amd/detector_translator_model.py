@@ -274,7 +274,7 @@ class DetectorTranslatorModel(BaseModel):
         (tests/test_model_gpu.py::test_graph_replay_is_bit_identical_to_the_eager_step).  Host state the step advances -- beta powers,
         global_step -- is advanced here per replay.  A capture that fails (a runtime without the needed support) falls back to eager."""
         im, fut = feed_dict['image'], feed_dict['future_image']
-        key = (tuple(im.shape), im.device.index)
+        key = (tuple(im.shape), im.device.index, ops.graph_knobs())
         ent = self._graphs.get(key)
         if ent is None:
             if self._eager_steps.get(key, 0) < GRAPH_WARMUP_STEPS:
@@ -294,6 +294,8 @@ class DetectorTranslatorModel(BaseModel):
             self._advance_beta_powers(which)
             self.store.touch(which)         # host-side bookkeeping of the replayed Adam updates: derived filter forms are stale for eager code
         self.global_step += 1
+        # NOTE: these tensors (losses, the forward outputs) are the capture's static buffers -- the next replayed step of this shape
+        # overwrites them in place; read (or clone) what is needed before calling train_step again.  Eager steps return fresh tensors.
         self.last = dict(outputs, lr=float(lr))
 
     def _capture_step(self, key, im, fut):
@@ -319,6 +321,10 @@ class DetectorTranslatorModel(BaseModel):
             log.warning('HIP graph capture of the train step failed (%s: %s); continuing with eager launches', type(e).__name__, e)
             self._graph_failed = True
             torch.cuda.synchronize(dev)
+            # the failed capture advanced host bookkeeping for launches that never ran (FilterBank.synced, pending side-stream joins, tile
+            # statistics in flight): mark every derived filter form stale and forget the rest before the eager fallback
+            self.store.touch()
+            ops.reset_after_failed_capture()
             return None
         finally:
             self._capturing = False

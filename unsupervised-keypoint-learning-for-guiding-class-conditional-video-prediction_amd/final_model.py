@@ -60,6 +60,13 @@ class FinalModel(BaseModel):
             z = torch.randn((im.shape[0], self.vae_dim), dtype=torch.float32, device=im.device)              # :71 (drawn outside the graph)
         key = (tuple(im.shape), tuple(act.shape), im.device.index)
         ent = self._graphs.get(key)
+        if ent is not None and ent[3] != self.store.version:
+            # The parameters changed since the capture (restore / load_numpy / assign -> VariableStore.touch()).  The graph holds the
+            # ADDRESSES of the batch-norm-folded filters and their Winograd forms, which touch() released: replaying it would read freed
+            # memory.  Drop it; the eager run below re-derives them for the new parameters and the next call captures again.
+            del self._graphs[key]
+            self._eager_runs[key] = 0
+            ent = None
         if ent is None:
             if self._eager_runs.get(key, 0) < 1:                     # one eager run first: it creates every lazily allocated buffer / attribute
                 self._eager_runs[key] = 1
@@ -76,9 +83,11 @@ class FinalModel(BaseModel):
                 log.warning('HIP graph capture of the rollout failed (%s: %s); continuing with eager launches', type(e).__name__, e)
                 self._graph_failed = True
                 torch.cuda.synchronize(im.device)
+                self.store.touch()          # host bookkeeping advanced for launches that were only recorded: derive everything again
+                ops.reset_after_failed_capture()
                 return self._run_eager(feed_dict, z)
-            ent = self._graphs[key] = (graph, static, out)
-        graph, static, out = ent
+            ent = self._graphs[key] = (graph, static, out, self.store.version)
+        graph, static, out, _ = ent
         for k_, v in (('image', im), ('action_code', act), ('z', z)):
             v = v.contiguous()
             ops.flat_copy_raw(v.data_ptr(), static[k_].data_ptr(), v.numel())

@@ -16,14 +16,19 @@ import os as _os
 FOLD_BN_INFERENCE = _os.environ.get('KPX_FOLD_BN_INFERENCE', '1') != '0'      # see conv_bn_relu
 
 
-def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', act=ACT_NONE, cin=None, head31=False, bias_grad=True, bn_stats=False):
-    """reference layers.conv (layers.py:4-10): tf.pad(pad) + tf.layers.conv2d(padding='same', xavier, bias)."""
+def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', act=ACT_NONE, cin=None, head31=False, bias_grad=True, bn_stats=False,
+         f43_fwd=True):
+    """reference layers.conv (layers.py:4-10): tf.pad(pad) + tf.layers.conv2d(padding='same', xavier, bias).
+    f43_fwd (a kernel attribute of the LAYER, recorded with its filter variable when the layer is declared): whether the forward of a 3x3
+    stride-1 layer may run the F(4x4,3x3) Winograd kernel (ops.WINO43: an accuracy policy taken from a whole-step measurement)."""
     st = default_store()
     channels = int(channels)          # the reference passes float filter counts after `filters /= 2` ([TF-sem 9])
     cin_ = int(cin) if cin is not None else int(x.shape[-1])
     with st.variable_scope(scope), st.variable_scope('conv2d'):
         kname = st.get_variable('kernel', (kernel, kernel, cin_, channels), 'kernel_head31' if head31 else 'kernel')
         bname = st.get_variable('bias', (channels,), 'zeros') if use_bias else None
+    if not st.materialised:
+        st.layer_attrs.setdefault(kname, {})['f43_fwd'] = bool(f43_fwd)
     if is_sym(x):
         n, h, w, _ = x.shape
         _, _, ho = ops.same_pad(h + 2 * pad, kernel, stride)
@@ -69,7 +74,7 @@ def batch_norm(x, train_mode, scope='batch_norm', act=ACT_NONE, groups=1, update
                           update_moving=update_moving and bool(train_mode), g_grad_out=gg, b_grad_out=bg)
 
 
-def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, groups=1, update_moving=True, cin=None):
+def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, groups=1, update_moving=True, cin=None, f43_fwd=True):
     """conv -> batch_norm -> relu, the repeating unit of every generator network (reference networks/__init__.py:10-12).
 
     The conv keeps its bias variable (reference layers.py:4 default use_bias=True), but d(loss)/d(bias) is exactly
@@ -88,7 +93,7 @@ def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, 
             wf, bf = st.folded_conv_bn(kname, bname, names[0], names[1], names[2], names[3], ops.BN_EPS)
             return ops.conv2d(x, wf, bf, stride=stride, pad=0, act=ACT_RELU, cin=cin)
     x = conv(x, channels, kernel=kernel, stride=stride, scope=conv_scope, cin=cin, bias_grad=not (EXACT_ZERO_BIAS_GRAD and train_mode),
-             bn_stats=bool(train_mode))       # the conv epilogue delivers the batch statistics when it can
+             bn_stats=bool(train_mode), f43_fwd=f43_fwd)       # the conv epilogue delivers the batch statistics when it can
     return batch_norm(x, train_mode, scope=bn_scope, act=ACT_RELU, groups=groups, update_moving=update_moving)
 
 

@@ -29,13 +29,14 @@ def encoder(x, train_mode, filters=32, bn_groups=1, skip_last_block=False, updat
     st = default_store()
     with st.variable_scope('encoder'):
         feats = []
-        x = layers.conv_bn_relu(x, filters, 7, 1, train_mode, 'conv_1', 'b_norm_1', bn_groups, update_moving=update_moving)
-        x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_2', 'b_norm_2', bn_groups, update_moving=update_moving)
+        # f43_fwd=False on every encoder / detector layer: their forward stays on F(2x2,3x3) (ops.WINO43: the float64-arbiter finding)
+        x = layers.conv_bn_relu(x, filters, 7, 1, train_mode, 'conv_1', 'b_norm_1', bn_groups, update_moving=update_moving, f43_fwd=False)
+        x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_2', 'b_norm_2', bn_groups, update_moving=update_moving, f43_fwd=False)
         feats.append(x)
         for i in range(3):
             filters *= 2
-            x = layers.conv_bn_relu(x, filters, 3, 2, train_mode, 'conv_%d' % (i * 2 + 3), 'b_norm_%d' % (i * 2 + 3), bn_groups, update_moving=update_moving)
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d' % (i * 2 + 4), 'b_norm_%d' % (i * 2 + 4), bn_groups, update_moving=update_moving)
+            x = layers.conv_bn_relu(x, filters, 3, 2, train_mode, 'conv_%d' % (i * 2 + 3), 'b_norm_%d' % (i * 2 + 3), bn_groups, update_moving=update_moving, f43_fwd=False)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d' % (i * 2 + 4), 'b_norm_%d' % (i * 2 + 4), bn_groups, update_moving=update_moving, f43_fwd=False)
             feats.append(x)
         return feats
 
@@ -57,17 +58,17 @@ def pose_encoder(x, n_pts, train_mode, final_res=128, filters=128, bn_groups=1, 
         conv_id = 1
         for i in range(4):
             # i > 0: x is already the [up-sampled ‖ skip] concat buffer written by the previous stage (:44)
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % conv_id, 'b_norm_%d_0' % conv_id, bn_groups, update_moving=update_moving)
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id, bn_groups, update_moving=update_moving)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % conv_id, 'b_norm_%d_0' % conv_id, bn_groups, update_moving=update_moving, f43_fwd=False)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id, bn_groups, update_moving=update_moving, f43_fwd=False)
             if size == final_res:
-                if FUSE_KEYPOINT_HEAD and not return_logits and (is_sym(x) or (x.is_cuda and x.shape[-1] % 4 == 0)):
+                if FUSE_KEYPOINT_HEAD and not return_logits and (is_sym(x) or (x.is_cuda and ops.keypoint_head_proj_eligible(x.shape, n_pts))):
                     # 1x1 head (:54) + get_coord x2 (:68-71) as one op: the logits are consumed by the two axis means only
                     gauss_mu, _, _ = layers.conv1x1_keypoints(x, n_pts)
                     return gauss_mu
                 x = layers.conv(x, n_pts, kernel=1, stride=1)        # default scope 'conv_0' (:54)
                 break
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1), bn_groups, update_moving=update_moving)
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % (conv_id + 1), 'b_norm_%d_1' % (conv_id + 1), bn_groups, update_moving=update_moving)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1), bn_groups, update_moving=update_moving, f43_fwd=False)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % (conv_id + 1), 'b_norm_%d_1' % (conv_id + 1), bn_groups, update_moving=update_moving, f43_fwd=False)
             x = _upsample_concat(x, block_features[-1 * (i + 2)])     # resize (:63) + next stage's concat (:44)
             size = 2 * size
             conv_id += 2
@@ -85,14 +86,16 @@ def translator(x, train_mode, final_res=128, filters=256, cin=None, update_movin
         size = x.shape[1]
         conv_id = 1
         while size <= final_res:
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % conv_id, 'b_norm_%d_0' % conv_id, cin=cin, update_moving=update_moving)
+            # the first stage (conv_1_*, conv_2_*: 256-deep sums over the fewest pixels) keeps F(2x2,3x3) in the forward direction (ops.WINO43)
+            f43 = conv_id > 1
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % conv_id, 'b_norm_%d_0' % conv_id, cin=cin, update_moving=update_moving, f43_fwd=f43)
             cin = None
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id, update_moving=update_moving)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id, update_moving=update_moving, f43_fwd=f43)
             if size == final_res:
                 # conv_N_0 (crude, 3 ch, :87) and conv_N_1 (mask, 1 ch, :88) as one 4-channel conv
                 return layers.conv(x, 4, kernel=3, stride=1, scope='conv_%d_0+1' % (conv_id + 1), head31=True)
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1), update_moving=update_moving)
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % (conv_id + 1), 'b_norm_%d_1' % (conv_id + 1), update_moving=update_moving)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1), update_moving=update_moving, f43_fwd=f43)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % (conv_id + 1), 'b_norm_%d_1' % (conv_id + 1), update_moving=update_moving, f43_fwd=f43)
             x = _upsample_concat(x, None)                              # :98
             size = 2 * size
             conv_id += 2

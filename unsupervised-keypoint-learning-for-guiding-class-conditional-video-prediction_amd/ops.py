@@ -154,6 +154,23 @@ def _claim_grad(dst):
     return first
 
 
+def reset_after_failed_capture():
+    """A stream capture that failed half way leaves host bookkeeping advanced for kernels that were only recorded: pending side-stream
+    joins, tensors kept alive for them, tile statistics handed between ops.  Forget all of it (the caller also touches its store so that
+    the derived filter forms are re-derived) before falling back to eager launches."""
+    _side_dirty.clear()
+    _side_keep.clear()
+    _pending_stats.clear()
+    _pending_bwd_stats.clear()
+
+
+def graph_knobs():
+    """Everything besides the input shape that a captured step freezes: the compute dtype and the module-level kernel-selection
+    switches.  Part of the graph cache keys, so that flipping one re-captures instead of replaying the old arithmetic."""
+    return (_compute_dtype[0], SIDE_WGRAD, FUSE_BN_STATS, FUSE_BN_BWD, FORK_BEFORE_DGRAD, WINO43, WINO43_FWD_ALL, WINO43_EXCLUDE_FWD, WINO43_EXCLUDE_DGRAD,
+            WINO43_MIN_WORKGROUPS, WINO43_NMIN)
+
+
 def normalize_device(device):
     """torch.device with an explicit index: 'cuda' (index None) becomes the current device, so that it compares equal to the
     ``tensor.device`` values the ops record (torch.device('cuda') != torch.device('cuda:0'))."""
@@ -189,17 +206,16 @@ def set_compute_dtype(name):
     if name not in ('f32', 'bf16'):
         raise ValueError("compute dtype must be 'f32' or 'bf16'")
     _compute_dtype[0] = name
-    # the implicit-GEMM kernels of the strided / 4x4 / 1x1 layers and the direct weight gradients: three bf16 terms per fp32 operand
-    # (fp32-equivalent) or one (bf16 operands, fp32 accumulation)
-    lib.kpx_set_gemm3_terms(1 if name == 'bf16' else 3)
-
-
-if _compute_dtype[0] == 'bf16':
-    lib.kpx_set_gemm3_terms(1)
 
 
 def compute_dtype():
     return _compute_dtype[0]
+
+
+def _arith():
+    """The `arith` argument of kpx_conv2d_{fwd,dgrad,wgrad}_f32 (include/kpx.h): the implicit-GEMM kernels of the strided / 4x4 / 1x1
+    layers and the direct weight gradients take three bf16 terms per fp32 operand (fp32-equivalent) or one (the bf16 configuration)."""
+    return 1 if _compute_dtype[0] == 'bf16' else 0
 
 
 def _bf16_conv(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad):
@@ -242,15 +258,19 @@ def _cached_u(table, w, dgrad):
 conv_kernel_uses = {'wino43': 0}      # diagnostics / tests: launches of the F(4x4,3x3) kernel
 
 # F(4x4,3x3) (csrc/conv_wino43.hip) does 2.25x fewer multiplies than F(2x2,3x3) at ~6x its rounding error (2-3e-6 rel-L2 per layer, still
-# inside the 1e-5 bar of one layer).  Where it runs is decided per filter NAME and direction, from the measured effect on a whole train
+# inside the 1e-5 bar of one layer).  Where it runs is a PER-LAYER ATTRIBUTE and a direction, from the measured effect on a whole train
 # step against the float64 arbiter (tests/test_model_gpu.py::test_configs0..., profiles/wino43_policy.py):
 #   * data gradients: everywhere (the detector's included: its eight eligible layers change no digit of the gradient-error figures);
-#   * forward: VGG19 and the translator's 64x64 / 128x128 layers (conv_3_* .. conv_5_*).  The detector, the image encoder and the
-#     translator's 32x32 layers (256-deep sums feeding batch norms over few pixels) stay on F(2x2,3x3): with them on F(4x4,3x3) the
+#   * forward: only layers declared with ``f43_fwd=True`` (the default of layers.conv; networks.py passes False where the measurement
+#     said so): VGG19 and the translator's second and third stage (conv_3_* .. conv_5_*).  The detector, the image encoder and the
+#     translator's first stage (256-deep sums feeding batch norms over few pixels) stay on F(2x2,3x3): with them on F(4x4,3x3) the
 #     generated frame moves 3e-5 instead of 1.7e-5 from the oracle's and the discriminator gradient 4.6x instead of 1.2x as far from the
 #     float64 gradient as the fp32 oracle's own.
+# The attribute lives with the layer's filter variable (VariableStore.layer_attrs), not in its name: renaming a scope changes no kernel.
+# Policy experiments: KPX_WINO43_FWD_ALL=1 ignores the attribute; KPX_WINO43_EXCLUDE_FWD / _DGRAD take extra name prefixes to exclude.
 WINO43 = _os.environ.get('KPX_WINO43', '1') != '0'
-WINO43_EXCLUDE_FWD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_FWD', 'pose_encoder,image_encoder,translator/conv_1,translator/conv_2').split(',') if p)
+WINO43_FWD_ALL = _os.environ.get('KPX_WINO43_FWD_ALL', '0') != '0'
+WINO43_EXCLUDE_FWD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_FWD', '').split(',') if p)
 # launches of at most this many F(4x4,3x3) workgroups stay on F(2x2,3x3).  Round 2 set 128 from a kernel measured ALONE (128 workgroups: 0.187 vs
 # 0.158 ms -- one F(4x4) workgroup owns its CU); inside the step, where the other streams fill the idle CUs, F(4x4,3x3) wins on those layers too:
 # 23.73-23.83 ms per step at 0 / 32 / 64 against 24.01-24.16 at 128 (three repetitions each, B=32) -- so no threshold
@@ -259,14 +279,20 @@ WINO43_NMIN = int(_os.environ.get('KPX_WINO43_NMIN', '33'))      # produced chan
 WINO43_EXCLUDE_DGRAD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_DGRAD', '').split(',') if p)
 
 
-def _wino43_wanted(name, cin, cout, dgrad):
+def _wino43_wanted(name, cin, cout, dgrad, f43_fwd=True):
+    """f43_fwd: the layer's attribute (layers.conv(..., f43_fwd=)); name: only for the experiment prefixes of the environment."""
     k, nn = (cout, cin) if dgrad else (cin, cout)
-    return WINO43 and k >= 16 and nn >= WINO43_NMIN and not any(name.startswith(p) for p in (WINO43_EXCLUDE_DGRAD if dgrad else WINO43_EXCLUDE_FWD))
+    if not (WINO43 and k >= 16 and nn >= WINO43_NMIN):
+        return False
+    if not dgrad and not (f43_fwd or WINO43_FWD_ALL):
+        return False
+    return not any(name.startswith(p) for p in (WINO43_EXCLUDE_DGRAD if dgrad else WINO43_EXCLUDE_FWD))
 
 
 class FilterBank:
-    def __init__(self, named_filters, device):
-        """named_filters: iterable of (name, [3,3,Cin,Cout] tensor views whose storage never moves)."""
+    def __init__(self, named_filters, device, attrs=None):
+        """named_filters: iterable of (name, [3,3,Cin,Cout] tensor views whose storage never moves); attrs: {name: {'f43_fwd': bool}}."""
+        attrs = attrs or {}
         self.version = 0            # bumped by whoever writes the filters (Adam step, restore)
         self.synced = -1
         self.filters = [(n, w) for n, w in named_filters if w.dim() == 4 and w.shape[0] == 3 and w.shape[1] == 3]
@@ -276,7 +302,7 @@ class FilterBank:
             return
         sizes = [lib.kpx_wino_u_bytes(int(w.shape[2]), int(w.shape[3])) // 4 for _, w in self.filters]
         sizes43 = [lib.kpx_wino43_u_bytes(int(w.shape[2]), int(w.shape[3])) // 4 for _, w in self.filters]
-        want43 = [[_wino43_wanted(n, int(w.shape[2]), int(w.shape[3]), d) for d in (0, 1)] for n, w in self.filters]
+        want43 = [[_wino43_wanted(n, int(w.shape[2]), int(w.shape[3]), d, attrs.get(n, {}).get('f43_fwd', True)) for d in (0, 1)] for n, w in self.filters]
         self.arena = torch.empty(2 * sum(sizes) + sum(n43 * sum(wt) for n43, wt in zip(sizes43, want43)), dtype=torch.float32, device=device)
         table, table43, off = b'', b'', 0
         for (_, w), n, n43, wt in zip(self.filters, sizes, sizes43, want43):
@@ -309,8 +335,9 @@ class FilterBank:
         return [(w.data_ptr(), dgrad) for _, w in self.filters for dgrad in (0, 1)]
 
 
-def register_constant_filter(w, name=''):
+def register_constant_filter(w, name='', f43_fwd=True):
     """Transform a filter that never changes (VGG19, reference vgg.py:57-61 tf.constant) once, for both directions.
+    f43_fwd: whether the layer's forward may run F(4x4,3x3) (see WINO43 above).
     Returns the cache keys; the owner must pass them to release_filters() when the filter memory is given up."""
     if w.dim() != 4 or w.shape[0] != 3 or w.shape[1] != 3 or not w.is_cuda:
         return []
@@ -321,7 +348,7 @@ def register_constant_filter(w, name=''):
         check(lib.kpx_wino_filter_transform_f32(w.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, u.data_ptr(), _stream()), 'kpx_wino_filter_transform_f32')
         _wino_u[(w.data_ptr(), dgrad)] = (u, None, _weakref.ref(w.untyped_storage()), (int(w.shape[2]), int(w.shape[3])))
         keys.append((w.data_ptr(), dgrad))
-        if _wino43_wanted(name, int(w.shape[2]), int(w.shape[3]), dgrad):
+        if _wino43_wanted(name, int(w.shape[2]), int(w.shape[3]), dgrad, f43_fwd):
             u = torch.empty(lib.kpx_wino43_u_bytes(int(w.shape[2]), int(w.shape[3])) // 4, dtype=torch.float32, device=w.device)
             check(lib.kpx_wino43_filter_transform_f32(w.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, u.data_ptr(), _stream()), 'kpx_wino43_filter_transform_f32')
             _wino43_u[(w.data_ptr(), dgrad)] = (u, None, _weakref.ref(w.untyped_storage()), (int(w.shape[2]), int(w.shape[3])))
@@ -430,7 +457,7 @@ def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act, want_s
     ws = scratch.get('splitk', nbytes, x.device) if nbytes else None
     check(lib.kpx_conv2d_fwd_f32(x.data_ptr(), n, hi, wi, cin, ldx, w.data_ptr(), kh, kw,
                                  bias.data_ptr() if bias is not None else None,
-                                 y.data_ptr(), y.shape[1], y.shape[2], cout, ldy, stride, pad_t, pad_l, act,
+                                 y.data_ptr(), y.shape[1], y.shape[2], cout, ldy, stride, pad_t, pad_l, act, _arith(),
                                  ws.data_ptr() if ws is not None else None, nbytes, _stream()),
           'kpx_conv2d_fwd_f32')
 
@@ -455,7 +482,7 @@ def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l, bn_src=None
     nbytes = lib.kpx_conv2d_dgrad_workspace_bytes(n, dx.shape[1], dx.shape[2], cin, cout, kh, kw, stride)
     ws = scratch.get('splitk', nbytes, dy.device) if nbytes else None
     check(lib.kpx_conv2d_dgrad_f32(dy.data_ptr(), n, ho, wo, cout, lddy, w.data_ptr(), kh, kw,
-                                   dx.data_ptr(), dx.shape[1], dx.shape[2], cin, lddx, stride, pad_t, pad_l,
+                                   dx.data_ptr(), dx.shape[1], dx.shape[2], cin, lddx, stride, pad_t, pad_l, _arith(),
                                    ws.data_ptr() if ws is not None else None, nbytes, _stream()),
           'kpx_conv2d_dgrad_f32')
 
@@ -467,7 +494,7 @@ def conv_wgrad_raw(x, ldx, cin, dy, lddy, dw, stride, pad_t, pad_l):
     nbytes = lib.kpx_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, cout, kh, kw)
     ws = scratch.get('wgrad', nbytes, x.device) if nbytes else None
     check(lib.kpx_conv2d_wgrad_f32(x.data_ptr(), n, hi, wi, cin, ldx, dy.data_ptr(), ho, wo, cout, lddy,
-                                   dw.data_ptr(), kh, kw, stride, pad_t, pad_l,
+                                   dw.data_ptr(), kh, kw, stride, pad_t, pad_l, _arith(),
                                    ws.data_ptr() if ws is not None else None, nbytes, _stream()),
           'kpx_conv2d_wgrad_f32')
 
@@ -907,6 +934,13 @@ class KeypointHeadProjFn(torch.autograd.Function):
         if direct:
             return dx, None, None, None, None
         return dx, dw_buf, db_buf, None, None
+
+
+def keypoint_head_proj_eligible(x_shape, k):
+    """True when the folded 1x1 + key-point head operator takes an activation of this [B,H,W,C] shape with K points
+    (kpx_keypoint_head_proj_eligible); the caller runs the conv + keypoint_head pair otherwise."""
+    b, h, w, c = (int(v) for v in x_shape)
+    return bool(lib.kpx_keypoint_head_proj_eligible(b, h, w, c, int(k)))
 
 
 def keypoint_head_proj(x, w, b=None, w_grad_out=None, b_grad_out=None):

@@ -52,6 +52,8 @@ class VariableStore:
         self._scope = []
         self.materialised = False
         self.frozen = ()                             # name substrings whose variables are used without gradients
+        self.layer_attrs = {}                        # filter variable name -> per-layer kernel attributes declared by layers.conv (e.g. f43_fwd)
+        self.version = 0                             # bumped by touch(): anything derived from the parameters (captured graphs included) is stale
 
     @contextlib.contextmanager
     def freeze(self, *substrings):
@@ -143,7 +145,7 @@ class VariableStore:
             # 3x3 layer, D_logit 2048 -> 1, is not one -- so an update of the D bucket never invalidates anything here, see touch())
             named = [(n, v.detach()) for n, v in self.vars.items()
                      if n.endswith('/kernel') and v.dim() == 4 and v.shape[0] == 3 and min(v.shape[2], v.shape[3]) >= 4]
-            self.filter_bank = ops.FilterBank(named, self.device)
+            self.filter_bank = ops.FilterBank(named, self.device, attrs=self.layer_attrs)
             self._bank_buckets = {'D' if 'discr' in n else 'G' for n, _ in named}        # same split as the buckets above
             weakref.finalize(self, ops.release_filters, self.filter_bank.keys())     # the bucket's addresses may be reused later
 
@@ -151,6 +153,7 @@ class VariableStore:
         """Call after writing parameters behind torch's back (fused Adam kernel, restore): derived filter forms are refreshed lazily.
         ``bucket``: the flat bucket that was written ('G' / 'D' / ...); an update of a bucket none of whose filters has a derived form
         (the discriminator's) leaves the forms valid."""
+        self.version += 1
         self.drop_folded()                            # inference-folded filters (layers.conv_bn_relu) are functions of the parameters
         bank = getattr(self, 'filter_bank', None)
         if bank is not None:
@@ -181,7 +184,7 @@ class VariableStore:
             check(lib.kpx_bn_fold_conv_f32(w.data_ptr(), b.data_ptr() if b is not None else None, w.numel() // w.shape[3], int(w.shape[3]),
                                            self.vars[gamma].data_ptr(), self.vars[beta].data_ptr(), self.vars[mm].data_ptr(), self.vars[mv].data_ptr(),
                                            float(eps), wf.data_ptr(), bf.data_ptr(), ops._stream()), 'kpx_bn_fold_conv_f32')
-            ent = folded[kname] = (wf, bf, ops.register_constant_filter(wf, kname))
+            ent = folded[kname] = (wf, bf, ops.register_constant_filter(wf, kname, f43_fwd=self.layer_attrs.get(kname, {}).get('f43_fwd', True)))
         return ent[0], ent[1]
 
     # ---- access ------------------------------------------------------------------------------------------------
