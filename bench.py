@@ -444,14 +444,17 @@ def main():
     enq = [t_enq / args.steps * 1e3]
     ms_by_rank = [dt / args.steps * 1e3]
     n_ranks_seen = 1
+    modes_by_rank, host_work_by_rank = [model.launch_mode()], [min(per_call) * 1e3]
     if launched:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         n_ranks_seen = torch.distributed.get_world_size()
-        e = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
-        torch.distributed.all_gather(e, torch.tensor([enq[0], ms_by_rank[0]], dtype=torch.float64, device=dev))
+        e = [torch.zeros(4, dtype=torch.float64, device=dev) for _ in range(world)]
+        torch.distributed.all_gather(e, torch.tensor([enq[0], ms_by_rank[0], float(model.launch_mode()), min(per_call) * 1e3], dtype=torch.float64, device=dev))
         enq = [float(x[0].item()) for x in e]
         ms_by_rank = [float(x[1].item()) for x in e]          # each rank's own clock around its K steps; `ms_per_step` is their maximum
+        modes_by_rank = [int(x[2].item()) for x in e]
+        host_work_by_rank = [float(x[3].item()) for x in e]
         dt = float(t.item())
     losses = model.loss_values()
     assert np.isfinite(losses['loss_D']) and np.isfinite(losses['loss_G']), losses
@@ -481,9 +484,10 @@ def main():
                'host_call_wall_ms_per_step': round(max(enq), 3), 'host_call_wall_ms_per_step_by_rank': [round(x, 3) for x in enq],
                'host_note': 'host_call_wall = wall time of the K train_step() calls / K: mostly launch-queue BACK-PRESSURE (a graph replay call blocks once '
                             'a few replays are in flight), not host work; host_work_ms_per_step_min = the shortest single call = the host work of one step',
-               'host_work_ms_per_step_min': round(min(per_call) * 1e3, 3),
-               'launch_mode': ('one HIP graph replay per step (captured after %d eager warm-up step(s); %d C-ABI kernel launches inside the graph)'
-                               % (1, getattr(model, '_graph_launches', 0))) if graphed else 'eager: every kernel enqueued from Python',
+               'host_work_ms_per_step_min': round(min(per_call) * 1e3, 3), 'host_work_ms_per_step_min_by_rank': [round(x, 3) for x in host_work_by_rank],
+               'launch_mode': model.LAUNCH_MODES[model.launch_mode()] + (' (captured after 1 eager warm-up step; %d C-ABI kernel launches inside the graph)'
+                                                                         % getattr(model, '_graph_launches', 0) if model.launch_mode() == 1 else ''),
+               'launch_mode_by_rank': [model.LAUNCH_MODES[m].split(':')[0] for m in modes_by_rank],
                'host_abi_calls_per_step': round(calls_per_step, 1),
                'loss_D': round(losses['loss_D'], 5), 'loss_G': round(losses['loss_G'], 5)}
         if world == 1 and not args.no_roofline:

@@ -245,6 +245,87 @@ def test_data_parallel_train_steps_keep_replicas_identical():
         assert out == {'D': True, 'G': True, 'finite': True}, (rank, out)
 
 
+def _dp_variant_worker(rank, world, port, q, env, seed_offset):
+    import sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), **env)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import kpx_amd
+    dev = torch.device('cuda:0')
+    res, k, b = 32, 3, 2
+    cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': b},
+           'model': {'n_pts': k}, 'paths': {'log_dir': '/tmp/kpx_test', 'vggnet': None}}
+    vgg = kpx_amd.Vgg19(weights=kpx_amd.synthetic_vgg19_weights(seed=19, width_div=8), device=dev)
+    model = kpx_amd.DetectorTranslatorModel(cfg, device=dev, vgg=vgg, image_size=res, seed=1234 + seed_offset * rank)
+    model.build()                               # (data parallel: ends with the broadcast of rank 0's state)
+    out = {'initial': model.store.buckets['G'].params.detach().cpu().numpy().copy()}
+    losses = []
+    for step in range(4):
+        im, fut = R.synthetic_pair(b, res=res, seed0=300 + 2 * (step * world + rank), seed1=301 + 2 * (step * world + rank))
+        model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, step, b)
+        lv = model.loss_values()
+        losses.append([lv['loss_D'], lv['loss_G_recon'], lv['loss_G_adv']])
+    out['losses'] = np.asarray(losses, np.float64)
+    for which in ('D', 'G'):
+        bk = model.store.buckets[which]
+        for nm, flat in (('params', bk.params), ('m', bk.m), ('v', bk.v)):
+            out[which + '_' + nm] = flat.detach().cpu().numpy().copy()
+    out['moving'] = np.concatenate([model.store.vars[n].detach().cpu().numpy().ravel() for n in sorted(model.store.vars) if 'moving_' in n])
+    out['powers'] = np.asarray([float(v) for w in ('D', 'G') for v in model.beta_power[w]] + [model.global_step], np.float64)
+    out['mode'] = model.launch_mode()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_dp_variant(env, seed_offset=0, port_base=32800):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = port_base + (os.getpid() % 1500)
+    procs = [ctx.Process(target=_dp_variant_worker, args=(r, 2, port, q, env, seed_offset)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return results
+
+
+def test_data_parallel_segment_graphs_equal_the_eager_segments_and_the_inline_step_bit_for_bit():
+    """The data-parallel step as four replayed HIP graphs around the two all-reduces (the default), the same segments launched eagerly
+    (KPX_GRAPH=0) and round 3's single eager pass with the collectives inline (KPX_DP_PHASED=0): two ranks (gloo, sharing cuda:0), four steps
+    on different local batches -- parameters, both Adam slots, each rank's moving statistics and losses, the beta powers and the step
+    counter must agree bit for bit between the three forms, and the replicas with each other."""
+    variants = {'graphs': {'KPX_GRAPH': '1', 'KPX_DP_PHASED': '1'}, 'eager_segments': {'KPX_GRAPH': '0', 'KPX_DP_PHASED': '1'},
+                'inline': {'KPX_GRAPH': '0', 'KPX_DP_PHASED': '0'}}
+    res = {name: _run_dp_variant(env, port_base=32800 + 37 * i) for i, (name, env) in enumerate(variants.items())}
+    assert all(res['graphs'][r]['mode'] == 2 for r in (0, 1)), 'steps 1..3 must have been graph replays'
+    assert all(res['eager_segments'][r]['mode'] == 0 and res['inline'][r]['mode'] == 0 for r in (0, 1))
+    ref = res['inline']
+    for name in ('graphs', 'eager_segments'):
+        for rank in (0, 1):
+            for key in ref[rank]:
+                if key not in ('mode', 'initial'):
+                    assert np.array_equal(ref[rank][key], res[name][rank][key]), (name, rank, key)
+    for key in ('D_params', 'G_params', 'D_m', 'G_v'):
+        assert np.array_equal(ref[0][key], ref[1][key]), key
+    assert not np.array_equal(ref[0]['moving'], ref[1]['moving'])          # per-replica batch-norm statistics (SURVEY 8e)
+
+
+def test_data_parallel_build_broadcasts_rank_zero_state():
+    """Replicas seeded DIFFERENTLY (a drifted seed, a half-restored replica) start from rank 0's parameters: build() ends with one broadcast
+    per flat buffer, and the replicas are bit-identical after training steps."""
+    res = _run_dp_variant({'KPX_GRAPH': '1', 'KPX_DP_PHASED': '1'}, seed_offset=7, port_base=34400)
+    assert np.array_equal(res[0]['initial'], res[1]['initial'])
+    for key in ('D_params', 'G_params', 'G_m', 'D_v'):
+        assert np.array_equal(res[0][key], res[1][key]), key
+    want = _run_dp_variant({'KPX_GRAPH': '1', 'KPX_DP_PHASED': '1'}, seed_offset=0, port_base=34500)
+    assert np.array_equal(res[0]['G_params'], want[0]['G_params'])         # = the run in which both replicas drew rank 0's seed
+
+
 def _dp_oracle_worker(rank, world, port, q):
     import sys
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

@@ -49,6 +49,11 @@ class _Bf16Exchange:
         if self.work is not None:
             self.work.wait()
         self.grads.copy_(self.buf)
+# Data parallel: the step as captured segments around the two all-reduces (_train_step_dp).  KPX_DP_PHASED=0: round 3's form -- one eager
+# pass with the collectives inline (A/B and the bit-identity test; separate-batch steps always take it)
+DP_PHASED = os.environ.get('KPX_DP_PHASED', '1') != '0'
+# measurement only: run the data-parallel code path WITHOUT its two collectives (what the segmentation alone costs on one GPU)
+DP_NO_COLLECTIVES = os.environ.get('KPX_DP_NO_COLLECTIVES', '0') != '0'
 GRAPH_WARMUP_STEPS = 1          # eager steps before the capture: they create every lazily allocated scratch buffer and kernel attribute
 
 log = logging.getLogger('kpx')
@@ -105,6 +110,8 @@ class DetectorTranslatorModel(BaseModel):
             self._one = torch.ones(1, dtype=torch.float32, device=dev)
         if self.is_training and self.vgg is None and dev.type == 'cuda':
             self.vgg = Vgg19(self.vgg19_path, device=dev)             # raises like vgg.py:9-10 when the file is missing
+        if self.distributed and self.world_size > 1:
+            self.broadcast_parameters(0)
 
     # ------------------------------------------------------------------------------------------------ forward
     def _define_forward_pass(self, im, future_im, with_vis_maps=False, update_moving=True):
@@ -189,7 +196,7 @@ class DetectorTranslatorModel(BaseModel):
         178.9 MB discriminator exchange overlaps the VGG19 forward of the generator's perceptual loss."""
         bucket = self.store.buckets[which]
         ops.join_side_stream(self.device)       # weight gradients are written on the side stream
-        if self.distributed:
+        if self.distributed and not DP_NO_COLLECTIVES:
             if which in DP_BF16_BUCKETS:
                 bufs = self.__dict__.setdefault('_bf16_exchange_bufs', {})
                 buf = bufs.get(which)
@@ -247,7 +254,9 @@ class DetectorTranslatorModel(BaseModel):
         pass that second batch as 'image_G' / 'future_image_G' and the G-run recomputes the forward on it, exactly like the
         reference's second sess.run (BN moving statistics then come from the G-run's batch only, :199-202)."""
         start_time = time.time()
-        if self._graph_eligible(feed_dict):
+        if self.distributed and self._phased_eligible(feed_dict):
+            self._train_step_dp(feed_dict)
+        elif self._graph_eligible(feed_dict):
             self._train_step_graphed(feed_dict)
         else:
             self._train_step_eager(feed_dict)
@@ -331,6 +340,191 @@ class DetectorTranslatorModel(BaseModel):
             self.beta_power, self.global_step, self.last = dict(saved[0]), saved[1], saved[2]      # nothing has executed yet
         ent = self._graphs[key] = (graph, static, outputs)
         return ent
+
+    # ---- the data-parallel step: captured segments around the two gradient exchanges ---------------------------------------
+    def _phased_eligible(self, feed_dict):
+        im = feed_dict['image']
+        return (DP_PHASED and 'image_G' not in feed_dict and self.device.type == 'cuda' and im.is_cuda and im.dtype == torch.float32
+                and feed_dict['future_image'].shape == im.shape)
+
+    def _step_phases(self, feed_dict, device_alpha):
+        """The shared-batch train step cut at its two gradient exchanges (a generator: everything between two yields is one segment):
+
+            A   generator forward; then the discriminator forward + backward on (real, generated) on the auxiliary stream
+                beside the VGG19 forward of the perceptual loss on the main stream                   -> yields 'exchange_D'
+            B1  VGG19 data gradients (the perceptual gradient at the generated frame): independent of the exchange -> yields 'wait_D'
+            B2  Adam-D, adversarial branch with the UPDATED discriminator, generator backward        -> yields 'exchange_G'
+            C   Adam-G
+
+        Same kernels on the same operands as _train_step_eager (bit-identical results); what differs is the stream layout: each segment forks
+        and joins inside itself (it must be capturable alone; every join goes into the main stream, so the discriminator's weight gradients
+        may use the side stream of the auxiliary stream here), and the 178.9 MB discriminator exchange -- launched by the caller between A
+        and B1 -- runs beside the VGG19 data-gradient chain.
+        ``device_alpha``: Adam reads its step size from self._alpha_dev (captured segments) instead of a host scalar."""
+        im, future_im = feed_dict['image'], feed_dict['future_image']
+        lr = self.current_lr()
+        dev = self.device
+
+        def join_all():
+            if getattr(self, '_aux', None) is not None:
+                torch.cuda.current_stream(dev).wait_stream(self._aux)
+            ops.join_side_stream(dev)
+
+        def adam(which):
+            bucket = self.store.buckets[which]
+            if device_alpha:
+                ops.adam_tf_flat_dev_alpha_(bucket.params, bucket.grads, bucket.m, bucket.v, self._alpha_dev[which], self.beta1, self.beta2,
+                                            self.adam_eps, gscale=1.0 / self.world_size)
+            else:
+                ops.adam_tf_flat_(bucket.params, bucket.grads, bucket.m, bucket.v, self._adam_alpha(which, lr), self.beta1, self.beta2,
+                                  self.adam_eps, gscale=1.0 / self.world_size)
+                self._advance_beta_powers(which)
+            self.store.touch(which)
+
+        with variables.as_default(self.store):
+            # ---- A
+            fwd = self._define_forward_pass(im, future_im)
+            final = fwd['final_output']
+            final_d = final.detach()
+            aux = self._aux_stream() if AUX_STREAM else None
+            if aux is not None:
+                aux.wait_stream(torch.cuda.current_stream(dev))      # (`final`, `final_d`, `future_im` predate the fork and outlive the join)
+            with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
+                d_losses = self._loss_D(final_d, future_im)
+                ops.begin_backward()
+                torch.autograd.backward([d_losses], [self._e0])
+            recon = self._loss_G_recon(final, future_im)              # VGG19 forward on (real, generated), beside the discriminator update
+            join_all()
+        yield 'exchange_D'
+        with variables.as_default(self.store):
+            # ---- B1
+            g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
+            join_all()
+        yield 'wait_D'
+        with variables.as_default(self.store):
+            # ---- B2
+            adam('D')
+            adv = self._loss_G_adv(final)                 # the UPDATED discriminator, like the reference's second sess.run
+            g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
+            ops.begin_backward()
+            final.backward(g_recon + g_adv)
+            join_all()
+        yield 'exchange_G'
+        with variables.as_default(self.store):
+            # ---- C
+            adam('G')
+        self._phase_out = dict(d_losses=d_losses.detach(), recon=recon.detach(), adv=adv.detach(), fwd={k: v.detach() for k, v in fwd.items()})
+        self._phase_lr = float(lr)
+
+    def _between_phases(self, tag, state):
+        """The collectives of the data-parallel step, always enqueued from Python between two segments."""
+        if tag == 'exchange_D':
+            state['pending'] = self.exchange_gradients('D', async_op=True)      # on RCCL's stream, beside segment B1
+        elif tag == 'wait_D':
+            if state.get('pending') is not None:
+                state['pending'].wait()                                         # stream-level: B2 starts behind the exchange
+        elif tag == 'exchange_G':
+            self.exchange_gradients('G')
+
+    def _train_step_dp(self, feed_dict):
+        """One data-parallel step: the segments of _step_phases with the two all-reduces between them.  From the second call on an input
+        shape the four segments are four captured HIP graphs (one shared memory pool, always replayed in capture order) and a step is four
+        replays + two collectives: ~1 ms of host work per rank instead of ~20 ms of launches (eight ranks share one host).  KPX_GRAPH=0, or a
+        failed capture, runs the same segments launch by launch.  Replicas stay bit-identical either way (2-rank tests)."""
+        im, fut = feed_dict['image'], feed_dict['future_image']
+        key = ('dp', tuple(im.shape), im.device.index, ops.graph_knobs())
+        ent = self._graphs.get(key) if (GRAPH and not self._graph_failed) else None
+        if ent is None and GRAPH and not self._graph_failed and self._eager_steps.get(key, 0) >= GRAPH_WARMUP_STEPS:
+            ent = self._capture_phases(key, im, fut)
+        if ent is None:
+            self._eager_steps[key] = self._eager_steps.get(key, 0) + 1
+            state = {}
+            for tag in self._step_phases(feed_dict, device_alpha=False):
+                self._between_phases(tag, state)
+            self.global_step += 1
+            self.last = dict(self._phase_out, lr=self._phase_lr)
+            return
+        graphs, static, outputs = ent
+        lr = self.current_lr()
+        ops.flat_copy_raw(im.contiguous().data_ptr(), static['image'].data_ptr(), im.numel())
+        ops.flat_copy_raw(fut.contiguous().data_ptr(), static['future_image'].data_ptr(), fut.numel())
+        for which in ('D', 'G'):
+            ops.fill_raw_(self._alpha_dev[which], float(self._adam_alpha(which, lr)))
+        state = {}
+        for graph, tag in zip(graphs, ('exchange_D', 'wait_D', 'exchange_G', None)):
+            graph.replay()
+            if tag is not None:
+                self._between_phases(tag, state)
+        for which in ('D', 'G'):
+            self._advance_beta_powers(which)
+            self.store.touch(which)
+        self.global_step += 1
+        self.last = dict(outputs, lr=float(lr))          # (the capture's static buffers: valid until the next step, see _train_step_graphed)
+
+    def _capture_phases(self, key, im, fut):
+        """Capture the four segments, in order, into four graphs that share one memory pool.  Nothing executes during the capture and no
+        collective is issued; the first real execution is the first replay."""
+        dev = self.device
+        if self._alpha_dev is None:
+            self._alpha_dev = {w: torch.zeros(1, dtype=torch.float32, device=dev) for w in ('D', 'G')}
+        static = {'image': torch.empty_like(im, memory_format=torch.contiguous_format),
+                  'future_image': torch.empty_like(fut, memory_format=torch.contiguous_format)}
+        saved = (dict(self.beta_power), self.global_step, self.last)
+        bank = getattr(self.store, 'filter_bank', None)
+        if bank is not None:
+            bank.touch()                    # segment A must CONTAIN the re-derivation of the filter forms, whatever ran before it
+        graphs = []
+        self._capturing = True
+        pool = None
+        try:
+            gen = self._step_phases(static, device_alpha=True)
+            done = False
+            while not done:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    try:
+                        next(gen)
+                    except StopIteration:
+                        done = True
+                pool = g.pool()
+                graphs.append(g)
+            assert len(graphs) == 4, len(graphs)
+            outputs = dict(self._phase_out)
+        except Exception as e:              # noqa: BLE001 -- whatever the runtime refuses: stay on the eager segments
+            log.warning('HIP graph capture of the data-parallel step failed (%s: %s); continuing with eager launches', type(e).__name__, e)
+            self._graph_failed = True
+            torch.cuda.synchronize(dev)
+            self.store.touch()
+            ops.reset_after_failed_capture()
+            return None
+        finally:
+            self._capturing = False
+            self.beta_power, self.global_step, self.last = dict(saved[0]), saved[1], saved[2]      # nothing has executed yet
+        ent = self._graphs[key] = (graphs, static, outputs)
+        return ent
+
+    def broadcast_parameters(self, src=0):
+        """Data parallel: every replica starts from rank ``src``'s state -- parameters, Adam slots, moving statistics, step counters.
+        The replicas are seeded identically anyway; this is insurance against a drifted seed or a partially restored replica (one
+        broadcast per flat buffer, once)."""
+        if not (torch.distributed.is_available() and torch.distributed.is_initialized()) or self.world_size <= 1:
+            return
+        group_src = torch.distributed.get_global_rank(self.process_group, src) if self.process_group is not None else src
+        with torch.no_grad():
+            for b in self.store.buckets.values():
+                for flat in (b.params, b.m, b.v):
+                    if flat is not None:
+                        torch.distributed.broadcast(flat, group_src, group=self.process_group)
+            for name, (shape, kind) in self.store.specs.items():
+                if not self.store.is_trainable(kind):
+                    torch.distributed.broadcast(self.store.vars[name], group_src, group=self.process_group)
+            counters = torch.tensor([float(self.global_step)] + [float(v) for w in ('D', 'G') for v in self.beta_power[w]],
+                                    dtype=torch.float64, device=self.device)
+            torch.distributed.broadcast(counters, group_src, group=self.process_group)
+            c = counters.cpu().numpy()
+        self.global_step = int(c[0])
+        self.beta_power = {'D': [np.float32(c[1]), np.float32(c[2])], 'G': [np.float32(c[3]), np.float32(c[4])]}
+        self.store.touch()
 
     def _train_step_eager(self, feed_dict):
         """The step enqueued launch by launch (also the function a capture records)."""
@@ -427,6 +621,15 @@ class DetectorTranslatorModel(BaseModel):
         self.global_step += 1                                             # incremented by the G optimiser (:201-202)
         self.last = dict(d_losses=d_losses.detach(), recon=recon.detach(), adv=adv.detach(), lr=float(lr),
                          fwd={k: v.detach() for k, v in fwd.items()})
+
+    LAUNCH_MODES = ('eager: every kernel enqueued from Python', 'one HIP graph replay per step',
+                    'data parallel: four captured segments replayed around the two gradient all-reduces')
+
+    def launch_mode(self):
+        """Index into LAUNCH_MODES: how train_step currently reaches the GPU."""
+        if self._graph_failed or not self._graphs:
+            return 0
+        return 2 if any(k[0] == 'dp' for k in self._graphs) else 1
 
     def loss_values(self):
         """Host copies of the last step's scalars (synchronises)."""
