@@ -201,6 +201,41 @@ def test_checkpoint_roundtrip_uses_reference_names(tmp_path):
         assert np.array_equal(np.asarray(v), np.asarray(a3[k_])), k_
 
 
+def _run_ranks(target, world, port, extra_args=(), timeout=420):
+    """Spawn ``world`` rank processes (spawn context, daemonic so that a stuck rank can never outlive the test run), collect one queue item per
+    rank, and ALWAYS end every process that is still alive: when one rank dies the others wait in a collective until the backend's own
+    timeout (30 min for gloo), and a non-daemonic child would keep pytest from exiting for as long."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra_args), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        results = []
+        import queue as _queue
+        import time as _time
+        deadline = _time.time() + timeout
+        while len(results) < world:
+            try:
+                results.append(q.get(timeout=2))
+            except _queue.Empty:
+                dead = [p for p in procs if p.exitcode not in (None, 0)]
+                assert not dead, 'rank process exited with code %s' % [p.exitcode for p in dead]
+                assert _time.time() < deadline, 'data-parallel ranks timed out'
+        for p in procs:
+            p.join(timeout=60)
+        return results
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+
+
 def _dp_gpu_worker(rank, world, port, q):
     import sys
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -230,17 +265,7 @@ def _dp_gpu_worker(rank, world, port, q):
 def test_data_parallel_train_steps_keep_replicas_identical():
     """Two ranks (gloo, sharing cuda:0), different data per rank: after the all-reduced Adam updates both replicas must
     hold bit-identical parameters (the summation order of a 2-rank all-reduce is symmetric)."""
-    import torch.multiprocessing as mp
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1500)
-    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    results = _run_ranks(_dp_gpu_worker, 2, 29700 + (os.getpid() % 1500))
     for rank, out in results:
         assert out == {'D': True, 'G': True, 'finite': True}, (rank, out)
 
@@ -280,18 +305,7 @@ def _dp_variant_worker(rank, world, port, q, env, seed_offset):
 
 
 def _run_dp_variant(env, seed_offset=0, port_base=32800):
-    import torch.multiprocessing as mp
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = port_base + (os.getpid() % 1500)
-    procs = [ctx.Process(target=_dp_variant_worker, args=(r, 2, port, q, env, seed_offset)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = dict(q.get(timeout=600) for _ in procs)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    return results
+    return dict(_run_ranks(_dp_variant_worker, 2, port_base + (os.getpid() % 1500), (env, seed_offset)))
 
 
 def test_data_parallel_segment_graphs_equal_the_eager_segments_and_the_inline_step_bit_for_bit():
@@ -352,21 +366,11 @@ def test_data_parallel_step_matches_the_oracle_mean_of_local_batch_gradients():
     key-points must be the restatement's for ITS batch (per-replica batch-norm statistics), the exchanged generator gradient the SUM of
     the two local-batch gradients (the mean after the 1/world in Adam), and the parameters after the two Adam updates the
     restatement's ``train_step_data_parallel``."""
-    import torch.multiprocessing as mp
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    port = 31200 + (os.getpid() % 1500)
-    procs = [ctx.Process(target=_dp_oracle_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
     res, k, b = 64, 5, 2
     torch.set_num_threads(min(8, len(os.sched_getaffinity(0))))
     st = R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=8))
     want = R.train_step_data_parallel(st, [R.synthetic_pair(b, res=res, seed0=200 + 2 * r, seed1=201 + 2 * r) for r in range(2)])
-    results = dict(q.get(timeout=600) for _ in procs)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    results = dict(_run_ranks(_dp_oracle_worker, 2, 31200 + (os.getpid() % 1500)))
     for rank in range(2):
         got, rep = results[rank], want['replicas'][rank]
         for key in ('loss_D', 'loss_D_real', 'loss_D_fake', 'loss_G_recon', 'loss_G_adv', 'loss_G'):

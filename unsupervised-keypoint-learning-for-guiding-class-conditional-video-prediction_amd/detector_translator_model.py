@@ -54,6 +54,17 @@ class _Bf16Exchange:
 DP_PHASED = os.environ.get('KPX_DP_PHASED', '1') != '0'
 # measurement only: run the data-parallel code path WITHOUT its two collectives (what the segmentation alone costs on one GPU)
 DP_NO_COLLECTIVES = os.environ.get('KPX_DP_NO_COLLECTIVES', '0') != '0'
+# opt-in: capture the data-parallel step INCLUDING its two RCCL all-reduces as ONE graph (ProcessGroupNCCL collectives are capturable; every
+# fork of the step, RCCL's internal stream included, joins into the main stream).  Saves the three segment boundaries; off by default because
+# a build session cannot run it on more than one rank -- the segmented form only ever issues plain eager collectives.
+DP_SINGLE_GRAPH = os.environ.get('KPX_DP_SINGLE_GRAPH', '0') != '0'
+# where the VGG19 forward of the perceptual loss sits: 'a' -- in segment A beside the discriminator update (the data gradients then run alone
+# beside the exchange, the adversarial branch alone after it); 'b' -- in segment B1 beside the exchange, and the adversarial branch (auxiliary
+# stream) beside the VGG19 data gradients in B2, as in the single-GPU step
+# 'c' (only where no segment boundary forces a join: the single captured graph, or eager launches): the single-GPU layout mirrored -- the whole
+# VGG19 chain on the auxiliary stream beside [discriminator update, exchange, Adam-D, adversarial branch] on the MAIN stream (the collective
+# must fork from and join into the main stream, see the stream discipline in ops.py)
+DP_SCHEDULE = os.environ.get('KPX_DP_SCHEDULE', 'c' if DP_SINGLE_GRAPH else 'b')
 GRAPH_WARMUP_STEPS = 1          # eager steps before the capture: they create every lazily allocated scratch buffer and kernel attribute
 
 log = logging.getLogger('kpx')
@@ -387,25 +398,74 @@ class DetectorTranslatorModel(BaseModel):
             final = fwd['final_output']
             final_d = final.detach()
             aux = self._aux_stream() if AUX_STREAM else None
-            if aux is not None:
+            sched = DP_SCHEDULE
+            if sched == 'c' and (aux is None or (self._capturing and not DP_SINGLE_GRAPH)):
+                sched = 'b'                                           # segments must join at their boundaries
+            if sched == 'c':
+                aux.wait_stream(torch.cuda.current_stream(dev))      # `final`, `future_im` predate the fork; recon / g_recon are read on main after the join in B2
+                with torch.cuda.stream(aux):
+                    recon = self._loss_G_recon(final, future_im)
+                    g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
+                d_losses = self._loss_D(final_d, future_im)
+                ops.begin_backward()
+                with ops.inline_wgrad():                              # (three busy streams measured slower than two)
+                    torch.autograd.backward([d_losses], [self._e0])
+                ops.join_side_stream(dev)
+        if sched == 'c':
+            yield 'exchange_D'
+            yield 'wait_D'
+            with variables.as_default(self.store):
+                adam('D')
+                adv = self._loss_G_adv(final)
+                g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
+                torch.cuda.current_stream(dev).wait_stream(aux)
+                ops.begin_backward()
+                final.backward(g_recon + g_adv)
+                join_all()
+            yield 'exchange_G'
+            with variables.as_default(self.store):
+                adam('G')
+            self._phase_out = dict(d_losses=d_losses.detach(), recon=recon.detach(), adv=adv.detach(), fwd={k: v.detach() for k, v in fwd.items()})
+            self._phase_lr = float(lr)
+            return
+        with variables.as_default(self.store):
+            beside = aux is not None and sched == 'a'
+            if beside:
                 aux.wait_stream(torch.cuda.current_stream(dev))      # (`final`, `final_d`, `future_im` predate the fork and outlive the join)
-            with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
+            with (torch.cuda.stream(aux) if beside else contextlib.nullcontext()):
                 d_losses = self._loss_D(final_d, future_im)
                 ops.begin_backward()
                 torch.autograd.backward([d_losses], [self._e0])
-            recon = self._loss_G_recon(final, future_im)              # VGG19 forward on (real, generated), beside the discriminator update
+            if sched == 'a':
+                recon = self._loss_G_recon(final, future_im)          # VGG19 forward on (real, generated), beside the discriminator update
             join_all()
         yield 'exchange_D'
         with variables.as_default(self.store):
             # ---- B1
-            g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
+            if sched == 'a':
+                g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
+            else:
+                recon = self._loss_G_recon(final, future_im)          # VGG19 forward beside the exchange
             join_all()
         yield 'wait_D'
         with variables.as_default(self.store):
             # ---- B2
-            adam('D')
-            adv = self._loss_G_adv(final)                 # the UPDATED discriminator, like the reference's second sess.run
-            g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
+            if sched == 'a' or aux is None:
+                adam('D')
+                adv = self._loss_G_adv(final)             # the UPDATED discriminator, like the reference's second sess.run
+                g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
+                if sched != 'a':
+                    g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
+            else:
+                # Adam-D and the adversarial branch (frozen discriminator: no weight gradients, nothing forks from this stream) on the auxiliary
+                # stream beside the VGG19 data gradients; `final` predates the fork, g_adv / adv are read on main after the join
+                aux.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(aux):
+                    adam('D')
+                    adv = self._loss_G_adv(final)
+                    g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
+                g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
+                torch.cuda.current_stream(dev).wait_stream(aux)
             ops.begin_backward()
             final.backward(g_recon + g_adv)
             join_all()
@@ -451,7 +511,7 @@ class DetectorTranslatorModel(BaseModel):
         for which in ('D', 'G'):
             ops.fill_raw_(self._alpha_dev[which], float(self._adam_alpha(which, lr)))
         state = {}
-        for graph, tag in zip(graphs, ('exchange_D', 'wait_D', 'exchange_G', None)):
+        for graph, tag in zip(graphs, ('exchange_D', 'wait_D', 'exchange_G', None) if len(graphs) == 4 else (None,)):
             graph.replay()
             if tag is not None:
                 self._between_phases(tag, state)
@@ -478,17 +538,25 @@ class DetectorTranslatorModel(BaseModel):
         pool = None
         try:
             gen = self._step_phases(static, device_alpha=True)
-            done = False
-            while not done:
+            if DP_SINGLE_GRAPH:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
-                    try:
-                        next(gen)
-                    except StopIteration:
-                        done = True
-                pool = g.pool()
+                with torch.cuda.graph(g):
+                    state = {}
+                    for tag in gen:
+                        self._between_phases(tag, state)          # the collectives are recorded into the graph
                 graphs.append(g)
-            assert len(graphs) == 4, len(graphs)
+            else:
+                done = False
+                while not done:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool):
+                        try:
+                            next(gen)
+                        except StopIteration:
+                            done = True
+                    pool = g.pool()
+                    graphs.append(g)
+                assert len(graphs) == 4, len(graphs)
             outputs = dict(self._phase_out)
         except Exception as e:              # noqa: BLE001 -- whatever the runtime refuses: stay on the eager segments
             log.warning('HIP graph capture of the data-parallel step failed (%s: %s); continuing with eager launches', type(e).__name__, e)
@@ -623,13 +691,15 @@ class DetectorTranslatorModel(BaseModel):
                          fwd={k: v.detach() for k, v in fwd.items()})
 
     LAUNCH_MODES = ('eager: every kernel enqueued from Python', 'one HIP graph replay per step',
-                    'data parallel: four captured segments replayed around the two gradient all-reduces')
+                    'data parallel: four captured segments replayed around the two gradient all-reduces',
+                    'data parallel: one HIP graph replay per step, the two all-reduces captured inside')
 
     def launch_mode(self):
         """Index into LAUNCH_MODES: how train_step currently reaches the GPU."""
         if self._graph_failed or not self._graphs:
             return 0
-        return 2 if any(k[0] == 'dp' for k in self._graphs) else 1
+        dp = [v for k, v in self._graphs.items() if k[0] == 'dp']
+        return (3 if len(dp[0][0]) == 1 else 2) if dp else 1
 
     def loss_values(self):
         """Host copies of the last step's scalars (synchronises)."""
