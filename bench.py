@@ -58,23 +58,26 @@ def time_kernel(fn, iters, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def _time_conv_3_1(dev, pretransformed=False, name='translator/conv_3_1', f43_fwd=True):
-    """f43_fwd: the layer attribute that selects F(4x4,3x3) or F(2x2,3x3) in the forward direction exactly as in the train step (ops.WINO43)."""
+def _time_conv_3_1(dev, pretransformed=False, name='translator/conv_3_1', f43_fwd=True, n=BATCH, h=64, c=128, act=0):
+    """One 3x3 stride-1 c -> c layer on [n,h,h,c] (default: translator conv_3_1 at the bench batch).  f43_fwd: the layer attribute that selects
+    F(4x4,3x3) or F(2x2,3x3) in the forward direction exactly as in the train step (ops.WINO43)."""
     from kpx_amd import ops
-    n, h, c = BATCH, 64, 128
     x = torch.randn(n, h, h, c, device=dev)
     w = torch.randn(3, 3, c, c, device=dev) * 0.03
     b = torch.zeros(c, device=dev)
     y = torch.empty(n, h, h, c, device=dev)
     keys = ops.register_constant_filter(w, name, f43_fwd=f43_fwd) if pretransformed else []     # the train step runs the kernel on filters transformed once per update
     try:
-        ms = time_kernel(lambda: ops.conv_fwd_raw(x, c, c, w, b, y, c, 1, 1, 1, 0), iters=100, warm=20)
+        ms = time_kernel(lambda: ops.conv_fwd_raw(x, c, c, w, b, y, c, 1, 1, 1, act), iters=100 if n * h * h <= 64 * 128 * 128 else 30, warm=20 if n * h * h <= 64 * 128 * 128 else 6)
     finally:
         ops.release_filters(keys)
-    return ms, 2.0 * 603979776 * n
+    return ms, 2.0 * 9 * c * c * h * h * n
 
 
-def _rocprof_avg_ms(kernel_substr, csv_name='r03_roofline_only_kernel_stats.csv'):
+PROFILE = 'r04'          # prefix of the committed rocprofv3 summaries under profiles/ the lines below point at (profiles/collect_r04.sh)
+
+
+def _rocprof_avg_ms(kernel_substr, csv_name=PROFILE + '_roofline_only_kernel_stats.csv'):
     """Average kernel duration from the committed rocprofv3 --kernel-trace --stats summary of `bench.py --roofline-only` (same command, same
     kernels): the live HIP-event figure includes the launch-to-launch gap (~1.5-3 us), which matters for a 12 us kernel."""
     import csv
@@ -88,9 +91,9 @@ def _rocprof_avg_ms(kernel_substr, csv_name='r03_roofline_only_kernel_stats.csv'
 
 
 def _profile_stamp():
-    """Commit the committed rocprofv3 summaries under profiles/ were collected at (profiles/r03_commit.txt, written by collect_r03.sh)."""
+    """Commit the committed rocprofv3 summaries under profiles/ were collected at (profiles/<round>_commit.txt, written by the collect script)."""
     try:
-        return open(os.path.join(ROOT, 'profiles', 'r03_commit.txt')).read().strip()
+        return open(os.path.join(ROOT, 'profiles', PROFILE + '_commit.txt')).read().strip()
     except OSError:
         return None
 
@@ -104,16 +107,16 @@ def _pmc_traffic(name):
         return None, None
 
 
-WINO43_PMC, WINO_PMC, DIRECT_PMC, RENDER_PMC = 'r03_wino43_pmc.json', 'r03_wino_pmc.json', 'r03_direct_pmc.json', 'r03_render_pmc.json'
-GEMM3_PMC, BF16_PMC = 'r03_gemm3_pmc.json', 'r03_bf16_pmc.json'
+WINO43_PMC, WINO_PMC, DIRECT_PMC, RENDER_PMC = PROFILE + '_wino43_pmc.json', PROFILE + '_wino_pmc.json', PROFILE + '_direct_pmc.json', PROFILE + '_render_pmc.json'
+GEMM3_PMC, BF16_PMC, WGRAD_PMC = PROFILE + '_gemm3_pmc.json', PROFILE + '_bf16_pmc.json', PROFILE + '_wgrad_pmc.json'
 
 
-def _roofline_wino(dev, name, kernel_substr, kernel_desc, reduction, pmc, f43_fwd=True):
-    ms, flops = _time_conv_3_1(dev, pretransformed=True, name=name, f43_fwd=f43_fwd)
+def _roofline_wino(dev, name, kernel_substr, kernel_desc, reduction, pmc, f43_fwd=True, csv_name=None, **shape):
+    ms, flops = _time_conv_3_1(dev, pretransformed=True, name=name, f43_fwd=f43_fwd, **shape)
     alg = flops / (ms * 1e-3) / 1e12
     ach = alg / reduction
     traffic, src = _pmc_traffic(pmc)
-    rp_ms, rp_src = _rocprof_avg_ms(kernel_substr)
+    rp_ms, rp_src = _rocprof_avg_ms(kernel_substr, csv_name) if csv_name else _rocprof_avg_ms(kernel_substr)
     return {'committed_profile': {'note': 'from files committed under profiles/, NOT measured in this run', 'collected_at_commit': _profile_stamp(),
                                   'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'traffic_source': src,
                                   'frac_at_rocprof_avg': round(flops / reduction / (rp_ms * 1e-3) / 157.3e12, 4) if rp_ms else None},
@@ -132,6 +135,44 @@ def roofline_conv(dev):
     return _roofline_wino(dev, 'translator/conv_3_1', 'conv_wino43_kernel<0, false>',
                           'conv_wino43_kernel<0, false> F(4x4,3x3) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), filter pre-transformed as in the train step',
                           4.0, WINO43_PMC)
+
+
+def roofline_conv_c3(dev, batch=16):
+    """--config c3 (BASELINE configs[3], 256x256, K=40, 16 pairs per GPU): its own dominant launch -- the translator's 128 -> 128 3x3 layers
+    now run at 128x128 (conv_3_1 / 4_0 / 4_1 of the 256x256 network: 2 415 919 104 MAC per image), F(4x4,3x3), 16 x 8 x 4 x 2 = 1 024 workgroups."""
+    return _roofline_wino(dev, 'translator/conv_3_1', 'conv_wino43_kernel<0, false>',
+                          'conv_wino43_kernel<0, false> F(4x4,3x3) fwd 3x3 s1 128->128 @128x128 B=%d (translator conv_3_1 of the 256x256 K=40 network)' % batch,
+                          4.0, PROFILE + '_wino43_c3_pmc.json', csv_name=PROFILE + '_roofline_only_c3_kernel_stats.csv', n=batch, h=128, c=128)
+
+
+def roofline_conv_c4(dev, frames=256):
+    """--config c4 (the rollout): the inference translator's dominant launch -- conv_3_1 (128 -> 128 at 64x64) on one slab of 256 predicted
+    frames (FinalModel.frames_per_launch; 2 048 frames per run = eight such slabs), batch norm folded into the filter, ReLU epilogue."""
+    return _roofline_wino(dev, 'translator/conv_3_1', 'conv_wino43_kernel<0, false>',
+                          'conv_wino43_kernel<0, false> F(4x4,3x3) fwd 3x3 s1 128->128 @64x64 on a %d-frame slab of the rollout (BN folded, ReLU epilogue)' % frames,
+                          4.0, PROFILE + '_wino43_c4_pmc.json', csv_name=PROFILE + '_roofline_only_c4_kernel_stats.csv', n=frames, h=64, c=128, act=1)
+
+
+def roofline_wgrad(dev):
+    """The slowest direction of the trainable 3x3 layers: the Winograd F(2x2,3x3) WEIGHT gradient of translator conv_3_0 (256 -> 128 at
+    64x64, batch 32; 1 207 959 552 MAC per image).  `achieved` counts the MFMA FLOPs the kernel executes (16 instead of 36 multiplies per
+    2x2 outputs: algorithmic / 2.25) over the time of the whole operator (conv_wino_wgrad_kernel + the fixed-order reduce of its split slabs)."""
+    from kpx_amd import ops
+    n, h, ci, co = BATCH, 64, 256, 128
+    x = torch.randn(n, h, h, ci, device=dev)
+    dy = torch.randn(n, h, h, co, device=dev)
+    dw = torch.empty(3, 3, ci, co, device=dev)
+    ms = time_kernel(lambda: ops.conv_wgrad_raw(x, ci, ci, dy, co, dw, 1, 1, 1), iters=50, warm=10)
+    flops = 2.0 * 9 * ci * co * h * h * n
+    ach = flops / 2.25 / (ms * 1e-3) / 1e12
+    traffic, src = _pmc_traffic(WGRAD_PMC)
+    rp_ms, rp_src = _rocprof_avg_ms('conv_wino_wgrad_kernel<2, 2>')
+    return {'committed_profile': {'note': 'from files committed under profiles/, NOT measured in this run', 'collected_at_commit': _profile_stamp(),
+                                  'rocprof_avg_launch_ms_main_kernel': rp_ms, 'rocprof_source': rp_src, 'traffic_source': src},
+            'bound': 'mfma', 'kernel': 'conv_wino_wgrad_kernel<2,2> (+ slab reduce) wgrad 3x3 s1 256->128 @64x64 B=32 (translator conv_3_0)',
+            'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4), 'traffic': traffic, 'traffic_source': src,
+            'avg_launch_ms': round(ms, 4), 'flops_per_launch_executed': flops / 2.25, 'flops_per_launch_algorithmic': flops,
+            'algorithmic_tflops': round(flops / (ms * 1e-3) / 1e12, 2)}
 
 
 def roofline_conv_f23(dev):
@@ -218,8 +259,14 @@ def roofline_render(dev, res=RES, k_pts=K_PTS, batch=BATCH):
     ms = time_kernel(run, iters=198, warm=18)
     nbytes = b * (RES * RES * K_PTS * 4 + K_PTS * 8)
     ach = nbytes / (ms * 1e-3) / 1e9
-    traffic, src = _pmc_traffic(RENDER_PMC) if (res, k_pts, batch) == (128, 15, 32) else (None, None)
-    rp_ms, rp_src = _rocprof_avg_ms('gauss_fwd_reg_kernel') if (res, k_pts, batch) == (128, 15, 32) else (None, None)
+    if (res, k_pts, batch) == (128, 15, 32):
+        traffic, src = _pmc_traffic(RENDER_PMC)
+        rp_ms, rp_src = _rocprof_avg_ms('gauss_fwd')
+    elif (res, k_pts, batch) == (256, 40, 16):
+        traffic, src = _pmc_traffic(PROFILE + '_render_c3_pmc.json')
+        rp_ms, rp_src = _rocprof_avg_ms('gauss_fwd', PROFILE + '_roofline_only_c3_kernel_stats.csv')
+    else:
+        traffic, src, rp_ms, rp_src = None, None, None, None
     return {'committed_profile': {'note': 'from files committed under profiles/, NOT measured in this run', 'collected_at_commit': _profile_stamp(),
                                   'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'traffic_source': src,
                                   'frac_at_rocprof_avg': round(nbytes / (rp_ms * 1e-3) / 8e12, 4) if rp_ms else None},
@@ -345,7 +392,7 @@ def bench_rollout(args, conf, dev, rank, world, launched, backend):
                 'step_algorithmic_frac_of_f32_peak': round(2 * gmac_frame * 1e9 * frames / dt / world / 157.3e12, 4),
                 'host_call_wall_ms_per_step': round(t_enq / args.steps * 1e3, 3), 'dist_backend': backend if launched else None}
         if world == 1:
-            line['roofline'] = roofline_conv(dev)          # the translator's 3x3 layers dominate the rollout as they do the train step
+            line['roofline'] = roofline_conv_c4(dev)       # the translator's 3x3 layers dominate the rollout; its own launch: a 256-frame slab
         print(json.dumps(line), flush=True)
     if launched:
         torch.distributed.barrier()
@@ -402,11 +449,17 @@ def main():
     RES, K_PTS = conf['res'], conf['k']
     if args.batch is None:
         args.batch = conf['batch']
+    if args.config == 'c4' and args.roofline_only:
+        print(json.dumps({'roofline': roofline_conv_c4(dev)}), flush=True)
+        return
     if args.config == 'c4':
         return bench_rollout(args, conf, dev, rank, world, launched, backend)
+    if args.roofline_only and args.config == 'c3':
+        print(json.dumps({'roofline': roofline_conv_c3(dev, args.batch), 'roofline_hbm_render': roofline_render(dev, RES, K_PTS, args.batch)}), flush=True)
+        return
     if args.roofline_only:
         kops.set_compute_dtype('f32')
-        print(json.dumps({'roofline': roofline_conv(dev), 'roofline_wino_f23': roofline_conv_f23(dev), 'roofline_direct_conv': roofline_conv_direct(dev), 'roofline_bf16x3_conv': roofline_conv_bf16x3(dev),
+        print(json.dumps({'roofline': roofline_conv(dev), 'roofline_wgrad': roofline_wgrad(dev), 'roofline_wino_f23': roofline_conv_f23(dev), 'roofline_direct_conv': roofline_conv_direct(dev), 'roofline_bf16x3_conv': roofline_conv_bf16x3(dev),
                           'roofline_hbm_render': roofline_render(dev), 'roofline_bf16_conv': roofline_conv_bf16(dev)}), flush=True)
         return
     cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': args.batch},
@@ -494,7 +547,8 @@ def main():
             kops.set_compute_dtype('f32')
             if args.dtype == 'bf16':
                 out['roofline_bf16_conv'] = roofline_conv_bf16(dev)
-            out['roofline'] = roofline_conv(dev)
+            out['roofline'] = roofline_conv(dev) if args.config == 'c1' else roofline_conv_c3(dev, args.batch)
+            out['roofline_wgrad'] = roofline_wgrad(dev)
             out['roofline_wino_f23'] = roofline_conv_f23(dev)
             out['roofline_direct_conv'] = roofline_conv_direct(dev)
             out['roofline_bf16x3_conv'] = roofline_conv_bf16x3(dev)

@@ -532,6 +532,42 @@ def train_step(state, im, future_im, same_batch=True, im_G=None, future_im_G=Non
                 future_points=fwd['future_points'].detach())
 
 
+def train_step_dt_gradients(state, im, future_im):
+    """The discriminator and TRANSLATOR gradients of ``train_step`` (same-batch convention) without the autograd tape of the key-point detector
+    and the image encoder: their forward runs under no_grad (the joint embedding is a constant of the translator's gradient), so a float64
+    run at the bench batch (B=32) fits a test host -- the arbiter for the large-launch code paths of the discriminator / translator / VGG19
+    kernels (tests/test_model_gpu.py).  Applies the D update like train_step; returns {'grads_D', 'grads_T'} (translator variables only)."""
+    p = state.params
+    dtype = getattr(state, 'dtype', torch.float32)
+    im = torch.as_tensor(im).to(dtype)
+    future_im = torch.as_tensor(future_im).to(dtype)
+    lr = state.lr()
+    t_names = [n for n in state.g_names if n.startswith('translator/')]
+    for n in state.d_names + t_names:
+        p[n].requires_grad_(True)
+    res = im.shape[1]
+    net = Net(p, train_mode=True)
+    with torch.no_grad():
+        embeddings = image_encoder(net, im)
+        cur_pt, fut_pt = pose_encoder(net, im, final_res=res), pose_encoder(net, future_im, final_res=res)
+        joint = torch.cat([embeddings[-2], get_gaussian_maps(cur_pt, [res // 4, res // 4]), get_gaussian_maps(fut_pt, [res // 4, res // 4])], dim=-1)
+        del embeddings
+        crude, mask = translator(net, joint, final_res=res)
+        final_d = im * mask + crude * (1 - mask)
+    l_d, _, _ = loss_D(net, final_d, future_im)
+    g_d = _grads(l_d, p, state.d_names)
+    del l_d
+    state.opt_D.step(p, g_d, lr)
+    net = Net(p, train_mode=True)
+    crude, mask = translator(net, joint, final_res=res)
+    final = im * mask + crude * (1 - mask)
+    l_g, _, _ = loss_G(net, state.vgg, final, future_im)
+    g_t = _grads(l_g, p, t_names)
+    for n in state.d_names + t_names:
+        p[n].requires_grad_(False)
+    return dict(grads_D=g_d, grads_T=g_t)
+
+
 def train_step_data_parallel(state, local_batches):
     """One data-parallel train step over ``len(local_batches)`` replicas: every replica runs the reference's D-run and G-run
     (:79-117) on ITS local batch from identical weights, batch-norm statistics are per replica (the reference has no cross-device batch

@@ -765,6 +765,33 @@ def test_configs1_train_step_at_the_bench_batch_32_matches_oracle():
         assert (num / den) ** 0.5 < 3e-2, (which, (num / den) ** 0.5)
 
 
+def test_configs1_batch_32_discriminator_and_translator_gradients_against_the_float64_arbiter():
+    """The tight gradient bound (distance from the float64 gradient <= 3x the fp32 oracle's own, as at B=4) AT THE BENCH BATCH: B=32 puts the
+    discriminator on the multi-round bf16x3 launches and the translator / VGG19 on 2 048-workgroup F(4x4,3x3) launches, code paths the
+    B=4 arbiter never reaches.  The float64 run of the whole step needs 47 GB of host memory; R.train_step_dt_gradients runs the detector and
+    the image encoder without a tape (they are constants of these gradients) and fits in 14 GB: discriminator + translator variables,
+    quarter-width VGG19 (every VGG19 layer still on its B=32 launch geometry: 64 images)."""
+    from kpx_amd import ops
+    dev = torch.device('cuda:0')
+    res, k, b, wd = 128, 15, 32, 4
+    model = make_model(res, k, b, dev, width_div=wd)
+    im, fut = R.synthetic_pair(b, res=res)
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    g32 = R.train_step_dt_gradients(R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=wd)), im, fut)
+    g64 = R.train_step_dt_gradients(R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=wd), dtype=torch.float64), im, fut)
+    used = ops.conv_kernel_uses['wino43']
+    model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, 0, b)
+    assert not ops.WINO43 or ops.conv_kernel_uses['wino43'] > used
+    for which, key in (('D', 'grads_D'), ('T', 'grads_T')):
+        names = [n for n in g32[key] if n.endswith('/kernel') and 'conv_6' not in n]
+        err_hip, err_o32 = grad_error_vs_f64(model, g32[key], g64[key], names)
+        print('configs1 B=32 %s: |g - g_f64| / |g_f64|  hip %.3e  fp32 oracle %.3e' % (which, err_hip, err_o32))
+        assert err_hip <= 3.0 * err_o32 + 1e-4, (which, err_hip, err_o32)
+        for n in names:                                   # and per variable (4x: single filters are noisier than the aggregate)
+            e_h, e_o = grad_error_vs_f64(model, g32[key], g64[key], [n])
+            assert e_h <= 4.0 * e_o + 2e-4, (n, e_h, e_o)
+
+
 def test_configs4_rollout_128_lstm1024_matches_oracle():
     """BASELINE configs[4] at the reference's sizes: 128x128 input, K=15, 2 x LSTMCell(1024), vae_dim 64, 32-frame rollout (B=2 ->
     64 translator frames), inference-mode batch norm (models/final_model.py:49-122)."""

@@ -733,6 +733,8 @@ GEMM3_CASES = [  # n, h, w, cin, cout, k, stride, pad, act
     (2, 64, 64, 16, 16, 1, 1, 0, 0),        # 1x1, half a K chunk, 16 produced channels
     (3, 17, 13, 40, 72, 3, 2, 0, 2),        # ragged: K = 40 (a partial chunk), 72 couts (masked tile columns), odd image sizes
     (2, 20, 20, 24, 20, 3, 1, 1, 0),        # explicit pad on a stride-1 3x3 (not the Winograd geometry), 20 couts
+    (64, 18, 18, 256, 512, 4, 2, 1, 2),     # img_discr conv_3 at the PROFILED launch: N = 64 = real + generated halves of the bench batch
+    (64, 10, 10, 512, 1024, 4, 2, 1, 2),    # img_discr conv_4 at the bench batch (multi-round split-K launch)
 ]
 
 

@@ -177,3 +177,18 @@ def test_data_parallel_restatement_with_one_replica_is_the_plain_train_step():
         assert torch.allclose(s1.params[n], s3.params[n], rtol=0, atol=2.1e-4), n     # (g + g) / 2 == g exactly; Adam is then identical
     for n, g in a['grads_G'].items():
         assert torch.equal(g, e['grads_G'][n]), n
+
+
+def test_lean_gradient_arbiter_equals_the_full_train_step():
+    """R.train_step_dt_gradients (discriminator + translator gradients with the detector / image encoder run under no_grad: the float64
+    arbiter that fits a host at the bench batch) must return exactly the gradients train_step returns for those variables."""
+    res, k, b = 32, 3, 2
+    im, fut = R.synthetic_pair(b, res=res, seed0=3, seed1=4)
+    full = R.train_step(R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=8)), im, fut)
+    lean = R.train_step_dt_gradients(R.TrainState(R.init_variables(k, res=res, seed=1234), R.synthetic_vgg(seed=19, width_div=8)), im, fut)
+    assert set(lean['grads_D']) == set(full['grads_D'])
+    for n, g in lean['grads_D'].items():
+        np.testing.assert_allclose(g.numpy(), full['grads_D'][n].numpy(), rtol=1e-5, atol=1e-9, err_msg=n)
+    assert lean['grads_T'] and all(n.startswith('translator/') for n in lean['grads_T'])
+    for n, g in lean['grads_T'].items():
+        np.testing.assert_allclose(g.numpy(), full['grads_G'][n].numpy(), rtol=1e-5, atol=1e-9, err_msg=n)
