@@ -1,0 +1,21 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/pmcw; rm -rf $O; mkdir -p $O
+i=0
+for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM" "SQ_WAIT_ANY SQ_ACTIVE_INST_MISC SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $c --kernel-trace -d $O/p$i -o p --output-format csv -- python3 scratch/wgrad_only.py > $O/out$i.txt 2>&1
+done
+python3 - <<'PY'
+import csv, glob, collections
+pmc = collections.defaultdict(list)
+for f in glob.glob('gpurun_out/pmcw/p*/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'conv_wino_wgrad_kernel' in r['Kernel_Name']:
+            pmc[r['Counter_Name']].append(float(r['Counter_Value']))
+out = open('gpurun_out/pmcw/summary.txt', 'w')
+for k in sorted(pmc):
+    line = '%-34s %16.0f  (%d dispatches)' % (k, sum(pmc[k]) / len(pmc[k]), len(pmc[k]))
+    print(line); out.write(line + '\n')
+PY
+tail -2 $O/out1.txt

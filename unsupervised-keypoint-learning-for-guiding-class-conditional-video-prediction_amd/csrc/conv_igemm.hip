@@ -1353,7 +1353,8 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     const int g3_first = (kpx_env()->no_gemm3 || kpx_env()->no_wgrad3 || Cin % 4 || Cout % 4 || Cin < 16 || Cout < 16 || ldx % 4 || lddy % 4 ||
                           !aligned16(x) || !aligned16(dy)) ? 0 : kpx_env()->wgrad3_first;
     if (g3_first < 2 && KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && ldx % 4 == 0 && lddy % 4 == 0 &&
-        ldx >= ((Cin + 3) & ~3) && aligned16(x) && aligned16(dy)) {
+        ldx >= ((Cin + 3) & ~3) && aligned16(x) && aligned16(dy) &&
+        (size_t)N * Hi * Wi * (size_t)(ldx > lddy ? ldx : lddy) * 4 < 0x60000000ull) {       // (the kernel addresses x / dy with 32-bit byte offsets)
         const int Sw = kpx_wino_wgrad_splits(N, Hi, Wi, Cin, Cout);
         const size_t slab = (size_t)9 * Cin * Cout;
         if (Sw >= 1 && (Sw == 1 || (workspace && workspace_bytes >= (size_t)Sw * slab * 4))) {

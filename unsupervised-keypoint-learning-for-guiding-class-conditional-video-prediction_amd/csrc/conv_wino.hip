@@ -549,43 +549,54 @@ struct WinoWgradGeom {
 };
 
 // CIT x COT = 32-channel MFMA tiles per workgroup block: (2,2) = 64 x 64, (2,1) = 64 x 32 (few output channels), (1,2) = 32 x 64
+//
+// Round 4: ONE barrier per chunk.  The first version staged the raw patch in LDS, transformed it, multiplied, with three barriers per
+// chunk and one workgroup per CU: the matrix pipe idled during staging and transform (SQ_VALU_MFMA_BUSY 0.49).  Now every thread loads
+// the eight x pixels (two patch rows x four columns) and four dy pixels of ITS transform item straight from global memory into registers
+// (neighbouring items re-read shared pixels from L1 / L2: 12 instead of 3 16-B loads per thread and chunk, no raw stage, no LDS reads in
+// the transform), V / D are double buffered (131 KB), and an iteration is: barrier, transform chunk k+1 from registers into the other
+// buffer, issue the loads of chunk k+2, multiply chunk k -- wavefronts 4-7 multiply first and transform afterwards, so that one of the
+// two wavefronts of a SIMD always has MFMAs to issue (the scheme of conv_wino_v2_kernel).
 template <int CIT, int COT>
 __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const WinoWgradGeom g) {
     constexpr int CI = 32 * CIT, CO = 32 * COT, SI = CI / 4, SO = CO / 4;     // channels and 16-B slots per pixel
-    constexpr int RAWX = 60 * CI, RAWD = 32 * CO, VF = 16 * 8 * CI;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* rawx = smem;                    // [6 rows][10 pixels][CI]
-    float* rawd = smem + RAWX;             // [4 rows][8 pixels][CO]
-    float* Vs = smem + RAWX + RAWD;        // [16 points][8 tiles][CI]
-    float* Ds = Vs + VF;                   // [16 points][8 tiles][CO]
+    constexpr int VF = 16 * 8 * CI, DF = 16 * 8 * CO, BUF = VF + DF;
+    extern __shared__ __attribute__((aligned(16))) float smem[];              // [2][V[16 points][8 tiles][CI] | D[16 points][8 tiles][CO]]
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), li = lane & 31, lh = lane >> 5;
     int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
     const int split = L % g.S; L /= g.S;
     const int cot = L % g.cot, cit = L / g.cot;
     const int c0 = cit * CI, n0 = cot * CO;
 
-    // staging units (fixed per thread): x patch 60 pixels x SI slots (<= 2 per thread), dy 32 pixels x SO slots (<= 1)
-    int xpr[2], xpc[2], xsl[2], xtail[2]; bool xin[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int u = t + 512 * i, px = u / SI;
-        xsl[i] = (u - px * SI) * 4; xin[i] = u < 60 * SI && c0 + xsl[i] < g.Cin; xpr[i] = px / 10; xpc[i] = px - xpr[i] * 10;
-        xtail[i] = g.Cin - (c0 + xsl[i]);        // valid channels of this 16-B unit (>= 4: all)
-    }
-    const int dpx = t / SO, dsl = (t - dpx * SO) * 4, dpr = dpx >> 3, dpc = dpx & 7;
-    const bool din = t < 32 * SO && n0 + dsl < g.Cout;
     // transform items: (16-B slot, tile 0..7, row 0..3 of the 4x4 transformed tile); the row is uniform per wavefront
     const int vsl = (t % SI) * 4, vtile = (t / SI) & 7, vrow = t / (8 * SI);         // x side
     const int esl = (t % SO) * 4, etile = (t / SO) & 7, erow = t / (8 * SO);         // dy side
-    const bool vact = t < 32 * SI, eact = t < 32 * SO;
+    const bool vthr = t < 32 * SI, ethr = t < 32 * SO;
+    const bool vact = vthr && c0 + vsl < g.Cin, eact = ethr && n0 + esl < g.Cout;
+    const int xtail = g.Cin - (c0 + vsl);                                             // valid channels of this 16-B unit (>= 4: all)
     const int ra = vrow == 0 ? 0 : (vrow == 2 ? 2 : 1), rb = vrow == 0 ? 2 : (vrow == 1 ? 2 : (vrow == 2 ? 1 : 3));
     const float sgn = vrow == 1 ? 1.f : -1.f;
-    const int xrd = ((2 * (vtile >> 2) + ra) * 10 + 2 * (vtile & 3)) * CI + vsl, xrb = (rb - ra) * 10 * CI;
+    const int pya = 2 * (vtile >> 2) + ra - 1, pyb = 2 * (vtile >> 2) + rb - 1, px0 = 2 * (vtile & 3) - 1;   // patch rows / first column, relative to the chunk origin
     const int vwr = (vrow * 4) * 8 * CI + vtile * CI + vsl;
-    const int drd = ((2 * (etile >> 2)) * 8 + 2 * (etile & 3)) * CO + esl;
     const float d0 = erow == 3 ? 0.f : 1.f, d1 = erow == 0 ? 0.f : (erow == 1 ? 1.f : -1.f);      // row i of A: t = d0*dY[0] + d1*dY[1]
-    const int dwr = (erow * 4) * 8 * CO + etile * CO + esl;
+    const int dwr = VF + (erow * 4) * 8 * CO + etile * CO + esl;
+    // Operands through buffer descriptors over the whole tensors: voffset = this item's pixels relative to the chunk origin (fixed for the
+    // life of the thread), soffset = the chunk origin (scalar).  An out-of-image pixel / out-of-range channel unit carries the offset
+    // 0x80000000 and reads as zero.  The x descriptor starts one row + one pixel BEFORE the tensor so that the patch's halo offsets
+    // (row -1, column -1) stay non-negative; those positions are only ever addressed with the out-of-range offset.
+    const int dyo = ((2 * (etile >> 2) * g.W + 2 * (etile & 3)) * g.lddy + n0 + esl) * 4;   // bytes: this item's dy pixel (0,0) inside the chunk
+    const int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x) - (size_t)(g.W + 1) * g.ldx, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dy), 0, 0x7fffffff, 0x00020000);
+    int vxa[4], vxb[4], vd[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        vxa[c] = vact ? (((pya + 1) * g.W + px0 + c + 1) * g.ldx + c0 + vsl) * 4 : OOB;
+        vxb[c] = vact ? (((pyb + 1) * g.W + px0 + c + 1) * g.ldx + c0 + vsl) * 4 : OOB;
+    }
+    vd[0] = eact ? dyo : OOB; vd[1] = eact ? dyo + g.lddy * 4 : OOB; vd[2] = eact ? dyo + g.W * g.lddy * 4 : OOB; vd[3] = eact ? dyo + (g.W + 1) * g.lddy * 4 : OOB;
+    const bool top_a = pya < 0, bot_a = pya > 3, top_b = pyb < 0, bot_b = pyb > 3, left0 = px0 < 0, right3 = px0 + 3 > 7;
     const int p0 = 2 * wave;
 
     f32x16 acc[2][CIT][COT];
@@ -600,61 +611,59 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const WinoWgrad
 
     const int ch_begin = split * g.cps;
     int ch_end = ch_begin + g.cps; if (ch_end > g.total_chunks) ch_end = g.total_chunks;
-    f32x4 rx[2], rd;
-    auto load_chunk = [&](int ch) {
-        const int cx = ch % g.chx; int q = ch / g.chx;
-        const int cy = q % g.chy, n = q / g.chy;
-        const int y0 = cy * 4, x0 = cx * 8;
+    const int nch = ch_end - ch_begin;
+    // chunk cursor (scalar): image n, chunk row cy, chunk column cx of the NEXT chunk to load
+    // (readfirstlane: integer division runs on the vector ALU, and a cursor left in vector registers would make every buffer load's scalar
+    //  offset a 13-instruction readfirstlane loop)
+    const int lq = ch_begin / g.chx;
+    int lcx = __builtin_amdgcn_readfirstlane(ch_begin - lq * g.chx);
+    int lcy = __builtin_amdgcn_readfirstlane(lq % g.chy), ln = __builtin_amdgcn_readfirstlane(lq / g.chy);
+    f32x4 rxa[4], rxb[4], rd[4];
+    auto load_next = [&]() {
+        const int pix = (ln * g.H + lcy * 4) * g.W + lcx * 8;             // chunk origin (scalar); byte offsets < 2^31 (checked by the planner)
+        const int sx = pix * g.ldx * 4, sd = pix * g.lddy * 4;
+        const bool s_top = lcy == 0, s_bot = lcy + 1 == g.chy, s_left = lcx == 0, s_right = lcx + 1 == g.chx;
+        // (a branch-free interior fast path -- plain offsets when no flag is set -- measured SLOWER: 0.368 vs 0.357 ms, A/B in one session)
+        const bool inv_a = (top_a && s_top) || (bot_a && s_bot), inv_b = (top_b && s_top) || (bot_b && s_bot);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            if (i * 512 < 60 * SI) {
-                const int iy = y0 - 1 + xpr[i], ix = x0 - 1 + xpc[i];
-                const bool ok = xin[i] && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-                rx[i] = *reinterpret_cast<const f32x4*>(ok ? g.x + ((size_t)(n * g.H + iy) * g.W + ix) * g.ldx + c0 + xsl[i] : wino_zero16);
-            }
+        for (int c = 0; c < 4; ++c) {
+            const bool inv_c = (c == 0 && left0 && s_left) || (c == 3 && right3 && s_right);
+            rxa[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (inv_a || inv_c) ? OOB : vxa[c], sx, 0));
+            rxb[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (inv_b || inv_c) ? OOB : vxb[c], sx, 0));
         }
-        rd = *reinterpret_cast<const f32x4*>(din ? g.dy + ((size_t)(n * g.H + y0 + dpr) * g.W + x0 + dpc) * g.lddy + n0 + dsl : wino_zero16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rd[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsd, vd[i], sd, 0));
+        if (++lcx == g.chx) { lcx = 0; if (++lcy == g.chy) { lcy = 0; ++ln; } }
     };
-    if (ch_begin < ch_end) load_chunk(ch_begin);
-    for (int ch = ch_begin; ch < ch_end; ++ch) {
-        if (g.Cin & 3) {                     // a 16-B unit straddling Cin: the row's pad channels must not count (masked here, at the
-#pragma unroll                              // consumer, so that the prefetch above stays asynchronous)
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 1; j < 4; ++j) if (j >= xtail[i]) rx[i][j] = 0.f;
-        }
-        if (t < 60 * SI) *reinterpret_cast<f32x4*>(&rawx[t * 4]) = rx[0];
-        if (60 * SI > 512 && t + 512 < 60 * SI) *reinterpret_cast<f32x4*>(&rawx[(t + 512) * 4]) = rx[1];
-        if (t < 32 * SO) *reinterpret_cast<f32x4*>(&rawd[t * 4]) = rd;
-        __syncthreads();
-        if (vact) {
+    auto transform = [&](float* buf) {
+        if (vthr) {
             f32x4 tr[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(&rawx[xrd + c * CI]);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(&rawx[xrd + c * CI + xrb]);
-                tr[c] = a + sgn * b;
+            for (int c = 0; c < 4; ++c) tr[c] = rxa[c] + sgn * rxb[c];
+            if (g.Cin & 3) {                 // a 16-B unit straddling Cin: the row's pad channels must not count
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) if (j >= xtail) tr[c][j] = 0.f;
             }
-            *reinterpret_cast<f32x4*>(&Vs[vwr]) = tr[0] - tr[2];
-            *reinterpret_cast<f32x4*>(&Vs[vwr + 8 * CI]) = tr[1] + tr[2];
-            *reinterpret_cast<f32x4*>(&Vs[vwr + 16 * CI]) = tr[2] - tr[1];
-            *reinterpret_cast<f32x4*>(&Vs[vwr + 24 * CI]) = tr[1] - tr[3];
+            *reinterpret_cast<f32x4*>(&buf[vwr]) = tr[0] - tr[2];
+            *reinterpret_cast<f32x4*>(&buf[vwr + 8 * CI]) = tr[1] + tr[2];
+            *reinterpret_cast<f32x4*>(&buf[vwr + 16 * CI]) = tr[2] - tr[1];
+            *reinterpret_cast<f32x4*>(&buf[vwr + 24 * CI]) = tr[1] - tr[3];
         }
-        if (eact) {
-            const f32x4 y00 = *reinterpret_cast<const f32x4*>(&rawd[drd]), y01 = *reinterpret_cast<const f32x4*>(&rawd[drd + CO]);
-            const f32x4 y10 = *reinterpret_cast<const f32x4*>(&rawd[drd + 8 * CO]), y11 = *reinterpret_cast<const f32x4*>(&rawd[drd + 9 * CO]);
-            const f32x4 t0 = d0 * y00 + d1 * y10, t1 = d0 * y01 + d1 * y11;
-            *reinterpret_cast<f32x4*>(&Ds[dwr]) = t0;
-            *reinterpret_cast<f32x4*>(&Ds[dwr + 8 * CO]) = t0 + t1;
-            *reinterpret_cast<f32x4*>(&Ds[dwr + 16 * CO]) = t0 - t1;
-            *reinterpret_cast<f32x4*>(&Ds[dwr + 24 * CO]) = -t1;
+        if (ethr) {
+            const f32x4 t0 = d0 * rd[0] + d1 * rd[2], t1 = d0 * rd[1] + d1 * rd[3];
+            *reinterpret_cast<f32x4*>(&buf[dwr]) = t0;
+            *reinterpret_cast<f32x4*>(&buf[dwr + 8 * CO]) = t0 + t1;
+            *reinterpret_cast<f32x4*>(&buf[dwr + 16 * CO]) = t0 - t1;
+            *reinterpret_cast<f32x4*>(&buf[dwr + 24 * CO]) = -t1;
         }
-        if (ch + 1 < ch_end) load_chunk(ch + 1);
-        __syncthreads();
+    };
+    auto mfma = [&](const float* buf) {
 #pragma unroll
         for (int pt = 0; pt < 2; ++pt) {
-            const float* Vp = Vs + (p0 + pt) * 8 * CI + lh * CI + li;
-            const float* Dp = Ds + (p0 + pt) * 8 * CO + lh * CO + li;
+            const float* Vp = buf + (p0 + pt) * 8 * CI + lh * CI + li;
+            const float* Dp = buf + VF + (p0 + pt) * 8 * CO + lh * CO + li;
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 float a[CIT], b[COT];
@@ -669,8 +678,23 @@ __global__ __launch_bounds__(512, 2) void conv_wino_wgrad_kernel(const WinoWgrad
                         acc[pt][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[pt][i][j], 0, 0, 0);
             }
         }
-        __syncthreads();
+    };
+    const bool late = wave >= 4;                              // wave-uniform
+    if (nch > 0) {
+        load_next();
+        transform(smem);
+        if (nch > 1) load_next();
     }
+    for (int k = 0; k < nch; ++k) {
+        float* const cur = smem + (k & 1) * BUF;
+        float* const nxt = smem + ((k & 1) ^ 1) * BUF;
+        __syncthreads();                                     // buffer `cur` (chunk k) is complete; everybody is done reading `nxt` (chunk k-1)
+        if (late) mfma(cur);
+        if (k + 1 < nch) transform(nxt);                     // the registers hold chunk k+1
+        if (k + 2 < nch) load_next();                        // chunk k+2: in flight under this iteration's MFMAs
+        if (!late) mfma(cur);
+    }
+    __syncthreads();                                         // the epilogue's M overlays the buffers
 
     // dg = G^T dU G per (c, n), one 32 x 32 quarter at a time through LDS: M[16][32 c][32 n]
     float* Ms = smem;
@@ -740,8 +764,8 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad3x3(const float* x, int N, int H, int W, int Cin, int ldx, const float* dy, int Cout, int lddy,
                                                                    float* slabs, int S, hipStream_t s) {
     static std::atomic<unsigned long long> attr_mask{0};
-    const int lds22 = (60 * 64 + 32 * 64 + 2 * 16 * 8 * 64) * 4, lds21 = (60 * 64 + 32 * 32 + 16 * 8 * 64 + 16 * 8 * 32) * 4,
-              lds12 = (60 * 32 + 32 * 64 + 16 * 8 * 32 + 16 * 8 * 64) * 4;
+    // V + D, double buffered (the epilogue's M[16][32][32], 64 KB, overlays them)
+    const int lds22 = 2 * (16 * 8 * 64 + 16 * 8 * 64) * 4, lds21 = 2 * (16 * 8 * 64 + 16 * 8 * 32) * 4, lds12 = 2 * (16 * 8 * 32 + 16 * 8 * 64) * 4;
     if (kpx_first_use_on_device(&attr_mask)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds22);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_wgrad_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds21 > 65536 ? lds21 : 65536);
