@@ -151,12 +151,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
     const int a_rdA = a_rd0 + offA * 256, a_rd4 = a_rd0 + off4 * 256, a_rdB = a_rd0 + offB * 256;
     const int KC = g.Kp >> 3, NB = g.Np >> 5;
     const int nb = nti * 2 + ct;
-    const size_t ub_pstride = (size_t)KC * NB * 256, ub_step = (size_t)NB * 256;
-    const float* ubpA = g.U + ((size_t)offA * KC * NB + nb) * 256 + lane * 4;
-    const float* ubp4 = g.U + ((size_t)off4 * KC * NB + nb) * 256 + lane * 4;
-    const float* ubpB = g.U + ((size_t)offB * KC * NB + nb) * 256 + lane * 4;
+    // B fragments through a buffer descriptor over U: voffset = lane * 16 (fixed), soffset = (point, chunk, cout block) in bytes -- scalar.
+    // (As 64-bit pointers this was 12 v_lshl_add_u64 + 18 s_add / s_addc per chunk and wavefront, beside an fp32 MFMA that hides none of it.)
+    const int ub_pstride = KC * NB * 1024, ub_step = NB * 1024;                        // bytes per point / per chunk
+    const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.U), 0, 36u * (unsigned)ub_pstride, 0x00020000);
+    const int ulane = lane * 16;
+    int ubsA = __builtin_amdgcn_readfirstlane((offA * KC * NB + nb) * 1024), ubs4 = __builtin_amdgcn_readfirstlane((off4 * KC * NB + nb) * 1024),
+        ubsB = __builtin_amdgcn_readfirstlane((offB * KC * NB + nb) * 1024);
 #define W4_AOFF(b) (((b) < 4 ? a_rdA : (b) == 4 ? a_rd4 : a_rdB) + (b) * 256)
-#define W4_UPTR(b) (((b) < 4 ? ubpA : (b) == 4 ? ubp4 : ubpB) + (size_t)(b) * ub_pstride)
+#define W4_ULOAD(b, extra) __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, ((b) < 4 ? ubsA : (b) == 4 ? ubs4 : ubsB) + (b) * ub_pstride + (extra), 0))
     const int nchunks = g.Kp / 8;
 
 #ifdef KPX_WINO_STAMP
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
     f32x4 ub[3];
 #pragma unroll
-    for (int b = 0; b < 3; ++b) ub[b] = *reinterpret_cast<const f32x4*>(W4_UPTR(b));
+    for (int b = 0; b < 3; ++b) ub[b] = W4_ULOAD(b, 0);
 
     if (PACK) {                                          // the halo slots of both raw buffers are never written again
         for (int i = t; i < 2 * W4_RAW / 4; i += 512) *reinterpret_cast<f32x4*>(&rawb[i * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -180,18 +183,18 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
     auto mfma = [&](const float* Vr, bool refill_next) {
         f32x4 av[2];
         av[0] = *reinterpret_cast<const f32x4*>(&Vr[W4_AOFF(0)]);
-        const size_t nx = refill_next ? ub_step : 0;                     // (last chunk: harmless re-read instead of a branch)
+        const int nx = refill_next ? ub_step : 0;                        // (last chunk: harmless re-read instead of a branch)
 #pragma unroll
         for (int b = 0; b < 9; ++b) {
             if (b < 8) av[(b + 1) & 1] = *reinterpret_cast<const f32x4*>(&Vr[W4_AOFF(b + 1)]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[b & 1][j], ub[b % 3][j], acc[b], 0, 0, 0);
-            if (b < 6) ub[b % 3] = *reinterpret_cast<const f32x4*>(W4_UPTR(b + 3));
-            else ub[b % 3] = *reinterpret_cast<const f32x4*>(W4_UPTR(b - 6) + nx);
+            if (b < 6) ub[b % 3] = W4_ULOAD(b + 3, 0);
+            else ub[b % 3] = W4_ULOAD(b - 6, nx);
             __builtin_amdgcn_sched_barrier(0);           // or the scheduler sinks each refill to its use, 3 points later, and waits for it there
         }
-        ubpA += ub_step; ubp4 += ub_step; ubpB += ub_step;
+        ubsA += ub_step; ubs4 += ub_step; ubsB += ub_step;
     };
 
     // The two roles run separate copies of the chunk loop (their register needs differ: 44 transient transform registers vs 40 of
@@ -206,8 +209,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
         const float a0 = w43_A[trow][0], a1 = w43_A[trow][1], a2 = w43_A[trow][2], a3 = w43_A[trow][3];
         const int vwr = (6 * trow) * 256 + ttile * 8 + ((thf ^ ((ttile >> 3) & 1)) << 2);
         const int ktail = g.Cin - (nchunks - 1) * 8 - thf * 4;       // valid channels of this thread's half in the LAST chunk
-        auto transform = [&](const float* rawR, float* Vw, bool mask_tail, auto three_tag) {
+        // MASK (compile time): the channel-tail select of a padded LAST chunk; as a run-time flag it was 18 v_cndmask per chunk for every chunk
+        auto transform_t = [&](const float* rawR, float* Vw, auto mask_tag, auto three_tag) {
             constexpr bool THREE = decltype(three_tag)::value;
+            constexpr bool mask_tail = decltype(mask_tag)::value;
             f32x4 tc[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
@@ -230,6 +235,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
             *reinterpret_cast<f32x4*>(&Vw[vwr + 768]) = 2.f * (tc[3] - tc[1]) - tc[2] + tc[4];
             *reinterpret_cast<f32x4*>(&Vw[vwr + 1024]) = 2.f * (tc[1] - tc[3]) - tc[2] + tc[4];
             *reinterpret_cast<f32x4*>(&Vw[vwr + 1280]) = 4.f * tc[1] - 5.f * tc[3] + tc[5];
+        };
+        auto transform = [&](const float* rawR, float* Vw, bool mask_tail, auto three_tag) {
+            if (mask_tail) transform_t(rawR, Vw, std::true_type{}, three_tag);          // (wave-uniform branch)
+            else transform_t(rawR, Vw, std::false_type{}, three_tag);
         };
         W4_STAMP(10);
         __syncthreads();                                 // raw[0] (chunk 0) staged by the loaders
