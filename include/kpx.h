@@ -110,6 +110,18 @@ int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int Cout, int l
                          int stride, int pad_t, int pad_l, int arith,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same data gradient multiplied by the activation backward of the tensor it belongs to: dx = dgrad(dy) * act_in'(y_in), y_in = the
+ * ACTIVATED tensor (same shape as dx, pixel stride ld_y_in), act_in = KPX_ACT_RELU / KPX_ACT_LRELU.  This is the chain
+ * conv -> leaky_relu -> conv of models/networks/__init__.py:141-151 (img_discr) walked backwards with the leaky-ReLU backward (tf.gradients
+ * of tf.nn.leaky_relu) applied in the epilogue of the data gradient ABOVE it instead of a pass of its own (kpx_act_bwd_f32).  Fused on the
+ * implicit-GEMM kernels (and their split-K reduce); the specialised kernels take one extra pass over dx (contiguous tensors). */
+int kpx_conv2d_dgrad_act_f32(const float* dy, int N, int Ho, int Wo, int Cout, int lddy,
+                             const float* w_hwio, int KH, int KW,
+                             float* dx, int Hi, int Wi, int Cin, int lddx,
+                             int stride, int pad_t, int pad_l, int arith,
+                             const float* y_in, int ld_y_in, int act_in,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* dw[r,q,c,k] = sum_{n,oh,ow} x[n, oh*s+r-pad_t, ow*s+q-pad_l, c] * dy[n,oh,ow,k].
  * `workspace` holds split-K partial slabs; query its size with kpx_conv2d_wgrad_workspace_bytes. */
 size_t kpx_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);

@@ -823,3 +823,39 @@ def test_batched_batch_norm_equals_one_call_per_group_bit_for_bit(kpx, dev, n, h
         out[mode] = [t2n(t).copy() for t in (y, mean, invstd, mm, mv, dx, dg, db)]
     for a, b, name in zip(out['per_group'], out['batched'], ('y', 'mean', 'invstd', 'moving_mean', 'moving_var', 'dx', 'dgamma', 'dbeta')):
         assert np.array_equal(a, b), name
+
+
+@pytest.mark.parametrize('n,h,c0,c1,c2,k,s,pad', [(4, 34, 16, 64, 128, 4, 2, 1),        # img_discr-shaped: 4x4 stride 2, implicit-GEMM kernels
+                                                  (8, 10, 64, 256, 512, 4, 2, 1),       # small maps: the split-K data gradient + its reduce
+                                                  (2, 6, 32, 48, 1, 3, 1, 1),           # D_logit-shaped: one produced channel (scalar-store kernel)
+                                                  (2, 32, 16, 16, 32, 3, 1, 0)])        # 3x3 stride 1 on the specialised kernels: the extra pass over dx
+def test_activation_backward_in_the_data_gradient_epilogue_equals_the_separate_pass(kpx, dev, n, h, c0, c1, c2, k, s, pad):
+    """conv -> leaky_relu -> conv (reference networks/__init__.py:141-151) walked backwards: with act_bwd_by_consumer / input_act the
+    leaky-ReLU backward of the first layer is applied in the epilogue of the second layer's data gradient (kpx_conv2d_dgrad_act_f32);
+    every gradient must equal the separate kpx_act_bwd_f32 pass bit for bit (the same multiplication on the same sums)."""
+    from kpx_amd import ops
+    rs = np.random.RandomState(n + h + c1)
+    x = rs.randn(n, h, h, c0).astype(np.float32)
+    w1 = (rs.randn(k, k, c0, c1) / np.sqrt(k * k * c0)).astype(np.float32); b1 = rs.randn(c1).astype(np.float32)
+    w2 = (rs.randn(k, k, c1, c2) / np.sqrt(k * k * c1)).astype(np.float32)
+    outs = {}
+    for fused in (False, True):
+        xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+        w1g = torch.from_numpy(w1).to(dev).requires_grad_(True); b1g = torch.from_numpy(b1).to(dev).requires_grad_(True)
+        w2g = torch.from_numpy(w2).to(dev).requires_grad_(True)
+        y1 = ops.conv2d(xg, w1g, b1g, stride=s, pad=pad, act=ops.ACT_LRELU, act_bwd_by_consumer=fused)
+        y2 = ops.conv2d(y1, w2g, None, stride=s, pad=pad, act=ops.ACT_NONE, input_act=ops.ACT_LRELU if fused else ops.ACT_NONE)
+        if fused:
+            assert y2.grad_fn.input_act == ops.ACT_LRELU and y1.grad_fn.act_bwd_by_consumer
+        gy = torch.from_numpy(np.random.RandomState(7).randn(*y2.shape).astype(np.float32)).to(dev)
+        y2.backward(gy)
+        ops.join_side_stream()
+        outs[fused] = [t2n(t) for t in (y2, xg.grad, w1g.grad, b1g.grad, w2g.grad)]
+    for a, b in zip(outs[False], outs[True]):
+        assert np.array_equal(a, b)
+    # and against the float64 restatement (the unfused path is covered elsewhere; this pins the fused one directly)
+    x64 = torch.from_numpy(x).double().requires_grad_(True); w164 = torch.from_numpy(w1).double().requires_grad_(True)
+    z1 = R.conv(x64, w164, torch.from_numpy(b1).double(), s, pad)
+    z2 = R.conv(torch.where(z1 > 0, z1, 0.01 * z1), torch.from_numpy(w2).double(), None, s, pad)
+    z2.backward(torch.from_numpy(np.random.RandomState(7).randn(*z2.shape).astype(np.float32)).double())
+    assert rel_l2(outs[True][1], t2n(x64.grad)) < 1e-5 and rel_l2(outs[True][2], t2n(w164.grad)) < 1e-5

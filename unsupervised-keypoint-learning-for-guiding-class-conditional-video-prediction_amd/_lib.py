@@ -38,6 +38,8 @@ SIGNATURES = {
     'kpx_conv2d_dgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_dgrad_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int,
                                      P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'kpx_conv2d_dgrad_act_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int,
+                                         P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_size_t, P]),
     'kpx_conv2d_wgrad_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv2d_wgrad_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int,
                                      P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3_kernel(const ConvG
                     if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                     else if (g.act == KPX_ACT_TANH) v = tanhf(v);
+                    if (g.mul_y) v *= kpx_act_grad_from_y(g.mul_y[(size_t)pix * g.ld_mul + col], g.mul_act);
                     g.y[(size_t)pix * g.ldy + col] = v;
                 }
             }

@@ -22,6 +22,7 @@ struct ConvGeom {
     ConvClass cls[4]; int ncls;   // blockIdx.y selects the class
     int ksplit; float* ws;        // split-K: blockIdx.z owns an equal slice of the K chunks; raw partials go to ws[z][pixel][Cout]
     size_t ws_slab;               // floats per split slab = N*Ho*Wo*Cout
+    const float* mul_y; int ld_mul, mul_act;   // optional epilogue factor act'(mul_y[pixel][col]) (data gradient of an activated tensor: kpx_conv2d_dgrad_act_f32)
     int terms;      // bf16 terms per fp32 operand on the bf16-pipe kernels (conv_gemm3.hip): 3 = fp32-equivalent, 1 = bf16 operands (the `arith` argument)
     int merge;      // >0: row-merged taps for tiny Cin (= original Cin): the KW*Cin floats of one filter row are
                     // contiguous in NHWC, so they are treated as one tap with KW*Cin channels (per-element x bounds)

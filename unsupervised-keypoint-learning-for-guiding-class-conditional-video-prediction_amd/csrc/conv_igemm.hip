@@ -306,6 +306,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
                     if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                     else if (g.act == KPX_ACT_TANH) v = tanhf(v);
+                    if (g.mul_y) v *= kpx_act_grad_from_y(g.mul_y[(size_t)pix * g.ld_mul + col], g.mul_act);
                     g.y[(size_t)pix * g.ldy + col] = v;
                 }
             }
@@ -315,7 +316,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
 
 // y[pix][c] = act( bias[c] + sum_s ws[s][pix][c] ), fixed summation order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, size_t slab, int S, size_t npix, int C,
-                                                            const float* __restrict__ bias, int act, float* __restrict__ y, int ldy) {
+                                                            const float* __restrict__ bias, int act, float* __restrict__ y, int ldy,
+                                                            const float* __restrict__ mul_y, int ld_mul, int mul_act) {
     const int C4 = C >> 2;                              // C % 4 == 0 is a precondition of the split-K path
     const size_t total = npix * (size_t)C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -334,6 +336,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             else if (act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
             else if (act == KPX_ACT_TANH) v = tanhf(v);
             a[j] = v;
+        }
+        if (mul_y) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] *= kpx_act_grad_from_y(mul_y[pix * ld_mul + c + j], mul_act);
         }
         *reinterpret_cast<f32x4*>(y + pix * ldy + c) = a;
     }
@@ -372,7 +378,7 @@ static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
         const size_t npix = (size_t)g.N * g.Ho * g.Wo;
         size_t nb = (npix * (g.Cout / 4) + 255) / 256; if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)g.ws, g.ws_slab, g.ksplit, npix, g.Cout,
-                           g.bias, g.act, g.y, g.ldy);
+                           g.bias, g.act, g.y, g.ldy, g.mul_y, g.ld_mul, g.mul_act);
         return kpx_launch_status();
     }
     // N tile: smallest padded width, ties -> wider tile
@@ -439,7 +445,7 @@ static int launch_gather_conv(const ConvGeom& g, hipStream_t s) {
         const size_t npix = (size_t)g.N * g.Ho * g.Wo;
         size_t nb = (npix * (g.Cout / 4) + 255) / 256; if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)g.ws, g.ws_slab, g.ksplit, npix, g.Cout,
-                           g.bias, g.act, g.y, g.ldy);
+                           g.bias, g.act, g.y, g.ldy, g.mul_y, g.ld_mul, g.mul_act);
         return kpx_launch_status();
     }
     if (g.merge) return launch_gather_conv_v<false, false, true, true>(g, s);
@@ -591,26 +597,61 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
     return launch_gather_conv<false>(g, kpx_stream(stream));
 }
 
+extern "C" int kpx_act_bwd_f32(const float* dy, const float* y, float* dz, size_t n, int act, void* stream);
+
+// dx = dgrad(dy) [* act_in'(y_in)]: the optional factor is the activation backward of the tensor dx is the gradient of (y_in = its ACTIVATED
+// value, same shape as dx).  Fused into the epilogue where the layer runs on the gather kernels; a second pass over dx otherwise.
+static int dgrad_impl(const float* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
+                      float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, int arith,
+                      const float* y_in, int ld_y_in, int act_in, void* workspace, size_t workspace_bytes, void* stream);
+
 extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int Cout, int lddy,
                                     const float* w, int KH, int KW,
                                     float* dx, int Hi, int Wi, int Cin, int lddx,
                                     int stride, int pad_t, int pad_l, int arith, void* workspace, size_t workspace_bytes, void* stream) {
+    return dgrad_impl(dy, N, Ho, Wo, Cout, lddy, w, KH, KW, dx, Hi, Wi, Cin, lddx, stride, pad_t, pad_l, arith, nullptr, 0, KPX_ACT_NONE,
+                      workspace, workspace_bytes, stream);
+}
+
+extern "C" int kpx_conv2d_dgrad_act_f32(const float* dy, int N, int Ho, int Wo, int Cout, int lddy,
+                                        const float* w, int KH, int KW,
+                                        float* dx, int Hi, int Wi, int Cin, int lddx,
+                                        int stride, int pad_t, int pad_l, int arith,
+                                        const float* y_in, int ld_y_in, int act_in, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!y_in || ld_y_in < Cin || (act_in != KPX_ACT_RELU && act_in != KPX_ACT_LRELU)) return KPX_EINVAL;
+    return dgrad_impl(dy, N, Ho, Wo, Cout, lddy, w, KH, KW, dx, Hi, Wi, Cin, lddx, stride, pad_t, pad_l, arith, y_in, ld_y_in, act_in,
+                      workspace, workspace_bytes, stream);
+}
+
+// the specialised data-gradient kernels have no factor in their epilogues: one pass over dx afterwards (contiguous tensors only)
+static int dgrad_act_pass(int rc, float* dx, int N, int Hi, int Wi, int Cin, int lddx, const float* y_in, int ld_y_in, int act_in, void* stream) {
+    if (rc || !y_in) return rc;
+    if (lddx != Cin || ld_y_in != Cin) return KPX_EINVAL;
+    return kpx_act_bwd_f32(dx, y_in, dx, (size_t)N * Hi * Wi * Cin, act_in, stream);
+}
+
+static int dgrad_impl(const float* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
+                      float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, int arith,
+                      const float* y_in, int ld_y_in, int act_in, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dy || !w || !dx || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || lddy < Cout || lddx < Cin || arith < 0 || arith > 1)
         return KPX_EINVAL;
     if (stride > 2) return KPX_EINVAL;             // at most 4 parity classes per launch (the path has strides 1 and 2)
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi &&
         kpx_conv3x3_c16_eligible(N, Hi, Wi, Cout, Cin, lddy, lddx, dy))
-        return kpx_conv3x3_c16_f32(dy, N, Hi, Wi, Cout, lddy, w, 1, nullptr, dx, lddx, KPX_ACT_NONE, nullptr, stream);
+        return dgrad_act_pass(kpx_conv3x3_c16_f32(dy, N, Hi, Wi, Cout, lddy, w, 1, nullptr, dx, lddx, KPX_ACT_NONE, nullptr, stream),
+                              dx, N, Hi, Wi, Cin, lddx, y_in, ld_y_in, act_in, stream);
     if (Cin <= 4) {                                // gradient towards an image: VALU kernel (conv_rgb.hip)
         const int rc = kpx_conv_rgb_dgrad(dy, N, Ho, Wo, Cout, lddy, w, KH, KW, dx, Hi, Wi, Cin, lddx, stride, pad_t, pad_l, kpx_stream(stream));
-        if (rc != -2) return rc;
+        if (rc != -2) return dgrad_act_pass(rc, dx, N, Hi, Wi, Cin, lddx, y_in, ld_y_in, act_in, stream);
     }
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi &&
         workspace && workspace_bytes >= wino_ws_bytes(Cin, Cout) && kpx_wino_eligible(N, Hi, Wi, Cout, Cin, lddy, dy))
-        return kpx_wino_conv3x3(dy, N, Hi, Wi, Cout, lddy, w, Cin, Cout, 1, nullptr, KPX_ACT_NONE, dx, Cin, lddx, (float*)workspace, kpx_stream(stream));
+        return dgrad_act_pass(kpx_wino_conv3x3(dy, N, Hi, Wi, Cout, lddy, w, Cin, Cout, 1, nullptr, KPX_ACT_NONE, dx, Cin, lddx, (float*)workspace, kpx_stream(stream)),
+                              dx, N, Hi, Wi, Cin, lddx, y_in, ld_y_in, act_in, stream);
     ConvGeom g{};
     g.x = dy; g.y = dx; g.w = w; g.bias = nullptr;
+    g.mul_y = y_in; g.ld_mul = ld_y_in; g.mul_act = act_in;
     g.N = N; g.Hi = Ho; g.Wi = Wo; g.Cin = Cout; g.ldx = lddy;       // "input" of the gather = dy
     g.Ho = Hi; g.Wo = Wi; g.Cout = Cin; g.ldy = lddx;                // "output" = dx
     g.osy = stride; g.osx = stride;

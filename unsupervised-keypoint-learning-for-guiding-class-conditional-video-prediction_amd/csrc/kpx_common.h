@@ -41,6 +41,11 @@ __device__ __forceinline__ float kpx_wave_max(float v) {
     return v;
 }
 
+// d(act)/d(pre-activation) from the ACTIVATED value y (relu / leaky relu keep the sign of their argument)
+__device__ __forceinline__ float kpx_act_grad_from_y(float y, int act) {
+    return act == KPX_ACT_RELU ? (y > 0.f ? 1.f : 0.f) : act == KPX_ACT_LRELU ? (y > 0.f ? 1.f : 0.01f) : 1.f;
+}
+
 // Large-LDS kernels need hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per device; `mask` is a per-kernel-family bitmask.
 // Thread-safe: the bit is claimed with an atomic fetch_or (two racing first callers both set the attribute, which is idempotent).
 static inline bool kpx_first_use_on_device(std::atomic<unsigned long long>* mask) {

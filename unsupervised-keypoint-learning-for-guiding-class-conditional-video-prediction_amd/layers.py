@@ -17,10 +17,12 @@ FOLD_BN_INFERENCE = _os.environ.get('KPX_FOLD_BN_INFERENCE', '1') != '0'      # 
 
 
 def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', act=ACT_NONE, cin=None, head31=False, bias_grad=True, bn_stats=False,
-         f43_fwd=True):
+         f43_fwd=True, input_act=ACT_NONE, act_bwd_by_consumer=False):
     """reference layers.conv (layers.py:4-10): tf.pad(pad) + tf.layers.conv2d(padding='same', xavier, bias).
     f43_fwd (a kernel attribute of the LAYER, recorded with its filter variable when the layer is declared): whether the forward of a 3x3
-    stride-1 layer may run the F(4x4,3x3) Winograd kernel (ops.WINO43: an accuracy policy taken from a whole-step measurement)."""
+    stride-1 layer may run the F(4x4,3x3) Winograd kernel (ops.WINO43: an accuracy policy taken from a whole-step measurement).
+    act_bwd_by_consumer / input_act: a contract between two chained layers -- the output of a layer with ``act`` and act_bwd_by_consumer=True
+    is read by exactly ONE layer, declared with input_act=act, whose data gradient applies the activation backward in its epilogue."""
     st = default_store()
     channels = int(channels)          # the reference passes float filter counts after `filters /= 2` ([TF-sem 9])
     cin_ = int(cin) if cin is not None else int(x.shape[-1])
@@ -36,7 +38,8 @@ def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', 
         return Sym(n, ho, wo, channels)
     w_, wg = st.param(kname)
     b_, bg = st.param(bname) if use_bias else (None, None)
-    return ops.conv2d(x, w_, b_, stride=stride, pad=pad, act=act, cin=cin, w_grad_out=wg, b_grad_out=bg, bias_grad=bias_grad, bn_stats=bn_stats)
+    return ops.conv2d(x, w_, b_, stride=stride, pad=pad, act=act, cin=cin, w_grad_out=wg, b_grad_out=bg, bias_grad=bias_grad, bn_stats=bn_stats,
+                      input_act=input_act, act_bwd_by_consumer=act_bwd_by_consumer)
 
 
 def conv1x1_keypoints(x, channels, scope='conv_0'):

@@ -109,11 +109,14 @@ def img_discr(x):
     st = default_store()
     with st.variable_scope('img_discr'):
         channel = 64
-        x = layers.conv(x, channel, kernel=4, stride=2, pad=1, use_bias=True, scope='conv_0', act=ACT_LRELU)
+        # a plain chain: every activated tensor has exactly one consumer, the next conv, whose data gradient applies the leaky-ReLU backward
+        # in its epilogue (layers.conv: act_bwd_by_consumer / input_act)
+        x = layers.conv(x, channel, kernel=4, stride=2, pad=1, use_bias=True, scope='conv_0', act=ACT_LRELU, act_bwd_by_consumer=True)
         for i in range(1, 6):
-            x = layers.conv(x, channel * 2, kernel=4, stride=2, pad=1, use_bias=True, scope='conv_' + str(i), act=ACT_LRELU)
+            x = layers.conv(x, channel * 2, kernel=4, stride=2, pad=1, use_bias=True, scope='conv_' + str(i), act=ACT_LRELU,
+                            input_act=ACT_LRELU, act_bwd_by_consumer=True)
             channel = channel * 2
-        return layers.conv(x, channels=1, kernel=3, stride=1, pad=1, use_bias=False, scope='D_logit', act=ACT_NONE)
+        return layers.conv(x, channels=1, kernel=3, stride=1, pad=1, use_bias=False, scope='D_logit', act=ACT_NONE, input_act=ACT_LRELU)
 
 
 def vae_decoder(x, f_pt, act_code, cell_info, vae_dim, n_pts, n_steps=32):

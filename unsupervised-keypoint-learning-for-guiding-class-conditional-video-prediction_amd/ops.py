@@ -85,6 +85,8 @@ scratch = _Scratch()
 # before the gradient exchange / Adam update.  KPX_SIDE_WGRAD=0 disables it.
 SIDE_WGRAD = _os.environ.get('KPX_SIDE_WGRAD', '1') != '0'
 FUSE_BN_STATS = _os.environ.get('KPX_FUSE_BN_STATS', '1') != '0'     # batch statistics from the conv epilogue
+# the discriminator's leaky-ReLU backward in the epilogue of the data gradient above it (kpx_conv2d_dgrad_act_f32) instead of a pass of its own
+FUSE_ACT_BWD = _os.environ.get('KPX_FUSE_ACT_BWD', '1') != '0' 
 # batch-norm backward sums from the dgrad epilogue: built and tested, OFF by default -- measured 31.4-31.7 ms per step against
 # 31.3 ms without it: the reduction passes it removes ran concurrently with the weight-gradient stream, while the longer
 # epilogue sits on the MFMA-bound critical path
@@ -167,7 +169,7 @@ def reset_after_failed_capture():
 def graph_knobs():
     """Everything besides the input shape that a captured step freezes: the compute dtype and the module-level kernel-selection
     switches.  Part of the graph cache keys, so that flipping one re-captures instead of replaying the old arithmetic."""
-    return (_compute_dtype[0], SIDE_WGRAD, FUSE_BN_STATS, FUSE_BN_BWD, FORK_BEFORE_DGRAD, WINO43, WINO43_FWD_ALL, WINO43_EXCLUDE_FWD, WINO43_EXCLUDE_DGRAD,
+    return (_compute_dtype[0], SIDE_WGRAD, FUSE_BN_STATS, FUSE_BN_BWD, FUSE_ACT_BWD, FORK_BEFORE_DGRAD, WINO43, WINO43_FWD_ALL, WINO43_EXCLUDE_FWD, WINO43_EXCLUDE_DGRAD,
             WINO43_MIN_WORKGROUPS, WINO43_NMIN)
 
 
@@ -462,11 +464,22 @@ def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act, want_s
           'kpx_conv2d_fwd_f32')
 
 
-def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l, bn_src=None):
+def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l, bn_src=None, mul=None):
     """bn_src = (y, beta) of the ReLU'd batch norm whose output this convolution read: when the layer runs on the fused Winograd kernel
-    its epilogue also reduces that batch norm's backward sums; returns (slab, tiles per image) then, else None."""
+    its epilogue also reduces that batch norm's backward sums; returns (slab, tiles per image) then, else None.
+    mul = (y_in, act): dx is the gradient of the ACTIVATED tensor y_in (the convolution's input); its activation backward is applied in the
+    data-gradient epilogue (kpx_conv2d_dgrad_act_f32) -- the producer of y_in then skips its own pass."""
     n, ho, wo = dy.shape[0], dy.shape[1], dy.shape[2]
     kh, kw, _, cout = w.shape
+    if mul is not None:
+        y_in, act_in = mul
+        nbytes = lib.kpx_conv2d_dgrad_workspace_bytes(n, dx.shape[1], dx.shape[2], cin, cout, kh, kw, stride)
+        ws = scratch.get('splitk', nbytes, dy.device) if nbytes else None
+        check(lib.kpx_conv2d_dgrad_act_f32(dy.data_ptr(), n, ho, wo, cout, lddy, w.data_ptr(), kh, kw,
+                                           dx.data_ptr(), dx.shape[1], dx.shape[2], cin, lddx, stride, pad_t, pad_l, _arith(),
+                                           y_in.data_ptr(), y_in.shape[3], act_in,
+                                           ws.data_ptr() if ws is not None else None, nbytes, _stream()), 'kpx_conv2d_dgrad_act_f32')
+        return
     if (_compute_dtype[0] == 'bf16' and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cout >= 8
             and dx.shape[1] == ho and dx.shape[2] == wo and _bf16_conv(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True)):
         return
@@ -538,8 +551,16 @@ class Conv2dFn(torch.autograd.Function):
     """layers.conv: tf.pad(pad) + conv2d(SAME) + bias [+ activation] (reference models/networks/layers.py:4-10)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad, bn_stats=False, bn_src=None):
+    def forward(ctx, x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad, bn_stats=False, bn_src=None, input_act=ACT_NONE,
+                act_bwd_by_consumer=False):
+        # input_act: x is the activated output of a layer declared with act_bwd_by_consumer=True -- this layer's data gradient applies that
+        # activation's backward in its epilogue (it saves x anyway) and the producer skips its own pass.  A static contract between the two
+        # layers, declared where the network is built (networks.img_discr): x must have NO other consumer.
         x, ldx = _nhwc(x)
+        ctx.input_act = input_act if (input_act != ACT_NONE and x.is_contiguous() and (cin is None or cin == x.shape[3])) else ACT_NONE
+        if input_act != ACT_NONE and ctx.input_act == ACT_NONE:
+            raise _lib.KpxError('input_act needs the whole contiguous activated tensor as the convolution input')
+        ctx.act_bwd_by_consumer = bool(act_bwd_by_consumer) and act != ACT_NONE
         ctx.bn_src = bn_src if (bn_src is not None and x.is_contiguous() and (cin is None or cin == x.shape[3])) else None
         _require_gpu(w)
         w = w.contiguous()
@@ -566,7 +587,7 @@ class Conv2dFn(torch.autograd.Function):
         stride, pad_t, pad_l, act, cin, ldx = ctx.geom
         dy = dy.contiguous()
         cout = w.shape[3]
-        if act != ACT_NONE:
+        if act != ACT_NONE and not ctx.act_bwd_by_consumer:
             dz = torch.empty_like(dy)          # the incoming gradient tensor is not ours to overwrite
             act_bwd_raw(dy, y, dz, act)
             dy = dz
@@ -590,7 +611,8 @@ class Conv2dFn(torch.autograd.Function):
             if cin < cx:
                 fill_raw_(dx, 0.0)
             st = conv_dgrad_raw(dy, cout, w, dx, cx, cin, stride, pad_t, pad_l,
-                                bn_src=(x, ctx.bn_src[0]) if ctx.bn_src is not None else None)
+                                bn_src=(x, ctx.bn_src[0]) if ctx.bn_src is not None else None,
+                                mul=(x, ctx.input_act) if ctx.input_act != ACT_NONE else None)
             if st is not None:
                 _pending_bwd_stats[dx.data_ptr()] = (st[0], st[1], ctx.bn_src[1])
         if side:
@@ -621,7 +643,7 @@ class Conv2dFn(torch.autograd.Function):
                 if ctx.b_grad_out is not None and not direct:
                     axpy_raw_(ctx.b_grad_out, db_buf)
                 db = None if ctx.b_grad_out is not None else db_buf
-        return dx, dw, db, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
 
 
 _pending_stats = {}      # output data_ptr -> (tile-statistics slab, tiles per image), handed from Conv2dFn.forward to conv2d()
@@ -630,12 +652,14 @@ _bn_counter = [0]
 fused_bn_uses = {'stats_from_conv_epilogue': 0, 'backward_sums_from_dgrad_epilogue': 0}    # diagnostics: how often the fused paths ran
 
 
-def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, cin=None, w_grad_out=None, b_grad_out=None, bias_grad=True, bn_stats=False):
+def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, cin=None, w_grad_out=None, b_grad_out=None, bias_grad=True, bn_stats=False,
+           input_act=ACT_NONE, act_bwd_by_consumer=False):
     """bias_grad=False: the bias gradient is known to be exactly zero (conv feeding a batch norm) and is not computed.
     bn_stats=True: a train-mode batch norm consumes the output next; when the layer runs on the fused Winograd kernel its epilogue
     also writes the per-tile channel sums, which ``batch_norm`` then uses instead of a statistics pass over the activation."""
     y = Conv2dFn.apply(x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad, bn_stats and FUSE_BN_STATS,
-                       getattr(x, '_kpx_bn', None) if FUSE_BN_BWD else None)
+                       getattr(x, '_kpx_bn', None) if FUSE_BN_BWD else None, input_act if FUSE_ACT_BWD else ACT_NONE,
+                       act_bwd_by_consumer and FUSE_ACT_BWD)
     if bn_stats:
         st = _pending_stats.pop(y.data_ptr(), None)
         if st is not None:
