@@ -205,7 +205,14 @@ int kpx_bn_train_fwd_f32(const float* x, size_t P, int groups, int C, int ldx, c
                          float* moving_mean, float* moving_var, float decay, float* y, int ldy, int act, void* scratch, void* stream);
 int kpx_bn_train_bwd_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int groups, int C,
                          const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
-                         float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* scratch, void* stream);
+                         float* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
+                         const float* tile_stats, size_t tiles_per_group, void* scratch, void* stream);
+/* (backward tile_stats, or NULL: per-tile sum(dz), sum(dz * (y - beta)) written by the epilogue of the data-gradient kernel that produced dy --
+ *  kpx_conv3x3_wino43_bnbwd_stats_f32 / kpx_conv3x3_wino_bnbwd_stats_f32, tiles_per_group tiles per group -- instead of the reduction pass over
+ *  (dy, x); dy must then already be zero wherever the batch norm's ReLU output is, which those kernels guarantee.) */
+int kpx_conv3x3_wino43_bnbwd_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u,
+                                       float* out, int Nn, int ldout, const float* bn_y, int ld_bn_y, const float* bn_beta,
+                                       float* tile_stats, void* stream);
 /* Inference-mode batch norm folded into the convolution in front of it (is_training = False: reference keypoint_model.py:48-50,
  * final_model.py:62,68,95): w_out[r][c] = w[r][c] * s[c], b_out[c] = (bias[c] - moving_mean[c]) * s[c] + beta[c] with
  * s = gamma * rsqrt(moving_var + eps); w = [rows = kh*kw*Cin][C] (HWIO), bias may be NULL.  conv(x, w_out) + b_out followed by ReLU then

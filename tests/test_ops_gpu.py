@@ -644,10 +644,13 @@ def test_batch_norm_statistics_from_the_conv_epilogue(kpx, dev, monkeypatch, n, 
     assert rel_l2(t2n(out1), t2n(want)) < 1e-5
 
 
-@pytest.mark.parametrize('n,h,w,c0,c1,c2,groups', [(4, 32, 32, 32, 64, 48, 1), (4, 16, 32, 64, 32, 64, 2), (2, 64, 64, 64, 128, 128, 1)])
-def test_batch_norm_backward_sums_from_the_dgrad_epilogue(kpx, dev, n, h, w, c0, c1, c2, groups):
-    """conv_a -> BN+ReLU -> conv_b: the data gradient of conv_b (Winograd kernel) also reduces BN's backward sums
-    (kpx_conv3x3_wino_bnbwd_stats_f32 + kpx_bn_bwd_from_tiles_f32).  Gradients wrt the input, gamma, beta and conv_a's filter
+@pytest.mark.parametrize('n,h,w,c0,c1,c2,groups,f43', [(4, 32, 32, 32, 64, 48, 1, False), (4, 16, 32, 64, 32, 64, 2, False), (2, 64, 64, 64, 128, 128, 1, False),
+                                                      (4, 32, 32, 32, 64, 48, 1, True), (4, 16, 32, 64, 128, 64, 2, True), (2, 64, 64, 64, 128, 128, 1, True),
+                                                      (2, 128, 128, 16, 64, 64, 2, True)])
+def test_batch_norm_backward_sums_from_the_dgrad_epilogue(kpx, dev, n, h, w, c0, c1, c2, groups, f43):
+    """conv_a -> BN+ReLU -> conv_b: the data gradient of conv_b (Winograd kernel) also reduces BN's backward sums in its epilogue --
+    F(2x2,3x3): kpx_conv3x3_wino_bnbwd_stats_f32, F(4x4,3x3): kpx_conv3x3_wino43_bnbwd_stats_f32 (which also stores the ReLU-masked gradient) --
+    and kpx_bn_train_bwd_f32 takes the per-tile sums instead of its reduction pass.  Gradients wrt the input, gamma, beta and conv_a's filter
     against torch autograd over the oracle, and against the path with the separate reduction pass."""
     ops = kpx.ops
     rs = np.random.RandomState(c0 + c1 + c2)
@@ -657,31 +660,32 @@ def test_batch_norm_backward_sums_from_the_dgrad_epilogue(kpx, dev, n, h, w, c0,
     gy = rs.randn(n, h, w, c2).astype(np.float32)
 
     def run(fused):
-        ops.FUSE_BN_BWD = True                  # (off by default: slower on the train step, see ops.py)
-        keep43, ops.WINO43 = ops.WINO43, False  # the fused reduction lives in the F(2x2,3x3) epilogue: keep every layer of this test on it
+        keep, keep43 = ops.FUSE_BN_BWD, ops.WINO43
+        ops.FUSE_BN_BWD, ops.WINO43 = fused, f43   # (which Winograd kernel takes conv_b's data gradient)
         try:
             return _run(fused)
         finally:
-            ops.FUSE_BN_BWD = False
-            ops.WINO43 = keep43
+            ops.FUSE_BN_BWD, ops.WINO43 = keep, keep43
 
     def _run(fused):
         t = {k_: torch.from_numpy(v).to(dev).requires_grad_(True) for k_, v in dict(x=x, wa=wa, wb=wb, ga=ga, be=be).items()}
-        keys = ops.register_constant_filter(t['wa'].detach()) + (ops.register_constant_filter(t['wb'].detach()) if fused else [])
+        keys = ops.register_constant_filter(t['wa'].detach()) + ops.register_constant_filter(t['wb'].detach())
         try:
             ya = ops.conv2d(t['x'], t['wa'], None, stride=1, pad=0, act=0, bn_stats=True)
             mm, mv = torch.zeros(c1, device=dev), torch.ones(c1, device=dev)
             yb = ops.batch_norm(ya, t['ga'], t['be'], mm, mv, train=True, act=1, groups=groups)
             out = ops.conv2d(yb, t['wb'], None, stride=1, pad=0, act=0)
             ops.begin_backward()
-            used = ops.fused_bn_uses['backward_sums_from_dgrad_epilogue']
+            used, used43 = ops.fused_bn_uses['backward_sums_from_dgrad_epilogue'], ops.conv_kernel_uses['wino43']
             out.backward(torch.from_numpy(gy).to(dev))
             hit = ops.fused_bn_uses['backward_sums_from_dgrad_epilogue'] - used
+            if fused:                            # the data gradient of conv_b ran on the kernel this case is about
+                assert (ops.conv_kernel_uses['wino43'] - used43 >= 1) == (f43 and c1 % 64 == 0 and w % 32 == 0), (f43, ops.conv_kernel_uses['wino43'] - used43)
         finally:
             ops.release_filters(keys)
         return {k_: t2n(v.grad) for k_, v in t.items()}, t2n(out), hit
     g1, o1, hit1 = run(True)
-    g0, o0, hit0 = run(False)          # conv_b not pre-transformed: direct path, batch norm reduces its own sums
+    g0, o0, hit0 = run(False)          # the same kernels without the sums: batch norm makes its own reduction pass
     assert hit1 == groups and hit0 == 0
     to = {k_: torch.from_numpy(v).requires_grad_(True) for k_, v in dict(x=x, wa=wa, wb=wb, ga=ga, be=be).items()}
     za = R.conv(to['x'], to['wa'], None, 1, 0)
@@ -690,9 +694,12 @@ def test_batch_norm_backward_sums_from_the_dgrad_epilogue(kpx, dev, n, h, w, c0,
     oo = R.conv(zb, to['wb'], None, 1, 0)
     oo.backward(torch.from_numpy(gy))
     assert rel_l2(o1, t2n(oo)) < 1e-5
+    # F(4x4,3x3)'s rounding error is input-correlated, and these zero-mean test tensors make the channel sums cancel to ~1 % of their terms:
+    # the oracle bound is looser there; fused vs separate reduction on the SAME kernels is held tight either way
+    tol = 2e-5 if f43 else 2e-6       # (measured: 3.3e-6 / 5.5e-7)
     for k_ in ('x', 'wa', 'wb', 'ga', 'be'):
-        assert rel_l2(g1[k_], t2n(to[k_].grad)) < 2e-4, (k_, rel_l2(g1[k_], t2n(to[k_].grad)))
-        assert rel_l2(g1[k_], g0[k_]) < 2e-4, (k_, rel_l2(g1[k_], g0[k_]))
+        assert rel_l2(g1[k_], t2n(to[k_].grad)) < tol, (k_, rel_l2(g1[k_], t2n(to[k_].grad)))
+        assert rel_l2(g1[k_], g0[k_]) < 2e-5, (k_, rel_l2(g1[k_], g0[k_]))
 
 
 @pytest.mark.parametrize('b,h,w,c,pooled', [(2, 16, 16, 8, True), (3, 10, 14, 12, True), (2, 7, 9, 4, True), (2, 8, 8, 16, False)])
@@ -818,7 +825,7 @@ def test_batched_batch_norm_equals_one_call_per_group_bit_for_bit(kpx, dev, n, h
                                            gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), invstd.data_ptr(), mm.data_ptr(), mv.data_ptr(), 0.999,
                                            y.data_ptr(), c, 1, sc.data_ptr(), st), 'train_fwd')
             check(lib.kpx_bn_train_bwd_f32(dy.data_ptr(), c, x.data_ptr(), c, pix, groups, c, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1,
-                                           dx.data_ptr(), c, dg.data_ptr(), db.data_ptr(), 1, sc.data_ptr(), st), 'train_bwd')
+                                           dx.data_ptr(), c, dg.data_ptr(), db.data_ptr(), 1, None, 0, sc.data_ptr(), st), 'train_bwd')
         torch.cuda.synchronize()
         out[mode] = [t2n(t).copy() for t in (y, mean, invstd, mm, mv, dx, dg, db)]
     for a, b, name in zip(out['per_group'], out['batched'], ('y', 'mean', 'invstd', 'moving_mean', 'moving_var', 'dx', 'dgamma', 'dbeta')):

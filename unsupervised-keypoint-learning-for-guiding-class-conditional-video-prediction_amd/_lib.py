@@ -75,7 +75,8 @@ SIGNATURES = {
     'kpx_bn_fold_conv_f32': (c_int, [P, P, c_size_t, c_int, P, P, P, P, c_float, P, P, P]),
     'kpx_bn_train_scratch_bytes': (c_size_t, [c_int, c_int]),
     'kpx_bn_train_fwd_f32': (c_int, [P, c_size_t, c_int, c_int, c_int, P, c_size_t, c_float, P, P, P, P, P, P, c_float, P, c_int, c_int, P, P]),
-    'kpx_bn_train_bwd_f32': (c_int, [P, c_int, P, c_int, c_size_t, c_int, c_int, P, P, P, P, c_int, P, c_int, P, P, c_int, P, P]),
+    'kpx_bn_train_bwd_f32': (c_int, [P, c_int, P, c_int, c_size_t, c_int, c_int, P, P, P, P, c_int, P, c_int, P, P, c_int, P, c_size_t, P, P]),
+    'kpx_conv3x3_wino43_bnbwd_stats_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, c_int, P, P, P]),
     'kpx_bn_apply_f32': (c_int, [P, c_size_t, c_int, c_int, P, P, P, P, P, c_int, c_int, P]),
     'kpx_bn_bwd_f32': (c_int, [P, c_int, P, c_int, c_size_t, c_int, P, P, P, P, c_int, P, c_int, P, P, c_int, P, P]),
     'kpx_resize2x_fwd_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),

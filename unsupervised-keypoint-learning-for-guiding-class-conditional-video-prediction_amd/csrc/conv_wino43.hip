@@ -35,8 +35,9 @@ struct Wino43Geom {
     int tiles_y, tiles_x;                    // 16 x 32-pixel regions per image
     const float* mask_y; int ld_mask;        // optional: zero the output where mask_y <= 0 (the ReLU backward of the tensor this gradient belongs to)
     float* pool_y; int ld_pool;              // optional: also write the 2x2 max-pool of the (activated) output
-    float* stats;                            // STATS: [N * tiles_y * tiles_x * 8 strips of 4 x 16 pixels][2][Cout] sum / sum of squares of the output
-};
+    float* stats;                            // STATS 1: [N * tiles_y * tiles_x * 8 strips of 4 x 16 pixels][2][Cout] sum / sum of squares of the output
+    const float* bn_beta;                    // STATS 2 (data gradient feeding a ReLU'd batch norm whose output is mask_y): per strip sum(dz), sum(dz * (y - beta)),
+};                                           //          dz = out where mask_y > 0 else 0; the masked gradient is what gets stored
 
 
 // U[p = 6 i + j][c][n] = (G g G^T)[i][j] in the fragment order of conv_wino.hip (Uf[p][kc][nb][lh][li][4]).
@@ -49,35 +50,38 @@ __device__ __forceinline__ void w43_transform_filter(const float* __restrict__ w
     const int nb = (int)(blk % NB), kc = (int)(blk / NB);
     const int c = 8 * kc + 4 * lh + j, n = 32 * nb + li;
     const bool real = c < K && n < Nn;
-    float g[3][3];
+    // In DOUBLE precision, rounded once at the end: G's entries (1/6, 1/12, 1/24) are not representable, and an error in U is the SAME for
+    // every tile of the layer -- a systematic, input-correlated output error that sums over pixels do not average out (it showed as 6e-4 in
+    // the bias / batch-norm gradient sums of a zero-mean test tensor).  The transform runs once per optimiser update: its cost is irrelevant.
+    double g[3][3];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int q = 0; q < 3; ++q)
-            g[r][q] = !real ? 0.f : (dg ? w[((size_t)((2 - r) * 3 + (2 - q)) * Cin + n) * Cout + c] : w[((size_t)(r * 3 + q) * Cin + c) * Cout + n]);
+            g[r][q] = !real ? 0.0 : (double)(dg ? w[((size_t)((2 - r) * 3 + (2 - q)) * Cin + n) * Cout + c] : w[((size_t)(r * 3 + q) * Cin + c) * Cout + n]);
     // rows of G: [1/4,0,0], [-1/6,-1/6,-1/6], [-1/6,1/6,-1/6], [1/24,1/12,1/6], [1/24,-1/12,1/6], [0,0,1]
-    float t[6][3];
+    double t[6][3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        const float a = g[0][q], b = g[1][q], c2 = g[2][q];
-        t[0][q] = 0.25f * a;
-        t[1][q] = (-1.0f / 6.0f) * (a + b + c2);
-        t[2][q] = (-1.0f / 6.0f) * (a - b + c2);
-        t[3][q] = (1.0f / 24.0f) * a + (1.0f / 12.0f) * b + (1.0f / 6.0f) * c2;
-        t[4][q] = (1.0f / 24.0f) * a - (1.0f / 12.0f) * b + (1.0f / 6.0f) * c2;
+        const double a = g[0][q], b = g[1][q], c2 = g[2][q];
+        t[0][q] = 0.25 * a;
+        t[1][q] = (-1.0 / 6.0) * (a + b + c2);
+        t[2][q] = (-1.0 / 6.0) * (a - b + c2);
+        t[3][q] = (1.0 / 24.0) * a + (1.0 / 12.0) * b + (1.0 / 6.0) * c2;
+        t[4][q] = (1.0 / 24.0) * a - (1.0 / 12.0) * b + (1.0 / 6.0) * c2;
         t[5][q] = c2;
     }
     const size_t pstride = (size_t)KC * NB * 256;
     float* o = Uf + blk * 256 + (idx & 255);
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const float a = t[i][0], b = t[i][1], c2 = t[i][2];
-        o[(size_t)(i * 6 + 0) * pstride] = 0.25f * a;
-        o[(size_t)(i * 6 + 1) * pstride] = (-1.0f / 6.0f) * (a + b + c2);
-        o[(size_t)(i * 6 + 2) * pstride] = (-1.0f / 6.0f) * (a - b + c2);
-        o[(size_t)(i * 6 + 3) * pstride] = (1.0f / 24.0f) * a + (1.0f / 12.0f) * b + (1.0f / 6.0f) * c2;
-        o[(size_t)(i * 6 + 4) * pstride] = (1.0f / 24.0f) * a - (1.0f / 12.0f) * b + (1.0f / 6.0f) * c2;
-        o[(size_t)(i * 6 + 5) * pstride] = c2;
+        const double a = t[i][0], b = t[i][1], c2 = t[i][2];
+        o[(size_t)(i * 6 + 0) * pstride] = (float)(0.25 * a);
+        o[(size_t)(i * 6 + 1) * pstride] = (float)((-1.0 / 6.0) * (a + b + c2));
+        o[(size_t)(i * 6 + 2) * pstride] = (float)((-1.0 / 6.0) * (a - b + c2));
+        o[(size_t)(i * 6 + 3) * pstride] = (float)((1.0 / 24.0) * a + (1.0 / 12.0) * b + (1.0 / 6.0) * c2);
+        o[(size_t)(i * 6 + 4) * pstride] = (float)((1.0 / 24.0) * a - (1.0 / 12.0) * b + (1.0 / 6.0) * c2);
+        o[(size_t)(i * 6 + 5) * pstride] = (float)c2;
     }
 }
 __global__ __launch_bounds__(256) void wino43_filter_transform_batch_kernel(const KpxWino43Desc* __restrict__ descs) {
@@ -386,7 +390,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
     const size_t cstr = (size_t)g.ldy, rstr = (size_t)g.W * g.ldy;
     const bool fast = (g.ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.y) & 15) == 0) && n0 + 64 <= g.Cout;    // block-uniform
     f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
-    if (fast && !STATS && (g.mask_y || g.pool_y)) {              // block-uniform: VGG19's fused ReLU backward / max-pool forward
+    if (STATS == 2) {
+        // data gradient dz of a ReLU'd batch norm's output z (= mask_y): store dz * [z > 0] and reduce this batch norm's backward sums
+        // sum(dz), sum(dz * (z - beta)) (x_hat = (z - beta) / gamma wherever z > 0; the finalize divides by gamma) -- the separate reduction
+        // pass over (dz, y) of kpx_bn_train_bwd_f32 is then not needed.  Launch preconditions (checked by the entry): fast stores, no bias / act.
+        const float* const mbase = g.mask_y + ((size_t)(on * g.H + oy) * g.W + ox) * g.ld_mask + c0o;
+        const size_t mc = (size_t)g.ld_mask, mr = (size_t)g.W * g.ld_mask;
+        const f32x4 be = *reinterpret_cast<const f32x4*>(g.bn_beta + c0o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 zm[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) zm[j] = *reinterpret_cast<const f32x4*>(mbase + i * mr + j * mc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float dz = zm[j][q] > 0.f ? Y[i][j][q] : 0.f;
+                    v[q] = dz; st_s[q] += dz; st_q[q] += dz * (zm[j][q] - be[q]);
+                }
+                *reinterpret_cast<f32x4*>(obase + i * rstr + j * cstr) = v;
+            }
+        }
+    } else if (fast && !STATS && (g.mask_y || g.pool_y)) {       // block-uniform: VGG19's fused ReLU backward / max-pool forward
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -451,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const Wino43Geom g)
                 for (int q = 0; q < 4; ++q) if (c0o + q < g.Cout) o[q] = v[q];
             }
     }
-    if (STATS) {
+    if (STATS != 0) {
         // batch-norm statistics: this wavefront's 64 threads cover one 4 x 16-pixel strip (4 tiles) x 64 couts; the 4 tiles are the lane
         // bits 4-5, added in a fixed butterfly order, so the slab -- and everything derived from it -- is bitwise reproducible.
 #pragma unroll
@@ -499,12 +526,13 @@ extern "C" int kpx_wino43_filter_transform_batch_f32(const void* descs_dev, int 
 }
 static int w43_launch(const float* in, int N, int H, int W, int K, int ldin, const float* U, const float* bias,
                       float* out, int Nn, int ldout, int act, float* tile_stats, void* stream,
-                      const float* mask_y = nullptr, int ld_mask = 0, float* pool_y = nullptr, int ld_pool = 0) {
+                      const float* mask_y = nullptr, int ld_mask = 0, float* pool_y = nullptr, int ld_pool = 0, const float* bn_beta = nullptr) {
     if (!in || !U || !out || ldin < K || ldout < Nn || act < 0 || act > 2 || !kpx_conv3x3_wino43_eligible(N, H, W, K, Nn, ldin, in)) return KPX_EINVAL;
     if (kpx_first_use_on_device(&w43_attr_mask)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel<0, false>), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, w43_lds_bytes());
         if (e != hipSuccess) return -(int)e;
     }
     Wino43Geom g{};
@@ -515,9 +543,10 @@ static int w43_launch(const float* in, int N, int H, int W, int K, int ldin, con
     if (pack && tile_stats) return KPX_EINVAL;           // (no batch-norm layer of the path is 16 x 16 with a forward on this kernel)
     g.tiles_y = H / 16; g.tiles_x = pack ? 1 : W / 32;
     g.stats = tile_stats;
-    g.mask_y = mask_y; g.ld_mask = ld_mask; g.pool_y = pool_y; g.ld_pool = ld_pool;
+    g.mask_y = mask_y; g.ld_mask = ld_mask; g.pool_y = pool_y; g.ld_pool = ld_pool; g.bn_beta = bn_beta;
     const unsigned blocks = (unsigned)((size_t)(pack ? N / 2 : N) * g.tiles_y * g.tiles_x * (g.Np / 64));
     if (pack) hipLaunchKernelGGL((conv_wino43_kernel<0, true>), dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
+    else if (tile_stats && bn_beta) hipLaunchKernelGGL((conv_wino43_kernel<2, false>), dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
     else if (tile_stats) hipLaunchKernelGGL((conv_wino43_kernel<1, false>), dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
     else hipLaunchKernelGGL((conv_wino43_kernel<0, false>), dim3(blocks), dim3(512), w43_lds_bytes(), kpx_stream(stream), g);
     return kpx_launch_status();
@@ -545,4 +574,17 @@ extern "C" int kpx_conv3x3_wino43_ex_f32(const float* in, int N, int H, int W, i
         (pool_y && (ld_pool % 4 || ld_pool < Nn || (((uintptr_t)pool_y) & 15) || (H & 1) || (W & 1))))
         return KPX_EINVAL;
     return w43_launch(in, N, H, W, K, ldin, U, bias, out, Nn, ldout, act, nullptr, stream, mask_y, ld_mask, pool_y, ld_pool);
+}
+
+// Data gradient towards a ReLU'd batch norm's output (the tensor `bn_y` this convolution read in the forward pass): out = dgrad * [bn_y > 0]
+// and tile_stats[strip][2][Nn] = per 4 x 16-pixel strip sum(out), sum(out * (bn_y - beta)) -- kpx_bn_train_bwd_f32 takes them instead of
+// its own reduction pass (tf.gradients of tf.contrib.layers.batch_norm + tf.nn.relu, models/networks/layers.py:13-14 behind
+// models/networks/__init__.py:10-24).  Nn a multiple of 64, H % 16 == 0, W % 32 == 0, 16-B aligned rows.
+extern "C" int kpx_conv3x3_wino43_bnbwd_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* U,
+                                                  float* out, int Nn, int ldout, const float* bn_y, int ld_bn_y, const float* bn_beta,
+                                                  float* tile_stats, void* stream) {
+    if (!tile_stats || !bn_y || !bn_beta || Nn % 64 || ldout % 4 || (((uintptr_t)out) & 15) || ld_bn_y % 4 || ld_bn_y < Nn || (((uintptr_t)bn_y) & 15) ||
+        (((uintptr_t)bn_beta) & 15) || W == 16)
+        return KPX_EINVAL;
+    return w43_launch(in, N, H, W, K, ldin, U, nullptr, out, Nn, ldout, KPX_ACT_NONE, tile_stats, stream, bn_y, ld_bn_y, nullptr, 0, bn_beta);
 }

@@ -665,7 +665,8 @@ extern "C" int kpx_bn_train_fwd_f32(const float* x, size_t P, int groups, int C,
     return 0;
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_groups_kernel(const double* part, size_t part_gstride, int nb, int groups, int C,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_groups_kernel(const double* part, size_t part_gstride, int nb, const float* __restrict__ ts, size_t tiles_per_group,
+                                                                     const float* __restrict__ gamma, int groups, int C,
                                                                      float* dgamma, float* dbeta, float* sums, int accumulate) {
     const int c = blockIdx.x, sg = threadIdx.x >> 8, t = threadIdx.x & 255, nseg = blockDim.x >> 8;
     __shared__ double sm[4][2][4];
@@ -673,10 +674,18 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_groups_kernel(const doub
         const int g = g0 + sg;
         double a0 = 0.0, a1 = 0.0;
         if (g < groups) {
-            const double* gp = part + (size_t)g * part_gstride;
-            for (int b = t; b < nb; b += 256) {
-                a0 += gp[((size_t)b * 2) * C + c];
-                a1 += gp[((size_t)b * 2 + 1) * C + c];
+            if (ts) {                                      // per-tile sums from the data-gradient epilogue that produced dy: sum(dz), sum(dz * (y - beta))
+                const size_t t0 = (size_t)g * tiles_per_group;
+                for (size_t b = t; b < tiles_per_group; b += 256) {
+                    a0 += (double)ts[((t0 + b) * 2) * C + c];
+                    a1 += (double)ts[((t0 + b) * 2 + 1) * C + c];
+                }
+            } else {
+                const double* gp = part + (size_t)g * part_gstride;
+                for (int b = t; b < nb; b += 256) {
+                    a0 += gp[((size_t)b * 2) * C + c];
+                    a1 += gp[((size_t)b * 2 + 1) * C + c];
+                }
             }
         }
         a0 = kpx_wave_sum_d(a0);
@@ -686,7 +695,9 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_groups_kernel(const doub
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int j = 0; j < nseg && g0 + j < groups; ++j) {
-                const double s = (sm[j][0][0] + sm[j][0][1]) + (sm[j][0][2] + sm[j][0][3]), q = (sm[j][1][0] + sm[j][1][1]) + (sm[j][1][2] + sm[j][1][3]);
+                const double s = (sm[j][0][0] + sm[j][0][1]) + (sm[j][0][2] + sm[j][0][3]);
+                double q = (sm[j][1][0] + sm[j][1][1]) + (sm[j][1][2] + sm[j][1][3]);
+                if (ts) { const double ga = (double)gamma[c]; q = ga != 0.0 ? q / ga : 0.0; }      // x_hat = (y - beta) / gamma wherever dz != 0
                 if (accumulate || g0 + j > 0) { dbeta[c] += (float)s; dgamma[c] += (float)q; } else { dbeta[c] = (float)s; dgamma[c] = (float)q; }
                 sums[(size_t)(g0 + j) * 2 * C + c] = (float)s; sums[(size_t)(g0 + j) * 2 * C + C + c] = (float)q;
             }
@@ -695,18 +706,23 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_groups_kernel(const doub
 }
 extern "C" int kpx_bn_train_bwd_f32(const float* dy, int lddy, const float* x, int ldx, size_t P, int groups, int C,
                                     const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
-                                    float* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* scratch, void* stream) {
+                                    float* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
+                                    const float* tile_stats, size_t tiles_per_group, void* scratch, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !scratch || groups <= 0 || groups > 65535 || C <= 0 ||
-        ldx < C || lddy < C || lddx < C || act < 0 || act > 1 || P == 0)
+        ldx < C || lddy < C || lddx < C || act < 0 || act > 1 || P == 0 || (tile_stats && (act != KPX_ACT_RELU || tiles_per_group == 0)))
         return KPX_EINVAL;
     hipStream_t s = kpx_stream(stream);
     const size_t gstride = (size_t)KPX_RED_BLOCKS * 2 * C;
-    RedArgs a{}; a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.P = P; a.C = C;
-    a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.act = act; a.part = (double*)scratch; a.part_gstride = gstride;
-    int nb; int rc = launch_chan_reduce(2, a, &nb, s, groups);
-    if (rc) return rc;
+    int nb = 0, rc = 0;
+    if (!tile_stats) {                                   // (with tile_stats the data-gradient epilogue that produced dy already reduced the two sums)
+        RedArgs a{}; a.x = x; a.ldx = ldx; a.dy = dy; a.lddy = lddy; a.P = P; a.C = C;
+        a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.act = act; a.part = (double*)scratch; a.part_gstride = gstride;
+        rc = launch_chan_reduce(2, a, &nb, s, groups);
+        if (rc) return rc;
+    }
     float* sums = reinterpret_cast<float*>((double*)scratch + (size_t)groups * gstride);          // [groups][2][C] behind the partials
-    hipLaunchKernelGGL(bn_bwd_finalize_groups_kernel, dim3(C), dim3(256 * (groups < 4 ? groups : 4)), 0, s, (const double*)scratch, gstride, nb, groups, C, dgamma, dbeta, sums, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_groups_kernel, dim3(C), dim3(256 * (groups < 4 ? groups : 4)), 0, s, (const double*)scratch, gstride, nb, tile_stats, tiles_per_group,
+                       gamma, groups, C, dgamma, dbeta, sums, accumulate);
     if ((rc = kpx_launch_status())) return rc;
     const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && (lddy % 4 == 0) && (lddx % 4 == 0) && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx)) & 15) == 0;
     const float inv_count = (float)(1.0 / (double)P);

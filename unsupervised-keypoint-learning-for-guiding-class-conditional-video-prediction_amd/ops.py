@@ -87,10 +87,10 @@ SIDE_WGRAD = _os.environ.get('KPX_SIDE_WGRAD', '1') != '0'
 FUSE_BN_STATS = _os.environ.get('KPX_FUSE_BN_STATS', '1') != '0'     # batch statistics from the conv epilogue
 # the discriminator's leaky-ReLU backward in the epilogue of the data gradient above it (kpx_conv2d_dgrad_act_f32) instead of a pass of its own
 FUSE_ACT_BWD = _os.environ.get('KPX_FUSE_ACT_BWD', '1') != '0' 
-# batch-norm backward sums from the dgrad epilogue: built and tested, OFF by default -- measured 31.4-31.7 ms per step against
-# 31.3 ms without it: the reduction passes it removes ran concurrently with the weight-gradient stream, while the longer
-# epilogue sits on the MFMA-bound critical path
-FUSE_BN_BWD = _os.environ.get('KPX_FUSE_BN_BWD', '0') != '0'
+# batch-norm backward sums (and the ReLU mask of the gradient) from the epilogue of the data gradient that produces it, F(4x4,3x3) and
+# F(2x2,3x3) kernels: the reduction pass over (dz, y) of kpx_bn_train_bwd_f32 is then skipped.  Round 2 measured the F(2x2,3x3)-only version a
+# wash (31.4-31.7 vs 31.3 ms); with the F(4x4,3x3) epilogue and the batched finalize it is -0.15 ms (23.05 vs 23.20, A/B in one session)
+FUSE_BN_BWD = _os.environ.get('KPX_FUSE_BN_BWD', '1') != '0'
 # where a layer's weight gradient forks from its stream: 'after' its data gradient has been enqueued, 'before' it, or 'capture' (default):
 # before it while the step is being captured into a HIP graph, after it in eager mode -- measured on MI355X at B=32: eager 26.57 ms (after) /
 # 27.22 ms (before); graph replay 27.44 ms (after) / 26.96 ms (before)
@@ -381,7 +381,21 @@ def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, wa
     tiles = lib.kpx_conv3x3_wino43_stats_tiles(n, h, wd) if want_stats else 1      # 0: no statistics from this kernel for the shape (16 x 16)
     # (WINO43_MIN_WORKGROUPS: see its definition -- 0 by default)
     wgs43 = (n // 2 if wd == 16 else n * (h // 16) * (wd // 32)) * ((nn + 63) // 64)
-    if (ent43 is not None and bn_src is None and tiles and wgs43 > WINO43_MIN_WORKGROUPS
+    if (ent43 is not None and bn_src is not None and dgrad and wd != 16 and nn % 64 == 0 and wgs43 > WINO43_MIN_WORKGROUPS
+            and lib.kpx_conv3x3_wino43_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr())):
+        # data gradient towards a ReLU'd batch norm's output on F(4x4,3x3): its epilogue masks the gradient and reduces the batch norm's backward sums
+        bn_y, beta = bn_src
+        tiles43 = lib.kpx_conv3x3_wino43_stats_tiles(n, h, wd)
+        slab = torch.empty(tiles43 * 2 * nn, dtype=torch.float32, device=inp.device)
+        rc = lib.kpx_conv3x3_wino43_bnbwd_stats_f32(inp.data_ptr(), n, h, wd, k, ld_in, ent43[0].data_ptr(), out.data_ptr(), nn, ld_out,
+                                                    bn_y.data_ptr(), bn_y.shape[3], beta.data_ptr(), slab.data_ptr(), _stream())
+        if rc != -1:
+            check(rc, 'kpx_conv3x3_wino43_bnbwd_stats_f32')
+            conv_kernel_uses['wino43'] += 1
+            return slab, tiles43 // n
+    # (a layer F(4x4,3x3) takes but whose shape its statistics epilogue does not -- 16x16 images, a produced-channel count that is not a
+    #  multiple of 64 -- stays on F(4x4,3x3) without the sums: the batch norm then makes its own reduction pass)
+    if (ent43 is not None and tiles and wgs43 > WINO43_MIN_WORKGROUPS
             and lib.kpx_conv3x3_wino43_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr())):
         conv_kernel_uses['wino43'] += 1
         if want_stats:
@@ -614,7 +628,10 @@ class Conv2dFn(torch.autograd.Function):
                                 bn_src=(x, ctx.bn_src[0]) if ctx.bn_src is not None else None,
                                 mul=(x, ctx.input_act) if ctx.input_act != ACT_NONE else None)
             if st is not None:
-                _pending_bwd_stats[dx.data_ptr()] = (st[0], st[1], ctx.bn_src[1])
+                # (dx itself is kept: a second reference stops the autograd engine from accumulating another consumer's gradient INTO this
+                #  buffer in place -- the sums would then belong to a part of the gradient only; a sum allocates a new tensor, whose address
+                #  does not match, and the batch norm falls back to its own reduction pass)
+                _pending_bwd_stats[dx.data_ptr()] = (st[0], st[1], ctx.bn_src[1], dx)
         if side:
             main = torch.cuda.current_stream(x.device)   # the stream this backward node runs on (= its forward's stream)
             skey, st = _side_stream(x.device, main.cuda_stream)
@@ -734,26 +751,15 @@ class BatchNormFn(torch.autograd.Function):
         ent = _pending_bwd_stats.pop(dy.data_ptr(), None)        # sums reduced by the epilogue of the dgrad kernel that produced dy
         if ent is not None and (ent[2] != ctx.bn_id or ctx.act != ACT_RELU or tuple(ent[0].shape) != (n * ent[1] * 2 * c,)):
             ent = None
-        if ent is None:                                          # reduction, finalize, apply: one launch each for all groups
-            sc = scratch.get('bn%d' % groups, lib.kpx_bn_train_scratch_bytes(c, groups), dev)
-            check(lib.kpx_bn_train_bwd_f32(dy.data_ptr(), c, x.data_ptr(), c, pix, groups, c, mean.data_ptr(), invstd.data_ptr(),
-                                           gamma.data_ptr(), beta.data_ptr(), ctx.act, dx.data_ptr(), c, dg.data_ptr(), db.data_ptr(),
-                                           0 if fresh else 1, sc.data_ptr(), _stream()), 'kpx_bn_train_bwd_f32')
-            return (dx, None if ctx.g_grad_out is not None else dg, None if ctx.b_grad_out is not None else db,
-                    None, None, None, None, None, None, None, None, None, None)
-        sc = scratch.reduce(c, dev)
-        for g in range(groups):
-            sl = slice(g * ng, (g + 1) * ng)
-            acc = 0 if (g == 0 and fresh) else 1        # later groups (and a variable already written this epoch) accumulate in the finalize kernel
-            if ent is not None:
-                fused_bn_uses['backward_sums_from_dgrad_epilogue'] += 1
-                check(lib.kpx_bn_bwd_from_tiles_f32(dy[sl].data_ptr(), c, x[sl].data_ptr(), c, pix, c, mean[g].data_ptr(), invstd[g].data_ptr(),
-                                                    gamma.data_ptr(), beta.data_ptr(), ctx.act, dx[sl].data_ptr(), c, dg.data_ptr(), db.data_ptr(), acc,
-                                                    ent[0].data_ptr(), g * ng * ent[1], ng * ent[1], sc.data_ptr(), _stream()), 'kpx_bn_bwd_from_tiles_f32')
-            else:
-                check(lib.kpx_bn_bwd_f32(dy[sl].data_ptr(), c, x[sl].data_ptr(), c, pix, c, mean[g].data_ptr(), invstd[g].data_ptr(),
-                                         gamma.data_ptr(), beta.data_ptr(), ctx.act, dx[sl].data_ptr(), c,
-                                         dg.data_ptr(), db.data_ptr(), acc, sc.data_ptr(), _stream()), 'kpx_bn_bwd_f32')
+        # (reduction,) finalize, apply: one launch each for all groups; with `ent` the reduction was done by the epilogue of the data-gradient
+        # kernel that produced dy (per-tile sums, ng * tiles-per-image tiles per group)
+        sc = scratch.get('bn%d' % groups, lib.kpx_bn_train_scratch_bytes(c, groups), dev)
+        if ent is not None:
+            fused_bn_uses['backward_sums_from_dgrad_epilogue'] += groups
+        check(lib.kpx_bn_train_bwd_f32(dy.data_ptr(), c, x.data_ptr(), c, pix, groups, c, mean.data_ptr(), invstd.data_ptr(),
+                                       gamma.data_ptr(), beta.data_ptr(), ctx.act, dx.data_ptr(), c, dg.data_ptr(), db.data_ptr(),
+                                       0 if fresh else 1, ent[0].data_ptr() if ent is not None else None, ng * ent[1] if ent is not None else 0,
+                                       sc.data_ptr(), _stream()), 'kpx_bn_train_bwd_f32')
         return (dx, None if ctx.g_grad_out is not None else dg, None if ctx.b_grad_out is not None else db,
                 None, None, None, None, None, None, None, None, None, None)
 
