@@ -310,11 +310,11 @@ def _run_dp_variant(env, seed_offset=0, port_base=32800):
 
 def test_data_parallel_segment_graphs_equal_the_eager_segments_and_the_inline_step_bit_for_bit():
     """The data-parallel step as four replayed HIP graphs around the two all-reduces (the default), the same segments launched eagerly
-    (KPX_GRAPH=0) and round 3's single eager pass with the collectives inline (KPX_DP_PHASED=0): two ranks (gloo, sharing cuda:0), four steps
+    (KPX_GRAPH=0) and round 3's single eager pass with the collectives inline (KPX_DP_GRAPH=inline): two ranks (gloo, sharing cuda:0), four steps
     on different local batches -- parameters, both Adam slots, each rank's moving statistics and losses, the beta powers and the step
     counter must agree bit for bit between the three forms, and the replicas with each other."""
-    variants = {'graphs': {'KPX_GRAPH': '1', 'KPX_DP_PHASED': '1'}, 'eager_segments': {'KPX_GRAPH': '0', 'KPX_DP_PHASED': '1'},
-                'inline': {'KPX_GRAPH': '0', 'KPX_DP_PHASED': '0'}}
+    variants = {'graphs': {'KPX_GRAPH': '1', 'KPX_DP_GRAPH': 'segments'}, 'eager_segments': {'KPX_GRAPH': '0', 'KPX_DP_GRAPH': 'segments'},
+                'inline': {'KPX_GRAPH': '0', 'KPX_DP_GRAPH': 'inline'}}
     res = {name: _run_dp_variant(env, port_base=32800 + 37 * i) for i, (name, env) in enumerate(variants.items())}
     assert all(res['graphs'][r]['mode'] == 2 for r in (0, 1)), 'steps 1..3 must have been graph replays'
     assert all(res['eager_segments'][r]['mode'] == 0 and res['inline'][r]['mode'] == 0 for r in (0, 1))
@@ -332,12 +332,58 @@ def test_data_parallel_segment_graphs_equal_the_eager_segments_and_the_inline_st
 def test_data_parallel_build_broadcasts_rank_zero_state():
     """Replicas seeded DIFFERENTLY (a drifted seed, a half-restored replica) start from rank 0's parameters: build() ends with one broadcast
     per flat buffer, and the replicas are bit-identical after training steps."""
-    res = _run_dp_variant({'KPX_GRAPH': '1', 'KPX_DP_PHASED': '1'}, seed_offset=7, port_base=34400)
+    res = _run_dp_variant({'KPX_GRAPH': '1'}, seed_offset=7, port_base=34400)
     assert np.array_equal(res[0]['initial'], res[1]['initial'])
     for key in ('D_params', 'G_params', 'G_m', 'D_v'):
         assert np.array_equal(res[0][key], res[1][key]), key
-    want = _run_dp_variant({'KPX_GRAPH': '1', 'KPX_DP_PHASED': '1'}, seed_offset=0, port_base=34500)
+    want = _run_dp_variant({'KPX_GRAPH': '1'}, seed_offset=0, port_base=34500)
     assert np.array_equal(res[0]['G_params'], want[0]['G_params'])         # = the run in which both replicas drew rank 0's seed
+
+
+def _dp_rccl_one_rank_worker(rank, world, port, q):
+    import sys
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', KPX_DP_FORCE_EXCHANGE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(0)
+    res, k, b = 32, 3, 2
+
+    def run(model):
+        for step in range(4):
+            im, fut = R.synthetic_pair(b, res=res, seed0=400 + 2 * step, seed1=401 + 2 * step)
+            model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, step, b)
+        out = {w + '_' + nm: getattr(model.store.buckets[w], nm).detach().cpu().numpy().copy() for w in ('D', 'G') for nm in ('params', 'm', 'v')}
+        lv = model.loss_values()
+        out['losses'] = np.asarray([lv['loss_D'], lv['loss_G_recon'], lv['loss_G_adv']], np.float64)
+        return out
+    plain = run(make_model(res, k, b, dev))                     # no process group yet: the plain single-GPU step (one graph)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    calls = [0]
+    real_all_reduce = dist.all_reduce
+
+    def counting_all_reduce(*a, **kw):
+        calls[0] += 1
+        return real_all_reduce(*a, **kw)
+    dist.all_reduce = counting_all_reduce
+    model = make_model(res, k, b, dev)
+    assert model.distributed and model.dp_graph == 'one'
+    got = run(model)
+    out = {'equal': {k_: bool(np.array_equal(plain[k_], got[k_])) for k_ in plain}, 'mode': model.launch_mode(), 'calls': calls[0],
+           'failed': bool(model._graph_failed), 'dp_graph': model.dp_graph}
+    q.put((rank, out))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_one_graph_with_the_rccl_all_reduces_captured_equals_the_plain_step():
+    """The default data-parallel form on RCCL: the single-GPU step captured as ONE graph with its two all-reduces inside (issued synchronously,
+    so that they run on the stream they belong to).  One rank is all a single-GPU box can give RCCL (KPX_DP_FORCE_EXCHANGE=1 keeps the
+    collectives): a sum over one rank is the identity, so four steps -- one eager, the capture, two replays -- must leave parameters, Adam
+    slots and losses bit-identical to the non-distributed model's, in launch mode 3, with the collectives really issued (2 eager + 2 captured)."""
+    (rank, out), = _run_ranks(_dp_rccl_one_rank_worker, 1, 35900 + (os.getpid() % 1500))
+    assert out['dp_graph'] == 'one' and not out['failed'] and out['mode'] == 3, out
+    assert out['calls'] == 4, out
+    assert all(out['equal'].values()), out['equal']
 
 
 def _dp_oracle_worker(rank, world, port, q):

@@ -49,22 +49,17 @@ class _Bf16Exchange:
         if self.work is not None:
             self.work.wait()
         self.grads.copy_(self.buf)
-# Data parallel: the step as captured segments around the two all-reduces (_train_step_dp).  KPX_DP_PHASED=0: round 3's form -- one eager
-# pass with the collectives inline (A/B and the bit-identity test; separate-batch steps always take it)
-DP_PHASED = os.environ.get('KPX_DP_PHASED', '1') != '0'
+# Data parallel, how the step reaches the GPU (KPX_DP_GRAPH):
+#   'one'      (default with the RCCL backend) ONE captured graph: the single-GPU step unchanged, with the two all-reduces issued synchronously
+#              (async_op=False) on the stream they belong to -- ProcessGroupNCCL runs such a collective on the caller's CURRENT stream, so nothing
+#              forks from the auxiliary stream (ops.py: stream discipline) and the collectives are two more nodes of the graph.  Measured at one
+#              rank with both collectives kept in (KPX_DP_FORCE_EXCHANGE=1): 22.76 ms against 22.74-22.78 ms for the non-distributed graph.
+#   'segments' (default with any other backend, and the fall-back when capturing 'one' fails) four captured segments replayed around the two
+#              collectives, which are enqueued from Python between them (_train_step_dp): +1.2 ms per step, host work 1.3 ms;
+#   'inline'   round 3's form: one eager pass with the collectives inline (also taken by separate-batch steps and with KPX_GRAPH=0 + this value).
+DP_GRAPH = os.environ.get('KPX_DP_GRAPH', '')
 # measurement only: run the data-parallel code path WITHOUT its two collectives (what the segmentation alone costs on one GPU)
 DP_NO_COLLECTIVES = os.environ.get('KPX_DP_NO_COLLECTIVES', '0') != '0'
-# opt-in: capture the data-parallel step INCLUDING its two RCCL all-reduces as ONE graph (ProcessGroupNCCL collectives are capturable; every
-# fork of the step, RCCL's internal stream included, joins into the main stream).  Saves the three segment boundaries; off by default because
-# a build session cannot run it on more than one rank -- the segmented form only ever issues plain eager collectives.
-DP_SINGLE_GRAPH = os.environ.get('KPX_DP_SINGLE_GRAPH', '0') != '0'
-# where the VGG19 forward of the perceptual loss sits: 'a' -- in segment A beside the discriminator update (the data gradients then run alone
-# beside the exchange, the adversarial branch alone after it); 'b' -- in segment B1 beside the exchange, and the adversarial branch (auxiliary
-# stream) beside the VGG19 data gradients in B2, as in the single-GPU step
-# 'c' (only where no segment boundary forces a join: the single captured graph, or eager launches): the single-GPU layout mirrored -- the whole
-# VGG19 chain on the auxiliary stream beside [discriminator update, exchange, Adam-D, adversarial branch] on the MAIN stream (the collective
-# must fork from and join into the main stream, see the stream discipline in ops.py)
-DP_SCHEDULE = os.environ.get('KPX_DP_SCHEDULE', 'c' if DP_SINGLE_GRAPH else 'b')
 GRAPH_WARMUP_STEPS = 1          # eager steps before the capture: they create every lazily allocated scratch buffer and kernel attribute
 
 log = logging.getLogger('kpx')
@@ -94,6 +89,8 @@ class DetectorTranslatorModel(BaseModel):
         in_group = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.world_size = torch.distributed.get_world_size(process_group) if in_group else 1
         self.distributed = in_group and (self.world_size > 1 or os.environ.get('KPX_DP_FORCE_EXCHANGE', '0') != '0')
+        backend = torch.distributed.get_backend(process_group) if in_group else ''
+        self.dp_graph = DP_GRAPH or ('one' if backend == 'nccl' else 'segments')
         self.store = variables.VariableStore(device=self.device, seed=seed)
         self.vgg = vgg
         # Adam state (two optimisers, reference :198 and :201): fp32 beta powers like TF's beta{1,2}_power variables
@@ -265,7 +262,7 @@ class DetectorTranslatorModel(BaseModel):
         pass that second batch as 'image_G' / 'future_image_G' and the G-run recomputes the forward on it, exactly like the
         reference's second sess.run (BN moving statistics then come from the G-run's batch only, :199-202)."""
         start_time = time.time()
-        if self.distributed and self._phased_eligible(feed_dict):
+        if self.distributed and self.dp_graph == 'segments' and self._phased_eligible(feed_dict):
             self._train_step_dp(feed_dict)
         elif self._graph_eligible(feed_dict):
             self._train_step_graphed(feed_dict)
@@ -280,7 +277,7 @@ class DetectorTranslatorModel(BaseModel):
     # ---- the step as a HIP graph ------------------------------------------------------------------------------------------
     def _graph_eligible(self, feed_dict):
         im = feed_dict['image']
-        return (GRAPH and not self._graph_failed and not self.distributed and 'image_G' not in feed_dict and self.device.type == 'cuda'
+        return (GRAPH and not self._graph_failed and (not self.distributed or self.dp_graph == 'one') and 'image_G' not in feed_dict and self.device.type == 'cuda'
                 and im.is_cuda and im.dtype == torch.float32 and feed_dict['future_image'].shape == im.shape)
 
     def _train_step_graphed(self, feed_dict):
@@ -318,7 +315,17 @@ class DetectorTranslatorModel(BaseModel):
         # overwrites them in place; read (or clone) what is needed before calling train_step again.  Eager steps return fresh tensors.
         self.last = dict(outputs, lr=float(lr))
 
+    def _quiesce_collectives(self):
+        """Before a capture in a process that has issued eager collectives: ProcessGroupNCCL's watchdog thread polls the completion events of
+        those collectives, and an event query from ANY thread is an error while a stream capture in global mode is open (it aborted a run:
+        'operation not permitted when stream is capturing' from WorkNCCL::isCompleted).  Finish the GPU work, then give the watchdog (a 100 ms
+        loop) time to retire what it tracks; collectives issued under capture are not handed to it."""
+        if self.distributed:
+            torch.cuda.synchronize(self.device)
+            time.sleep(0.5)
+
     def _capture_step(self, key, im, fut):
+        self._quiesce_collectives()
         dev = self.device
         if self._alpha_dev is None:
             self._alpha_dev = {w: torch.zeros(1, dtype=torch.float32, device=dev) for w in ('D', 'G')}
@@ -338,8 +345,12 @@ class DetectorTranslatorModel(BaseModel):
             outputs = {k: v for k, v in self.last.items() if k != 'lr'}
             self._graph_launches = _lib.abi_calls[0] - calls0          # diagnostics: C-ABI launches recorded in the graph
         except Exception as e:              # noqa: BLE001 -- whatever the runtime refuses: stay on the eager path
-            log.warning('HIP graph capture of the train step failed (%s: %s); continuing with eager launches', type(e).__name__, e)
-            self._graph_failed = True
+            if self.distributed and self.dp_graph == 'one':
+                log.warning('capturing the data-parallel step with its collectives failed (%s: %s); continuing with captured segments', type(e).__name__, e)
+                self.dp_graph = 'segments'
+            else:
+                log.warning('HIP graph capture of the train step failed (%s: %s); continuing with eager launches', type(e).__name__, e)
+                self._graph_failed = True
             torch.cuda.synchronize(dev)
             # the failed capture advanced host bookkeeping for launches that never ran (FilterBank.synced, pending side-stream joins, tile
             # statistics in flight): mark every derived filter form stale and forget the rest before the eager fallback
@@ -355,22 +366,23 @@ class DetectorTranslatorModel(BaseModel):
     # ---- the data-parallel step: captured segments around the two gradient exchanges ---------------------------------------
     def _phased_eligible(self, feed_dict):
         im = feed_dict['image']
-        return (DP_PHASED and 'image_G' not in feed_dict and self.device.type == 'cuda' and im.is_cuda and im.dtype == torch.float32
+        return ('image_G' not in feed_dict and self.device.type == 'cuda' and im.is_cuda and im.dtype == torch.float32
                 and feed_dict['future_image'].shape == im.shape)
 
     def _step_phases(self, feed_dict, device_alpha):
         """The shared-batch train step cut at its two gradient exchanges (a generator: everything between two yields is one segment):
 
-            A   generator forward; then the discriminator forward + backward on (real, generated) on the auxiliary stream
-                beside the VGG19 forward of the perceptual loss on the main stream                   -> yields 'exchange_D'
-            B1  VGG19 data gradients (the perceptual gradient at the generated frame): independent of the exchange -> yields 'wait_D'
-            B2  Adam-D, adversarial branch with the UPDATED discriminator, generator backward        -> yields 'exchange_G'
+            A   generator forward, discriminator forward + backward on (real, generated)                 -> yields 'exchange_D'
+            B1  VGG19 forward of the perceptual loss: independent of the exchange, runs beside it        -> yields 'wait_D'
+            B2  Adam-D + adversarial branch with the UPDATED discriminator (auxiliary stream) beside the VGG19 data gradients
+                (main stream), then the generator backward                                               -> yields 'exchange_G'
             C   Adam-G
 
         Same kernels on the same operands as _train_step_eager (bit-identical results); what differs is the stream layout: each segment forks
-        and joins inside itself (it must be capturable alone; every join goes into the main stream, so the discriminator's weight gradients
-        may use the side stream of the auxiliary stream here), and the 178.9 MB discriminator exchange -- launched by the caller between A
-        and B1 -- runs beside the VGG19 data-gradient chain.
+        and joins inside itself (it must be capturable alone; every join goes into the main stream), and the 178.9 MB discriminator exchange --
+        launched by the caller between A and B1 -- runs beside the VGG19 forward.  (Measured alternatives, one rank: the VGG19 forward in A
+        beside the discriminator update 24.66 ms; this 24.61 ms; all four segments in one graph with the collectives captured 24.62 ms -- the
+        +1.2 ms over the single-GPU step is the stream layout the boundaries force, not the boundaries.)
         ``device_alpha``: Adam reads its step size from self._alpha_dev (captured segments) instead of a host scalar."""
         im, future_im = feed_dict['image'], feed_dict['future_image']
         lr = self.current_lr()
@@ -398,64 +410,23 @@ class DetectorTranslatorModel(BaseModel):
             final = fwd['final_output']
             final_d = final.detach()
             aux = self._aux_stream() if AUX_STREAM else None
-            sched = DP_SCHEDULE
-            if sched == 'c' and (aux is None or (self._capturing and not DP_SINGLE_GRAPH)):
-                sched = 'b'                                           # segments must join at their boundaries
-            if sched == 'c':
-                aux.wait_stream(torch.cuda.current_stream(dev))      # `final`, `future_im` predate the fork; recon / g_recon are read on main after the join in B2
-                with torch.cuda.stream(aux):
-                    recon = self._loss_G_recon(final, future_im)
-                    g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
-                d_losses = self._loss_D(final_d, future_im)
-                ops.begin_backward()
-                with ops.inline_wgrad():                              # (three busy streams measured slower than two)
-                    torch.autograd.backward([d_losses], [self._e0])
-                ops.join_side_stream(dev)
-        if sched == 'c':
-            yield 'exchange_D'
-            yield 'wait_D'
-            with variables.as_default(self.store):
-                adam('D')
-                adv = self._loss_G_adv(final)
-                g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
-                torch.cuda.current_stream(dev).wait_stream(aux)
-                ops.begin_backward()
-                final.backward(g_recon + g_adv)
-                join_all()
-            yield 'exchange_G'
-            with variables.as_default(self.store):
-                adam('G')
-            self._phase_out = dict(d_losses=d_losses.detach(), recon=recon.detach(), adv=adv.detach(), fwd={k: v.detach() for k, v in fwd.items()})
-            self._phase_lr = float(lr)
-            return
-        with variables.as_default(self.store):
-            beside = aux is not None and sched == 'a'
-            if beside:
-                aux.wait_stream(torch.cuda.current_stream(dev))      # (`final`, `final_d`, `future_im` predate the fork and outlive the join)
-            with (torch.cuda.stream(aux) if beside else contextlib.nullcontext()):
-                d_losses = self._loss_D(final_d, future_im)
-                ops.begin_backward()
-                torch.autograd.backward([d_losses], [self._e0])
-            if sched == 'a':
-                recon = self._loss_G_recon(final, future_im)          # VGG19 forward on (real, generated), beside the discriminator update
+            d_losses = self._loss_D(final_d, future_im)
+            ops.begin_backward()
+            torch.autograd.backward([d_losses], [self._e0])
             join_all()
         yield 'exchange_D'
         with variables.as_default(self.store):
             # ---- B1
-            if sched == 'a':
-                g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
-            else:
-                recon = self._loss_G_recon(final, future_im)          # VGG19 forward beside the exchange
+            recon = self._loss_G_recon(final, future_im)              # VGG19 forward beside the exchange
             join_all()
         yield 'wait_D'
         with variables.as_default(self.store):
             # ---- B2
-            if sched == 'a' or aux is None:
+            if aux is None:
                 adam('D')
                 adv = self._loss_G_adv(final)             # the UPDATED discriminator, like the reference's second sess.run
                 g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
-                if sched != 'a':
-                    g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
+                g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
             else:
                 # Adam-D and the adversarial branch (frozen discriminator: no weight gradients, nothing forks from this stream) on the auxiliary
                 # stream beside the VGG19 data gradients; `final` predates the fork, g_adv / adv are read on main after the join
@@ -511,7 +482,7 @@ class DetectorTranslatorModel(BaseModel):
         for which in ('D', 'G'):
             ops.fill_raw_(self._alpha_dev[which], float(self._adam_alpha(which, lr)))
         state = {}
-        for graph, tag in zip(graphs, ('exchange_D', 'wait_D', 'exchange_G', None) if len(graphs) == 4 else (None,)):
+        for graph, tag in zip(graphs, ('exchange_D', 'wait_D', 'exchange_G', None)):
             graph.replay()
             if tag is not None:
                 self._between_phases(tag, state)
@@ -524,6 +495,7 @@ class DetectorTranslatorModel(BaseModel):
     def _capture_phases(self, key, im, fut):
         """Capture the four segments, in order, into four graphs that share one memory pool.  Nothing executes during the capture and no
         collective is issued; the first real execution is the first replay."""
+        self._quiesce_collectives()
         dev = self.device
         if self._alpha_dev is None:
             self._alpha_dev = {w: torch.zeros(1, dtype=torch.float32, device=dev) for w in ('D', 'G')}
@@ -538,25 +510,17 @@ class DetectorTranslatorModel(BaseModel):
         pool = None
         try:
             gen = self._step_phases(static, device_alpha=True)
-            if DP_SINGLE_GRAPH:
+            done = False
+            while not done:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    state = {}
-                    for tag in gen:
-                        self._between_phases(tag, state)          # the collectives are recorded into the graph
+                with torch.cuda.graph(g, pool=pool):
+                    try:
+                        next(gen)
+                    except StopIteration:
+                        done = True
+                pool = g.pool()
                 graphs.append(g)
-            else:
-                done = False
-                while not done:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, pool=pool):
-                        try:
-                            next(gen)
-                        except StopIteration:
-                            done = True
-                    pool = g.pool()
-                    graphs.append(g)
-                assert len(graphs) == 4, len(graphs)
+            assert len(graphs) == 4, len(graphs)
             outputs = dict(self._phase_out)
         except Exception as e:              # noqa: BLE001 -- whatever the runtime refuses: stay on the eager segments
             log.warning('HIP graph capture of the data-parallel step failed (%s: %s); continuing with eager launches', type(e).__name__, e)
@@ -647,7 +611,8 @@ class DetectorTranslatorModel(BaseModel):
                     # stream: a side stream forked from a forked stream must never be joined back into it (ops: stream discipline)
                     with (ops.inline_wgrad() if aux is not None else contextlib.nullcontext()):
                         torch.autograd.backward([d_losses], [self._e0])
-                    pending = self.exchange_gradients('D', async_op=True)
+                    # (under capture the collective is issued synchronously: it then runs on THIS stream, see DP_GRAPH 'one')
+                    pending = self.exchange_gradients('D', async_op=not self._capturing)
                     if aux is not None:
                         self._apply_adam('D', lr, pending=pending, exchanged=True)
                 # ---- G run (:94): the perceptual forward does not involve the discriminator, so it runs first ...
@@ -698,8 +663,9 @@ class DetectorTranslatorModel(BaseModel):
         """Index into LAUNCH_MODES: how train_step currently reaches the GPU."""
         if self._graph_failed or not self._graphs:
             return 0
-        dp = [v for k, v in self._graphs.items() if k[0] == 'dp']
-        return (3 if len(dp[0][0]) == 1 else 2) if dp else 1
+        if any(k[0] == 'dp' for k in self._graphs):
+            return 2
+        return 3 if self.distributed else 1
 
     def loss_values(self):
         """Host copies of the last step's scalars (synchronises)."""
