@@ -37,7 +37,7 @@ static void env_parse(KpxEnv* e) {
     e->ww_comin = (int)env_long("KPX_WW_COMIN", 4);
     e->ww_target = env_long("KPX_WW_TARGET", 256);
     e->bf16_wide = (int)env_long("KPX_BF16_WIDE", 1);
-    e->gauss_blocks = (int)env_long("KPX_GAUSS_BLOCKS", 768);
+    e->gauss_blocks = (int)env_long("KPX_GAUSS_BLOCKS", 0);          // 0: sized from the tensor (keypoints.hip)
     e->gauss_nt = (int)env_long("KPX_GAUSS_NT", 1);
     e->no_gemm3 = env_flag("KPX_NO_GEMM3");
     e->no_wgrad3 = env_flag("KPX_NO_WGRAD3");
