@@ -37,6 +37,21 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert lib.kpx_bn_stats_f32(None, 10, 4, 4, 1e-5, None, None, None, None, None, 0.999, None, None) == -1
     assert lib.kpx_conv2d_wgrad_workspace_bytes(32, 128, 128, 64, 64, 3, 3) > 0
     assert lib.kpx_conv2d_wgrad_workspace_bytes(1, 4, 4, 1024, 2048, 4, 4) == 0
+    # per-call arithmetic selector and the activation-backward factor: range-checked before anything touches a device
+    assert lib.kpx_conv2d_fwd_f32(1, 1, 8, 8, 4, 4, 1, 3, 3, None, 1, 8, 8, 4, 4, 1, 1, 1, 0, 2, None, 0, None) == -1           # arith = 2
+    assert lib.kpx_conv2d_dgrad_act_f32(1, 1, 8, 8, 4, 4, 1, 3, 3, 1, 8, 8, 4, 4, 1, 1, 1, 0, None, 4, 2, None, 0, None) == -1   # y_in = NULL
+    assert lib.kpx_conv2d_dgrad_act_f32(1, 1, 8, 8, 4, 4, 1, 3, 3, 1, 8, 8, 4, 4, 1, 1, 1, 0, 1, 4, 3, None, 0, None) == -1      # tanh: not an epilogue factor
+
+
+def test_keypoint_head_fold_eligibility_is_a_host_question():
+    """networks.pose_encoder asks kpx_keypoint_head_proj_eligible before choosing the folded 1x1 + key-point head operator; a shape outside
+    the operator's limits (channels, key-points, profile rows within 64 KB of LDS) takes the conv + head pair instead of failing in the launch."""
+    from kpx_amd._lib import lib
+    assert lib.kpx_keypoint_head_proj_eligible(64, 128, 128, 16, 15) == 1 and lib.kpx_keypoint_head_proj_eligible(32, 256, 256, 16, 40) == 1
+    assert lib.kpx_keypoint_head_proj_eligible(2, 128, 128, 18, 15) == 0        # C % 4
+    assert lib.kpx_keypoint_head_proj_eligible(2, 128, 128, 512, 15) == 0       # C > 256
+    assert lib.kpx_keypoint_head_proj_eligible(2, 1024, 1024, 16, 15) == 0      # image side > 512
+    assert lib.kpx_keypoint_head_proj_eligible(2, 128, 128, 16, 100) == 0       # K > 64
 
 
 def test_ops_refuse_cpu_tensors():
