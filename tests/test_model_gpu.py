@@ -340,9 +340,11 @@ def test_data_parallel_build_broadcasts_rank_zero_state():
     assert np.array_equal(res[0]['G_params'], want[0]['G_params'])         # = the run in which both replicas drew rank 0's seed
 
 
-def _dp_rccl_one_rank_worker(rank, world, port, q):
+def _dp_rccl_one_rank_worker(rank, world, port, q, fail_capture=False):
     import sys
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', KPX_DP_FORCE_EXCHANGE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if fail_capture:
+        os.environ['KPX_TEST_FAIL_CAPTURE'] = '1' 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
     dev = torch.device('cuda:0')
@@ -369,6 +371,8 @@ def _dp_rccl_one_rank_worker(rank, world, port, q):
     model = make_model(res, k, b, dev)
     assert model.distributed and model.dp_graph == 'one'
     got = run(model)
+    if fail_capture:
+        assert model.dp_graph == 'segments' and not model._graph_failed       # fell back in process, and captured the segments instead
     out = {'equal': {k_: bool(np.array_equal(plain[k_], got[k_])) for k_ in plain}, 'mode': model.launch_mode(), 'calls': calls[0],
            'failed': bool(model._graph_failed), 'dp_graph': model.dp_graph}
     q.put((rank, out))
@@ -383,6 +387,14 @@ def test_data_parallel_one_graph_with_the_rccl_all_reduces_captured_equals_the_p
     (rank, out), = _run_ranks(_dp_rccl_one_rank_worker, 1, 35900 + (os.getpid() % 1500))
     assert out['dp_graph'] == 'one' and not out['failed'] and out['mode'] == 3, out
     assert out['calls'] == 4, out
+    assert all(out['equal'].values()), out['equal']
+
+
+def test_data_parallel_capture_failure_falls_back_to_segments_in_process():
+    """A capture of the one-graph form that fails (simulated: KPX_TEST_FAIL_CAPTURE=1 raises inside the open capture) must leave a working model:
+    the same process continues with the segmented form -- four captured segments around eager collectives -- and the same bits."""
+    (rank, out), = _run_ranks(_dp_rccl_one_rank_worker, 1, 36100 + (os.getpid() % 1500), (True,))
+    assert out['dp_graph'] == 'segments' and not out['failed'] and out['mode'] == 2, out
     assert all(out['equal'].values()), out['equal']
 
 

@@ -342,6 +342,8 @@ class DetectorTranslatorModel(BaseModel):
         try:
             with torch.cuda.graph(graph):
                 self._train_step_eager(static)
+                if self.distributed and os.environ.get('KPX_TEST_FAIL_CAPTURE') == '1':
+                    raise RuntimeError('KPX_TEST_FAIL_CAPTURE=1: simulated capture failure (tests the in-process fall-back)')
             outputs = {k: v for k, v in self.last.items() if k != 'lr'}
             self._graph_launches = _lib.abi_calls[0] - calls0          # diagnostics: C-ABI launches recorded in the graph
         except Exception as e:              # noqa: BLE001 -- whatever the runtime refuses: stay on the eager path
