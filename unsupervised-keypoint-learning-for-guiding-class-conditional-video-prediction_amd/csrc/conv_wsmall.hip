@@ -92,29 +92,43 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_small_kernel(const Wsma
     typedef typename std::conditional<VD, wf32x4, float>::type dunit;
     xunit xv[XU];
     dunit dv[DU];
-    auto fetch = [&](int tile) {
-        int L = tile;
-        const int tx = L % g.tiles_x; L /= g.tiles_x;
-        const int ty = L % g.tiles_y;
-        const int n = L / g.tiles_y;
-        const int oy0 = ty * g.TH, ox0 = tx * TW;
+    // Operands through buffer descriptors (round 4; as 64-bit pointers with a bounds branch per unit the fetch was ~20 instructions per unit
+    // beside an fp32 MFMA that hides none of them): voffset = the unit's place relative to the tile origin (fixed), soffset = the tile origin
+    // (scalar), an out-of-image unit carries the out-of-range offset and reads as zero.  The x descriptor starts (pad_t rows + pad_l pixels)
+    // before the tensor so that the padded patch origin is never negative; those positions are only addressed with the out-of-range offset.
+    const int WS_OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x) - ((size_t)g.pad_t * g.Wi + g.pad_l) * g.ldx, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dy), 0, 0x7fffffff, 0x00020000);
+    int xvo[XU], dvo[DU];
+#pragma unroll
+    for (int i = 0; i < XU; ++i) xvo[i] = xl[i] >= 0 ? (((xrc[i] >> 16) * g.Wi + (xrc[i] & 0xffff)) * g.ldx + xco[i]) * 4 : WS_OOB;
+#pragma unroll
+    for (int i = 0; i < DU; ++i) dvo[i] = dl[i] >= 0 ? (((drc[i] >> 16) * g.Wo + (drc[i] & 0xffff)) * g.lddy + dco[i]) * 4 : WS_OOB;
+    // tile cursor (scalar; readfirstlane: integer division runs on the vector ALU): tiles of one workgroup are consecutive
+    const int t0 = blockIdx.x * g.tpb, t1 = min(t0 + g.tpb, g.total_tiles);
+    int ctx = __builtin_amdgcn_readfirstlane(t0 % g.tiles_x), cty = __builtin_amdgcn_readfirstlane((t0 / g.tiles_x) % g.tiles_y),
+        cn = __builtin_amdgcn_readfirstlane(t0 / (g.tiles_x * g.tiles_y));
+    auto fetch = [&]() {                                      // the tile under the cursor, then advance it
+        const int oy0 = cty * g.TH, ox0 = ctx * TW;
         const int iy0 = oy0 * ST - g.pad_t, ix0 = ox0 * ST - g.pad_l;
-        const float* const xn = g.x + (size_t)n * g.Hi * g.Wi * g.ldx;
-        const float* const dn = g.dy + (size_t)n * g.Ho * g.Wo * g.lddy;
+        const int sx = ((cn * g.Hi + oy0 * ST) * g.Wi + ox0 * ST) * g.ldx * 4;       // byte offsets < 2^31 (checked by the planner)
+        const int sd = ((cn * g.Ho + oy0) * g.Wo + ox0) * g.lddy * 4;
 #pragma unroll
         for (int i = 0; i < XU; ++i) {
             const int iy = iy0 + (xrc[i] >> 16), ix = ix0 + (xrc[i] & 0xffff);
-            const bool ok = xl[i] >= 0 && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
-            const float* src = xn + ((size_t)iy * g.Wi + ix) * g.ldx + xco[i];
-            xv[i] = ok ? *reinterpret_cast<const xunit*>(src) : xunit{};
+            const bool ok = (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+            const int vo = ok ? xvo[i] : WS_OOB;
+            if constexpr (VX) xv[i] = __builtin_bit_cast(xunit, __builtin_amdgcn_raw_buffer_load_b128(rsx, vo, sx, 0));
+            else xv[i] = __builtin_bit_cast(xunit, __builtin_amdgcn_raw_buffer_load_b32(rsx, vo, sx, 0));
         }
 #pragma unroll
         for (int i = 0; i < DU; ++i) {
             const int oy = oy0 + (drc[i] >> 16), ox = ox0 + (drc[i] & 0xffff);
-            const bool ok = dl[i] >= 0 && oy < g.Ho && ox < g.Wo;
-            const float* src = dn + ((size_t)oy * g.Wo + ox) * g.lddy + dco[i];
-            dv[i] = ok ? *reinterpret_cast<const dunit*>(src) : dunit{};
+            const int vo = (oy < g.Ho && ox < g.Wo) ? dvo[i] : WS_OOB;
+            if constexpr (VD) dv[i] = __builtin_bit_cast(dunit, __builtin_amdgcn_raw_buffer_load_b128(rsd, vo, sd, 0));
+            else dv[i] = __builtin_bit_cast(dunit, __builtin_amdgcn_raw_buffer_load_b32(rsd, vo, sd, 0));
         }
+        if (++ctx == g.tiles_x) { ctx = 0; if (++cty == g.tiles_y) { cty = 0; ++cn; } }
     };
     auto stage = [&]() {
 #pragma unroll
@@ -123,13 +137,12 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_small_kernel(const Wsma
         for (int i = 0; i < DU; ++i) if (dl[i] >= 0) *reinterpret_cast<dunit*>(&dys[dl[i]]) = dv[i];
     };
 
-    const int t0 = blockIdx.x * g.tpb, t1 = min(t0 + g.tpb, g.total_tiles);
-    if (t0 < t1) fetch(t0);
+    if (t0 < t1) fetch();
     for (int tile = t0; tile < t1; ++tile) {
         __syncthreads();                                      // the previous tile's reads are done
         stage();
         __syncthreads();
-        if (tile + 1 < t1) fetch(tile + 1);                   // in flight while this tile is multiplied
+        if (tile + 1 < t1) fetch();                           // in flight while this tile is multiplied
         // ---- every wavefront sweeps all pixel quads of the tile; the operands of quad q + 1 are read before quad q is multiplied ----
         for (int rr = 0; rr < g.TH; ++rr) {
             const float* xa[RBW];
@@ -212,6 +225,7 @@ static void wsmall_geom(int variant, int N, int Hi, int Wi, int ldx, int Ho, int
 extern "C" __attribute__((visibility("hidden"))) int kpx_wsmall_splits(int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride) {
     const int variant = wsmall_variant(Cin, Cout, KH, KW, stride);
     if (!variant || (long)N * Ho * Wo < 32768) return 0;
+    if ((size_t)N * Hi * Wi * (size_t)((Cin + 3) & ~3) * 4 >= 0x60000000ull || (size_t)N * Ho * Wo * (size_t)((Cout + 3) & ~3) * 4 >= 0x60000000ull) return 0;   // 32-bit byte offsets in the kernel
     WsmallGeom g{}; int lds, threads;
     wsmall_geom(variant, N, Hi, Wi, Cin, Ho, Wo, Cout, Cout, KH, KW, stride, 0, 0, Cin, &g, &lds, &threads);
     // persistent workgroups: as many as are resident at once (LDS and, at ~200 VGPRs, two wavefronts per SIMD), at least 2 tiles each
