@@ -202,6 +202,15 @@ def test_checkpoint_roundtrip_uses_reference_names(tmp_path):
 
 
 def _run_ranks(target, world, port, extra_args=(), timeout=420):
+    """``_run_ranks_once`` with ONE retry on another port when the ranks never report (a rendezvous that did not form: a port still in
+    TIME_WAIT, a slow first import on a fresh box); a rank that exits with an error or a failed assertion is never retried."""
+    try:
+        return _run_ranks_once(target, world, port, extra_args, timeout)
+    except TimeoutError:
+        return _run_ranks_once(target, world, port + 53, extra_args, timeout)
+
+
+def _run_ranks_once(target, world, port, extra_args=(), timeout=420):
     """Spawn ``world`` rank processes (spawn context, daemonic so that a stuck rank can never outlive the test run), collect one queue item per
     rank, and ALWAYS end every process that is still alive: when one rank dies the others wait in a collective until the backend's own
     timeout (30 min for gloo), and a non-daemonic child would keep pytest from exiting for as long."""
@@ -222,7 +231,8 @@ def _run_ranks(target, world, port, extra_args=(), timeout=420):
             except _queue.Empty:
                 dead = [p for p in procs if p.exitcode not in (None, 0)]
                 assert not dead, 'rank process exited with code %s' % [p.exitcode for p in dead]
-                assert _time.time() < deadline, 'data-parallel ranks timed out'
+                if _time.time() >= deadline:
+                    raise TimeoutError('data-parallel ranks timed out')
         for p in procs:
             p.join(timeout=60)
         return results
