@@ -311,38 +311,171 @@ def cpu_baseline():
             'sec_per_step': round(med, 3)}
 
 
-def self_launch(n):
-    """`python bench.py --gpus N` without a launcher: start one child per GPU (fresh processes: this parent never initialises
-    the GPU and never exec()s), rank 0 prints the JSON line on the inherited stdout; non-zero if any rank fails."""
+# ---------------------------------------------------------------------------------------------- N > 1: ranks under a supervisor
+# `bench.py --gpus N` must not be able to hang: a data-parallel step that deadlocks inside a collective (a captured graph with RCCL nodes that
+# never completes, a rank that dies in the rendezvous) would leave the driver without a number.  So for N > 1 the ranks that do the work are
+# always CHILD processes of a supervisor that never touches a GPU:
+#   * `python bench.py --gpus N`                         -- this process supervises all N children;
+#   * `python -m torch.distributed.run ... bench.py`     -- each launched process supervises ONE child (its own rank); the N supervisors agree
+#                                                            through marker files in a shared directory (one node: the contract's --nnodes=1).
+# An attempt = N fresh children with one KPX_DP_GRAPH form.  A child that exits non-zero, does not finish its warm-up steps inside
+# KPX_BENCH_WARM_DEADLINE_S or its timed steps inside KPX_BENCH_RUN_DEADLINE_S makes every supervisor kill its children (fresh processes are the
+# only safe restart: a process that has initialised the GPU must never exec) and start the next form: 'segments' (captured segments, the
+# collectives enqueued from Python between them), then 'inline' without graphs (every launch eager).  KPX_DP_GRAPH=one (the whole step with
+# both all-reduces in ONE captured graph) goes first only when asked for explicitly.  Rank 0's JSON line names the form that ran
+# (`launch_mode_by_rank`) and the attempts before it (`dp_fallbacks`).  The reference has no counterpart (train.py:25-29: one session, one device).
+DP_FORMS = (('segments', {}), ('inline', {'KPX_GRAPH': '0'}))
+
+
+def dp_attempt_plan():
+    first = os.environ.get('KPX_DP_GRAPH', '')
+    plan = [f for f in DP_FORMS if f[0] != first]
+    if first:
+        plan.insert(0, (first, dict(dict(DP_FORMS).get(first, {}))))
+    return plan
+
+
+def _touch(path, text=''):
+    tmp = path + '.tmp%d' % os.getpid()
+    with open(tmp, 'w') as f:
+        f.write(text)
+    os.replace(tmp, path)
+
+
+def supervise(my_ranks, world, child_argv, key, plan=None, warm_deadline=None, run_deadline=None, settle=60.0, log=sys.stderr):
+    """Run the ranks `my_ranks` of a `world`-rank job as child processes, attempt by attempt (see above).  Returns (exit code, attempts)."""
+    import shutil
     import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(('127.0.0.1', 0))
-        port = sock.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    try:
-        pending = list(procs)
-        while pending:
-            for p in list(pending):
-                code = p.poll()
-                if code is None:
-                    continue
-                pending.remove(p)
-                if code != 0 and rc == 0:
-                    rc = code if code > 0 else 1
-                    for q in pending:                # one rank failed: the others would wait in a collective forever
-                        q.terminate()
+    import tempfile
+    plan = list(plan if plan is not None else dp_attempt_plan())
+    warm_deadline = float(os.environ.get('KPX_BENCH_WARM_DEADLINE_S', '300')) if warm_deadline is None else warm_deadline
+    run_deadline = float(os.environ.get('KPX_BENCH_RUN_DEADLINE_S', '180')) if run_deadline is None else run_deadline
+    d = os.path.join(tempfile.gettempdir(), 'kpx_bench_%d_%s' % (os.getuid(), key))
+    os.makedirs(d, exist_ok=True)
+    lead = 0 in my_ranks
+    for name in os.listdir(d):                       # markers of an earlier run that died with this key
+        if any(name.endswith('_r%d.%s' % (r, sfx)) for r in my_ranks for sfx in ('warm', 'done', 'killed')) or (lead and name.startswith('a') and '_r' not in name):
+            try:
+                os.remove(os.path.join(d, name))
+            except OSError:
+                pass
+    attempts = []
+
+    def say(msg):
+        print('[bench supervisor ranks %s] %s' % (','.join(map(str, my_ranks)), msg), file=log, flush=True)
+
+    def wait_for(path, seconds):
+        t_end = time.time() + seconds
+        while not os.path.exists(path):
+            if time.time() > t_end:
+                return False
+            time.sleep(0.02)
+        return True
+    rc = 1
+    for k, (form, extra) in enumerate(plan):
+        port_file = os.path.join(d, 'a%d.port' % k)
+        if lead:
+            with socket.socket() as sock:
+                sock.bind(('127.0.0.1', 0))
+                _touch(port_file, str(sock.getsockname()[1]))
+        if not wait_for(port_file, settle + warm_deadline):
+            say('no port for attempt %d: the supervisor of rank 0 is gone' % k)
+            return 1, attempts
+        port = open(port_file).read().strip()
+        procs = {}
+        for r in my_ranks:
+            env = {kk: v for kk, v in os.environ.items() if not kk.startswith('TORCHELASTIC_')}      # (the agent's store is not reused: keys of a killed attempt would remain)
+            env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
+                       HSA_ENABLE_IPC_MODE_LEGACY='0', KPX_BENCH_CHILD='1', KPX_BENCH_DIR=d, KPX_BENCH_ATTEMPT=str(k), KPX_DP_GRAPH=form,
+                       KPX_BENCH_FALLBACKS=json.dumps(attempts))
+            env.update(extra)
+            procs[r] = subprocess.Popen(list(child_argv), env=env)
+        mark = lambda r, sfx: os.path.join(d, 'a%d_r%d.%s' % (k, r, sfx))       # noqa: E731
+        abort_file = os.path.join(d, 'a%d.abort' % k)
+        t0, t_warm, why = time.time(), None, None
+        while why is None:
+            codes = {r: p.poll() for r, p in procs.items()}
+            bad = [r for r, c in codes.items() if c not in (None, 0)]
+            if bad:
+                why = 'rank %d exited with code %s' % (bad[0], codes[bad[0]])
+            elif all(c == 0 for c in codes.values()):
+                break
+            elif os.path.exists(abort_file):
+                why = 'aborted by another supervisor: ' + open(abort_file).read().strip()
+            elif t_warm is None:
+                if all(os.path.exists(mark(r, 'warm')) or codes[r] == 0 for r in my_ranks):
+                    t_warm = time.time()
+                elif time.time() - t0 > warm_deadline:
+                    why = 'no completed warm-up step after %.0f s (form %r)' % (warm_deadline, form)
+            elif time.time() - t_warm > run_deadline:
+                why = 'timed steps not finished %.0f s after the warm-up (form %r)' % (run_deadline, form)
             time.sleep(0.05)
-    finally:
-        for p in procs:
+        if why is None and not lead:
+            # my ranks are through; the attempt counts once rank 0 has printed the line (or fails with the others)
+            t_end = time.time() + run_deadline
+            while not os.path.exists(mark(0, 'done')) and why is None:
+                if os.path.exists(abort_file):
+                    why = 'aborted by another supervisor: ' + open(abort_file).read().strip()
+                elif time.time() > t_end:
+                    why = 'rank 0 never reported its result'
+                time.sleep(0.05)
+        if why is None and lead and not os.path.exists(mark(0, 'done')):
+            why = 'rank 0 exited without a result'
+        if os.path.exists(mark(0, 'done')):                      # rank 0 has printed the JSON line: the result stands, never another attempt
+            for p in procs.values():                             # (stragglers, e.g. a rank stuck tearing the process group down, get 30 s)
+                try:
+                    p.wait(timeout=30)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            if why is not None:
+                say('after the result was printed: ' + why)
+            for r in my_ranks:
+                _touch(mark(r, 'ack'))
+            rc = 0
+            break
+        if not os.path.exists(abort_file):
+            _touch(abort_file, why)
+        say('attempt %d (KPX_DP_GRAPH=%s) failed: %s' % (k, form, why))
+        for p in procs.values():
             if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 5
+        for p in procs.values():
+            try:
+                p.wait(timeout=max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
                 p.kill()
-    return rc
+                p.wait()
+        for r in my_ranks:
+            _touch(mark(r, 'killed'))
+        for r in range(world):                                   # every rank's child is gone before the GPUs are used again
+            wait_for(mark(r, 'killed'), settle)
+        attempts.append({'form': form, 'failed': why})
+    if lead and rc == 0:
+        for r in range(world):                                   # the other supervisors read rank 0's marker: leave the directory until they have
+            wait_for(os.path.join(d, 'a%d_r%d.ack' % (k, r)), 30.0)
+        shutil.rmtree(d, ignore_errors=True)
+    return rc, attempts
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: this process supervises one child per GPU (it never initialises the GPU and never
+    exec()s); rank 0's child prints the JSON line on the inherited stdout."""
+    return supervise(list(range(n)), n, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], 'pid%d' % os.getpid())[0]
+
+
+def supervise_own_rank():
+    """Under torch.distributed.run: this launched process supervises a child that does its rank's work."""
+    world, rank = int(os.environ['WORLD_SIZE']), int(os.environ['RANK'])
+    key = 'ppid%d_port%s' % (os.getppid(), os.environ.get('MASTER_PORT', '0'))
+    return supervise([rank], world, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], key)[0]
+
+
+def child_mark(suffix):
+    """A supervised rank reports progress ('warm': warm-up steps done, 'done': result printed) to its supervisor."""
+    if os.environ.get('KPX_BENCH_CHILD') == '1':
+        _touch(os.path.join(os.environ['KPX_BENCH_DIR'], 'a%s_r%s.%s' % (os.environ['KPX_BENCH_ATTEMPT'], os.environ.get('RANK', '0'), suffix)))
 
 
 def bench_rollout(args, conf, dev, rank, world, launched, backend):
@@ -367,6 +500,7 @@ def bench_rollout(args, conf, dev, rank, world, launched, backend):
     for _ in range(args.warmup):
         out = fm.run(None, feed, z=z)
     sync()
+    child_mark('warm')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = fm.run(None, feed, z=z)
@@ -394,9 +528,12 @@ def bench_rollout(args, conf, dev, rank, world, launched, backend):
         if world == 1:
             line['roofline'] = roofline_conv_c4(dev)       # the translator's 3x3 layers dominate the rollout; its own launch: a 256-frame slab
         print(json.dumps(line), flush=True)
+        child_mark('done')
     if launched:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank != 0:
+        child_mark('done')
 
 
 def main():
@@ -419,6 +556,8 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args.gpus))             # nothing in this process has touched the GPU yet
+    if args.gpus > 1 and os.environ.get('KPX_BENCH_CHILD') != '1' and os.environ.get('KPX_BENCH_SUPERVISE', '1') != '0':
+        sys.exit(supervise_own_rank())               # under a launcher: the launched process only supervises (no GPU use, no exec)
     launched = 'WORLD_SIZE' in os.environ            # under torch.distributed.run (or self_launch): always build the process group
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -479,6 +618,7 @@ def main():
     for i in range(args.warmup):
         model.train_step(None, feed, i, args.batch)
     sync()
+    child_mark('warm')
     if rank == 0:
         print('[bench] warmup %d steps: %.2fs' % (args.warmup, time.perf_counter() - tw), file=sys.stderr, flush=True)
     from kpx_amd import _lib as klib
@@ -543,6 +683,10 @@ def main():
                'launch_mode_by_rank': [model.LAUNCH_MODES[m].split(':')[0] for m in modes_by_rank],
                'host_abi_calls_per_step': round(calls_per_step, 1),
                'loss_D': round(losses['loss_D'], 5), 'loss_G': round(losses['loss_G'], 5)}
+        if launched:
+            # N > 1 runs under bench.py's supervisor (DP_FORMS): the attempts that failed or hung before this one
+            out['dp_graph_form'] = model.dp_graph if model.distributed else None
+            out['dp_fallbacks'] = json.loads(os.environ.get('KPX_BENCH_FALLBACKS', '[]'))
         if world == 1 and not args.no_roofline:
             kops.set_compute_dtype('f32')
             if args.dtype == 'bf16':
@@ -556,9 +700,12 @@ def main():
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
+        child_mark('done')
     if launched:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if rank != 0:
+        child_mark('done')
 
 
 if __name__ == '__main__':

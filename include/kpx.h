@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define KPX_EINVAL (-1)
-#define KPX_ABI_VERSION 1
+#define KPX_ABI_VERSION 2
 
 enum { KPX_ACT_NONE = 0, KPX_ACT_RELU = 1, KPX_ACT_LRELU = 2 /* slope 0.01 */, KPX_ACT_TANH = 3 /* forward only */ };
 

@@ -28,7 +28,8 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, 'no ctypes signature for %s' % name
         assert len(_lib.SIGNATURES[name][1]) == nargs, (name, len(_lib.SIGNATURES[name][1]), nargs)
     assert set(_lib.SIGNATURES) == set(decl)
-    assert lib.kpx_abi_version() == 1
+    header_version = int(re.search(r'#define\s+KPX_ABI_VERSION\s+(\d+)', open(os.path.join(REPO, 'include', 'kpx.h')).read()).group(1))
+    assert lib.kpx_abi_version() == header_version == _lib.ABI_VERSION          # header, library and ctypes table agree
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

@@ -192,3 +192,79 @@ def test_f43_layer_policy_follows_the_float64_arbiter_findings():
     # the attribute, not the name, decides: the same filter name with the attribute cleared stays off F(4x4,3x3) in the forward direction only
     assert not ops._wino43_wanted('translator/conv_3_1/conv2d/kernel', 128, 128, 0, False) and ops._wino43_wanted('translator/conv_3_1/conv2d/kernel', 128, 128, 1, False)
     assert ops._wino43_wanted('pose_encoder/renamed_scope/conv2d/kernel', 128, 128, 0, True)
+
+
+# ------------------------------------------------------------------------------------------------ bench.py supervisor (N > 1 cannot hang)
+_STUB_CHILD = r'''
+import json, os, sys, time
+d, k, r = os.environ['KPX_BENCH_DIR'], os.environ['KPX_BENCH_ATTEMPT'], os.environ['RANK']
+form = os.environ['KPX_DP_GRAPH']
+mark = lambda sfx: open(os.path.join(d, 'a%s_r%s.%s' % (k, r, sfx)), 'w').close()
+behaviour = os.environ.get('STUB_' + form.upper(), 'ok')
+if behaviour == 'hang_before_warmup' and r == os.environ.get('STUB_BAD_RANK', '1'):
+    time.sleep(3600)
+if behaviour == 'crash' and r == os.environ.get('STUB_BAD_RANK', '1'):
+    sys.exit(7)
+mark('warm')
+while not all(os.path.exists(os.path.join(d, 'a%s_r%d.warm' % (k, q))) for q in range(int(os.environ['WORLD_SIZE']))):
+    time.sleep(0.02)          # (the real ranks meet in a barrier here: rank 0 cannot print while another rank hangs)
+if behaviour == 'hang_in_steps':
+    time.sleep(3600)
+if r == '0':
+    print(json.dumps({'form': form, 'graph_env': os.environ.get('KPX_GRAPH', ''), 'world': os.environ['WORLD_SIZE'],
+                      'dp_fallbacks': json.loads(os.environ['KPX_BENCH_FALLBACKS'])}), flush=True)
+mark('done')
+'''
+
+
+def _supervisor_proc(ranks, world, stub, key, q):
+    sys.path.insert(0, REPO)
+    import bench
+    rc, attempts = bench.supervise(ranks, world, [sys.executable, stub], key, plan=[('one', {}), ('segments', {}), ('inline', {'KPX_GRAPH': '0'})],
+                                   warm_deadline=3.0, run_deadline=3.0, settle=10.0, log=open(os.devnull, 'w'))
+    q.put((ranks, rc, attempts))
+
+
+@pytest.mark.parametrize('one,segments,want_form', [('hang_before_warmup', 'ok', 'segments'), ('hang_in_steps', 'crash', 'inline'), ('ok', 'ok', 'one')])
+@pytest.mark.parametrize('layout', ['one_supervisor', 'supervisor_per_rank'])
+def test_bench_supervisor_restarts_hung_or_failed_ranks_with_the_next_form(tmp_path, capfd, monkeypatch, one, segments, want_form, layout):
+    """`bench.py --gpus N` cannot hang: a rank that hangs before its warm-up completes, hangs in the timed steps or crashes makes the
+    supervisor(s) kill every child of the attempt and start FRESH children with the next data-parallel form; the line rank 0 prints names
+    the failed attempts.  Both layouts: one supervisor for all ranks (`python bench.py --gpus 2`) and one supervisor per rank that agree
+    through the shared directory (under torch.distributed.run)."""
+    import multiprocessing as mp
+    stub = str(tmp_path / 'stub_child.py')
+    open(stub, 'w').write(_STUB_CHILD)
+    monkeypatch.setenv('STUB_ONE', one)
+    monkeypatch.setenv('STUB_SEGMENTS', segments)
+    key = 'test_%d_%s_%s' % (os.getpid(), layout, want_form)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    groups = [[0, 1]] if layout == 'one_supervisor' else [[0], [1]]
+    procs = [ctx.Process(target=_supervisor_proc, args=(g, 2, stub, key, q)) for g in groups]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=90) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    for ranks, rc, attempts in results:
+        assert rc == 0, (ranks, attempts)
+    lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, lines                                    # exactly ONE JSON line, from the attempt that worked
+    import json
+    line = json.loads(lines[0])
+    assert line['form'] == want_form and line['world'] == '2'
+    failed = {'segments': ['one'], 'inline': ['one', 'segments'], 'one': []}[want_form]
+    assert [a['form'] for a in line['dp_fallbacks']] == failed
+    assert line['graph_env'] == ('0' if want_form == 'inline' else '')
+
+
+def test_bench_attempt_plan_puts_an_explicit_form_first(monkeypatch):
+    sys.path.insert(0, REPO)
+    import bench
+    monkeypatch.delenv('KPX_DP_GRAPH', raising=False)
+    assert [f for f, _ in bench.dp_attempt_plan()] == ['segments', 'inline']
+    monkeypatch.setenv('KPX_DP_GRAPH', 'one')
+    assert [f for f, _ in bench.dp_attempt_plan()] == ['one', 'segments', 'inline']
+    monkeypatch.setenv('KPX_DP_GRAPH', 'inline')
+    assert bench.dp_attempt_plan() == [('inline', {'KPX_GRAPH': '0'}), ('segments', {})]

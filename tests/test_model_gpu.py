@@ -353,8 +353,6 @@ def test_data_parallel_build_broadcasts_rank_zero_state():
 def _dp_rccl_one_rank_worker(rank, world, port, q, fail_capture=False):
     import sys
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', KPX_DP_FORCE_EXCHANGE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    if fail_capture:
-        os.environ['KPX_TEST_FAIL_CAPTURE'] = '1' 
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch.distributed as dist
     dev = torch.device('cuda:0')
@@ -379,7 +377,12 @@ def _dp_rccl_one_rank_worker(rank, world, port, q, fail_capture=False):
         return real_all_reduce(*a, **kw)
     dist.all_reduce = counting_all_reduce
     model = make_model(res, k, b, dev)
-    assert model.distributed and model.dp_graph == 'one'
+    assert model.distributed and model.dp_graph == 'one'          # a ONE-rank RCCL group takes the one-graph form by default
+    if fail_capture:
+        def fault():
+            if model.dp_graph == 'one':
+                raise RuntimeError('simulated capture failure (tests the in-process fall-back)')
+        model._capture_fault = fault
     got = run(model)
     if fail_capture:
         assert model.dp_graph == 'segments' and not model._graph_failed       # fell back in process, and captured the segments instead
@@ -401,7 +404,7 @@ def test_data_parallel_one_graph_with_the_rccl_all_reduces_captured_equals_the_p
 
 
 def test_data_parallel_capture_failure_falls_back_to_segments_in_process():
-    """A capture of the one-graph form that fails (simulated: KPX_TEST_FAIL_CAPTURE=1 raises inside the open capture) must leave a working model:
+    """A capture of the one-graph form that fails (simulated: the test replaces the model's _capture_fault seam, which raises inside the open capture) must leave a working model:
     the same process continues with the segmented form -- four captured segments around eager collectives -- and the same bits."""
     (rank, out), = _run_ranks(_dp_rccl_one_rank_worker, 1, 36100 + (os.getpid() % 1500), (True,))
     assert out['dp_graph'] == 'segments' and not out['failed'] and out['mode'] == 2, out

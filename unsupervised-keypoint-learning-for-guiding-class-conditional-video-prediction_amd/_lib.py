@@ -29,6 +29,7 @@ lib = ctypes.CDLL(LIB_PATH)
 
 P = c_void_p
 # name -> (restype, argtypes); mirrors include/kpx.h one to one (tests/test_abi.py checks header vs this table)
+ABI_VERSION = 2        # = KPX_ABI_VERSION of include/kpx.h (tests/test_abi.py holds the two equal); bumped whenever a signature changes
 SIGNATURES = {
     'kpx_abi_version': (c_int, []),
     'kpx_reload_env': (c_int, []),
@@ -126,7 +127,7 @@ for _name, (_res, _args) in SIGNATURES.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
-if lib.kpx_abi_version() != 1:
+if lib.kpx_abi_version() != ABI_VERSION:
     raise ImportError('libkpx_hip.so ABI version mismatch')
 
 

@@ -1378,7 +1378,9 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
         return KPX_EINVAL;
     {   // tiny filters over very many pixels (image-input layers, 16 -> 16 at full resolution, the 64 -> 4 head): conv_wsmall.hip
         // (16-B staging units: dy always, x when it has a multiple of 4 channels)
-        const bool units_ok = Cout % 4 == 0 && lddy % 4 == 0 && aligned16(dy) && (Cin % 4 != 0 || (ldx % 4 == 0 && aligned16(x)));
+        // the kernel addresses x and dy with 32-bit byte offsets at their PIXEL STRIDES (a channel slice of a wider buffer has ldx > Cin)
+        const bool off32_ok = (size_t)N * Hi * Wi * (size_t)ldx * 4 < 0x60000000ull && (size_t)N * Ho * Wo * (size_t)lddy * 4 < 0x60000000ull;
+        const bool units_ok = off32_ok && Cout % 4 == 0 && lddy % 4 == 0 && aligned16(dy) && (Cin % 4 != 0 || (ldx % 4 == 0 && aligned16(x)));
         const int Ss = units_ok ? kpx_wsmall_splits(N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride) : 0;
         const size_t slab = (size_t)KH * KW * Cin * Cout;
         if (Ss >= 1 && (Ss == 1 || (workspace && workspace_bytes >= (size_t)Ss * slab * 4))) {

@@ -50,15 +50,19 @@ class _Bf16Exchange:
             self.work.wait()
         self.grads.copy_(self.buf)
 # Data parallel, how the step reaches the GPU (KPX_DP_GRAPH):
-#   'one'      (default with the RCCL backend) ONE captured graph: the single-GPU step unchanged, with the two all-reduces issued synchronously
-#              (async_op=False) on the stream they belong to -- ProcessGroupNCCL runs such a collective on the caller's CURRENT stream, so nothing
-#              forks from the auxiliary stream (ops.py: stream discipline) and the collectives are two more nodes of the graph.  Measured at one
-#              rank with both collectives kept in (KPX_DP_FORCE_EXCHANGE=1): 22.76 ms against 22.74-22.78 ms for the non-distributed graph.
-#   'segments' (default with any other backend, and the fall-back when capturing 'one' fails) four captured segments replayed around the two
-#              collectives, which are enqueued from Python between them (_train_step_dp): +1.2 ms per step, host work 1.3 ms;
+#   'segments' (default on every backend with more than one rank) four captured segments replayed around the two collectives, which are
+#              enqueued from Python between them (_train_step_dp): +1.2 ms per step, host work 1.3 ms.  The form two-rank runs have proven
+#              (gloo tests: replicas bit-identical to the eager and inline forms);
+#   'one'      ONE captured graph: the single-GPU step unchanged, with the two all-reduces issued synchronously (async_op=False) on the stream
+#              they belong to -- ProcessGroupNCCL (torch 2.10) runs such a collective on the caller's CURRENT stream, so nothing forks from the
+#              auxiliary stream (ops.py: stream discipline) and the collectives are two more nodes of the graph.  Measured at one rank with both
+#              collectives kept in (KPX_DP_FORCE_EXCHANGE=1): 22.76 ms against 22.74-22.78 ms for the non-distributed graph.  It has only ever
+#              run with a ONE-rank RCCL communicator, so it is opt-in (KPX_DP_GRAPH=one; a one-rank group takes it by default) until a run
+#              with two or more ranks has shown the replicas bit-identical under it; a failed capture falls back to 'segments' in process,
+#              a capture that HANGS is bench.py's supervisor's business (fresh processes with the next form);
 #   'inline'   round 3's form: one eager pass with the collectives inline (also taken by separate-batch steps and with KPX_GRAPH=0 + this value).
 DP_GRAPH = os.environ.get('KPX_DP_GRAPH', '')
-# measurement only: run the data-parallel code path WITHOUT its two collectives (what the segmentation alone costs on one GPU)
+# measurement only, ONE rank only (refused otherwise: replicas would diverge silently): the data-parallel code path WITHOUT its two collectives
 DP_NO_COLLECTIVES = os.environ.get('KPX_DP_NO_COLLECTIVES', '0') != '0'
 GRAPH_WARMUP_STEPS = 1          # eager steps before the capture: they create every lazily allocated scratch buffer and kernel attribute
 
@@ -90,7 +94,11 @@ class DetectorTranslatorModel(BaseModel):
         self.world_size = torch.distributed.get_world_size(process_group) if in_group else 1
         self.distributed = in_group and (self.world_size > 1 or os.environ.get('KPX_DP_FORCE_EXCHANGE', '0') != '0')
         backend = torch.distributed.get_backend(process_group) if in_group else ''
-        self.dp_graph = DP_GRAPH or ('one' if backend == 'nccl' else 'segments')
+        if DP_GRAPH not in ('', 'one', 'segments', 'inline'):
+            raise ValueError("KPX_DP_GRAPH must be 'one', 'segments' or 'inline' (got %r)" % DP_GRAPH)
+        self.dp_graph = DP_GRAPH or ('one' if (backend == 'nccl' and self.world_size == 1) else 'segments')
+        if DP_NO_COLLECTIVES and self.world_size > 1:
+            raise ValueError('KPX_DP_NO_COLLECTIVES=1 is a one-rank measurement switch: with %d ranks the replicas would diverge' % self.world_size)
         self.store = variables.VariableStore(device=self.device, seed=seed)
         self.vgg = vgg
         # Adam state (two optimisers, reference :198 and :201): fp32 beta powers like TF's beta{1,2}_power variables
@@ -315,14 +323,22 @@ class DetectorTranslatorModel(BaseModel):
         # overwrites them in place; read (or clone) what is needed before calling train_step again.  Eager steps return fresh tensors.
         self.last = dict(outputs, lr=float(lr))
 
+    def _capture_mode(self):
+        """Stream-capture error mode of the step captures.  In a process with a process group, ProcessGroupNCCL's watchdog THREAD polls the
+        completion events of the eager collectives issued so far, and an event query from any thread is an error while a capture in the
+        default 'global' mode is open (it aborted a run: 'operation not permitted when stream is capturing' from WorkNCCL::isCompleted).
+        'thread_local' restricts the check to the capturing thread -- which only enqueues kernels -- so the watchdog's queries are legal
+        whenever they come: no sleep, no race.  Single-process runs keep the stricter default."""
+        return 'thread_local' if self.distributed else 'global'
+
     def _quiesce_collectives(self):
-        """Before a capture in a process that has issued eager collectives: ProcessGroupNCCL's watchdog thread polls the completion events of
-        those collectives, and an event query from ANY thread is an error while a stream capture in global mode is open (it aborted a run:
-        'operation not permitted when stream is capturing' from WorkNCCL::isCompleted).  Finish the GPU work, then give the watchdog (a 100 ms
-        loop) time to retire what it tracks; collectives issued under capture are not handed to it."""
+        """Before a capture: finish the GPU work of the eager steps (the collectives among it), so that nothing issued before the capture is
+        still running beside it."""
         if self.distributed:
             torch.cuda.synchronize(self.device)
-            time.sleep(0.5)
+
+    def _capture_fault(self):
+        """Test seam: tests replace this to raise inside an open capture (the in-process fall-back is what they check)."""
 
     def _capture_step(self, key, im, fut):
         self._quiesce_collectives()
@@ -340,10 +356,9 @@ class DetectorTranslatorModel(BaseModel):
         from . import _lib
         calls0 = _lib.abi_calls[0]
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=self._capture_mode()):
                 self._train_step_eager(static)
-                if self.distributed and os.environ.get('KPX_TEST_FAIL_CAPTURE') == '1':
-                    raise RuntimeError('KPX_TEST_FAIL_CAPTURE=1: simulated capture failure (tests the in-process fall-back)')
+                self._capture_fault()
             outputs = {k: v for k, v in self.last.items() if k != 'lr'}
             self._graph_launches = _lib.abi_calls[0] - calls0          # diagnostics: C-ABI launches recorded in the graph
         except Exception as e:              # noqa: BLE001 -- whatever the runtime refuses: stay on the eager path
@@ -515,7 +530,7 @@ class DetectorTranslatorModel(BaseModel):
             done = False
             while not done:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool, capture_error_mode=self._capture_mode()):
                     try:
                         next(gen)
                     except StopIteration:
