@@ -202,20 +202,32 @@ def roofline_conv_direct(dev):
             'traffic': traffic, 'traffic_source': src, 'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops}
 
 
-def roofline_conv_bf16(dev):
-    """The bf16-MFMA direct 3x3 kernel (BASELINE configs[2]) on the same layer: fp32 tensors in HBM, so the bound is HBM traffic
-    (x read + y written = 134.2 MB algorithmic) rather than the 2.5 PFLOP/s bf16 matrix peak; both fractions are reported."""
+def roofline_conv_bf16(dev, n=BATCH, h=64, c=128):
+    """The bf16-storage 3x3 kernel (BASELINE configs[2]; csrc/conv_bf16s.hip) on the roofline layer: bf16 tensors in HBM, fp32 accumulate,
+    filters prepared once.  Two bounds are reported: the dense bf16 matrix peak (2.5 PFLOP/s; `frac`) and the HBM time of the ALGORITHMIC
+    bytes (bf16 x read once + bf16 y written once + the fp32 filter's bf16 copy)."""
     from kpx_amd import ops
-    ops.set_compute_dtype('bf16')
-    try:
-        ms, flops = _time_conv_3_1(dev)
-    finally:
-        ops.set_compute_dtype('f32')
-    nbytes = 2 * BATCH * 64 * 64 * 128 * 4 + 9 * 128 * 128 * 4
-    return {'bound': 'hbm', 'kernel': 'conv3x3_bf16_wide_kernel<4> (16x32 pixels x 128 couts per workgroup; + weight prepare) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)',
-            'achieved': round(nbytes / (ms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s', 'frac': round(nbytes / (ms * 1e-3) / 8e12, 4),
-            'traffic': _pmc_traffic(BF16_PMC)[0], 'traffic_source': _pmc_traffic(BF16_PMC)[1], 'avg_launch_ms': round(ms, 4), 'bytes_per_launch': nbytes,
-            'mfma_tflops_bf16': round(flops / (ms * 1e-3) / 1e12, 1), 'mfma_frac_of_bf16_peak': round(flops / (ms * 1e-3) / 2.5e15, 4)}
+    from kpx_amd._lib import lib, check
+    x = torch.randn(n, h, h, c, device=dev).bfloat16()
+    w = torch.randn(3, 3, c, c, device=dev) * 0.03
+    b = torch.zeros(c, device=dev)
+    y = torch.empty(n, h, h, c, dtype=torch.bfloat16, device=dev)
+    wf = torch.empty(lib.kpx_conv3x3_bf16s_weights_bytes(c, c), dtype=torch.uint8, device=dev)
+    check(lib.kpx_conv3x3_bf16s_prepare_f32(w.data_ptr(), c, c, 0, wf.data_ptr(), ops._stream()), 'prepare')
+    ms = time_kernel(lambda: check(lib.kpx_conv3x3_bf16s(x.data_ptr(), n, h, h, c, c, wf.data_ptr(), b.data_ptr(), y.data_ptr(), c, c, 0, 1, None, 0, None, ops._stream()), 'conv'),
+                     iters=100, warm=20)
+    flops = 2.0 * 9 * c * c * h * h * n
+    nbytes = 2 * n * h * h * c * 2 + 9 * c * c * 2
+    ach = flops / (ms * 1e-3) / 1e12
+    traffic, src = _pmc_traffic(BF16_PMC)
+    rp_ms, rp_src = _rocprof_avg_ms('conv3x3_bf16s_kernel<2, 2, 4, 32, 0>')
+    return {'committed_profile': {'note': 'from files committed under profiles/, NOT measured in this run', 'collected_at_commit': _profile_stamp(),
+                                  'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'traffic_source': src},
+            'bound': 'mfma', 'kernel': 'conv3x3_bf16s_kernel<2,2,4,32,0> (512 pixels x 128 couts per workgroup, LDS-DMA operands, filters prepared once) fwd 3x3 s1 '
+                                       '%d->%d @%dx%d B=%d (translator conv_3_1), bf16 tensors' % (c, c, h, h, n),
+            'achieved': round(ach, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(ach / 2500.0, 4), 'traffic': traffic, 'traffic_source': src,
+            'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops, 'bytes_per_launch_algorithmic': nbytes,
+            'hbm_gbps_algorithmic': round(nbytes / (ms * 1e-3) / 1e9, 1), 'hbm_frac_algorithmic': round(nbytes / (ms * 1e-3) / 8e12, 4)}
 
 
 def roofline_conv_bf16x3(dev):
@@ -546,9 +558,8 @@ def main():
                     help='c1: BASELINE configs[1], the headline (128x128, K=15, 32 pairs per GPU).  c3: configs[3] (256x256, K=40, 16 pairs per GPU = 128 '
                          'over 8).  c4: configs[4], the evaluate.py rollout (64 source images -> 2048 predicted frames per step, inference only)')
     ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32',
-                    help="f32: the headline / parity configuration (BASELINE configs[1]).  bf16: BASELINE configs[2]'s arithmetic -- forward and "
-                         'data gradient of the 3x3 stride-1 layers on the bf16 matrix pipe (fp32 tensors, accumulate, master weights, BN '
-                         'statistics, weight gradients); a SEPARATE configuration, never the headline')
+                    help="f32: the headline / parity configuration (BASELINE configs[1]).  bf16: BASELINE configs[2] -- bf16 activation tensors in "
+                         'HBM, fp32 accumulate / batch-norm statistics / master weights / Adam; a SEPARATE configuration, never the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true', help='skip the kernel microbenchmarks after the timed steps (clean per-step rocprofv3 kernel statistics)')
     ap.add_argument('--roofline-only', action='store_true', help='only the two kernel microbenchmarks (used for the rocprofv3 cross-check)')
@@ -659,7 +670,7 @@ def main():
         out = {'metric': conf['metric'], 'value': round(value, 2),
                'unit': 'image pairs/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f32' if args.dtype == 'f32' else 'bf16 operands on the 3x3 stride-1 fwd/dgrad convs (fp32 storage, accumulate, wgrad, BN, Adam)',
+               'dtype': 'f32' if args.dtype == 'f32' else 'bf16 (activation tensors bf16 in HBM; fp32 accumulate, batch-norm statistics, master weights, gradients, Adam)',
                'data': 'synthetic',
                'config': {'workload': 'Penn %dx%d K=%d detector_translator %s, batch=%d per GPU (BASELINE configs[%d])'
                                       % (RES, RES, K_PTS, 'fp32' if args.dtype == 'f32' else 'bf16 + VGG19 perceptual loss', args.batch,
@@ -688,9 +699,10 @@ def main():
             out['dp_graph_form'] = model.dp_graph if model.distributed else None
             out['dp_fallbacks'] = json.loads(os.environ.get('KPX_BENCH_FALLBACKS', '[]'))
         if world == 1 and not args.no_roofline:
-            kops.set_compute_dtype('f32')
             if args.dtype == 'bf16':
+                out['fp32_kernel_fallbacks'] = dict(kops.fallback_uses)       # bf16 tensors routed through an fp32 kernel between two conversions (whole run)
                 out['roofline_bf16_conv'] = roofline_conv_bf16(dev)
+            kops.set_compute_dtype('f32')
             out['roofline'] = roofline_conv(dev) if args.config == 'c1' else roofline_conv_c3(dev, args.batch)
             out['roofline_wgrad'] = roofline_wgrad(dev)
             out['roofline_wino_f23'] = roofline_conv_f23(dev)

@@ -86,20 +86,24 @@ size_t kpx_conv3x3_wino_stats_tiles(int N, int H, int W);
 int kpx_conv3x3_wino_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u, const float* bias,
                                float* out, int Nn, int ldout, int act, float* tile_stats, void* stream);
 
-/* ---- bf16-MFMA variant of the 3x3 stride-1 SAME convolution (BASELINE configs[2]: "bf16"; same reference call sites as above:
- *      models/networks/layers.py:6-9 for kernel=3, stride=1; models/networks/vgg.py:51-54).  Tensors stay float32 in HBM (fp32
- *      master weights, fp32 bias / BN statistics); operands are rounded to bf16 on the way into the matrix pipe
- *      (v_mfma_f32_32x32x16_bf16), accumulation is fp32.  Two steps:
- *        kpx_conv3x3_bf16_prepare_f32: HWIO fp32 filter -> fragment-ordered bf16 copy `wf` (size kpx_conv3x3_bf16_weights_bytes);
- *            dgrad != 0 prepares the flipped / transposed filter of the data gradient;
- *        kpx_conv3x3_bf16_f32: out[N,H,W,Nn] = act(conv3x3_same(in[N,H,W,K], wf) + bias).  Forward: in = x, K = Cin, Nn = Cout;
- *            data gradient: in = dy, K = Cout, Nn = Cin, wf prepared with dgrad = 1, bias NULL.
- *      H and W must be multiples of 16, ldin a multiple of 4, `in` 16-byte aligned (kpx_conv3x3_bf16_eligible tells). */
-size_t kpx_conv3x3_bf16_weights_bytes(int Cin, int Cout);
-int kpx_conv3x3_bf16_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in);
-int kpx_conv3x3_bf16_prepare_f32(const float* w_hwio, int Cin, int Cout, int dgrad, void* wf, void* stream);
-int kpx_conv3x3_bf16_f32(const float* in, int N, int H, int W, int K, int ldin, const void* wf, const float* bias,
-                         float* out, int Nn, int ldout, int act, void* stream);
+/* ---- bf16 STORAGE (the bf16 configuration proper, BASELINE configs[2] "bf16 storage + fp32 accumulate"): the same layers.conv call sites
+ *      (layers.py:4-10; networks/__init__.py:13-24,50-62,80-97; vgg.py:20-40) with bf16 activation tensors in HBM.  `in` is bf16
+ *      [N,H,W,K] (pixel stride ldin ELEMENTS, a multiple of 8; 16-byte aligned), `out` bf16 [N,H,W,Nn] (out_f32 = 0; Nn, ldout multiples
+ *      of 8) or fp32 (out_f32 = 1; multiples of 4).  Filters stay fp32 masters; kpx_conv3x3_bf16s_prepare_f32 (or the batched form: one
+ *      launch per optimiser update over a device table of {const float* w; void* wf; int Cin, Cout, dgrad, NB = 4 * ceil(Nn / 128)}
+ *      entries, 32 bytes each) writes the fragment-ordered bf16 copy of one direction (kpx_conv3x3_bf16s_weights_bytes(K, Nn) bytes).
+ *      out = mask_gate( act( conv3x3_same(in, wf) + bias ) ): `mask` (optional, bf16 [N,H,W,Nn], pixel stride ldmask) zeroes the output
+ *      where mask <= 0 (ReLU backward of the tensor a data gradient belongs to); `stats` (optional) receives per-workgroup channel sums
+ *      and sums of squares of the fp32 results before the activation, [kpx_conv3x3_bf16s_stats_tiles(...)][2][Nn] floats, for the batch
+ *      norm that follows (layers.py:13-14).  Shapes: W a multiple of 32, or W = 16 / 8 (whole images per tile); K a multiple of 32 or
+ *      8 / 16; kpx_conv3x3_bf16s_eligible tells. */
+size_t kpx_conv3x3_bf16s_weights_bytes(int K, int Nn);
+int kpx_conv3x3_bf16s_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in);
+int kpx_conv3x3_bf16s_stats_tiles(int N, int H, int W, int K, int Nn);
+int kpx_conv3x3_bf16s_prepare_f32(const float* w_hwio, int Cin, int Cout, int dgrad, void* wf, void* stream);
+int kpx_conv3x3_bf16s_prepare_batch_f32(const void* table, int ndesc, void* stream);
+int kpx_conv3x3_bf16s(const void* in, int N, int H, int W, int K, int ldin, const void* wf, const float* bias,
+                      void* out, int Nn, int ldout, int out_f32, int act, const void* mask, int ldmask, float* stats, void* stream);
 
 /* dx = d(loss)/dx given dy (gradient of the conv output BEFORE activation).  Writes every element of dx.
  * stride <= 2.  `workspace`: optional split-K scratch, see kpx_conv2d_fwd_f32. */
@@ -357,6 +361,28 @@ int kpx_u8_to_unit_f32(const unsigned char* src, size_t n, float* dst, void* str
 /* Host utility (no device access): CRC-32C of n bytes continuing from `crc` (0 to start) -- the checksum of TensorFlow V2
  * checkpoint bundles (next row; models/base_model.py:74-91 saves / restores through tf.train.Saver). */
 unsigned int kpx_crc32c_host(unsigned int crc, const void* data, size_t n);
+
+/* ---- bf16 STORAGE variants of the streaming kernels (BASELINE configs[2]): bf16 tensors in HBM, fp32 arithmetic, fp64 reductions, fp32
+ *      statistics / parameter gradients.  C and the pixel strides (in ELEMENTS) are multiples of 8, pointers 16-byte aligned, unless an
+ *      entry says otherwise.  Reference call sites as the fp32 entries of the same name above. */
+/* dst[p][0:C] = src[p][0:C] with conversion: kind 0 = f32 -> bf16, 1 = bf16 -> f32, 2 = bf16 -> bf16 (tf.concat channel slices); any C. */
+int kpx_cast_channels(const void* src, int ldsrc, void* dst, int lddst, size_t P, int C, int kind, void* stream);
+int kpx_chan_sum_bf16(const void* x, size_t P, int C, int ldx, float* sum_out, void* scratch, void* stream);
+/* layers.batch_norm, train mode, all weight-sharing groups in one launch per phase (kpx_bn_train_fwd_f32 / _bwd_f32): x bf16, y bf16
+ * (y_f32 = 0) or fp32 (y_f32 = 1: the tensor the fp32 key-point head reads); backward: dy bf16 (dy_f32 = 0) or fp32, dx bf16. */
+int kpx_bn_train_fwd_bf16(const void* x, size_t P, int groups, int C, int ldx, const float* tile_stats, size_t tiles_per_group,
+                          float eps, const float* gamma, const float* beta, float* mean, float* invstd,
+                          float* moving_mean, float* moving_var, float decay, void* y, int ldy, int y_f32, int act, void* scratch, void* stream);
+int kpx_bn_train_bwd_bf16(const void* dy, int lddy, int dy_f32, const void* x, int ldx, size_t P, int groups, int C,
+                          const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                          void* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* scratch, void* stream);
+int kpx_act_bwd_bf16(const void* dy, const void* y, void* dz, size_t n, int act, void* stream);
+int kpx_resize2x_fwd_bf16(const void* x, int N, int H, int W, int C, int ldx, void* y, int ldy, void* stream);
+int kpx_resize2x_bwd_bf16(const void* dy, int N, int H, int W, int C, int lddy, void* dx, int lddx, void* stream);
+int kpx_maxpool2_fwd_bf16(const void* x, int N, int H, int W, int C, void* y, void* stream);
+int kpx_vgg_feat_bwd_bf16(const void* f, size_t half, const float* gscale_dev, float gscale_host, const void* dy_pooled,
+                          int B, int H, int W, int C, void* d, void* stream);
+int kpx_l1_pair_fwd_bf16(const void* f, size_t half, float* loss_out, void* scratch, void* stream);
 
 #ifdef __cplusplus
 }

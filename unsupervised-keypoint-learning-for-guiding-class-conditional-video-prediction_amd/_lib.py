@@ -64,10 +64,22 @@ SIGNATURES = {
     'kpx_conv3x3_wino_bnbwd_stats_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, c_int, P, P, P]),
     'kpx_bn_bwd_from_tiles_f32': (c_int, [P, c_int, P, c_int, c_size_t, c_int, P, P, P, P, c_int, P, c_int, P, P, c_int, P, c_size_t, c_size_t, P, P]),
     'kpx_bn_stats_from_tiles_f32': (c_int, [P, c_size_t, c_size_t, c_int, c_int, c_float, P, P, P, P, P, c_float, P]),
-    'kpx_conv3x3_bf16_weights_bytes': (c_size_t, [c_int, c_int]),
-    'kpx_conv3x3_bf16_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    'kpx_conv3x3_bf16_prepare_f32': (c_int, [P, c_int, c_int, c_int, P, P]),
-    'kpx_conv3x3_bf16_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
+    'kpx_conv3x3_bf16s_weights_bytes': (c_size_t, [c_int, c_int]),
+    'kpx_conv3x3_bf16s_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'kpx_conv3x3_bf16s_stats_tiles': (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    'kpx_conv3x3_bf16s_prepare_f32': (c_int, [P, c_int, c_int, c_int, P, P]),
+    'kpx_conv3x3_bf16s_prepare_batch_f32': (c_int, [P, c_int, P]),
+    'kpx_conv3x3_bf16s': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P]),
+    'kpx_cast_channels': (c_int, [P, c_int, P, c_int, c_size_t, c_int, c_int, P]),
+    'kpx_chan_sum_bf16': (c_int, [P, c_size_t, c_int, c_int, P, P, P]),
+    'kpx_bn_train_fwd_bf16': (c_int, [P, c_size_t, c_int, c_int, c_int, P, c_size_t, c_float, P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, P, P]),
+    'kpx_bn_train_bwd_bf16': (c_int, [P, c_int, c_int, P, c_int, c_size_t, c_int, c_int, P, P, P, P, c_int, P, c_int, P, P, c_int, P, P]),
+    'kpx_act_bwd_bf16': (c_int, [P, P, P, c_size_t, c_int, P]),
+    'kpx_resize2x_fwd_bf16': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
+    'kpx_resize2x_bwd_bf16': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
+    'kpx_maxpool2_fwd_bf16': (c_int, [P, c_int, c_int, c_int, c_int, P, P]),
+    'kpx_vgg_feat_bwd_bf16': (c_int, [P, c_size_t, P, c_float, P, c_int, c_int, c_int, c_int, P, P]),
+    'kpx_l1_pair_fwd_bf16': (c_int, [P, c_size_t, P, P, P]),
     'kpx_act_bwd_f32': (c_int, [P, P, P, c_size_t, c_int, P]),
     'kpx_chan_reduce_scratch_bytes': (c_size_t, [c_int]),
     'kpx_chan_sum_f32': (c_int, [P, c_size_t, c_int, c_int, P, P, P]),

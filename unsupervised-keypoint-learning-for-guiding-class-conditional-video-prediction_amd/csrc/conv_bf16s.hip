@@ -1,0 +1,500 @@
+// 3x3 stride-1 SAME convolution with bf16 TENSORS IN HBM (bf16 in, bf16 or fp32 out, fp32 accumulate) on v_mfma_f32_32x32x16_bf16 for
+// gfx950: the bf16 configuration (BASELINE configs[2]) of layers.conv (reference models/networks/layers.py:4-10) for the translator /
+// VGG19 / encoders / key-point detector 3x3 layers (models/networks/__init__.py:13-24,50-62,80-97, models/networks/vgg.py:20-40), forward
+// and data gradient (the same kernel on filters prepared flipped / transposed).
+//
+// Structure (one workgroup = 8 wavefronts = MB x 32 output pixels x NBT x 32 output channels; one workgroup per CU):
+//   * operands reach LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write.  Input patch: pixel q of the
+//     (TH+2) x PW patch owns five 16-B slots (32 channels of a chunk + one pad slot: pitch 80 B), so sixteen consecutive pixels start in
+//     sixteen different 16-B columns of the 256-B bank row -- every fragment read of every tap is conflict-free (scratch/lds_conflicts_bf16s.py)
+//     and a tap is an IMMEDIATE offset from one base register per pixel block.  Out-of-image pixels, pad slots and channel tails carry an
+//     out-of-range buffer offset and land as zeros.  Filters: fragment-ordered by kpx_conv3x3_bf16s_prepare (once per optimiser update),
+//     1 KB = one wave-instruction per (tap, k16 step, cout block).
+//   * K loop: chunks of 32 channels x three phases (one filter ROW each: 3 taps x 2 k16 steps).  The filter row of phase p+1 and a third
+//     of the next chunk's patch are in flight during phase p; counted s_waitcnt vmcnt + one raw s_barrier per phase (the patch is double
+//     buffered per chunk, the filter rows per phase).
+//   * MFMA operand roles are swapped against the textbook im2col form: A = filter fragment (rows = output channels), B = pixel fragment
+//     (columns = pixels).  The accumulator then holds, per lane = pixel, sixteen output channels in groups of four consecutive ones: after
+//     one v_permlane32_swap per dword (guide T21) a lane stores 16 contiguous bytes of its pixel's NHWC row.
+//   * wavefront (wm, wn) owns P pixel blocks x Q cout blocks: P + Q fragment reads per P*Q MFMAs.
+// Epilogue options: bias, activation, a ReLU mask (data gradient towards an activated tensor: VGG19), per-workgroup batch-norm sums of the
+// fp32 accumulators (consumed by kpx_bn_train_fwd: no statistics pass over the activation).
+#include "kpx_common.h"
+#include "kpx_env.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#define S16_OOB 0x7ffffff0
+#define S16_PIX 80                       // bytes of one patch pixel in LDS: 32 channels + one 16-B pad slot
+
+struct S16Geom {
+    const void* x; void* y; const void* Wf; const float* bias; const void* mask; float* stats;
+    int N, H, W, K, ldx, Nn, ldy, ldm, act;
+    int KC, NB;                          // 32-channel chunks of K, 32-cout blocks of the prepared filters (Nn rounded up to the tile)
+    int tiles_y, tiles_x, ngrp, ntc;     // ngrp: image groups (G images per tile), ntc: cout tiles
+    int out_f32;
+};
+
+// Wf[kc][tap 9][ks 2][nb][lane 64][8] bf16: element j of lane (li, lh) = w'[tap][c = 32 kc + 16 ks + 8 lh + j][n = 32 nb + li]
+// (the A operand of v_mfma_f32_32x32x16_bf16: row li = output channel, k = 8 lh + j).  dgrad: w'[r][q][c'][n'] = w[2-r][2-q][n'][c'].
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void conv_bf16s_prepare_kernel(const float* __restrict__ w, int Cin, int Cout, int KC, int NB, unsigned short* __restrict__ Wf) {
+    const int K = DGRAD ? Cout : Cin, Nn = DGRAD ? Cin : Cout;
+    const size_t total = (size_t)KC * 9 * 2 * NB * 512;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int j = (int)(idx & 7), li = (int)((idx >> 3) & 31), lh = (int)((idx >> 8) & 1);
+        size_t blk = idx >> 9;
+        const int nb = (int)(blk % NB); blk /= NB;
+        const int ks = (int)(blk & 1); blk >>= 1;
+        const int tap = (int)(blk % 9);
+        const int kc = (int)(blk / 9);
+        const int c = 32 * kc + 16 * ks + 8 * lh + j, n = 32 * nb + li;
+        float v = 0.f;
+        if (c < K && n < Nn) v = DGRAD ? w[((size_t)(8 - tap) * Cin + n) * Cout + c] : w[((size_t)tap * Cin + c) * Cout + n];
+        const __bf16 b = (__bf16)v;
+        Wf[idx] = *reinterpret_cast<const unsigned short*>(&b);
+    }
+}
+
+// batched form: one launch per optimiser update for every trainable 3x3 filter (table entry: w, Wf, Cin, Cout, dgrad, NB)
+struct S16PrepDesc { const float* w; unsigned short* Wf; int Cin, Cout, dgrad, NB; };
+__global__ __launch_bounds__(256) void conv_bf16s_prepare_batch_kernel(const S16PrepDesc* __restrict__ table, int ndesc) {
+    const S16PrepDesc d = table[blockIdx.y];
+    const int K = d.dgrad ? d.Cout : d.Cin, Nn = d.dgrad ? d.Cin : d.Cout;
+    const int KC = (K + 31) / 32;
+    const size_t total = (size_t)KC * 9 * 2 * d.NB * 512;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int j = (int)(idx & 7), li = (int)((idx >> 3) & 31), lh = (int)((idx >> 8) & 1);
+        size_t blk = idx >> 9;
+        const int nb = (int)(blk % d.NB); blk /= d.NB;
+        const int ks = (int)(blk & 1); blk >>= 1;
+        const int tap = (int)(blk % 9);
+        const int kc = (int)(blk / 9);
+        const int c = 32 * kc + 16 * ks + 8 * lh + j, n = 32 * nb + li;
+        float v = 0.f;
+        if (c < K && n < Nn) v = d.dgrad ? d.w[((size_t)(8 - tap) * d.Cin + n) * d.Cout + c] : d.w[((size_t)tap * d.Cin + c) * d.Cout + n];
+        const __bf16 b = (__bf16)v;
+        d.Wf[idx] = *reinterpret_cast<const unsigned short*>(&b);
+    }
+}
+
+__device__ __forceinline__ unsigned s16_pack2(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 p = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ float s16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float s16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+
+// geometry of a tile at compile time
+template <int WN, int Q, int P, int BW>
+struct S16Tile {
+    static constexpr int WM = 8 / WN, MB = WM * P, NBT = WN * Q;
+    static constexpr int R = 32 / BW;                       // rows of one 32-pixel block
+    static constexpr int ROWS = MB * R;                     // output rows of a tile (stacked over its images)
+    static constexpr int PW = BW + 2;
+};
+
+// STATS: 0 none, 1 per-workgroup channel sums of the accumulators (before bias / activation) -> stats[tile][2][Nn]
+template <int WN, int Q, int P, int BW, int STATS>
+__global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, const int TH, const int G) {
+    using T = S16Tile<WN, Q, P, BW>;
+    constexpr int WM = T::WM, NBT = T::NBT, R = T::R, PW = T::PW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int PH = TH + 2;
+    const int NPX = G * PH * PW;                            // patch pixels
+    const int APIECES = (NPX * 5 + 63) >> 6;                // 1-KB LDS-DMA pieces of one patch
+    const int ABYTES = APIECES << 10;
+    constexpr int BPIECES = 6 * NBT, BBYTES = BPIECES << 10;
+    constexpr int BPW = (BPIECES + 7) / 8;                  // filter pieces per wavefront and phase
+    constexpr int APW = 9;                                  // patch pieces per wavefront and chunk (host: APIECES <= 72), up to three per phase
+    unsigned char* const Asm = smem;                        // [2][ABYTES]
+    unsigned char* const Bsm = smem + 2 * ABYTES;           // [2][BBYTES]
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int wm = wave % WM, wn = wave / WM;
+    int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    const int nti = L % g.ntc; L /= g.ntc;
+    const int bx = L % g.tiles_x; L /= g.tiles_x;
+    const int by = L % g.tiles_y;
+    const int grp = L / g.tiles_y;
+    const int oy0 = by * TH, ox0 = bx * BW, n0 = grp * G, c0 = nti * NBT * 32;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, (int)((size_t)g.N * g.H * g.W * g.ldx * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.Wf), 0, (int)((size_t)g.KC * 18 * g.NB * 1024), 0x00020000);
+
+    // ---- patch pieces of this wavefront: piece wave + 8 i covers slots 64 (wave + 8 i) .. + 63; slot = 5 q + u
+    int a_voff[APW];
+    unsigned a_tail = 0;                                    // bit i: the unit exists in the LAST chunk too (channel tail)
+    const int ktail = g.K - 32 * (g.KC - 1);
+#pragma unroll
+    for (int i = 0; i < APW; ++i) {
+        const int piece = wave + 8 * i;
+        const int S = piece * 64 + lane, q = S / 5, u = S - 5 * q;
+        const int gi = q / (PH * PW), rem = q - gi * (PH * PW), pr = rem / PW, pc = rem - pr * PW;
+        const int n = n0 + gi, iy = oy0 - 1 + pr, ix = ox0 - 1 + pc;
+        const bool ok = piece < APIECES && u < 4 && q < NPX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W && n < g.N;
+        a_voff[i] = ok ? (int)((((size_t)n * g.H + iy) * g.W + ix) * g.ldx * 2 + u * 16) : S16_OOB;
+        if (ok && u * 8 < ktail) a_tail |= 1u << i;
+    }
+    // ---- fragment read bases
+    int pb[P];                                              // pixel block p of this wavefront: LDS byte offset of (lane's pixel, tap (0,0), unit lh)
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int mb = wm * P + p;
+        const int tr0 = mb * R + li / BW;                   // row inside the tile's stacked images
+        const int gi = tr0 / TH, row = tr0 - gi * TH;
+        const int j = li % BW;
+        const int rot = (BW == 16 && (li / BW) == 1) ? 2 : (BW == 8 && (li / BW) == 3) ? 2 : 0;
+        const int col = (j - rot) & (BW - 1);
+        pb[p] = ((gi * PH + row) * PW + col) * S16_PIX + lh * 16;
+    }
+    const int wb = (wn * Q) * 1024 + lane * 16;
+
+    f32x16 acc[P][Q];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
+
+    auto issue_b = [&](int kc, int r, int buf) {           // filter row r of chunk kc -> Bsm[buf]
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) {
+            const int piece = wave * BPW + i;               // = (s * 2 + ks) * NBT + nb
+            if (BPIECES % 8 == 0 || piece < BPIECES) {
+                const int sk = piece / NBT, nb = piece - sk * NBT;
+                const int soff = ((((kc * 3 + r) * 3) * 2 + sk) * g.NB + nti * NBT + nb) * 1024;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bsm + buf * BBYTES + piece * 1024), 16, lane * 16, soff, 0, 0);
+            }
+        }
+    };
+    auto issue_a = [&](int kc, int part, int buf) {        // pieces part, part + 3, part + 6 of this wavefront, chunk kc -> Asm[buf]
+        const bool last = kc == g.KC - 1;
+#pragma unroll
+        for (int ii = 0; ii < 3; ++ii) {
+            const int i = part + 3 * ii;
+            const int piece = wave + 8 * i;
+            if (piece < APIECES) {
+                const int vo = (last && !((a_tail >> i) & 1u)) ? S16_OOB : a_voff[i];
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(Asm + buf * ABYTES + piece * 1024), 16, vo, kc * 64, 0, 0);
+            }
+        }
+    };
+
+    // ---- prologue: chunk 0's patch and filter row 0
+    issue_b(0, 0, 0);
+    issue_a(0, 0, 0); issue_a(0, 1, 0); issue_a(0, 2, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int phase = 0;
+    for (int kc = 0; kc < g.KC; ++kc) {
+        const int abuf = (kc & 1) * ABYTES;
+        const bool more = kc + 1 < g.KC;
+#pragma unroll
+        for (int r = 0; r < 3; ++r, ++phase) {
+            const int bbuf = (phase & 1) * BBYTES;
+            // prefetch: the next phase's filter row, a third of the next chunk's patch
+            if (r < 2) issue_b(kc, r + 1, (phase + 1) & 1);
+            else if (more) issue_b(kc + 1, 0, (phase + 1) & 1);
+            int na = 0;                                      // patch pieces this wavefront issues in this phase (wave-uniform)
+            if (more) { issue_a(kc + 1, r, (kc + 1) & 1); na = (wave + 8 * r < APIECES) + (wave + 8 * (r + 3) < APIECES) + (wave + 8 * (r + 6) < APIECES); }
+            const unsigned char* const Ab = Asm + abuf;
+            const unsigned char* const Bb = Bsm + bbuf + wb;
+            // six (tap, k16) steps; the fragments of step i+1 are read before the MFMAs of step i (two register sets)
+            auto rd = [&](int st, bf16x8* xf, bf16x8* wf) {
+                const int s = st >> 1, ks = st & 1;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) wf[q] = *reinterpret_cast<const bf16x8*>(Bb + (st * NBT + q) * 1024);
+#pragma unroll
+                for (int p = 0; p < P; ++p) xf[p] = *reinterpret_cast<const bf16x8*>(Ab + pb[p] + (r * PW + s) * S16_PIX + ks * 32);
+            };
+            auto mm = [&](const bf16x8* xf, const bf16x8* wf) {
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+#pragma unroll
+                    for (int q = 0; q < Q; ++q)
+                        acc[p][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[q], xf[p], acc[p][q], 0, 0, 0);
+            };
+            bf16x8 xa[P], wa[Q], xb[P], wc[Q];
+            rd(0, xa, wa);
+#pragma unroll
+            for (int st = 0; st < 6; st += 2) {
+                // (sched_barrier: hipcc otherwise sinks every fragment read to its first use and waits lgkmcnt(0) there)
+                rd(st + 1, xb, wc);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(xa, wa);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 2 < 6) rd(st + 2, xa, wa);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(xb, wc);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the next phase's operands have landed (the patch pieces issued in this phase may still be in flight, except before a new chunk)
+            if (r < 2 && na == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (r < 2 && na == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (r < 2 && na == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // ---- epilogue.  acc[p][q][e]: pixel = lane li of block p, output channel = c0 + 32 (wn Q + q) + 8 (e >> 2) + 4 lh + (e & 3)
+    if (g.bias) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ch = c0 + 32 * (wn * Q + q) + 8 * (e >> 2) + 4 * lh + (e & 3);
+                const float b = ch < g.Nn ? g.bias[ch] : 0.f;
+#pragma unroll
+                for (int p = 0; p < P; ++p) acc[p][q][e] += b;
+            }
+    }
+    if (STATS) {
+        // per-channel sums over the workgroup's pixels, from the fp32 (biased, not yet activated) outputs: per lane over its P blocks, then a halving butterfly over
+        // the 32 lanes of a half-wave (16 values -> 1 per lane), then over the WM wavefronts through LDS
+        float* const red = reinterpret_cast<float*>(smem);                 // [2 (sum, sumsq)][WM][NBT * 32]
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            float s1[16], s2[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float a = 0.f, b = 0.f;
+#pragma unroll
+                for (int p = 0; p < P; ++p) { const float v = acc[p][q][e]; a += v; b = fmaf(v, v, b); }
+                s1[e] = a; s2[e] = b;
+            }
+            // butterfly: after the step with distance d a lane keeps half of its values
+#pragma unroll
+            for (int d = 16, cnt = 16; d >= 1; d >>= 1, cnt >>= 1) {
+                const bool up = (li & d) != 0;
+#pragma unroll
+                for (int e = 0; e < cnt / 2; ++e) {
+                    const float keep1 = up ? s1[e + cnt / 2] : s1[e], send1 = up ? s1[e] : s1[e + cnt / 2];
+                    const float keep2 = up ? s2[e + cnt / 2] : s2[e], send2 = up ? s2[e] : s2[e + cnt / 2];
+                    s1[e] = keep1 + __shfl_xor(send1, d, 64);
+                    s2[e] = keep2 + __shfl_xor(send2, d, 64);
+                }
+                if (cnt == 2) break;
+            }
+            // now s1[0] / s2[0] hold the sum over 16 of the 32 lanes for value index ((li>>4)&1)*8 + ((li>>3)&1)*4 + ((li>>2)&1)*2 + ((li>>1)&1);
+            // lanes li and li^1 hold the two halves of the same value
+            const float t1 = s1[0] + __shfl_xor(s1[0], 1, 64), t2 = s2[0] + __shfl_xor(s2[0], 1, 64);
+            const int e = ((li >> 4) & 1) * 8 + ((li >> 3) & 1) * 4 + ((li >> 2) & 1) * 2 + ((li >> 1) & 1);
+            const int ch = 32 * (wn * Q + q) + 8 * (e >> 2) + 4 * lh + (e & 3);
+            if ((li & 1) == 0) {
+                red[wm * (NBT * 32) + ch] = t1;
+                red[(WM + wm) * (NBT * 32) + ch] = t2;
+            }
+        }
+        __syncthreads();
+        if (t < 2 * NBT * 32) {
+            const int which = t / (NBT * 32), ch = t - which * (NBT * 32);
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) a += red[(which * WM + w) * (NBT * 32) + ch];
+            const int tile = ((grp * g.tiles_y + by) * g.tiles_x + bx);
+            if (c0 + ch < g.Nn) g.stats[((size_t)tile * 2 + which) * g.Nn + c0 + ch] = a;
+        }
+    }
+
+    size_t pix_off[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int mb = wm * P + p;
+        const int tr0 = mb * R + li / BW;
+        const int gi = tr0 / TH, row = tr0 - gi * TH;
+        const int j = li % BW;
+        const int rot = (BW == 16 && (li / BW) == 1) ? 2 : (BW == 8 && (li / BW) == 3) ? 2 : 0;
+        const int col = (j - rot) & (BW - 1);
+        pix_off[p] = (((size_t)(n0 + gi) * g.H + oy0 + row) * g.W + ox0 + col);
+    }
+    const bool img_ok = true;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int cb = c0 + 32 * (wn * Q + q);              // first output channel of this 32-block
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float a = acc[p][q][e];
+                if (g.act == KPX_ACT_RELU) a = fmaxf(a, 0.f);
+                else if (g.act == KPX_ACT_LRELU) a = a > 0.f ? a : 0.01f * a;
+                v[e] = a;
+            }
+            if (g.out_f32) {
+                float* const yo = reinterpret_cast<float*>(g.y) + pix_off[p] * g.ldy;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int ch = cb + 8 * gq + 4 * lh;
+                    if (img_ok && ch < g.Nn) *reinterpret_cast<f32x4*>(yo + ch) = f32x4{v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
+                }
+            } else {
+                unsigned short* const yo = reinterpret_cast<unsigned short*>(g.y) + pix_off[p] * g.ldy;
+                const unsigned short* const mo = g.mask ? reinterpret_cast<const unsigned short*>(g.mask) + pix_off[p] * g.ldm : nullptr;
+#pragma unroll
+                for (int k = 0; k < 4; k += 2) {
+                    // groups k, k+1 (channels 8k + 4lh .. and 8(k+1) + 4lh ..): after the half exchange lanes 0-31 hold channels 8k .. 8k+7,
+                    // lanes 32-63 channels 8(k+1) .. 8(k+1)+7 of their pixel
+                    unsigned a0 = s16_pack2(v[4 * k], v[4 * k + 1]), a1 = s16_pack2(v[4 * k + 2], v[4 * k + 3]);
+                    unsigned b0 = s16_pack2(v[4 * k + 4], v[4 * k + 5]), b1 = s16_pack2(v[4 * k + 6], v[4 * k + 7]);
+                    auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    u32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+                    const int ch = cb + 8 * (k + lh);
+                    if (img_ok && ch < g.Nn) {
+                        if (mo) {
+                            const u32x4 m = *reinterpret_cast<const u32x4*>(mo + ch);
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) {
+                                // zero where the mask tensor is <= 0 (bf16 sign / zero test on the raw halves)
+                                const unsigned ml = m[d] & 0xffffu, mh = m[d] >> 16;
+                                const bool pl = ml != 0 && ml < 0x8000u, ph = mh != 0 && mh < 0x8000u;
+                                o[d] = (pl ? (o[d] & 0xffffu) : 0u) | (ph ? (o[d] & 0xffff0000u) : 0u);
+                            }
+                        }
+                        *reinterpret_cast<u32x4*>(yo + ch) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+static std::atomic<unsigned long long> s16_attr_mask{0};
+
+struct S16Plan { int variant, BW, TH, G, MB, NBT, lds; };
+// variant 0: 512 pixels x 128 couts (WN 2, Q 2, P 4); 1: 256 x 128 (P 2); 2: 512 x 64 (WN 1, Q 2, P 2); 3: 512 x 32 (WN 1, Q 1, P 2);
+// 4: 128 x 128 (WN 2, Q 2, P 1); 5: 128 x 64 (WN 2, Q 1, P 1) -- the small tiles for layers of few pixels
+static bool s16_plan(int N, int H, int W, int K, int Nn, S16Plan* pl) {
+    int BW = 0;
+    if (W % 32 == 0) BW = 32; else if (W == 16) BW = 16; else if (W == 8) BW = 8; else return false;
+    if (!((K % 32 == 0) || K == 16 || K == 8)) return false;
+    const int R = 32 / BW;
+    int variant, MB, NBT;
+    const long px = (long)N * H * W;
+    const int force = kpx_env()->bf16s_variant;        // KPX_BF16S_VARIANT (experiments): 0 = planner's choice, v + 1 forces variant v
+    if (Nn > 64) {
+        NBT = 4;
+        const long ct = (Nn + 127) / 128;
+        if ((px / 512) * ct >= 256) { variant = 0; MB = 16; }
+        else if ((px / 256) * ct >= 192) { variant = 1; MB = 8; }
+        else if ((px / 128) * ct >= 192) { variant = 4; MB = 4; }
+        else { variant = 5; MB = 4; NBT = 2; }
+    } else if (Nn > 32) { variant = 2; MB = 16; NBT = 2; }
+    else { variant = 3; MB = 16; NBT = 1; }
+    if (force > 0) {
+        variant = force - 1;
+        static const int mbs[6] = {16, 8, 16, 16, 4, 4}, nbts[6] = {4, 4, 2, 1, 4, 2};
+        if (variant > 5) return false;
+        MB = mbs[variant]; NBT = nbts[variant];
+    }
+    int rows = MB * R, TH, G;
+    if (H >= rows) { if (H % rows) return false; TH = rows; G = 1; }
+    else { if (rows % H) return false; TH = H; G = rows / H; if (N % G) return false; }
+    if (BW != 32 && W != BW) return false;
+    const int NPX = G * (TH + 2) * (BW + 2);
+    const int apieces = (NPX * 5 + 63) / 64;
+    if (apieces > 72) return false;
+    pl->variant = variant; pl->BW = BW; pl->TH = TH; pl->G = G; pl->MB = MB; pl->NBT = NBT;
+    pl->lds = 2 * apieces * 1024 + 2 * 6 * NBT * 1024;
+    if (pl->lds > 160 * 1024) return false;
+    return true;
+}
+
+extern "C" int kpx_conv3x3_bf16s_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
+    S16Plan pl;
+    if (N <= 0 || K <= 0 || Nn <= 0 || ldin % 8 || (((uintptr_t)in_ptr) & 15) || ldin < K) return 0;
+    if ((size_t)N * H * W * ldin * 2 >= 0x7fffffffu) return 0;
+    return s16_plan(N, H, W, K, Nn, &pl) ? 1 : 0;
+}
+
+// bytes of the prepared filters of one direction (chunks of 32 over the gathered, blocks of 32 over the produced channels rounded up to 128)
+extern "C" size_t kpx_conv3x3_bf16s_weights_bytes(int K, int Nn) {
+    const int KC = (K + 31) / 32, NB = ((Nn + 127) / 128) * 4;
+    return (size_t)KC * 18 * NB * 1024;
+}
+
+extern "C" int kpx_conv3x3_bf16s_prepare_f32(const float* w_hwio, int Cin, int Cout, int dgrad, void* Wf, void* stream) {
+    if (!w_hwio || !Wf || Cin <= 0 || Cout <= 0) return KPX_EINVAL;
+    const int K = dgrad ? Cout : Cin, Nn = dgrad ? Cin : Cout;
+    const int KC = (K + 31) / 32, NB = ((Nn + 127) / 128) * 4;
+    const size_t total = (size_t)KC * 18 * NB * 512;
+    size_t nb = (total + 255) / 256; if (nb > 2048) nb = 2048;
+    if (dgrad) hipLaunchKernelGGL(conv_bf16s_prepare_kernel<true>, dim3((unsigned)nb), dim3(256), 0, kpx_stream(stream), w_hwio, Cin, Cout, KC, NB, (unsigned short*)Wf);
+    else hipLaunchKernelGGL(conv_bf16s_prepare_kernel<false>, dim3((unsigned)nb), dim3(256), 0, kpx_stream(stream), w_hwio, Cin, Cout, KC, NB, (unsigned short*)Wf);
+    return kpx_launch_status();
+}
+
+// table: ndesc entries of {const float* w; void* Wf; int Cin, Cout, dgrad, NB} (32 bytes each) in device memory
+extern "C" int kpx_conv3x3_bf16s_prepare_batch_f32(const void* table, int ndesc, void* stream) {
+    if (!table || ndesc <= 0) return KPX_EINVAL;
+    hipLaunchKernelGGL(conv_bf16s_prepare_batch_kernel, dim3(64, (unsigned)ndesc), dim3(256), 0, kpx_stream(stream), (const S16PrepDesc*)table, ndesc);
+    return kpx_launch_status();
+}
+
+extern "C" int kpx_conv3x3_bf16s_stats_tiles(int N, int H, int W, int K, int Nn) {
+    S16Plan pl;
+    if (!s16_plan(N, H, W, K, Nn, &pl)) return 0;
+    return (int)(((long)N * H * W) / (pl.MB * 32));
+}
+
+template <int WN, int Q, int P, int BW, int STATS>
+static hipError_t s16_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16s_kernel<WN, Q, P, BW, STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <int WN, int Q, int P, int STATS>
+static void s16_go_bw(const S16Geom& g, const S16Plan& pl, unsigned blocks, hipStream_t s) {
+    if (pl.BW == 32) hipLaunchKernelGGL((conv3x3_bf16s_kernel<WN, Q, P, 32, STATS>), dim3(blocks), dim3(512), pl.lds, s, g, pl.TH, pl.G);
+    else if (pl.BW == 16) hipLaunchKernelGGL((conv3x3_bf16s_kernel<WN, Q, P, 16, STATS>), dim3(blocks), dim3(512), pl.lds, s, g, pl.TH, pl.G);
+    else hipLaunchKernelGGL((conv3x3_bf16s_kernel<WN, Q, P, 8, STATS>), dim3(blocks), dim3(512), pl.lds, s, g, pl.TH, pl.G);
+}
+template <int STATS>
+static void s16_go(const S16Geom& g, const S16Plan& pl, unsigned blocks, hipStream_t s) {
+    switch (pl.variant) {
+        case 0: s16_go_bw<2, 2, 4, STATS>(g, pl, blocks, s); break;
+        case 1: s16_go_bw<2, 2, 2, STATS>(g, pl, blocks, s); break;
+        case 2: s16_go_bw<1, 2, 2, STATS>(g, pl, blocks, s); break;
+        case 3: s16_go_bw<1, 1, 2, STATS>(g, pl, blocks, s); break;
+        case 4: s16_go_bw<2, 2, 1, STATS>(g, pl, blocks, s); break;
+        default: s16_go_bw<2, 1, 1, STATS>(g, pl, blocks, s); break;
+    }
+}
+
+// in [N,H,W,K] bf16 (pixel stride ldin elements), Wf prepared for (K gathered, Nn produced), out [N,H,W,Nn] bf16 (out_f32 = 0) or fp32
+// (pixel stride ldout elements).  mask (optional, bf16 [N,H,W,Nn], pixel stride ldmask): the output is zeroed where mask <= 0.
+// stats (optional): [tiles][2][Nn] fp32 per-workgroup sums / sums of squares of the fp32 outputs before the activation (kpx_conv3x3_bf16s_stats_tiles tiles).
+extern "C" int kpx_conv3x3_bf16s(const void* in, int N, int H, int W, int K, int ldin, const void* Wf, const float* bias,
+                                 void* out, int Nn, int ldout, int out_f32, int act, const void* mask, int ldmask, float* stats, void* stream) {
+    S16Plan pl;
+    if (!in || !Wf || !out || !kpx_conv3x3_bf16s_eligible(N, H, W, K, Nn, ldin, in) || ldout < Nn || (mask && (out_f32 || ldmask % 8 || ldmask < Nn))) return KPX_EINVAL;
+    if (out_f32 ? (Nn % 4 || ldout % 4 || (((uintptr_t)out) & 15)) : (Nn % 8 || ldout % 8 || (((uintptr_t)out) & 15))) return KPX_EINVAL;
+    if (!s16_plan(N, H, W, K, Nn, &pl)) return KPX_EINVAL;
+    if (kpx_first_use_on_device(&s16_attr_mask)) {
+        hipError_t e = hipSuccess;
+#define S16_ATTR(wn, q, p) \
+        if (e == hipSuccess) e = s16_attr<wn, q, p, 32, 0>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 16, 0>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 8, 0>(); \
+        if (e == hipSuccess) e = s16_attr<wn, q, p, 32, 1>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 16, 1>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 8, 1>();
+        S16_ATTR(2, 2, 4) S16_ATTR(2, 2, 2) S16_ATTR(1, 2, 2) S16_ATTR(1, 1, 2) S16_ATTR(2, 2, 1) S16_ATTR(2, 1, 1)
+#undef S16_ATTR
+        if (e != hipSuccess) return -(int)e;
+    }
+    S16Geom g{};
+    g.x = in; g.y = out; g.Wf = Wf; g.bias = bias; g.mask = mask; g.stats = stats;
+    g.N = N; g.H = H; g.W = W; g.K = K; g.ldx = ldin; g.Nn = Nn; g.ldy = ldout; g.ldm = ldmask; g.act = act; g.out_f32 = out_f32;
+    g.KC = (K + 31) / 32; g.NB = ((Nn + 127) / 128) * 4;
+    g.tiles_y = H / pl.TH; g.tiles_x = W / pl.BW; g.ngrp = N / pl.G; g.ntc = (Nn + pl.NBT * 32 - 1) / (pl.NBT * 32);
+    const unsigned blocks = (unsigned)((size_t)g.ngrp * g.tiles_y * g.tiles_x * g.ntc);
+    hipStream_t s = kpx_stream(stream);
+    if (stats) s16_go<1>(g, pl, blocks, s); else s16_go<0>(g, pl, blocks, s);
+    return kpx_launch_status();
+}

@@ -11,7 +11,7 @@ struct KpxEnv {
     long wgrad_target;          // KPX_WGRAD_TARGET (0: per-tile default)
     int wino_kmin, wino_nmin, wino_ct, wino_stagger;
     int ww_comin; long ww_target;
-    int bf16_wide;
+    int bf16s_variant;
     int gauss_blocks, gauss_nt;
     int no_gemm3, no_wgrad3, wgrad3_first;  // bf16x3 implicit-GEMM family (conv_gemm3.hip)
     int no_wsmall, no_wsmall32, wsmall_c64_max;                       // tiny-filter weight gradients (conv_wsmall.hip); Cout limit of its 64-channel 3x3 variant

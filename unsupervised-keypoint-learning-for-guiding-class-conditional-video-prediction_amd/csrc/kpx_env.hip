@@ -36,7 +36,7 @@ static void env_parse(KpxEnv* e) {
     e->wino_stagger = (int)env_long("KPX_WINO_STAGGER", 1);
     e->ww_comin = (int)env_long("KPX_WW_COMIN", 4);
     e->ww_target = env_long("KPX_WW_TARGET", 256);
-    e->bf16_wide = (int)env_long("KPX_BF16_WIDE", 1);
+    e->bf16s_variant = (int)env_long("KPX_BF16S_VARIANT", 0);
     e->gauss_blocks = (int)env_long("KPX_GAUSS_BLOCKS", 0);          // 0: sized from the tensor (keypoints.hip)
     e->gauss_nt = (int)env_long("KPX_GAUSS_NT", 1);
     e->no_gemm3 = env_flag("KPX_NO_GEMM3");

@@ -1085,3 +1085,511 @@ extern "C" int kpx_maxpool2_bwd_f32(const float* dy, const float* x, int N, int 
     hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(items)), dim3(256), 0, kpx_stream(stream), dy, x, N, H, W, C, dx);
     return kpx_launch_status();
 }
+
+// ================================================================================================ bf16 STORAGE variants (BASELINE configs[2])
+// The same streaming kernels for bf16 tensors in HBM (layers.py:13-14 batch norm, networks/__init__.py:63,98 resize, vgg.py:25-45 pools,
+// detector_translator_model.py:274-289 feature L1): 16-B accesses = EIGHT channels per lane, arithmetic in fp32, per-channel reductions in
+// fp64 through the same block partials and fixed-order finalize kernels as the fp32 entries (statistics, moving averages, gamma / beta
+// gradients stay fp32).  Every entry wants C, the pixel strides multiples of 8 and 16-byte aligned pointers (KPX_EINVAL otherwise) unless
+// it says otherwise.
+typedef unsigned int pw_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ float pw_bf(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ unsigned short pw_to_bf(float v) { const __bf16 b = (__bf16)v; return __builtin_bit_cast(unsigned short, b); }
+__device__ __forceinline__ void pw_ld8(const bf16_t* p, float* v) {
+    const pw_u32x4 r = *reinterpret_cast<const pw_u32x4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[2 * j] = __builtin_bit_cast(float, r[j] << 16); v[2 * j + 1] = __builtin_bit_cast(float, r[j] & 0xffff0000u); }
+}
+__device__ __forceinline__ unsigned pw_pack2(float a, float b) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 p = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ void pw_st8(bf16_t* p, const float* v) {
+    const pw_u32x4 r = {pw_pack2(v[0], v[1]), pw_pack2(v[2], v[3]), pw_pack2(v[4], v[5]), pw_pack2(v[6], v[7])};
+    *reinterpret_cast<pw_u32x4*>(p) = r;
+}
+static inline bool pw_al16(const void* a, const void* b = nullptr, const void* c = nullptr) { return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0; }
+
+// ---- casts / copies between channel slices: dst[p][0:C] = src[p][0:C] (any C; vector path when everything is 8-aligned)
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cast_channels_kernel(const TS* __restrict__ src, int lds_, TD* __restrict__ dst, int ldd, size_t P, int C, int vec) {
+    if (vec) {
+        const int G = C >> 3;
+        const size_t total = P * (size_t)G;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const size_t p = i / G; const int c = (int)(i - p * G) * 8;
+            float v[8];
+            if (sizeof(TS) == 2) pw_ld8(reinterpret_cast<const bf16_t*>(src) + p * lds_ + c, v);
+            else {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + p * lds_ + c), b = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(src) + p * lds_ + c + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+            }
+            if (sizeof(TD) == 2) pw_st8(reinterpret_cast<bf16_t*>(dst) + p * ldd + c, v);
+            else {
+                float* o = reinterpret_cast<float*>(dst) + p * ldd + c;
+                *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+        }
+        return;
+    }
+    const size_t total = P * (size_t)C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t p = i / C; const int c = (int)(i - p * C);
+        float v;
+        if (sizeof(TS) == 2) v = pw_bf(reinterpret_cast<const bf16_t*>(src)[p * lds_ + c]); else v = reinterpret_cast<const float*>(src)[p * lds_ + c];
+        if (sizeof(TD) == 2) reinterpret_cast<bf16_t*>(dst)[p * ldd + c] = pw_to_bf(v); else reinterpret_cast<float*>(dst)[p * ldd + c] = v;
+    }
+}
+// kind: 0 = f32 -> bf16, 1 = bf16 -> f32, 2 = bf16 -> bf16 (channel-slice copy: tf.concat)
+extern "C" int kpx_cast_channels(const void* src, int ldsrc, void* dst, int lddst, size_t P, int C, int kind, void* stream) {
+    if (!src || !dst || C <= 0 || ldsrc < C || lddst < C || kind < 0 || kind > 2) return KPX_EINVAL;
+    if (P == 0) return 0;
+    const int sa = kind == 0 ? 4 : 2, da = kind == 1 ? 4 : 2;
+    const int vec = (C % 8 == 0) && (((size_t)ldsrc * sa) % 16 == 0) && (((size_t)lddst * da) % 16 == 0) && pw_al16(src, dst);
+    const unsigned nb = grid_for(vec ? P * (C / 8) : P * C);
+    hipStream_t s = kpx_stream(stream);
+    if (kind == 0) hipLaunchKernelGGL((cast_channels_kernel<float, bf16_t>), dim3(nb), dim3(256), 0, s, (const float*)src, ldsrc, (bf16_t*)dst, lddst, P, C, vec);
+    else if (kind == 1) hipLaunchKernelGGL((cast_channels_kernel<bf16_t, float>), dim3(nb), dim3(256), 0, s, (const bf16_t*)src, ldsrc, (float*)dst, lddst, P, C, vec);
+    else hipLaunchKernelGGL((cast_channels_kernel<bf16_t, bf16_t>), dim3(nb), dim3(256), 0, s, (const bf16_t*)src, ldsrc, (bf16_t*)dst, lddst, P, C, vec);
+    return kpx_launch_status();
+}
+
+// ---- per-channel reductions over bf16 tensors (modes as chan_reduce_kernel); DYF32: the gradient operand of mode 2 is fp32
+template <int MODE, bool DYF32>
+__global__ __launch_bounds__(256) void chan_reduce_bf16_kernel(const RedArgs a) {
+    const int G = a.C >> 3, Gb = G < 256 ? G : 256, PPB = 256 / Gb;
+    const int t = threadIdx.x, cgl = t % Gb, prow = t / Gb;
+    const int cg = blockIdx.y * Gb + cgl;
+    const bool active = prow < PPB && cg < G;
+    const int grp = blockIdx.z;
+    const bf16_t* const gx = reinterpret_cast<const bf16_t*>(a.x) + (size_t)grp * a.P * a.ldx;
+    const bf16_t* const gdy = MODE == 2 && !DYF32 ? reinterpret_cast<const bf16_t*>(a.dy) + (size_t)grp * a.P * a.lddy : nullptr;
+    const float* const gdf = MODE == 2 && DYF32 ? a.dy + (size_t)grp * a.P * a.lddy : nullptr;
+    double s0[8], s1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.0; s1[j] = 0.0; }
+    float mu[8], is[8], ga[8], be[8];
+    if (MODE == 2 && active) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int c = cg * 8 + j; mu[j] = a.mean[grp * a.C + c]; is[j] = a.invstd[grp * a.C + c]; ga[j] = a.gamma[c]; be[j] = a.beta[c]; }
+    }
+    if (active) {
+        const size_t step = (size_t)gridDim.x * PPB;
+        for (size_t p0 = (size_t)blockIdx.x * PPB + prow; p0 < a.P; p0 += step * 2) {
+            float xv[2][8], gv[2][8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const size_t p = p0 + u * step;
+                if (p < a.P) {
+                    pw_ld8(gx + p * a.ldx + cg * 8, xv[u]);
+                    if (MODE == 2) {
+                        if (DYF32) {
+                            const f32x4 d0 = *reinterpret_cast<const f32x4*>(gdf + p * a.lddy + cg * 8), d1 = *reinterpret_cast<const f32x4*>(gdf + p * a.lddy + cg * 8 + 4);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { gv[u][j] = d0[j]; gv[u][4 + j] = d1[j]; }
+                        } else pw_ld8(gdy + p * a.lddy + cg * 8, gv[u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (p0 + u * step >= a.P) break;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (MODE == 0) s0[j] += (double)xv[u][j];
+                    if (MODE == 1) { s0[j] += (double)xv[u][j]; s1[j] += (double)xv[u][j] * (double)xv[u][j]; }
+                    if (MODE == 2) {
+                        const float xh = (xv[u][j] - mu[j]) * is[j];
+                        const float yv = fmaf(xh, ga[j], be[j]);
+                        const float dz = (a.act == KPX_ACT_RELU && !(yv > 0.f)) ? 0.f : gv[u][j];
+                        s0[j] += (double)dz; s1[j] += (double)dz * (double)xh;
+                    }
+                }
+            }
+        }
+    }
+    __shared__ double sm[2][256 * 8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sm[0][t * 8 + j] = s0[j]; sm[1][t * 8 + j] = s1[j]; }
+    __syncthreads();
+    if (t < Gb && blockIdx.y * Gb + t < G) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double r0 = 0.0, r1 = 0.0;
+            for (int pr = 0; pr < PPB; ++pr) { r0 += sm[0][(pr * Gb + t) * 8 + j]; r1 += sm[1][(pr * Gb + t) * 8 + j]; }
+            const int c = (blockIdx.y * Gb + t) * 8 + j;
+            double* const gp = a.part + (size_t)grp * a.part_gstride;
+            gp[((size_t)blockIdx.x * 2 + 0) * a.C + c] = r0;
+            gp[((size_t)blockIdx.x * 2 + 1) * a.C + c] = r1;
+        }
+    }
+}
+static int launch_chan_reduce_bf16(int mode, bool dyf32, RedArgs a, int* nb_out, hipStream_t s, int groups = 1) {
+    const int G = a.C / 8, Gb = G < 256 ? G : 256, PPB = 256 / Gb;
+    size_t nb = a.P / ((size_t)PPB * 8);
+    if (nb < 1) nb = 1;
+    if (nb > KPX_RED_BLOCKS) nb = KPX_RED_BLOCKS;
+    *nb_out = (int)nb;
+    const dim3 grid((unsigned)nb, (unsigned)((G + Gb - 1) / Gb), (unsigned)groups), block(256);
+    if (mode == 0) hipLaunchKernelGGL((chan_reduce_bf16_kernel<0, false>), grid, block, 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((chan_reduce_bf16_kernel<1, false>), grid, block, 0, s, a);
+    else if (dyf32) hipLaunchKernelGGL((chan_reduce_bf16_kernel<2, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((chan_reduce_bf16_kernel<2, false>), grid, block, 0, s, a);
+    return kpx_launch_status();
+}
+// bias gradient of a bf16 gradient tensor: sum over pixels, fp32 out (same scratch as kpx_chan_sum_f32)
+extern "C" int kpx_chan_sum_bf16(const void* x, size_t P, int C, int ldx, float* sum_out, void* scratch, void* stream) {
+    if (!x || !sum_out || !scratch || C <= 0 || C % 8 || ldx % 8 || ldx < C || P == 0 || !pw_al16(x)) return KPX_EINVAL;
+    RedArgs a{}; a.x = (const float*)x; a.ldx = ldx; a.P = P; a.C = C; a.part = (double*)scratch;
+    int nb; int rc = launch_chan_reduce_bf16(0, false, a, &nb, kpx_stream(stream));
+    if (rc) return rc;
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3(C), dim3(256), 0, kpx_stream(stream), (const double*)scratch, nb, C, sum_out);
+    return kpx_launch_status();
+}
+
+// ---- batch norm, train mode, all weight-sharing groups per launch (as kpx_bn_train_fwd_f32 / _bwd_f32)
+template <bool OUTF32>
+__global__ __launch_bounds__(256) void bn_apply_strip_bf16_kernel(const bf16_t* __restrict__ x, size_t P, int C, int ldx, const float* __restrict__ mean,
+                                                                  const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  void* __restrict__ yv, int ldy, int act) {
+    const int G = C >> 3, Gb = G < 256 ? G : 256, PPB = 256 / Gb;
+    const int t = threadIdx.x, cgl = t % Gb, prow = t / Gb;
+    const int cg = blockIdx.y * Gb + cgl;
+    if (prow >= PPB || cg >= G) return;
+    x += (size_t)blockIdx.z * P * ldx; mean += blockIdx.z * C; invstd += blockIdx.z * C;
+    float sc[8], sh[8];                                   // y = x * sc + sh with sc = invstd * gamma, sh = beta - mean * sc: the fp32 kernel's value up to one rounding
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int c = cg * 8 + j; sc[j] = invstd[c] * gamma[c]; sh[j] = fmaf(-mean[c], sc[j], beta[c]); }
+    const size_t step = (size_t)gridDim.x * PPB;
+    for (size_t p0 = (size_t)blockIdx.x * PPB + prow; p0 < P; p0 += step * 4) {
+        float v[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const size_t p = p0 + u * step; if (p < P) pw_ld8(x + p * ldx + cg * 8, v[u]); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t p = p0 + u * step;
+            if (p >= P) break;
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { r[j] = fmaf(v[u][j], sc[j], sh[j]); if (act == KPX_ACT_RELU) r[j] = fmaxf(r[j], 0.f); }
+            if (OUTF32) {
+                float* o = reinterpret_cast<float*>(yv) + ((size_t)blockIdx.z * P + p) * ldy + cg * 8;
+                *reinterpret_cast<f32x4*>(o) = f32x4{r[0], r[1], r[2], r[3]}; *reinterpret_cast<f32x4*>(o + 4) = f32x4{r[4], r[5], r[6], r[7]};
+            } else pw_st8(reinterpret_cast<bf16_t*>(yv) + ((size_t)blockIdx.z * P + p) * ldy + cg * 8, r);
+        }
+    }
+}
+static inline dim3 strip_grid8(size_t P, int C, int groups) {
+    const int G = C >> 3, Gb = G < 256 ? G : 256, PPB = 256 / Gb;
+    size_t nb = (P + (size_t)PPB * 4 - 1) / ((size_t)PPB * 4);
+    if (nb < 1) nb = 1;
+    if (nb > KPX_MAX_BLOCKS) nb = KPX_MAX_BLOCKS;
+    return dim3((unsigned)nb, (unsigned)((G + Gb - 1) / Gb), (unsigned)groups);
+}
+// x bf16 [groups*P, C]; y bf16 (y_f32 = 0) or fp32 (y_f32 = 1); tile_stats as kpx_bn_train_fwd_f32 (kpx_conv3x3_bf16s writes them)
+extern "C" int kpx_bn_train_fwd_bf16(const void* x, size_t P, int groups, int C, int ldx, const float* tile_stats, size_t tiles_per_group,
+                                     float eps, const float* gamma, const float* beta, float* mean, float* invstd,
+                                     float* moving_mean, float* moving_var, float decay, void* y, int ldy, int y_f32, int act, void* scratch, void* stream) {
+    if (!x || !y || !gamma || !beta || !mean || !invstd || !scratch || groups <= 0 || groups > 65535 || C <= 0 || C % 8 || ldx % 8 || ldy % 8 || ldx < C || ldy < C ||
+        act < 0 || act > 1 || P == 0 || !pw_al16(x, y))
+        return KPX_EINVAL;
+    hipStream_t s = kpx_stream(stream);
+    const size_t gstride = (size_t)KPX_RED_BLOCKS * 2 * C;
+    int nb = 0;
+    if (!tile_stats) {
+        RedArgs a{}; a.x = (const float*)x; a.ldx = ldx; a.P = P; a.C = C; a.part = (double*)scratch; a.part_gstride = gstride;
+        int rc = launch_chan_reduce_bf16(1, false, a, &nb, s, groups);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(bn_stats_finalize_groups_kernel, dim3(C), dim3(256 * (groups < 4 ? groups : 4)), 0, s, (const double*)scratch, gstride, nb, tile_stats, tiles_per_group,
+                       groups, C, (double)P, eps, mean, invstd, moving_mean, moving_var, decay);
+    int rc = kpx_launch_status();
+    if (rc) return rc;
+    if (y_f32) hipLaunchKernelGGL(bn_apply_strip_bf16_kernel<true>, strip_grid8(P, C, groups), dim3(256), 0, s, (const bf16_t*)x, P, C, ldx, mean, invstd, gamma, beta, y, ldy, act);
+    else hipLaunchKernelGGL(bn_apply_strip_bf16_kernel<false>, strip_grid8(P, C, groups), dim3(256), 0, s, (const bf16_t*)x, P, C, ldx, mean, invstd, gamma, beta, y, ldy, act);
+    return kpx_launch_status();
+}
+
+template <bool DYF32>
+__global__ __launch_bounds__(256) void bn_bwd_apply_strip_bf16_kernel(const void* __restrict__ dyv, int lddy, const bf16_t* __restrict__ x, int ldx, size_t P, int C,
+                                                                      const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                      const float* __restrict__ beta, int act, const float* __restrict__ sums, float inv_count,
+                                                                      bf16_t* __restrict__ dx, int lddx) {
+    const int G = C >> 3, Gb = G < 256 ? G : 256, PPB = 256 / Gb;
+    const int t = threadIdx.x, cgl = t % Gb, prow = t / Gb;
+    const int cg = blockIdx.y * Gb + cgl;
+    if (prow >= PPB || cg >= G) return;
+    x += (size_t)blockIdx.z * P * ldx; dx += (size_t)blockIdx.z * P * lddx;
+    mean += blockIdx.z * C; invstd += blockIdx.z * C; sums += blockIdx.z * 2 * C;
+    float mu[8], is[8], ga[8], be[8], gi[8], m0[8], m1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        mu[j] = mean[c]; is[j] = invstd[c]; ga[j] = gamma[c]; be[j] = beta[c];
+        gi[j] = ga[j] * is[j]; m0[j] = sums[c] * inv_count; m1[j] = sums[C + c] * inv_count;
+    }
+    const size_t step = (size_t)gridDim.x * PPB;
+    for (size_t p0 = (size_t)blockIdx.x * PPB + prow; p0 < P; p0 += step * 2) {
+        float xv[2][8], gv[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const size_t p = p0 + u * step;
+            if (p < P) {
+                pw_ld8(x + p * ldx + cg * 8, xv[u]);
+                if (DYF32) {
+                    const float* q = reinterpret_cast<const float*>(dyv) + ((size_t)blockIdx.z * P + p) * lddy + cg * 8;
+                    const f32x4 d0 = *reinterpret_cast<const f32x4*>(q), d1 = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { gv[u][j] = d0[j]; gv[u][4 + j] = d1[j]; }
+                } else pw_ld8(reinterpret_cast<const bf16_t*>(dyv) + ((size_t)blockIdx.z * P + p) * lddy + cg * 8, gv[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const size_t p = p0 + u * step;
+            if (p >= P) break;
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (xv[u][j] - mu[j]) * is[j];
+                const float yv = fmaf(xh, ga[j], be[j]);
+                const float dz = (act == KPX_ACT_RELU && !(yv > 0.f)) ? 0.f : gv[u][j];
+                r[j] = gi[j] * (dz - m0[j] - xh * m1[j]);
+            }
+            pw_st8(dx + p * lddx + cg * 8, r);
+        }
+    }
+}
+// dy bf16 (dy_f32 = 0) or fp32 (dy_f32 = 1: the batch norm whose output stayed fp32), x bf16 (the batch norm's input) -> dx bf16
+extern "C" int kpx_bn_train_bwd_bf16(const void* dy, int lddy, int dy_f32, const void* x, int ldx, size_t P, int groups, int C,
+                                     const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                                     void* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* scratch, void* stream) {
+    if (!dy || !x || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !scratch || groups <= 0 || groups > 65535 || C <= 0 || C % 8 ||
+        ldx % 8 || lddy % 8 || lddx % 8 || ldx < C || lddy < C || lddx < C || act < 0 || act > 1 || P == 0 || !pw_al16(dy, x, dx))
+        return KPX_EINVAL;
+    hipStream_t s = kpx_stream(stream);
+    const size_t gstride = (size_t)KPX_RED_BLOCKS * 2 * C;
+    int nb = 0, rc = 0;
+    RedArgs a{}; a.x = (const float*)x; a.ldx = ldx; a.dy = (const float*)dy; a.lddy = lddy; a.P = P; a.C = C;
+    a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.act = act; a.part = (double*)scratch; a.part_gstride = gstride;
+    rc = launch_chan_reduce_bf16(2, dy_f32 != 0, a, &nb, s, groups);
+    if (rc) return rc;
+    float* sums = reinterpret_cast<float*>((double*)scratch + (size_t)groups * gstride);
+    hipLaunchKernelGGL(bn_bwd_finalize_groups_kernel, dim3(C), dim3(256 * (groups < 4 ? groups : 4)), 0, s, (const double*)scratch, gstride, nb, (const float*)nullptr, (size_t)0,
+                       gamma, groups, C, dgamma, dbeta, sums, accumulate);
+    if ((rc = kpx_launch_status())) return rc;
+    const float inv_count = (float)(1.0 / (double)P);
+    if (dy_f32) hipLaunchKernelGGL(bn_bwd_apply_strip_bf16_kernel<true>, strip_grid8(P, C, groups), dim3(256), 0, s, dy, lddy, (const bf16_t*)x, ldx, P, C, mean, invstd, gamma, beta, act, sums, inv_count, (bf16_t*)dx, lddx);
+    else hipLaunchKernelGGL(bn_bwd_apply_strip_bf16_kernel<false>, strip_grid8(P, C, groups), dim3(256), 0, s, dy, lddy, (const bf16_t*)x, ldx, P, C, mean, invstd, gamma, beta, act, sums, inv_count, (bf16_t*)dx, lddx);
+    return kpx_launch_status();
+}
+
+// ---- activation backward: dz = dy * act'(y) on bf16 tensors (n multiple of 8)
+__global__ __launch_bounds__(256) void act_bwd_bf16_kernel(const bf16_t* dy, const bf16_t* y, bf16_t* dz, size_t n8, int act) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        float g[8], v[8];
+        pw_ld8(dy + 8 * i, g); pw_ld8(y + 8 * i, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] *= kpx_act_grad_from_y(v[j], act);
+        pw_st8(dz + 8 * i, g);
+    }
+}
+extern "C" int kpx_act_bwd_bf16(const void* dy, const void* y, void* dz, size_t n, int act, void* stream) {
+    if (!dy || !y || !dz || n % 8 || !pw_al16(dy, y, dz)) return KPX_EINVAL;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(act_bwd_bf16_kernel, dim3(grid_for(n / 8)), dim3(256), 0, kpx_stream(stream), (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dz, n / 8, act);
+    return kpx_launch_status();
+}
+
+// ---- bilinear x2 (legacy TF sampling), one thread per INPUT pixel and channel octet (as resize2x_fwd_quad_kernel)
+__global__ __launch_bounds__(256) void resize2x_fwd_bf16_kernel(const bf16_t* __restrict__ x, int N, int H, int W, int C, int ldx, bf16_t* __restrict__ y, int ldy) {
+    const unsigned G = (unsigned)C >> 3, total = (unsigned)N * H * W * G;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned cq = i % G; unsigned p = i / G;
+        const unsigned ix = p % (unsigned)W; p /= (unsigned)W;
+        const unsigned iy = p % (unsigned)H, n = p / (unsigned)H;
+        const unsigned iy1 = iy + 1 < (unsigned)H ? iy + 1 : iy, ix1 = ix + 1 < (unsigned)W ? ix + 1 : ix;
+        const bf16_t* r0 = x + ((size_t)(n * H + iy) * W) * ldx + cq * 8;
+        const bf16_t* r1 = x + ((size_t)(n * H + iy1) * W) * ldx + cq * 8;
+        float tl[8], tr[8], bl[8], br[8];
+        pw_ld8(r0 + (size_t)ix * ldx, tl); pw_ld8(r0 + (size_t)ix1 * ldx, tr); pw_ld8(r1 + (size_t)ix * ldx, bl); pw_ld8(r1 + (size_t)ix1 * ldx, br);
+        bf16_t* o = y + ((size_t)(n * 2 * H + 2 * iy) * (2 * W) + 2 * ix) * ldy + cq * 8;
+        const size_t rs = (size_t)2 * W * ldy;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float ty = a ? 0.5f : 0.f, tx = b ? 0.5f : 0.f;
+                float r[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float top = tl[j] + (tr[j] - tl[j]) * tx, bot = bl[j] + (br[j] - bl[j]) * tx; r[j] = top + (bot - top) * ty; }
+                pw_st8(o + a * rs + (size_t)b * ldy, r);
+            }
+    }
+}
+extern "C" int kpx_resize2x_fwd_bf16(const void* x, int N, int H, int W, int C, int ldx, void* y, int ldy, void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8 || ldx < C || ldy < C || !pw_al16(x, y) || (size_t)N * H * W * (C / 8) >= 0x7fffffffu) return KPX_EINVAL;
+    size_t nb = ((size_t)N * H * W * (C / 8) + 255) / 256; if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(resize2x_fwd_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, kpx_stream(stream), (const bf16_t*)x, N, H, W, C, ldx, (bf16_t*)y, ldy);
+    return kpx_launch_status();
+}
+__global__ __launch_bounds__(256) void resize2x_bwd_bf16_kernel(const bf16_t* __restrict__ dy, int N, int H, int W, int C, int lddy, bf16_t* __restrict__ dx, int lddx) {
+    const int G = C >> 3, W2 = 2 * W, H2 = 2 * H;
+    const size_t total = (size_t)N * H * W * G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % G) * 8;
+        size_t p = i / G;
+        const int ix = (int)(p % W); p /= W;
+        const int iy = (int)(p % H);
+        const int n = (int)(p / H);
+        float wy[3], wx[3];
+        wy[0] = iy >= 1 ? 0.5f : 0.f; wy[1] = 1.f; wy[2] = iy == H - 1 ? 1.f : 0.5f;
+        wx[0] = ix >= 1 ? 0.5f : 0.f; wx[1] = 1.f; wx[2] = ix == W - 1 ? 1.f : 0.5f;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int oy = 2 * iy - 1 + a;
+            if (oy < 0) continue;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int ox = 2 * ix - 1 + b;
+                if (ox < 0) continue;
+                const float wgt = wy[a] * wx[b];
+                float v[8];
+                pw_ld8(dy + ((size_t)(n * H2 + oy) * W2 + ox) * lddy + c, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(wgt, v[j], acc[j]);
+            }
+        }
+        pw_st8(dx + ((size_t)(n * H + iy) * W + ix) * lddx + c, acc);
+    }
+}
+extern "C" int kpx_resize2x_bwd_bf16(const void* dy, int N, int H, int W, int C, int lddy, void* dx, int lddx, void* stream) {
+    if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || lddy % 8 || lddx % 8 || lddy < C || lddx < C || !pw_al16(dy, dx)) return KPX_EINVAL;
+    hipLaunchKernelGGL(resize2x_bwd_bf16_kernel, dim3(grid_for((size_t)N * H * W * (C / 8))), dim3(256), 0, kpx_stream(stream), (const bf16_t*)dy, N, H, W, C, lddy, (bf16_t*)dx, lddx);
+    return kpx_launch_status();
+}
+
+// ---- VGG19: 2x2 max-pool (even H, W), the one-pass feature gradient, feature L1
+__global__ __launch_bounds__(256) void maxpool2_fwd_bf16_kernel(const bf16_t* __restrict__ x, int N, int H, int W, int C, bf16_t* __restrict__ y) {
+    const int G = C >> 3, Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)N * Ho * Wo * G;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % G) * 8;
+        size_t p = i / G;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float m[8], v[8];
+        pw_ld8(x + ((size_t)(n * H + 2 * oy) * W + 2 * ox) * C + c, m);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            pw_ld8(x + ((size_t)(n * H + 2 * oy + (k >> 1)) * W + 2 * ox + (k & 1)) * C + c, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], v[j]);
+        }
+        pw_st8(y + ((size_t)(n * Ho + oy) * Wo + ox) * C + c, m);
+    }
+}
+extern "C" int kpx_maxpool2_fwd_bf16(const void* x, int N, int H, int W, int C, void* y, void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || C <= 0 || C % 8 || !pw_al16(x, y)) return KPX_EINVAL;
+    hipLaunchKernelGGL(maxpool2_fwd_bf16_kernel, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0, kpx_stream(stream), (const bf16_t*)x, N, H, W, C, (bf16_t*)y);
+    return kpx_launch_status();
+}
+// d[pix][c] = [y_pred > 0] * ( (pix is the first maximum of its 2x2 window ? dy_pooled : 0) + g * sign(y_pred - y_gt) )   (as vgg_feat_bwd_kernel)
+__global__ __launch_bounds__(256) void vgg_feat_bwd_bf16_kernel(const bf16_t* __restrict__ f, size_t half, const float* gdev, float ghost,
+                                                                const bf16_t* __restrict__ dyp, int B, int H, int W, int C, bf16_t* __restrict__ d) {
+    const float g = ghost * (gdev ? *gdev : 1.0f);
+    const int C8 = C >> 3, Ho = H / 2, Wo = W / 2;
+    const bf16_t* fp = f + half;
+    if (!dyp) {
+        const size_t total = half >> 3;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            float yp[8], yg[8], o[8];
+            pw_ld8(fp + 8 * i, yp); pw_ld8(f + 8 * i, yg);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float df = yg[e] - yp[e]; const float l1 = df > 0.f ? -g : (df < 0.f ? g : 0.f); o[e] = yp[e] > 0.f ? l1 : 0.f; }
+            pw_st8(d + 8 * i, o);
+        }
+        return;
+    }
+    const size_t total = (size_t)B * Ho * Wo * C8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C8) * 8;
+        size_t p = i / C8;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int n = (int)(p / Ho);
+        float v[4][8], gt[4][8], best[8], gp[8]; size_t off[4]; int bi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            off[k] = ((size_t)(n * H + 2 * oy + (k >> 1)) * W + 2 * ox + (k & 1)) * C + c;
+            pw_ld8(fp + off[k], v[k]); pw_ld8(f + off[k], gt[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (v[k][e] > best[e]) { best[e] = v[k][e]; bi[e] = k; }
+        }
+        pw_ld8(dyp + (((size_t)(n * Ho + oy) * Wo + ox) * C + c), gp);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float df = gt[k][e] - v[k][e];
+                const float l1 = df > 0.f ? -g : (df < 0.f ? g : 0.f);
+                o[e] = v[k][e] > 0.f ? ((bi[e] == k ? gp[e] : 0.f) + l1) : 0.f;
+            }
+            pw_st8(d + off[k], o);
+        }
+    }
+}
+extern "C" int kpx_vgg_feat_bwd_bf16(const void* f, size_t half, const float* gscale_dev, float gscale_host, const void* dy_pooled,
+                                     int B, int H, int W, int C, void* d, void* stream) {
+    if (!f || !d || half == 0 || B <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8 || half != (size_t)B * H * W * C || (dy_pooled && (H % 2 || W % 2)) || !pw_al16(f, d, dy_pooled))
+        return KPX_EINVAL;
+    const size_t items = dy_pooled ? (size_t)B * (H / 2) * (W / 2) * (C / 8) : half / 8;
+    hipLaunchKernelGGL(vgg_feat_bwd_bf16_kernel, dim3(grid_for(items)), dim3(256), 0, kpx_stream(stream), (const bf16_t*)f, half, gscale_dev, gscale_host, (const bf16_t*)dy_pooled, B, H, W, C, (bf16_t*)d);
+    return kpx_launch_status();
+}
+// mean |f[0:half] - f[half:2 half]| of a bf16 feature tensor [gt ; pred] (half a multiple of 8): partials in fp64, out fp32
+__global__ __launch_bounds__(256) void l1_pair_partial_bf16_kernel(const bf16_t* __restrict__ f, size_t half, double* __restrict__ part) {
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < half / 8; i += (size_t)gridDim.x * 256) {
+        float a[8], b[8];
+        pw_ld8(f + 8 * i, a); pw_ld8(f + half + 8 * i, b);
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += fabsf(a[j] - b[j]);
+        s += (double)t;
+    }
+    s = kpx_wave_sum_d(s);
+    __shared__ double sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ void l1_pair_finalize_bf16_kernel(const double* part, int nb, double count, float* out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) s += part[i];
+    s = kpx_wave_sum_d(s);
+    if (threadIdx.x == 0) *out = (float)(s / count);
+}
+extern "C" int kpx_l1_pair_fwd_bf16(const void* f, size_t half, float* loss_out, void* scratch, void* stream) {
+    if (!f || !loss_out || !scratch || half == 0 || half % 8 || !pw_al16(f)) return KPX_EINVAL;
+    size_t nb = (half / 8 + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > 1024) nb = 1024;
+    hipStream_t s = kpx_stream(stream);
+    hipLaunchKernelGGL(l1_pair_partial_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const bf16_t*)f, half, (double*)scratch);
+    int rc = kpx_launch_status();
+    if (rc) return rc;
+    hipLaunchKernelGGL(l1_pair_finalize_bf16_kernel, dim3(1), dim3(64), 0, s, (const double*)scratch, (int)nb, (double)half, loss_out);
+    return kpx_launch_status();
+}

@@ -17,7 +17,7 @@ FOLD_BN_INFERENCE = _os.environ.get('KPX_FOLD_BN_INFERENCE', '1') != '0'      # 
 
 
 def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', act=ACT_NONE, cin=None, head31=False, bias_grad=True, bn_stats=False,
-         f43_fwd=True, input_act=ACT_NONE, act_bwd_by_consumer=False):
+         f43_fwd=True, input_act=ACT_NONE, act_bwd_by_consumer=False, out_f32=False):
     """reference layers.conv (layers.py:4-10): tf.pad(pad) + tf.layers.conv2d(padding='same', xavier, bias).
     f43_fwd (a kernel attribute of the LAYER, recorded with its filter variable when the layer is declared): whether the forward of a 3x3
     stride-1 layer may run the F(4x4,3x3) Winograd kernel (ops.WINO43: an accuracy policy taken from a whole-step measurement).
@@ -38,8 +38,9 @@ def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', 
         return Sym(n, ho, wo, channels)
     w_, wg = st.param(kname)
     b_, bg = st.param(bname) if use_bias else (None, None)
+    # out_f32: the output stays fp32 in the bf16 configuration too (tensors read by fp32-only consumers: head blend, the losses)
     return ops.conv2d(x, w_, b_, stride=stride, pad=pad, act=act, cin=cin, w_grad_out=wg, b_grad_out=bg, bias_grad=bias_grad, bn_stats=bn_stats,
-                      input_act=input_act, act_bwd_by_consumer=act_bwd_by_consumer)
+                      input_act=input_act, act_bwd_by_consumer=act_bwd_by_consumer, out_dtype=torch.float32 if out_f32 else None)
 
 
 def conv1x1_keypoints(x, channels, scope='conv_0'):
@@ -60,7 +61,7 @@ def conv1x1_keypoints(x, channels, scope='conv_0'):
     return ops.keypoint_head_proj(x, w_, b_, w_grad_out=wg, b_grad_out=bg)
 
 
-def batch_norm(x, train_mode, scope='batch_norm', act=ACT_NONE, groups=1, update_moving=True):
+def batch_norm(x, train_mode, scope='batch_norm', act=ACT_NONE, groups=1, update_moving=True, out_f32=False):
     """reference layers.batch_norm (layers.py:13-14): contrib batch_norm(eps=1e-5, center, scale, is_training)."""
     st = default_store()
     c = int(x.shape[-1])
@@ -74,10 +75,10 @@ def batch_norm(x, train_mode, scope='batch_norm', act=ACT_NONE, groups=1, update
     g_, gg = st.param(gamma)
     b_, bg = st.param(beta)
     return ops.batch_norm(x, g_, b_, st[mm], st[mv], train=bool(train_mode), act=act, groups=groups,
-                          update_moving=update_moving and bool(train_mode), g_grad_out=gg, b_grad_out=bg)
+                          update_moving=update_moving and bool(train_mode), g_grad_out=gg, b_grad_out=bg, out_f32=out_f32)
 
 
-def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, groups=1, update_moving=True, cin=None, f43_fwd=True):
+def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, groups=1, update_moving=True, cin=None, f43_fwd=True, out_f32=False):
     """conv -> batch_norm -> relu, the repeating unit of every generator network (reference networks/__init__.py:10-12).
 
     The conv keeps its bias variable (reference layers.py:4 default use_bias=True), but d(loss)/d(bias) is exactly
@@ -97,7 +98,7 @@ def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, 
             return ops.conv2d(x, wf, bf, stride=stride, pad=0, act=ACT_RELU, cin=cin)
     x = conv(x, channels, kernel=kernel, stride=stride, scope=conv_scope, cin=cin, bias_grad=not (EXACT_ZERO_BIAS_GRAD and train_mode),
              bn_stats=bool(train_mode), f43_fwd=f43_fwd)       # the conv epilogue delivers the batch statistics when it can
-    return batch_norm(x, train_mode, scope=bn_scope, act=ACT_RELU, groups=groups, update_moving=update_moving)
+    return batch_norm(x, train_mode, scope=bn_scope, act=ACT_RELU, groups=groups, update_moving=update_moving, out_f32=out_f32)
 
 
 def fully_connected(x, num_outputs, scope='fully_connected', act=ACT_RELU, trainable=False):

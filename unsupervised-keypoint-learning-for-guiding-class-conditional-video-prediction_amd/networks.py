@@ -59,13 +59,15 @@ def pose_encoder(x, n_pts, train_mode, final_res=128, filters=128, bn_groups=1, 
         for i in range(4):
             # i > 0: x is already the [up-sampled ‖ skip] concat buffer written by the previous stage (:44)
             x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % conv_id, 'b_norm_%d_0' % conv_id, bn_groups, update_moving=update_moving, f43_fwd=False)
-            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id, bn_groups, update_moving=update_moving, f43_fwd=False)
+            # (the last block's output is read by the fp32 key-point head: it stays fp32 in the bf16 configuration too)
+            x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id, bn_groups, update_moving=update_moving, f43_fwd=False,
+                                    out_f32=size == final_res)
             if size == final_res:
                 if FUSE_KEYPOINT_HEAD and not return_logits and (is_sym(x) or (x.is_cuda and ops.keypoint_head_proj_eligible(x.shape, n_pts))):
                     # 1x1 head (:54) + get_coord x2 (:68-71) as one op: the logits are consumed by the two axis means only
                     gauss_mu, _, _ = layers.conv1x1_keypoints(x, n_pts)
                     return gauss_mu
-                x = layers.conv(x, n_pts, kernel=1, stride=1)        # default scope 'conv_0' (:54)
+                x = layers.conv(x, n_pts, kernel=1, stride=1, out_f32=True)        # default scope 'conv_0' (:54)
                 break
             x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1), bn_groups, update_moving=update_moving, f43_fwd=False)
             x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % (conv_id + 1), 'b_norm_%d_1' % (conv_id + 1), bn_groups, update_moving=update_moving, f43_fwd=False)
@@ -93,7 +95,7 @@ def translator(x, train_mode, final_res=128, filters=256, cin=None, update_movin
             x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % conv_id, 'b_norm_%d_1' % conv_id, update_moving=update_moving, f43_fwd=f43)
             if size == final_res:
                 # conv_N_0 (crude, 3 ch, :87) and conv_N_1 (mask, 1 ch, :88) as one 4-channel conv
-                return layers.conv(x, 4, kernel=3, stride=1, scope='conv_%d_0+1' % (conv_id + 1), head31=True)
+                return layers.conv(x, 4, kernel=3, stride=1, scope='conv_%d_0+1' % (conv_id + 1), head31=True, out_f32=True)
             x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_0' % (conv_id + 1), 'b_norm_%d_0' % (conv_id + 1), update_moving=update_moving, f43_fwd=f43)
             x = layers.conv_bn_relu(x, filters, 3, 1, train_mode, 'conv_%d_1' % (conv_id + 1), 'b_norm_%d_1' % (conv_id + 1), update_moving=update_moving, f43_fwd=f43)
             x = _upsample_concat(x, None)                              # :98
@@ -116,7 +118,7 @@ def img_discr(x):
             x = layers.conv(x, channel * 2, kernel=4, stride=2, pad=1, use_bias=True, scope='conv_' + str(i), act=ACT_LRELU,
                             input_act=ACT_LRELU, act_bwd_by_consumer=True)
             channel = channel * 2
-        return layers.conv(x, channels=1, kernel=3, stride=1, pad=1, use_bias=False, scope='D_logit', act=ACT_NONE, input_act=ACT_LRELU)
+        return layers.conv(x, channels=1, kernel=3, stride=1, pad=1, use_bias=False, scope='D_logit', act=ACT_NONE, input_act=ACT_LRELU, out_f32=True)
 
 
 def vae_decoder(x, f_pt, act_code, cell_info, vae_dim, n_pts, n_steps=32):

@@ -35,8 +35,8 @@ def _stream():
 def _require_gpu(t):
     if not t.is_cuda:
         raise _lib.KpxError('kpx ops run on MI355X only (got a %s tensor); there is no CPU fallback' % t.device)
-    if t.dtype != torch.float32:
-        raise _lib.KpxError('kpx ops are fp32 (got %s)' % t.dtype)
+    if t.dtype != torch.float32 and t.dtype != torch.bfloat16:
+        raise _lib.KpxError('kpx ops take fp32 tensors, or bf16 activation tensors in the bf16 configuration (got %s)' % t.dtype)
 
 
 def same_pad(in_size, k, s):
@@ -198,10 +198,14 @@ def join_side_stream(device=None):
 
 
 # ----------------------------------------------------------------------------------------------- compute dtype
-# 'f32' (default, the parity configuration) or 'bf16' (BASELINE configs[2]): in bf16 mode the forward and the data gradient of
-# every eligible 3x3 stride-1 SAME layer run on the bf16 matrix pipe (fp32 tensors, fp32 accumulate, fp32 master weights, fp32
-# batch-norm statistics); everything else -- and the weight gradients -- stays on the fp32 kernels.
+# 'f32' (default, the parity configuration) or 'bf16' (BASELINE configs[2], "bf16 storage + fp32 accumulate"): ACTIVATION TENSORS ARE bf16
+# IN HBM -- every producer writes bf16, every consumer reads bf16 -- with fp32 accumulation, fp32 batch-norm statistics, fp32 master
+# weights / gradient buckets / Adam.  Images, the generated frame, the translator's 4-channel head, the tensor the key-point head reads,
+# key-points, heat-map arithmetic and all losses stay fp32.  A layer whose shape the bf16 kernels do not take runs through the fp32 kernel
+# of the fp32 configuration between two conversion passes (`_fallback_uses` counts them: the bench configuration should not need any).
 _compute_dtype = [_os.environ.get('KPX_DTYPE', 'f32')]
+BF16 = torch.bfloat16
+fallback_uses = {'conv_fwd': 0, 'conv_dgrad': 0, 'conv_wgrad': 0, 'other': 0}        # diagnostics: bf16 tensors routed through fp32 kernels
 
 
 def set_compute_dtype(name):
@@ -214,22 +218,104 @@ def compute_dtype():
     return _compute_dtype[0]
 
 
+def act_dtype():
+    """Storage type of activation tensors in the current configuration."""
+    return BF16 if _compute_dtype[0] == 'bf16' else torch.float32
+
+
 def _arith():
     """The `arith` argument of kpx_conv2d_{fwd,dgrad,wgrad}_f32 (include/kpx.h): the implicit-GEMM kernels of the strided / 4x4 / 1x1
     layers and the direct weight gradients take three bf16 terms per fp32 operand (fp32-equivalent) or one (the bf16 configuration)."""
     return 1 if _compute_dtype[0] == 'bf16' else 0
 
 
-def _bf16_conv(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad):
-    """3x3 stride-1 SAME convolution on the bf16 matrix pipe; returns False when the shape is not eligible."""
+def cast_channels_raw(src_ptr, ldsrc, dst_ptr, lddst, pixels, c, kind):
+    """dst[p][0:c] = src[p][0:c]; kind 0: f32 -> bf16, 1: bf16 -> f32, 2: bf16 -> bf16."""
+    check(lib.kpx_cast_channels(src_ptr, ldsrc, dst_ptr, lddst, pixels, c, kind, _stream()), 'kpx_cast_channels')
+
+
+def cast(t, dtype):
+    """A contiguous copy of ``t`` in ``dtype`` (fp32 <-> bf16); ``t`` itself when it already has it."""
+    if t.dtype == dtype:
+        return t
+    t = t.contiguous()
+    out = torch.empty(t.shape, dtype=dtype, device=t.device)
+    n = t.numel()
+    c = next(k for k in (4096, 512, 64, 8, 1) if n % k == 0)
+    if n:
+        cast_channels_raw(t.data_ptr(), c, out.data_ptr(), c, n // c, c, 0 if dtype == BF16 else 1)
+    return out
+
+
+def _esz(t):
+    return 2 if t.dtype == BF16 else 4
+
+
+def _slice_f32(x, ldx, cin):
+    """fp32 contiguous [N,H,W,cin] copy of the first ``cin`` channels of the NHWC tensor ``x`` (pixel stride ldx)."""
+    n, h, w = x.shape[0], x.shape[1], x.shape[2]
+    out = torch.empty((n, h, w, cin), dtype=torch.float32, device=x.device)
+    if x.dtype == BF16:
+        cast_channels_raw(x.data_ptr(), ldx, out.data_ptr(), cin, n * h * w, cin, 1)
+    else:
+        copy_channels_raw(x.data_ptr(), ldx, out.data_ptr(), cin, n * h * w, cin)
+    return out
+
+
+# prepared (fragment-ordered bf16) filters of the bf16-storage 3x3 kernel: (filter data_ptr, dgrad) -> (Wf, owning FilterBank or None, weak ref, (Cin, Cout))
+_bf16s_w = {}
+conv_kernel_uses_bf16s = [0]
+
+
+def _bf16s_prepared(w, dgrad):
+    ent = _cached_u(_bf16s_w, w, dgrad)
+    if ent is None:
+        # a filter nobody registered (tests, one-off layers): prepare per call
+        cin, cout = int(w.shape[2]), int(w.shape[3])
+        k, nn = (cout, cin) if dgrad else (cin, cout)
+        wf = scratch.get('bf16s_w%d' % (1 if dgrad else 0), lib.kpx_conv3x3_bf16s_weights_bytes(k, nn), w.device)
+        check(lib.kpx_conv3x3_bf16s_prepare_f32(w.data_ptr(), cin, cout, 1 if dgrad else 0, wf.data_ptr(), _stream()), 'kpx_conv3x3_bf16s_prepare_f32')
+        return wf
+    if ent[1] is not None:
+        ent[1].ensure_fresh()
+    return ent[0]
+
+
+def _bf16s_conv(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, want_stats=False, mask=None):
+    """3x3 stride-1 SAME convolution on bf16 tensors (csrc/conv_bf16s.hip); False when the shape is not one the kernel takes.
+    With want_stats returns (slab, tiles per image as a Fraction)."""
     n, h, wd = inp.shape[0], inp.shape[1], inp.shape[2]
-    if not lib.kpx_conv3x3_bf16_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr()):
+    out_f32 = out.dtype == torch.float32
+    if inp.dtype != BF16:
         return False
-    cin, cout = w.shape[2], w.shape[3]
-    wf = scratch.get('bf16w', lib.kpx_conv3x3_bf16_weights_bytes(cin, cout), inp.device)
-    check(lib.kpx_conv3x3_bf16_prepare_f32(w.data_ptr(), cin, cout, 1 if dgrad else 0, wf.data_ptr(), _stream()), 'kpx_conv3x3_bf16_prepare_f32')
-    check(lib.kpx_conv3x3_bf16_f32(inp.data_ptr(), n, h, wd, k, ld_in, wf.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                   out.data_ptr(), nn, ld_out, act, _stream()), 'kpx_conv3x3_bf16_f32')
+    # ragged channel counts (the 158-channel joint embedding in its 160-wide buffer): the kernel runs on the rounded-up counts -- the
+    # prepared filters are zero there, so the extra gathered channels (zero-filled / finite by the producer's contract) contribute nothing
+    # and the extra produced channels come out as zeros
+    if not (k % 32 == 0 or k in (8, 16)):
+        k = (k + 31) // 32 * 32
+        if ld_in < k:
+            return False
+    g = 4 if out_f32 else 8
+    if nn % g:
+        nn = (nn + g - 1) // g * g
+        if ld_out < nn:
+            return False
+    if ld_out % g or not lib.kpx_conv3x3_bf16s_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr()):
+        return False
+    if out.data_ptr() % 16 or (mask is not None and (out_f32 or mask.dtype != BF16 or mask.data_ptr() % 16)):
+        return False
+    wf = _bf16s_prepared(w, dgrad)
+    slab = None
+    if want_stats:
+        tiles = lib.kpx_conv3x3_bf16s_stats_tiles(n, h, wd, k, nn)
+        slab = torch.empty(tiles * 2 * nn, dtype=torch.float32, device=inp.device)
+    check(lib.kpx_conv3x3_bf16s(inp.data_ptr(), n, h, wd, k, ld_in, wf.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                out.data_ptr(), nn, ld_out, 1 if out_f32 else 0, act, mask.data_ptr() if mask is not None else None,
+                                mask.stride(2) if mask is not None else 0, slab.data_ptr() if slab is not None else None, _stream()), 'kpx_conv3x3_bf16s')
+    conv_kernel_uses_bf16s[0] += 1
+    if want_stats:
+        from fractions import Fraction
+        return slab, Fraction(tiles, n)
     return True
 
 
@@ -326,8 +412,30 @@ class FilterBank:
     def touch(self):
         self.version += 1
 
+    def _build_bf16s(self):
+        """The fragment-ordered bf16 copies of every filter for the bf16-storage kernel (both directions), one arena, one descriptor table."""
+        sizes = [[lib.kpx_conv3x3_bf16s_weights_bytes(*((int(w.shape[3]), int(w.shape[2])) if d else (int(w.shape[2]), int(w.shape[3])))) for d in (0, 1)]
+                 for _, w in self.filters]
+        self.arena16 = torch.empty(sum(sum(sz) for sz in sizes), dtype=torch.uint8, device=self.device)
+        table, off = b'', 0
+        for (_, w), sz in zip(self.filters, sizes):
+            cin, cout = int(w.shape[2]), int(w.shape[3])
+            for dgrad in (0, 1):
+                wf = self.arena16[off:off + sz[dgrad]]
+                off += sz[dgrad]
+                _bf16s_w[(w.data_ptr(), dgrad)] = (wf, self, None, (cin, cout))
+                nn = cin if dgrad else cout
+                table += _struct.pack('<QQiiii', w.data_ptr(), wf.data_ptr(), cin, cout, dgrad, (nn + 127) // 128 * 4)
+        self.table16 = torch.frombuffer(bytearray(table), dtype=torch.uint8).to(self.device)
+        self.n_desc16 = len(table) // 32
+
     def ensure_fresh(self):
-        if self.synced != self.version and self.filters:
+        if (self.synced != self.version or getattr(self, 'synced_mode', None) != _compute_dtype[0]) and self.filters:
+            self.synced_mode = _compute_dtype[0]
+            if _compute_dtype[0] == 'bf16':
+                if getattr(self, 'table16', None) is None:
+                    self._build_bf16s()
+                check(lib.kpx_conv3x3_bf16s_prepare_batch_f32(self.table16.data_ptr(), self.n_desc16, _stream()), 'kpx_conv3x3_bf16s_prepare_batch_f32')
             check(lib.kpx_wino_filter_transform_batch_f32(self.table.data_ptr(), self.n_desc, _stream()), 'kpx_wino_filter_transform_batch_f32')
             if self.n_desc43:
                 check(lib.kpx_wino43_filter_transform_batch_f32(self.table43.data_ptr(), self.n_desc43, _stream()), 'kpx_wino43_filter_transform_batch_f32')
@@ -335,6 +443,9 @@ class FilterBank:
 
     def keys(self):
         return [(w.data_ptr(), dgrad) for _, w in self.filters for dgrad in (0, 1)]
+
+    def mode_key(self):
+        return _compute_dtype[0]
 
 
 def register_constant_filter(w, name='', f43_fwd=True):
@@ -354,6 +465,12 @@ def register_constant_filter(w, name='', f43_fwd=True):
             u = torch.empty(lib.kpx_wino43_u_bytes(int(w.shape[2]), int(w.shape[3])) // 4, dtype=torch.float32, device=w.device)
             check(lib.kpx_wino43_filter_transform_f32(w.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, u.data_ptr(), _stream()), 'kpx_wino43_filter_transform_f32')
             _wino43_u[(w.data_ptr(), dgrad)] = (u, None, _weakref.ref(w.untyped_storage()), (int(w.shape[2]), int(w.shape[3])))
+        if _compute_dtype[0] == 'bf16' and int(w.shape[2]) % 8 == 0:
+            cin, cout = int(w.shape[2]), int(w.shape[3])
+            k, nn = (cout, cin) if dgrad else (cin, cout)
+            wf = torch.empty(lib.kpx_conv3x3_bf16s_weights_bytes(k, nn), dtype=torch.uint8, device=w.device)
+            check(lib.kpx_conv3x3_bf16s_prepare_f32(w.data_ptr(), cin, cout, dgrad, wf.data_ptr(), _stream()), 'kpx_conv3x3_bf16s_prepare_f32')
+            _bf16s_w[(w.data_ptr(), dgrad)] = (wf, None, _weakref.ref(w.untyped_storage()), (cin, cout))
     return keys
 
 
@@ -362,6 +479,7 @@ def release_filters(keys):
     for k in keys:
         _wino_u.pop(k, None)
         _wino43_u.pop(k, None)
+        _bf16s_w.pop(k, None)
 
 
 def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, want_stats=False, bn_src=None):
@@ -454,9 +572,20 @@ def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act, want_s
     """Returns None, or (tile-statistics slab, tiles per image) when ``want_stats`` and the layer ran on the kernel that provides them."""
     n, hi, wi = x.shape[0], x.shape[1], x.shape[2]
     kh, kw, _, cout = w.shape
-    if (_compute_dtype[0] == 'bf16' and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cin >= 8
-            and y.shape[1] == hi and y.shape[2] == wi and _bf16_conv(x, ldx, cin, w, bias, y, ldy, cout, act, False)):
-        return
+    if x.dtype == BF16 or y.dtype == BF16:
+        # bf16 configuration: the bf16-storage kernel, or (shapes it does not take, image-input layers) the fp32 kernel between conversions
+        if (x.dtype == BF16 and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and act != ACT_TANH and y.shape[1] == hi and y.shape[2] == wi):
+            r = _bf16s_conv(x, ldx, cin, w, bias, y, ldy, cout, act, False, want_stats=want_stats)
+            if r:
+                return r if isinstance(r, tuple) else None
+        if x.dtype == BF16:
+            fallback_uses['conv_fwd'] += 1
+            x, ldx = _slice_f32(x, ldx, cin), cin
+        yf = y if y.dtype == torch.float32 else torch.empty((n, y.shape[1], y.shape[2], cout), dtype=torch.float32, device=x.device)
+        conv_fwd_raw(x, ldx, cin, w, bias, yf, ldy if yf is y else cout, stride, pad_t, pad_l, act)
+        if yf is not y:
+            cast_channels_raw(yf.data_ptr(), cout, y.data_ptr(), ldy, n * y.shape[1] * y.shape[2], cout, 0)
+        return None
     if (kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and act != ACT_TANH and cout == 16 and y.shape[1] == hi and y.shape[2] == wi
             and lib.kpx_conv3x3_c16_eligible(n, hi, wi, cin, cout, ldx, ldy, x.data_ptr())):
         # exactly 16 produced channels: 16x16x4 MFMA blocks, no cout padding (csrc/conv_c16.hip)
@@ -485,6 +614,20 @@ def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l, bn_src=None
     data-gradient epilogue (kpx_conv2d_dgrad_act_f32) -- the producer of y_in then skips its own pass."""
     n, ho, wo = dy.shape[0], dy.shape[1], dy.shape[2]
     kh, kw, _, cout = w.shape
+    if dy.dtype == BF16 or dx.dtype == BF16:
+        if (dy.dtype == BF16 and mul is None and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and dx.shape[1] == ho and dx.shape[2] == wo
+                and _bf16s_conv(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True)):
+            return None
+        if dy.dtype == BF16:
+            fallback_uses['conv_dgrad'] += 1
+            dy, lddy = _slice_f32(dy, lddy, cout), cout
+        dxf = dx if dx.dtype == torch.float32 else torch.empty((n, dx.shape[1], dx.shape[2], cin), dtype=torch.float32, device=dy.device)
+        if mul is not None and mul[0].dtype == BF16:
+            mul = (cast(mul[0], torch.float32), mul[1])
+        conv_dgrad_raw(dy, lddy, w, dxf, lddx if dxf is dx else cin, cin, stride, pad_t, pad_l, mul=mul)
+        if dxf is not dx:
+            cast_channels_raw(dxf.data_ptr(), cin, dx.data_ptr(), lddx, n * dx.shape[1] * dx.shape[2], cin, 0)
+        return None
     if mul is not None:
         y_in, act_in = mul
         nbytes = lib.kpx_conv2d_dgrad_workspace_bytes(n, dx.shape[1], dx.shape[2], cin, cout, kh, kw, stride)
@@ -493,9 +636,6 @@ def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l, bn_src=None
                                            dx.data_ptr(), dx.shape[1], dx.shape[2], cin, lddx, stride, pad_t, pad_l, _arith(),
                                            y_in.data_ptr(), y_in.shape[3], act_in,
                                            ws.data_ptr() if ws is not None else None, nbytes, _stream()), 'kpx_conv2d_dgrad_act_f32')
-        return
-    if (_compute_dtype[0] == 'bf16' and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cout >= 8
-            and dx.shape[1] == ho and dx.shape[2] == wo and _bf16_conv(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True)):
         return
     if (kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and cin == 16 and bn_src is None and dx.shape[1] == ho and dx.shape[2] == wo
             and lib.kpx_conv3x3_c16_eligible(n, ho, wo, cout, cin, lddy, lddx, dy.data_ptr())):
@@ -518,6 +658,12 @@ def conv_wgrad_raw(x, ldx, cin, dy, lddy, dw, stride, pad_t, pad_l):
     n, hi, wi = x.shape[0], x.shape[1], x.shape[2]
     ho, wo = dy.shape[1], dy.shape[2]
     kh, kw, _, cout = dw.shape
+    if x.dtype == BF16 or dy.dtype == BF16:
+        fallback_uses['conv_wgrad'] += 1
+        if x.dtype == BF16:
+            x, ldx = _slice_f32(x, ldx, cin), cin
+        if dy.dtype == BF16:
+            dy, lddy = _slice_f32(dy, lddy, cout), cout
     nbytes = lib.kpx_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, cout, kh, kw)
     ws = scratch.get('wgrad', nbytes, x.device) if nbytes else None
     check(lib.kpx_conv2d_wgrad_f32(x.data_ptr(), n, hi, wi, cin, ldx, dy.data_ptr(), ho, wo, cout, lddy,
@@ -527,12 +673,24 @@ def conv_wgrad_raw(x, ldx, cin, dy, lddy, dw, stride, pad_t, pad_l):
 
 
 def chan_sum_raw(x, ldx, pixels, c, out):
+    if x.dtype == BF16:
+        if c % 8 == 0 and ldx % 8 == 0 and x.data_ptr() % 16 == 0:
+            check(lib.kpx_chan_sum_bf16(x.data_ptr(), pixels, c, ldx, out.data_ptr(), scratch.reduce(c, x.device).data_ptr(), _stream()), 'kpx_chan_sum_bf16')
+            return
+        fallback_uses['other'] += 1
+        xf = torch.empty((pixels, c), dtype=torch.float32, device=x.device)
+        cast_channels_raw(x.data_ptr(), ldx, xf.data_ptr(), c, pixels, c, 1)
+        x, ldx = xf, c
     check(lib.kpx_chan_sum_f32(x.data_ptr(), pixels, c, ldx, out.data_ptr(), scratch.reduce(c, x.device).data_ptr(), _stream()),
           'kpx_chan_sum_f32')
 
 
 def act_bwd_raw(dy, y, dz, act):
     """dz = dy * act'(y); dz may be dy itself (in place)."""
+    if dy.dtype == BF16:
+        assert y.dtype == BF16 and dz.dtype == BF16 and dy.numel() % 8 == 0
+        check(lib.kpx_act_bwd_bf16(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), act, _stream()), 'kpx_act_bwd_bf16')
+        return
     check(lib.kpx_act_bwd_f32(dy.data_ptr(), y.data_ptr(), dz.data_ptr(), dy.numel(), act, _stream()), 'kpx_act_bwd_f32')
 
 
@@ -545,11 +703,22 @@ def axpy_raw_(y, x, a=1.0):
 
 
 def fill_raw_(t, v=0.0):
+    if t.dtype == BF16:
+        assert v == 0.0 and t.numel() % 2 == 0, 'bf16 tensors are only ever zero-filled'
+        check(lib.kpx_fill_f32(t.data_ptr(), t.numel() // 2, 0.0, _stream()), 'kpx_fill_f32')
+        return
     check(lib.kpx_fill_f32(t.data_ptr(), t.numel(), v, _stream()), 'kpx_fill_f32')
 
 
 def copy_channels_raw(src_ptr, ldsrc, dst_ptr, lddst, pixels, c):
     check(lib.kpx_copy_channels_f32(src_ptr, ldsrc, dst_ptr, lddst, pixels, c, _stream()), 'kpx_copy_channels_f32')
+
+
+def flat_copy_tensor(src, dst_ptr):
+    """dst[0:numel] = src (contiguous, fp32 or bf16) as a raw copy."""
+    nbytes = src.numel() * _esz(src)
+    assert nbytes % 4 == 0
+    flat_copy_raw(src.data_ptr(), dst_ptr, nbytes // 4)
 
 
 def flat_copy_raw(src_ptr, dst_ptr, n):
@@ -566,7 +735,7 @@ class Conv2dFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad, bn_stats=False, bn_src=None, input_act=ACT_NONE,
-                act_bwd_by_consumer=False):
+                act_bwd_by_consumer=False, out_dtype=None):
         # input_act: x is the activated output of a layer declared with act_bwd_by_consumer=True -- this layer's data gradient applies that
         # activation's backward in its epilogue (it saves x anyway) and the producer skips its own pass.  A static contract between the two
         # layers, declared where the network is built (networks.img_discr): x must have NO other consumer.
@@ -585,7 +754,7 @@ class Conv2dFn(torch.autograd.Function):
         pt, _, ho = same_pad(h + 2 * pad, kh, stride)
         pl, _, wo = same_pad(wd + 2 * pad, kw, stride)
         pad_t, pad_l = pad + pt, pad + pl
-        y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+        y = torch.empty((n, ho, wo, cout), dtype=out_dtype if out_dtype is not None else act_dtype(), device=x.device)
         st = conv_fwd_raw(x, ldx, cin, w, b, y, cout, stride, pad_t, pad_l, act, want_stats=bn_stats and act == ACT_NONE)
         if st is not None:
             _pending_stats[y.data_ptr()] = st
@@ -621,7 +790,7 @@ class Conv2dFn(torch.autograd.Function):
             fork.record(torch.cuda.current_stream(x.device))
         if ctx.needs_input_grad[0]:
             cx = x.shape[3]
-            dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
             if cin < cx:
                 fill_raw_(dx, 0.0)
             st = conv_dgrad_raw(dy, cout, w, dx, cx, cin, stride, pad_t, pad_l,
@@ -660,7 +829,7 @@ class Conv2dFn(torch.autograd.Function):
                 if ctx.b_grad_out is not None and not direct:
                     axpy_raw_(ctx.b_grad_out, db_buf)
                 db = None if ctx.b_grad_out is not None else db_buf
-        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 _pending_stats = {}      # output data_ptr -> (tile-statistics slab, tiles per image), handed from Conv2dFn.forward to conv2d()
@@ -670,13 +839,15 @@ fused_bn_uses = {'stats_from_conv_epilogue': 0, 'backward_sums_from_dgrad_epilog
 
 
 def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, cin=None, w_grad_out=None, b_grad_out=None, bias_grad=True, bn_stats=False,
-           input_act=ACT_NONE, act_bwd_by_consumer=False):
-    """bias_grad=False: the bias gradient is known to be exactly zero (conv feeding a batch norm) and is not computed.
+           input_act=ACT_NONE, act_bwd_by_consumer=False, out_dtype=None):
+    """out_dtype: storage type of the output (default: the configuration's activation type; torch.float32 keeps a tensor fp32 in the bf16
+    configuration -- the translator's 4-channel head, the discriminator's logits).
+    bias_grad=False: the bias gradient is known to be exactly zero (conv feeding a batch norm) and is not computed.
     bn_stats=True: a train-mode batch norm consumes the output next; when the layer runs on the fused Winograd kernel its epilogue
     also writes the per-tile channel sums, which ``batch_norm`` then uses instead of a statistics pass over the activation."""
     y = Conv2dFn.apply(x, w, b, w_grad_out, b_grad_out, stride, pad, act, cin, bias_grad, bn_stats and FUSE_BN_STATS,
                        getattr(x, '_kpx_bn', None) if FUSE_BN_BWD else None, input_act if FUSE_ACT_BWD else ACT_NONE,
-                       act_bwd_by_consumer and FUSE_ACT_BWD)
+                       act_bwd_by_consumer and FUSE_ACT_BWD, out_dtype)
     if bn_stats:
         st = _pending_stats.pop(y.data_ptr(), None)
         if st is not None:
@@ -694,15 +865,34 @@ class BatchNormFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving, tile_stats=None, bn_id=0):
+    def forward(ctx, x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving, tile_stats=None, bn_id=0, out_f32=False):
         ctx.bn_id = bn_id
         _require_gpu(x)
         x = x.contiguous()
         n, h, w, c = x.shape
         assert n % groups == 0
-        y = torch.empty_like(x)
         dev = x.device
-        if train:
+        if x.dtype == BF16 and not (train and c % 8 == 0):
+            fallback_uses['other'] += 1                  # (inference-mode / ragged batch norm on bf16 tensors: through the fp32 kernels)
+            x = cast(x, torch.float32)
+        ctx.x16 = x.dtype == BF16
+        y = torch.empty(x.shape, dtype=torch.float32 if (out_f32 or not ctx.x16) else BF16, device=dev)
+        if train and ctx.x16:
+            mean = torch.empty((groups, c), dtype=torch.float32, device=dev)
+            invstd = torch.empty((groups, c), dtype=torch.float32, device=dev)
+            ng = n // groups
+            pix = ng * h * w
+            sc = scratch.get('bn%d' % groups, lib.kpx_bn_train_scratch_bytes(c, groups), dev)
+            slab_ptr, tpg = None, 0
+            if tile_stats is not None:
+                slab, tpi = tile_stats
+                fused_bn_uses['stats_from_conv_epilogue'] += groups
+                slab_ptr, tpg = slab.data_ptr(), int(ng * tpi)
+            check(lib.kpx_bn_train_fwd_bf16(x.data_ptr(), pix, groups, c, c, slab_ptr, tpg, BN_EPS, gamma.data_ptr(), beta.data_ptr(),
+                                            mean.data_ptr(), invstd.data_ptr(), moving_mean.data_ptr() if update_moving else None,
+                                            moving_var.data_ptr() if update_moving else None, BN_DECAY, y.data_ptr(), c, 1 if y.dtype == torch.float32 else 0, act,
+                                            sc.data_ptr(), _stream()), 'kpx_bn_train_fwd_bf16')
+        elif train:
             # all `groups` weight-sharing calls in one launch per phase (statistics finalize + apply; + one reduction pass when the
             # producing convolution's epilogue did not deliver the per-tile sums)
             mean = torch.empty((groups, c), dtype=torch.float32, device=dev)
@@ -714,7 +904,7 @@ class BatchNormFn(torch.autograd.Function):
             if tile_stats is not None:                   # sums from the producing convolution's epilogue: no pass over x
                 slab, tpi = tile_stats
                 fused_bn_uses['stats_from_conv_epilogue'] += groups
-                slab_ptr, tpg = slab.data_ptr(), ng * tpi
+                slab_ptr, tpg = slab.data_ptr(), int(ng * tpi)
             check(lib.kpx_bn_train_fwd_f32(x.data_ptr(), pix, groups, c, c, slab_ptr, tpg, BN_EPS, gamma.data_ptr(), beta.data_ptr(),
                                            mean.data_ptr(), invstd.data_ptr(), moving_mean.data_ptr() if update_moving else None,
                                            moving_var.data_ptr() if update_moving else None, BN_DECAY, y.data_ptr(), c, act, sc.data_ptr(), _stream()),
@@ -741,7 +931,7 @@ class BatchNormFn(torch.autograd.Function):
         ng = n // groups
         pix = ng * h * w
         dev = x.device
-        dx = torch.empty_like(x)
+        dx = torch.empty_like(x)                         # (the batch norm's input type: bf16 in the bf16 configuration)
         dg = ctx.g_grad_out if ctx.g_grad_out is not None else torch.empty(c, dtype=torch.float32, device=dev)
         db = ctx.b_grad_out if ctx.b_grad_out is not None else torch.empty(c, dtype=torch.float32, device=dev)
         fresh = True
@@ -754,6 +944,14 @@ class BatchNormFn(torch.autograd.Function):
         # (reduction,) finalize, apply: one launch each for all groups; with `ent` the reduction was done by the epilogue of the data-gradient
         # kernel that produced dy (per-tile sums, ng * tiles-per-image tiles per group)
         sc = scratch.get('bn%d' % groups, lib.kpx_bn_train_scratch_bytes(c, groups), dev)
+        if ctx.x16:
+            check(lib.kpx_bn_train_bwd_bf16(dy.data_ptr(), c, 1 if dy.dtype == torch.float32 else 0, x.data_ptr(), c, pix, groups, c, mean.data_ptr(), invstd.data_ptr(),
+                                            gamma.data_ptr(), beta.data_ptr(), ctx.act, dx.data_ptr(), c, dg.data_ptr(), db.data_ptr(), 0 if fresh else 1,
+                                            sc.data_ptr(), _stream()), 'kpx_bn_train_bwd_bf16')
+            return (dx, None if ctx.g_grad_out is not None else dg, None if ctx.b_grad_out is not None else db,
+                    None, None, None, None, None, None, None, None, None, None, None)
+        if dy.dtype == BF16:
+            dy = cast(dy, torch.float32)
         if ent is not None:
             fused_bn_uses['backward_sums_from_dgrad_epilogue'] += groups
         check(lib.kpx_bn_train_bwd_f32(dy.data_ptr(), c, x.data_ptr(), c, pix, groups, c, mean.data_ptr(), invstd.data_ptr(),
@@ -761,16 +959,16 @@ class BatchNormFn(torch.autograd.Function):
                                        0 if fresh else 1, ent[0].data_ptr() if ent is not None else None, ng * ent[1] if ent is not None else 0,
                                        sc.data_ptr(), _stream()), 'kpx_bn_train_bwd_f32')
         return (dx, None if ctx.g_grad_out is not None else dg, None if ctx.b_grad_out is not None else db,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 def batch_norm(x, gamma, beta, moving_mean, moving_var, train=True, act=ACT_RELU, groups=1, update_moving=True,
-               g_grad_out=None, b_grad_out=None):
+               g_grad_out=None, b_grad_out=None, out_f32=False):
     ts = getattr(x, '_kpx_tile_stats', None) if train else None
     if ts is not None and (x.shape[0] % groups or tuple(ts[0].shape) != (x.shape[0] * ts[1] * 2 * x.shape[3],)):
         ts = None
     _bn_counter[0] += 1
-    y = BatchNormFn.apply(x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving, ts, _bn_counter[0])
+    y = BatchNormFn.apply(x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving, ts, _bn_counter[0], out_f32)
     if train and act == ACT_RELU:
         y._kpx_bn = (beta.detach(), _bn_counter[0])      # a 3x3 conv reading y can reduce this batch norm's backward sums in its dgrad epilogue
     return y
@@ -792,10 +990,16 @@ class UpsampleConcatFn(torch.autograd.Function):
             assert skip.shape[:3] == (n, 2 * h, 2 * w)
             c2 = skip.shape[3]
         ld = c1 + c2
-        out = torch.empty((n, 2 * h, 2 * w, ld), dtype=torch.float32, device=x.device)
-        check(lib.kpx_resize2x_fwd_f32(x.data_ptr(), n, h, w, c1, c1, out.data_ptr(), ld, _stream()), 'kpx_resize2x_fwd_f32')
-        if c2:
-            copy_channels_raw(skip.data_ptr(), c2, out.data_ptr() + 4 * c1, ld, n * 4 * h * w, c2)
+        out = torch.empty((n, 2 * h, 2 * w, ld), dtype=x.dtype, device=x.device)
+        if x.dtype == BF16:
+            check(lib.kpx_resize2x_fwd_bf16(x.data_ptr(), n, h, w, c1, c1, out.data_ptr(), ld, _stream()), 'kpx_resize2x_fwd_bf16')
+            if c2:
+                skip = cast(skip, BF16)
+                cast_channels_raw(skip.data_ptr(), c2, out.data_ptr() + 2 * c1, ld, n * 4 * h * w, c2, 2)
+        else:
+            check(lib.kpx_resize2x_fwd_f32(x.data_ptr(), n, h, w, c1, c1, out.data_ptr(), ld, _stream()), 'kpx_resize2x_fwd_f32')
+            if c2:
+                copy_channels_raw(cast(skip, torch.float32).data_ptr(), c2, out.data_ptr() + 4 * c1, ld, n * 4 * h * w, c2)
         ctx.dims = (n, h, w, c1, c2)
         return out
 
@@ -806,11 +1010,17 @@ class UpsampleConcatFn(torch.autograd.Function):
         ld = c1 + c2
         dx = dskip = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty((n, h, w, c1), dtype=torch.float32, device=dout.device)
-            check(lib.kpx_resize2x_bwd_f32(dout.data_ptr(), n, h, w, c1, ld, dx.data_ptr(), c1, _stream()), 'kpx_resize2x_bwd_f32')
+            dx = torch.empty((n, h, w, c1), dtype=dout.dtype, device=dout.device)
+            if dout.dtype == BF16:
+                check(lib.kpx_resize2x_bwd_bf16(dout.data_ptr(), n, h, w, c1, ld, dx.data_ptr(), c1, _stream()), 'kpx_resize2x_bwd_bf16')
+            else:
+                check(lib.kpx_resize2x_bwd_f32(dout.data_ptr(), n, h, w, c1, ld, dx.data_ptr(), c1, _stream()), 'kpx_resize2x_bwd_f32')
         if c2 and ctx.needs_input_grad[1]:
-            dskip = torch.empty((n, 2 * h, 2 * w, c2), dtype=torch.float32, device=dout.device)
-            copy_channels_raw(dout.data_ptr() + 4 * c1, ld, dskip.data_ptr(), c2, n * 4 * h * w, c2)
+            dskip = torch.empty((n, 2 * h, 2 * w, c2), dtype=dout.dtype, device=dout.device)
+            if dout.dtype == BF16:
+                cast_channels_raw(dout.data_ptr() + 2 * c1, ld, dskip.data_ptr(), c2, n * 4 * h * w, c2, 2)
+            else:
+                copy_channels_raw(dout.data_ptr() + 4 * c1, ld, dskip.data_ptr(), c2, n * 4 * h * w, c2)
         return dx, dskip
 
 
@@ -827,9 +1037,13 @@ class ConcatChannelsFn(torch.autograd.Function):
         _require_gpu(a)
         n, h, w, c1 = a.shape
         c2 = b.shape[3]
-        out = torch.empty((n, h, w, c1 + c2), dtype=torch.float32, device=a.device)
-        copy_channels_raw(a.data_ptr(), c1, out.data_ptr(), c1 + c2, n * h * w, c1)
-        copy_channels_raw(b.data_ptr(), c2, out.data_ptr() + 4 * c1, c1 + c2, n * h * w, c2)
+        out = torch.empty((n, h, w, c1 + c2), dtype=a.dtype, device=a.device)
+        if a.dtype == BF16:
+            cast_channels_raw(a.data_ptr(), c1, out.data_ptr(), c1 + c2, n * h * w, c1, 2)
+            cast_channels_raw(cast(b, BF16).data_ptr(), c2, out.data_ptr() + 2 * c1, c1 + c2, n * h * w, c2, 2)
+        else:
+            copy_channels_raw(a.data_ptr(), c1, out.data_ptr(), c1 + c2, n * h * w, c1)
+            copy_channels_raw(cast(b, torch.float32).data_ptr(), c2, out.data_ptr() + 4 * c1, c1 + c2, n * h * w, c2)
         ctx.dims = (n, h, w, c1, c2)
         return out
 
@@ -837,10 +1051,14 @@ class ConcatChannelsFn(torch.autograd.Function):
     def backward(ctx, dout):
         n, h, w, c1, c2 = ctx.dims
         dout = dout.contiguous()
-        da = torch.empty((n, h, w, c1), dtype=torch.float32, device=dout.device)
-        db = torch.empty((n, h, w, c2), dtype=torch.float32, device=dout.device)
-        copy_channels_raw(dout.data_ptr(), c1 + c2, da.data_ptr(), c1, n * h * w, c1)
-        copy_channels_raw(dout.data_ptr() + 4 * c1, c1 + c2, db.data_ptr(), c2, n * h * w, c2)
+        da = torch.empty((n, h, w, c1), dtype=dout.dtype, device=dout.device)
+        db = torch.empty((n, h, w, c2), dtype=dout.dtype, device=dout.device)
+        if dout.dtype == BF16:
+            cast_channels_raw(dout.data_ptr(), c1 + c2, da.data_ptr(), c1, n * h * w, c1, 2)
+            cast_channels_raw(dout.data_ptr() + 2 * c1, c1 + c2, db.data_ptr(), c2, n * h * w, c2, 2)
+        else:
+            copy_channels_raw(dout.data_ptr(), c1 + c2, da.data_ptr(), c1, n * h * w, c1)
+            copy_channels_raw(dout.data_ptr() + 4 * c1, c1 + c2, db.data_ptr(), c2, n * h * w, c2)
         return da, db
 
 
@@ -855,10 +1073,10 @@ class ConcatBatchFn(torch.autograd.Function):
     def forward(ctx, a, b):
         a, b = a.contiguous(), b.contiguous()
         _require_gpu(a)
-        assert a.shape[1:] == b.shape[1:]
-        out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), dtype=torch.float32, device=a.device)
-        flat_copy_raw(a.data_ptr(), out.data_ptr(), a.numel())
-        flat_copy_raw(b.data_ptr(), out.data_ptr() + 4 * a.numel(), b.numel())
+        assert a.shape[1:] == b.shape[1:] and a.dtype == b.dtype
+        out = torch.empty((a.shape[0] + b.shape[0],) + tuple(a.shape[1:]), dtype=a.dtype, device=a.device)
+        flat_copy_tensor(a, out.data_ptr())
+        flat_copy_tensor(b, out.data_ptr() + _esz(a) * a.numel())
         ctx.na = a.shape[0]
         return out
 
@@ -1018,6 +1236,23 @@ class JointEmbeddingFn(torch.autograd.Function):
         emb, cur_pt, fut_pt = emb.contiguous(), cur_pt.contiguous(), fut_pt.contiguous()
         b, h, w, c = emb.shape
         k = cur_pt.shape[1]
+        if emb.dtype == BF16:
+            # bf16 configuration: the joint buffer is bf16 with its pixel stride rounded up to a multiple of 32 channels (the consumer's
+            # chunk size; the pad channels are zeros and meet zero filter rows).  The two heat-maps are rendered in fp32 (key-point / heat-map
+            # arithmetic stays fp32) into a small [B,h,w,2K(+pad)] tensor and rounded into their channel slice.
+            ld = (c + 2 * k + 31) // 32 * 32
+            out = torch.empty((b, h, w, ld), dtype=BF16, device=emb.device)
+            cast_channels_raw(emb.data_ptr(), c, out.data_ptr(), ld, b * h * w, c, 2)
+            maps = torch.empty((b, h, w, ld - c), dtype=torch.float32, device=emb.device)
+            if ld - c > 2 * k:
+                fill_raw_(maps, 0.0)
+            for i, pt in enumerate((cur_pt, fut_pt)):
+                check(lib.kpx_gaussian_maps_fwd_f32(pt.data_ptr(), b, k, h, w, float(inv_std), maps.data_ptr() + 4 * i * k, ld - c, _stream()),
+                      'kpx_gaussian_maps_fwd_f32')
+            cast_channels_raw(maps.data_ptr(), ld - c, out.data_ptr() + 2 * c, ld, b * h * w, ld - c, 0)
+            ctx.dims = (b, h, w, c, k, ld, float(inv_std))
+            ctx.save_for_backward(cur_pt, fut_pt)
+            return out
         ld = (c + 2 * k + 3) // 4 * 4
         out = torch.empty((b, h, w, ld), dtype=torch.float32, device=emb.device)
         if ld > c + 2 * k:
@@ -1035,6 +1270,18 @@ class JointEmbeddingFn(torch.autograd.Function):
         cur_pt, fut_pt = ctx.saved_tensors
         b, h, w, c, k, ld, inv_std = ctx.dims
         dout = dout.contiguous()
+        if dout.dtype == BF16:
+            demb = torch.empty((b, h, w, c), dtype=BF16, device=dout.device)
+            cast_channels_raw(dout.data_ptr(), ld, demb.data_ptr(), c, b * h * w, c, 2)
+            dmaps = torch.empty((b, h, w, 2 * k), dtype=torch.float32, device=dout.device)
+            cast_channels_raw(dout.data_ptr() + 2 * c, ld, dmaps.data_ptr(), 2 * k, b * h * w, 2 * k, 1)
+            grads = []
+            for i, pt in enumerate((cur_pt, fut_pt)):
+                d = torch.empty_like(pt)
+                check(lib.kpx_gaussian_maps_bwd_f32(dmaps.data_ptr() + 4 * i * k, 2 * k, pt.data_ptr(), b, k, h, w, inv_std, d.data_ptr(), _stream()),
+                      'kpx_gaussian_maps_bwd_f32')
+                grads.append(d)
+            return demb, grads[0], grads[1], None
         demb = torch.empty((b, h, w, c), dtype=torch.float32, device=dout.device)
         copy_channels_raw(dout.data_ptr(), ld, demb.data_ptr(), c, b * h * w, c)
         grads = []

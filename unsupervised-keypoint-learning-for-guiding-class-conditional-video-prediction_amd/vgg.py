@@ -86,6 +86,9 @@ def _vgg_forward(vgg, images):
             nn_, hh, ww, cc = x.shape
             if pooled is not None:
                 y = pooled
+            elif x.dtype == ops.BF16:
+                y = torch.empty((nn_, hh // 2, ww // 2, cc), dtype=ops.BF16, device=dev)
+                check(lib.kpx_maxpool2_fwd_bf16(x.data_ptr(), nn_, hh, ww, cc, y.data_ptr(), ops._stream()), 'kpx_maxpool2_fwd_bf16')
             else:
                 y = torch.empty((nn_, (hh + 1) // 2, (ww + 1) // 2, cc), dtype=torch.float32, device=dev)
                 check(lib.kpx_maxpool2_fwd_f32(x.data_ptr(), nn_, hh, ww, cc, y.data_ptr(), ops._stream()), 'kpx_maxpool2_fwd_f32')
@@ -96,9 +99,9 @@ def _vgg_forward(vgg, images):
             wgt, b = vgg.params[item]
             nn_, hh, ww, cc = x.shape
             cout = wgt.shape[3]
-            y = torch.empty((nn_, hh, ww, cout), dtype=torch.float32, device=dev)
+            y = torch.empty((nn_, hh, ww, cout), dtype=ops.act_dtype(), device=dev)
             pooled = None
-            if FUSE_POOL_FWD and 'P' in VGG_SEQ[pos + 1:pos + 3] and hh % 2 == 0 and ww % 2 == 0:      # conv -> ('F' ->) pool: pool in the epilogue
+            if FUSE_POOL_FWD and y.dtype == torch.float32 and 'P' in VGG_SEQ[pos + 1:pos + 3] and hh % 2 == 0 and ww % 2 == 0:      # conv -> ('F' ->) pool: pool in the epilogue
                 pooled = torch.empty((nn_, hh // 2, ww // 2, cout), dtype=torch.float32, device=dev)
                 if not ops.conv3x3_wino43_ex(x, cc, cc, wgt, b, y, cout, cout, ops.ACT_RELU, False, pool_out=pooled):
                     pooled = None
@@ -127,7 +130,10 @@ class _PerceptualLossFn(torch.autograd.Function):
         sc = ops.scratch.get('l1', 8192, dev)
         for k, f in enumerate(feats):
             half = f.numel() // 2
-            check(lib.kpx_l1_pair_fwd_f32(f.data_ptr(), half, losses[k:].data_ptr(), sc.data_ptr(), ops._stream()), 'kpx_l1_pair_fwd_f32')
+            if f.dtype == ops.BF16:
+                check(lib.kpx_l1_pair_fwd_bf16(f.data_ptr(), half, losses[k:].data_ptr(), sc.data_ptr(), ops._stream()), 'kpx_l1_pair_fwd_bf16')
+            else:
+                check(lib.kpx_l1_pair_fwd_f32(f.data_ptr(), half, losses[k:].data_ptr(), sc.data_ptr(), ops._stream()), 'kpx_l1_pair_fwd_f32')
         ctx.vgg, ctx.tape, ctx.feats, ctx.b = vgg, tape, feats, b
         ctx.per_feature = losses
         return losses.mean().reshape(1)                               # tf.reduce_mean(losses) (:287): 5-element glue
@@ -145,20 +151,26 @@ class _PerceptualLossFn(torch.autograd.Function):
         def feat_grad(f, dy_pooled):
             """ReLU mask of (max-pool backward of dy_pooled + L1 backward of feature f) in one pass (kpx_vgg_feat_bwd_f32)."""
             half = f.numel() // 2
-            out = torch.empty((b,) + tuple(f.shape[1:]), dtype=torch.float32, device=f.device)
+            out = torch.empty((b,) + tuple(f.shape[1:]), dtype=f.dtype, device=f.device)
+            if f.dtype == ops.BF16:
+                check(lib.kpx_vgg_feat_bwd_bf16(f.data_ptr(), half, g.data_ptr(), 1.0 / (nfeat * half), dy_pooled.data_ptr() if dy_pooled is not None else None,
+                                                b, f.shape[1], f.shape[2], f.shape[3], out.data_ptr(), ops._stream()), 'kpx_vgg_feat_bwd_bf16')
+                return out
             check(lib.kpx_vgg_feat_bwd_f32(f.data_ptr(), half, g.data_ptr(), 1.0 / (nfeat * half), dy_pooled.data_ptr() if dy_pooled is not None else None,
                                            b, f.shape[1], f.shape[2], f.shape[3], out.data_ptr(), ops._stream()), 'kpx_vgg_feat_bwd_f32')
             return out
         for kind, name, x, y in reversed(tape):
-            if kind == 'pool' and id(x) in feat_ids and x.shape[3] % 4 == 0 and FUSE_FEAT_BWD:
+            if kind == 'pool' and id(x) in feat_ids and x.shape[3] % (8 if x.dtype == ops.BF16 else 4) == 0 and FUSE_FEAT_BWD:
                 d = feat_grad(x, d)                                   # every pooled tensor of VGG_SEQ is a returned feature
                 done.add(id(x))
                 continue
             k = feat_ids.get(id(y))
-            if k is not None and d is None and kind == 'conv' and y.shape[3] % 4 == 0 and FUSE_FEAT_BWD:
+            if k is not None and d is None and kind == 'conv' and y.shape[3] % (8 if y.dtype == ops.BF16 else 4) == 0 and FUSE_FEAT_BWD:
                 d = feat_grad(y, None)                                # the last feature: nothing behind it
                 done.add(id(y))
             elif k is not None and id(y) not in done:                 # y is a returned feature: add its L1 gradient
+                if y.dtype == ops.BF16:
+                    raise ops._lib.KpxError('bf16 configuration: the separate feature-L1 gradient pass is not built (KPX_FUSE_FEAT_BWD=0 / odd channel counts)')
                 half = y.numel() // 2
                 dl = torch.empty((b,) + tuple(y.shape[1:]), dtype=torch.float32, device=y.device)
                 check(lib.kpx_l1_pair_bwd_f32(y.data_ptr(), half, g.data_ptr(), 1.0 / (nfeat * half), dl.data_ptr(), ops._stream()),
@@ -169,6 +181,8 @@ class _PerceptualLossFn(torch.autograd.Function):
                     ops.axpy_raw_(d, dl)
             xp, yp = x[b:], y[b:]
             if kind == 'pool':
+                if xp.dtype == ops.BF16:
+                    raise ops._lib.KpxError('bf16 configuration: the separate max-pool backward pass is not built (every pooled tensor is a returned feature)')
                 dx = torch.empty(xp.shape, dtype=torch.float32, device=xp.device)
                 nn_, hh, ww, cc = xp.shape
                 check(lib.kpx_maxpool2_bwd_f32(d.data_ptr(), xp.data_ptr(), nn_, hh, ww, cc, dx.data_ptr(), ops._stream()), 'kpx_maxpool2_bwd_f32')
@@ -176,9 +190,12 @@ class _PerceptualLossFn(torch.autograd.Function):
                 wgt, _ = vgg.params[name]
                 if id(y) not in done:
                     ops.act_bwd_raw_(d, yp, ops.ACT_RELU)             # d is ours: in place
-                dx = torch.empty(xp.shape, dtype=torch.float32, device=xp.device)
+                dx = torch.empty(xp.shape, dtype=xp.dtype, device=xp.device)
                 # x is the ReLU output of the conv below (not a pooled tensor, not the image): its ReLU backward rides in this epilogue
-                if (FUSE_RELU_BWD and id(x) in conv_outputs and id(x) not in feat_ids
+                if (FUSE_RELU_BWD and d.dtype == ops.BF16 and id(x) in conv_outputs and id(x) not in feat_ids
+                        and ops._bf16s_conv(d, wgt.shape[3], wgt.shape[3], wgt, None, dx, xp.shape[3], xp.shape[3], ops.ACT_NONE, True, mask=xp)):
+                    done.add(id(x))
+                elif (FUSE_RELU_BWD and d.dtype == torch.float32 and id(x) in conv_outputs and id(x) not in feat_ids
                         and ops.conv3x3_wino43_ex(d, wgt.shape[3], wgt.shape[3], wgt, None, dx, xp.shape[3], xp.shape[3], ops.ACT_NONE, True, mask=xp)):
                     done.add(id(x))
                 else:
