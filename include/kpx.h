@@ -362,6 +362,14 @@ int kpx_u8_to_unit_f32(const unsigned char* src, size_t n, float* dst, void* str
  * checkpoint bundles (next row; models/base_model.py:74-91 saves / restores through tf.train.Saver). */
 unsigned int kpx_crc32c_host(unsigned int crc, const void* data, size_t n);
 
+/* Weight gradient of a 3x3 stride-1 SAME layer in the bf16 configuration (gradient of layers.py:6-9): x bf16 [N,H,W,>=Cin] (pixel stride ldx;
+ * the pad channels up to the next multiple of 8 must hold finite values), dy bf16 [N,H,W,>=Cout], dw fp32 HWIO [3,3,Cin,Cout], written.
+ * W a multiple of 16; workspace = kpx_conv3x3_wgrad_bf16_workspace_bytes (partial slabs of the pixel splits, summed in fixed order). */
+int kpx_conv3x3_wgrad_bf16_eligible(int N, int H, int W, int Cin, int ldx, int Cout, int lddy, const void* x, const void* dy);
+size_t kpx_conv3x3_wgrad_bf16_workspace_bytes(int N, int H, int W, int Cin, int Cout);
+int kpx_conv3x3_wgrad_bf16(const void* x, int N, int H, int W, int Cin, int ldx, const void* dy, int Cout, int lddy,
+                           float* dw, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- bf16 STORAGE variants of the streaming kernels (BASELINE configs[2]): bf16 tensors in HBM, fp32 arithmetic, fp64 reductions, fp32
  *      statistics / parameter gradients.  C and the pixel strides (in ELEMENTS) are multiples of 8, pointers 16-byte aligned, unless an
  *      entry says otherwise.  Reference call sites as the fp32 entries of the same name above. */

@@ -658,6 +658,13 @@ def conv_wgrad_raw(x, ldx, cin, dy, lddy, dw, stride, pad_t, pad_l):
     n, hi, wi = x.shape[0], x.shape[1], x.shape[2]
     ho, wo = dy.shape[1], dy.shape[2]
     kh, kw, _, cout = dw.shape
+    if (x.dtype == BF16 and dy.dtype == BF16 and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and ho == hi and wo == wi
+            and lib.kpx_conv3x3_wgrad_bf16_eligible(n, hi, wi, cin, ldx, cout, lddy, x.data_ptr(), dy.data_ptr())):
+        nbytes = lib.kpx_conv3x3_wgrad_bf16_workspace_bytes(n, hi, wi, cin, cout)
+        ws = scratch.get('wgrad', nbytes, x.device)
+        check(lib.kpx_conv3x3_wgrad_bf16(x.data_ptr(), n, hi, wi, cin, ldx, dy.data_ptr(), cout, lddy, dw.data_ptr(), ws.data_ptr(), nbytes, _stream()),
+              'kpx_conv3x3_wgrad_bf16')
+        return
     if x.dtype == BF16 or dy.dtype == BF16:
         fallback_uses['conv_wgrad'] += 1
         if x.dtype == BF16:
