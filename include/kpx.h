@@ -362,6 +362,20 @@ int kpx_u8_to_unit_f32(const unsigned char* src, size_t n, float* dst, void* str
  * checkpoint bundles (next row; models/base_model.py:74-91 saves / restores through tf.train.Saver). */
 unsigned int kpx_crc32c_host(unsigned int crc, const void* data, size_t n);
 
+/* The strided / 4x4 / 1x1 layers (discriminator, the encoders' stride-2 layers: networks/__init__.py:16-24,141-151) in the bf16 configuration:
+ * the gather convolution of kpx_conv2d_fwd_f32 / _dgrad_f32 / _wgrad_f32 with KPX_ARITH_BF16 on bf16 TENSORS (pixel strides in elements, multiples
+ * of 8; 16-byte aligned).  y / dx are bf16 (y_f32 / dx_f32 = 0) or fp32; y_in (dgrad, optional): the bf16 activated tensor dx is the gradient
+ * of (as kpx_conv2d_dgrad_act_f32).  Workspaces: the fp32 entries' queries.  KPX_EINVAL for shapes the bf16-pipe kernels do not take (Cin, Cout
+ * multiples of 8 / 4 and >= 16): convert and use the fp32 entry. */
+int kpx_conv2d_fwd_bf16(const void* x, int N, int Hi, int Wi, int Cin, int ldx, const float* w, int KH, int KW, const float* bias,
+                        void* y, int y_f32, int Ho, int Wo, int Cout, int ldy, int stride, int pad_t, int pad_l, int act,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int kpx_conv2d_dgrad_bf16(const void* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
+                          void* dx, int dx_f32, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l,
+                          const void* y_in, int ld_y_in, int act_in, void* workspace, size_t workspace_bytes, void* stream);
+int kpx_conv2d_wgrad_bf16(const void* x, int N, int Hi, int Wi, int Cin, int ldx, const void* dy, int Ho, int Wo, int Cout, int lddy,
+                          float* dw, int KH, int KW, int stride, int pad_t, int pad_l, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Weight gradient of a 3x3 stride-1 SAME layer in the bf16 configuration (gradient of layers.py:6-9): x bf16 [N,H,W,>=Cin] (pixel stride ldx;
  * the pad channels up to the next multiple of 8 must hold finite values), dy bf16 [N,H,W,>=Cout], dw fp32 HWIO [3,3,Cin,Cout], written.
  * W a multiple of 16; workspace = kpx_conv3x3_wgrad_bf16_workspace_bytes (partial slabs of the pixel splits, summed in fixed order). */

@@ -52,9 +52,12 @@ template <int V> struct g3_ic { static constexpr int value = V; };
                                // the 16-lane ds_write_b64 groups of the transposing B store are all conflict-free without an XOR swizzle
 #define G3_OOB 0x7ffffff0      // voffset beyond any buffer: the load returns zeros (out-of-image taps, channel tails, chunks past the end)
 
-template <int BM, int BN, int WM, int WN, bool BT, int TERMS>
+// IO16 (bf16 configuration, TERMS == 1): the gathered tensor is bf16 in HBM -- a staging unit is ONE 16-byte load of eight channels and
+// goes to LDS as it is; the produced tensor is bf16 when g.io16 says so.
+template <int BM, int BN, int WM, int WN, bool BT, int TERMS, bool IO16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3_kernel(const ConvGeom g) {
-    constexpr int NT = WM * WN * 64, BK = 32;
+    static_assert(!IO16 || TERMS == 1, "bf16 tensors carry one term");
+    constexpr int NT = WM * WN * 64, BK = 32, ESZ = IO16 ? 2 : 4;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int APL = BM * G3_PITCH, BPL = BN * G3_PITCH;        // bytes of one bf16 plane
     constexpr int ASZ = TERMS * APL;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3_kernel(const ConvG
     // Operands are fetched through buffer descriptors: an invalid unit (tap outside the image, channel tail, tile row / column past the
     // tensor, chunk past the end of the K loop) simply carries an out-of-range offset and reads as zeros -- the chunk body has no branch.
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0,
-                                            (int)((size_t)g.N * g.Hi * g.Wi * g.ldx * 4), 0x00020000);
+                                            (int)((size_t)g.N * g.Hi * g.Wi * g.ldx * ESZ), 0x00020000);
     const size_t w_bytes = (size_t)g.KW * ((size_t)k.wr0 + (size_t)(k.Tr > 0 ? k.Tr - 1 : 0) * g.wrs + 1) * g.wts * 4;     // up to the last filter row this class reads
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w), 0, (int)(w_bytes < 0x7fffffffu ? w_bytes : 0x7fffffffu), 0x00020000);
 
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3_kernel(const ConvG
         const int mm = ok ? m : 0;
         const int n = mm / HW, rem = mm - n * HW, a = rem / k.Wa, b = rem - a * k.Wa;
         const int ih0 = a * g.isy + k.iy0, iw0 = b * g.isx + k.ix0;
-        a_voff[i] = ((n * g.Hi * g.Wi + ih0 * g.Wi + iw0) * g.ldx + oct * 8) * 4;
+        a_voff[i] = ((n * g.Hi * g.Wi + ih0 * g.Wi + iw0) * g.ldx + oct * 8) * ESZ;
         unsigned vm = 0;
         for (int r = 0; r < k.Tr; ++r)
             for (int q = 0; q < k.Tq; ++q)
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3_kernel(const ConvG
 
     f32x4 ra[RA][2], rb[RB][2];                         // (the narrow B units fill only part of rb)
     auto load_chunk = [&]() {                           // registers <- the next chunk in K order (zeros once the K loop is exhausted)
-        const int a_off = (((tr * g.ity) * g.Wi + tq * g.itx) * g.ldx + c0) * 4;          // wave-uniform byte offsets
+        const int a_off = (((tr * g.ity) * g.Wi + tq * g.itx) * g.ldx + c0) * ESZ;        // wave-uniform byte offsets
         const int tapbit = tr * k.Tq + tq;
         const int tap = (k.wr0 + tr * g.wrs) * g.KW + (k.wq0 + tq * g.wqs);
         const int b_off = (tap * g.wts + (BT ? c0 : c0 * g.ldw)) * 4;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3_kernel(const ConvG
             const bool va = live & (((a_vm[i] >> tapbit) & 1u) != 0) & (c0 + a_k[i] < g.Cin);       // (bitwise: no short-circuit branches)
             const int av = va ? a_voff[i] + a_off : G3_OOB;
             ra[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, av, 0, 0));
-            ra[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, av + 16, 0, 0));
+            if (!IO16) ra[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, av + 16, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3_kernel(const ConvG
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             unsigned char* const Ab = Asm + a_st[i];
+            if (IO16) { *reinterpret_cast<u32x4*>(Ab) = __builtin_bit_cast(u32x4, ra[i][0]); continue; }
             unsigned p[4][3];
             g3_split2<TERMS>(ra[i][0][0], ra[i][0][1], p[0]); g3_split2<TERMS>(ra[i][0][2], ra[i][0][3], p[1]);
             g3_split2<TERMS>(ra[i][1][0], ra[i][1][1], p[2]); g3_split2<TERMS>(ra[i][1][2], ra[i][1][3], p[3]);
@@ -330,8 +334,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_gemm3_kernel(const ConvG
                     if (g.act == KPX_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (g.act == KPX_ACT_LRELU) v = v > 0.f ? v : 0.01f * v;
                     else if (g.act == KPX_ACT_TANH) v = tanhf(v);
-                    if (g.mul_y) v *= kpx_act_grad_from_y(g.mul_y[(size_t)pix * g.ld_mul + col], g.mul_act);
-                    g.y[(size_t)pix * g.ldy + col] = v;
+                    if (g.mul_y) {
+                        const float my = (g.io16 & 4) ? g3_float((unsigned)reinterpret_cast<const unsigned short*>(g.mul_y)[(size_t)pix * g.ld_mul + col] << 16)
+                                                      : g.mul_y[(size_t)pix * g.ld_mul + col];
+                        v *= kpx_act_grad_from_y(my, g.mul_act);
+                    }
+                    if (g.io16 & 2) { const __bf16 b = (__bf16)v; reinterpret_cast<unsigned short*>(g.y)[(size_t)pix * g.ldy + col] = __builtin_bit_cast(unsigned short, b); }
+                    else g.y[(size_t)pix * g.ldy + col] = v;
                 }
             }
         }
@@ -344,16 +353,16 @@ static std::atomic<unsigned long long> g3_attr_mask{0};
 // of 32 x 32.  (Measured alternatives, img_discr layers at N = 64, forward / data gradient per step: 4 wavefronts of 64 x 64: 1.98 / 1.49 ms;
 // this: 1.82 / 1.34 ms; one double-buffered workgroup per CU: 1.89 / 1.50 ms; the fp32-MFMA kernel: 2.75 / 1.99 ms.)
 template <int BN> struct g3_waves { static constexpr int wm = BN == 128 ? 2 : 4, wn = BN == 128 ? 4 : 2; };
-template <int BM, int BN, bool BT, int TERMS>
+template <int BM, int BN, bool BT, int TERMS, bool IO16 = false>
 static int g3_launch_one(const ConvGeom& g, dim3 grid, hipStream_t s) {
     constexpr int lds = TERMS * (BM + BN) * G3_PITCH;
-    hipLaunchKernelGGL((conv_gemm3_kernel<BM, BN, g3_waves<BN>::wm, g3_waves<BN>::wn, BT, TERMS>), grid, dim3(g3_waves<BN>::wm * g3_waves<BN>::wn * 64), lds, s, g);
+    hipLaunchKernelGGL((conv_gemm3_kernel<BM, BN, g3_waves<BN>::wm, g3_waves<BN>::wn, BT, TERMS, IO16>), grid, dim3(g3_waves<BN>::wm * g3_waves<BN>::wn * 64), lds, s, g);
     return kpx_launch_status();
 }
-template <int BM, int BN, bool BT, int TERMS>
+template <int BM, int BN, bool BT, int TERMS, bool IO16 = false>
 static hipError_t g3_set_attr() {
     constexpr int lds = TERMS * (BM + BN) * G3_PITCH;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm3_kernel<BM, BN, g3_waves<BN>::wm, g3_waves<BN>::wn, BT, TERMS>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm3_kernel<BM, BN, g3_waves<BN>::wm, g3_waves<BN>::wn, BT, TERMS, IO16>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
@@ -363,6 +372,7 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_gemm3_eligible(const Co
     const KpxEnv* e = kpx_env();
     if (e->no_gemm3 || g->merge || !g->vecA || !g->vecB) return 0;
     if (g->Cin % 8 != 0 || g->Cin < 16 || g->Cout % 4 != 0 || g->Cout < 16 || g->ldx % 4 != 0 || g->ldw % 4 != 0) return 0;
+    if ((g->io16 & 1) && (g->ldx % 8 != 0 || g->terms != 1)) return 0;
     return 1;
 }
 
@@ -378,6 +388,10 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_gemm3_launch(ConvGeom g
         if (e == hipSuccess) e = g3_set_attr<128, 128, true, 1>();
         if (e == hipSuccess) e = g3_set_attr<128, 64, false, 1>();
         if (e == hipSuccess) e = g3_set_attr<128, 64, true, 1>();
+        if (e == hipSuccess) e = g3_set_attr<128, 128, false, 1, true>();
+        if (e == hipSuccess) e = g3_set_attr<128, 128, true, 1, true>();
+        if (e == hipSuccess) e = g3_set_attr<128, 64, false, 1, true>();
+        if (e == hipSuccess) e = g3_set_attr<128, 64, true, 1, true>();
         if (e != hipSuccess) return -(int)e;
     }
     if (g.ncls <= 0) { g.ncls = 1; g.cls[0] = ConvClass{g.Ha, g.Wa, g.oy0, g.ox0, g.Tr, g.Tq, g.iy0, g.ix0, g.wr0, g.wq0, 0, 0}; }
@@ -391,6 +405,11 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_gemm3_launch(ConvGeom g
     g.mt = mtmax;
     const dim3 grid((unsigned)(g.mt * g.nt), (unsigned)g.ncls, (unsigned)(g.ksplit > 1 ? g.ksplit : 1));
 #define G3_GO(bn, btv, tv) return g3_launch_one<128, bn, btv, tv>(g, grid, s)
+    if (g.io16 & 1) {                                    // bf16 tensors (terms == 1 by eligibility)
+        if (BN == 128) { if (bt) return g3_launch_one<128, 128, true, 1, true>(g, grid, s); return g3_launch_one<128, 128, false, 1, true>(g, grid, s); }
+        if (bt) return g3_launch_one<128, 64, true, 1, true>(g, grid, s);
+        return g3_launch_one<128, 64, false, 1, true>(g, grid, s);
+    }
     if (terms == 1) {
         if (BN == 128) { if (bt) G3_GO(128, true, 1); else G3_GO(128, false, 1); }
         else { if (bt) G3_GO(64, true, 1); else G3_GO(64, false, 1); }
@@ -407,9 +426,10 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_gemm3_launch(ConvGeom g
 // like the forward kernel's n-contiguous weights: a unit = 2 pixels x 4 channels (two 16-B loads), transposed in registers -- each channel
 // becomes one bf16 pair per term, written to LDS row `channel` of the operand's plane (pitch G3_PITCH: conflict-free).  Workgroup =
 // (split, tap, Cin tile, Cout tile) as in conv_wgrad_kernel (conv_igemm.hip), partial slabs reduced in fixed order by wgrad_reduce_kernel.
-template <int BM, int WM, int WN, int TERMS>
+template <int BM, int WM, int WN, int TERMS, bool IO16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad3_kernel(const WgradGeom g) {
-    constexpr int NT = WM * WN * 64, BKP = 32, BN = BM;
+    static_assert(!IO16 || TERMS == 1, "bf16 tensors carry one term");
+    constexpr int NT = WM * WN * 64, BKP = 32, BN = BM, ESZ = IO16 ? 2 : 4;
     constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
     constexpr int APL = BM * G3_PITCH, BPL = BN * G3_PITCH;
     constexpr int ASZ = TERMS * APL;
@@ -433,8 +453,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad3_kernel(const Wgra
     const int pend = min(g.P, pbeg + g.pps);
     const int wrow = wm * TM * 32, wcol = wn * TN * 32;
 
-    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, (int)((size_t)g.N * g.Hi * g.Wi * g.ldx * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dy), 0, (int)((size_t)g.P * g.lddy * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, (int)((size_t)g.N * g.Hi * g.Wi * g.ldx * ESZ), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dy), 0, (int)((size_t)g.P * g.lddy * ESZ), 0x00020000);
+    // bf16 tensors: a unit's four channels of one pixel are 8 bytes = two dword loads (raw_buffer_load_b64 is mis-lowered, see above), widened
+    // to fp32 in registers -- the one-term split below then packs the very same bf16 values
+    auto load4 = [&](const __amdgpu_buffer_rsrc_t& rs, int voff) -> f32x4 {
+        if (!IO16) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+        const unsigned lo = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0), hi = __builtin_amdgcn_raw_buffer_load_b32(rs, voff == G3_OOB ? G3_OOB : voff + 4, 0, 0);
+        return f32x4{g3_float(lo << 16), g3_float(lo & 0xffff0000u), g3_float(hi << 16), g3_float(hi & 0xffff0000u)};
+    };
 
     // this thread's unit: pixel pair kp of the 32-pixel chunk, channel quad cq (kp fastest: conflict-free ds_write_b32 at pitch 80)
     const int kp = t & 15, cq = t >> 4;
@@ -473,11 +500,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad3_kernel(const Wgra
         for (int j = 0; j < 2; ++j) {
             const int ih = pho[j] * g.stride + r - g.pad_t, iw = pwo[j] * g.stride + q - g.pad_l;
             const bool va = a_cok & (p0 + j < pend) & ((unsigned)ih < (unsigned)g.Hi) & ((unsigned)iw < (unsigned)g.Wi);
-            const int av = va ? (((pn[j] * g.Hi + ih) * g.Wi + iw) * g.ldx + ac) * 4 : G3_OOB;
-            ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, av, 0, 0));
+            const int av = va ? (((pn[j] * g.Hi + ih) * g.Wi + iw) * g.ldx + ac) * ESZ : G3_OOB;
+            ra[j] = load4(rs_a, av);
             const bool vb = b_cok & (p0 + j < pend);
-            const int bv = vb ? ((p0 + j) * g.lddy + bc) * 4 : G3_OOB;
-            rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv, 0, 0));
+            const int bv = vb ? ((p0 + j) * g.lddy + bc) * ESZ : G3_OOB;
+            rb[j] = load4(rs_b, bv);
             // advance this pixel by one chunk (32 pixels): at most a few row wraps for narrow images
             pwo[j] += BKP;
             while (pwo[j] >= g.Wo) {
@@ -569,11 +596,17 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wgrad3_eligible(const W
     if (e->no_gemm3 || e->no_wgrad3 || g->merge || !g->vecA || !g->vecB) return 0;
     if (g->Cin % 4 != 0 || g->Cout % 4 != 0 || g->Cin < 16 || g->Cout < 16) return 0;
     if ((size_t)g->N * g->Hi * g->Wi * g->ldx * 4 >= 0x7fffffffu || (size_t)g->P * g->lddy * 4 >= 0x7fffffffu) return 0;     // 32-bit buffer offsets
+    if (g->io16 && g->terms != 1) return 0;
     return 1;
 }
 // bm: the square channel tile conv_igemm.hip planned the grid for (128 or 64); the grid is g.S * taps * g.ct * g.kt workgroups.
 extern "C" __attribute__((visibility("hidden"))) int kpx_wgrad3_launch(WgradGeom g, int bm, int terms, hipStream_t s) {
     const dim3 grid((unsigned)(g.S * g.KH * g.KW * g.ct * g.kt));
+    if (g.io16) {
+        if (bm == 128) hipLaunchKernelGGL((conv_wgrad3_kernel<128, 2, 4, 1, true>), grid, dim3(512), 256 * G3_PITCH, s, g);
+        else hipLaunchKernelGGL((conv_wgrad3_kernel<64, 2, 2, 1, true>), grid, dim3(256), 128 * G3_PITCH, s, g);
+        return kpx_launch_status();
+    }
     if (bm == 128) {
         constexpr int lds = 3 * 256 * G3_PITCH;
         if (terms == 1) hipLaunchKernelGGL((conv_wgrad3_kernel<128, 2, 4, 1>), grid, dim3(512), lds / 3, s, g);

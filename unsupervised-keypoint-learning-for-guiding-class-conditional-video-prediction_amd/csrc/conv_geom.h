@@ -26,6 +26,8 @@ struct ConvGeom {
     int terms;      // bf16 terms per fp32 operand on the bf16-pipe kernels (conv_gemm3.hip): 3 = fp32-equivalent, 1 = bf16 operands (the `arith` argument)
     int merge;      // >0: row-merged taps for tiny Cin (= original Cin): the KW*Cin floats of one filter row are
                     // contiguous in NHWC, so they are treated as one tap with KW*Cin channels (per-element x bounds)
+    int io16;       // bf16 configuration (conv_gemm3.hip only, terms == 1): bit 0: x is bf16, bit 1: y is bf16, bit 2: mul_y is bf16
+                    // (the pointers above are then bf16 tensors behind their float* type; pixel strides count ELEMENTS either way)
 };
 
 
@@ -42,4 +44,5 @@ struct WgradGeom {
     int terms;              // see ConvGeom::terms
     int merge;              // >0: row-merged taps (see ConvGeom::merge); Cin/KW below are the merged values
     size_t slab;            // floats per slab = KH*KW*Cin*Cout
+    int io16;               // bf16 configuration (conv_gemm3.hip only, terms == 1): x AND dy are bf16 tensors
 };

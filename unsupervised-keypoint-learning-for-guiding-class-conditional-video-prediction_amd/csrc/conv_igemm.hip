@@ -317,7 +317,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_kernel(const ConvGeom
 // y[pix][c] = act( bias[c] + sum_s ws[s][pix][c] ), fixed summation order
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, size_t slab, int S, size_t npix, int C,
                                                             const float* __restrict__ bias, int act, float* __restrict__ y, int ldy,
-                                                            const float* __restrict__ mul_y, int ld_mul, int mul_act) {
+                                                            const float* __restrict__ mul_y, int ld_mul, int mul_act, int io16 = 0) {
     const int C4 = C >> 2;                              // C % 4 == 0 is a precondition of the split-K path
     const size_t total = npix * (size_t)C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -339,9 +339,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         }
         if (mul_y) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) a[j] *= kpx_act_grad_from_y(mul_y[pix * ld_mul + c + j], mul_act);
+            for (int j = 0; j < 4; ++j) {
+                const float my = (io16 & 4) ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(mul_y)[pix * ld_mul + c + j] << 16) : mul_y[pix * ld_mul + c + j];
+                a[j] *= kpx_act_grad_from_y(my, mul_act);
+            }
         }
-        *reinterpret_cast<f32x4*>(y + pix * ldy + c) = a;
+        if (io16 & 2) {                                  // bf16 output (the bf16 configuration): four channels = 8 bytes
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            const bf16x4 o = {(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+            *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned short*>(y) + pix * ldy + c) = o;
+        } else *reinterpret_cast<f32x4*>(y + pix * ldy + c) = a;
     }
 }
 
@@ -445,9 +452,10 @@ static int launch_gather_conv(const ConvGeom& g, hipStream_t s) {
         const size_t npix = (size_t)g.N * g.Ho * g.Wo;
         size_t nb = (npix * (g.Cout / 4) + 255) / 256; if (nb > 2048) nb = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)nb), dim3(256), 0, s, (const float*)g.ws, g.ws_slab, g.ksplit, npix, g.Cout,
-                           g.bias, g.act, g.y, g.ldy, g.mul_y, g.ld_mul, g.mul_act);
+                           g.bias, g.act, g.y, g.ldy, g.mul_y, g.ld_mul, g.mul_act, g.io16);
         return kpx_launch_status();
     }
+    if (g.io16) return KPX_EINVAL;                       // bf16 tensors: only the kernel above reads them
     if (g.merge) return launch_gather_conv_v<false, false, true, true>(g, s);
     if (g.vecA && g.vecB) {
         if (g.Cin % 4 == 0 && g.Cout % 4 == 0) return launch_gather_conv_v<BT, true, false, false>(g, s);
@@ -552,13 +560,31 @@ extern "C" size_t kpx_conv2d_dgrad_workspace_bytes(int N, int Hi, int Wi, int Ci
     return b;
 }
 
+static int fwd_impl(const float* x, int N, int Hi, int Wi, int Cin, int ldx, const float* w, int KH, int KW, const float* bias,
+                    float* y, int Ho, int Wo, int Cout, int ldy, int stride, int pad_t, int pad_l, int act, int arith, int io16,
+                    void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin, int ldx,
                                   const float* w, int KH, int KW, const float* bias,
                                   float* y, int Ho, int Wo, int Cout, int ldy,
                                   int stride, int pad_t, int pad_l, int act, int arith, void* workspace, size_t workspace_bytes, void* stream) {
+    return fwd_impl(x, N, Hi, Wi, Cin, ldx, w, KH, KW, bias, y, Ho, Wo, Cout, ldy, stride, pad_t, pad_l, act, arith, 0, workspace, workspace_bytes, stream);
+}
+// bf16 configuration: x bf16 (pixel stride ldx elements, a multiple of 8), y bf16 (y_f32 = 0) or fp32; only shapes the bf16-pipe gather kernel
+// takes (KPX_EINVAL otherwise: the caller converts and uses the fp32 entry)
+extern "C" int kpx_conv2d_fwd_bf16(const void* x, int N, int Hi, int Wi, int Cin, int ldx, const float* w, int KH, int KW, const float* bias,
+                                   void* y, int y_f32, int Ho, int Wo, int Cout, int ldy, int stride, int pad_t, int pad_l, int act,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    if (ldx % 8 || !aligned16(x) || !aligned16(y) || (!y_f32 && ldy % 4)) return KPX_EINVAL;
+    return fwd_impl((const float*)x, N, Hi, Wi, Cin, ldx, w, KH, KW, bias, (float*)y, Ho, Wo, Cout, ldy, stride, pad_t, pad_l, act, KPX_ARITH_BF16, 1 | (y_f32 ? 0 : 2),
+                    workspace, workspace_bytes, stream);
+}
+static int fwd_impl(const float* x, int N, int Hi, int Wi, int Cin, int ldx, const float* w, int KH, int KW, const float* bias,
+                    float* y, int Ho, int Wo, int Cout, int ldy, int stride, int pad_t, int pad_l, int act, int arith, int io16,
+                    void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !w || !y || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || ldx < Cin || ldy < Cout || act < 0 || act > 3 || arith < 0 || arith > 1)
         return KPX_EINVAL;
+    if (io16) goto gather;                               // bf16 tensors: the specialised fp32 kernels below do not read them
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && act != KPX_ACT_TANH &&
         kpx_conv3x3_c16_eligible(N, Hi, Wi, Cin, Cout, ldx, ldy, x))                 // exactly 16 produced channels: 16x16x4 MFMA blocks (conv_c16.hip)
         return kpx_conv3x3_c16_f32(x, N, Hi, Wi, Cin, ldx, w, 0, bias, y, ldy, act, nullptr, stream);
@@ -573,8 +599,9 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
         const int rc = kpx_conv_rgb_fwd(x, N, Hi, Wi, Cin, w, KH, KW, bias, y, Ho, Wo, Cout, ldy, stride, pad_t, pad_l, act, kpx_stream(stream));
         if (rc != -2) return rc;
     }
+gather:
     ConvGeom g{};
-    g.x = x; g.y = y; g.w = w; g.bias = bias;
+    g.x = x; g.y = y; g.w = w; g.bias = bias; g.io16 = io16;
     g.N = N; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.ldx = ldx;
     g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
     g.Ha = Ho; g.Wa = Wo; g.osy = 1; g.oy0 = 0; g.osx = 1; g.ox0 = 0;
@@ -587,7 +614,8 @@ extern "C" int kpx_conv2d_fwd_f32(const float* x, int N, int Hi, int Wi, int Cin
     if (!(kpx_env()->no_merge_kh && kpx_env()->no_merge_kh == KH) && Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64) {      // image inputs (Cin = 3): merge each filter row
         g.merge = Cin; g.Tq = 1; g.KW = 1; g.Cin = KW * Cin; g.wts = KW * Cin * Cout; g.vecA = 0;
     }
-    if (!kpx_env()->no_smallcout && Cout <= 4 && Cin % 4 == 0 && Cin >= 256 && g.vecA && g.vecB == (Cout == 4))
+    if (io16 && !kpx_gemm3_eligible(&g)) return KPX_EINVAL;
+    if (!io16 && !kpx_env()->no_smallcout && Cout <= 4 && Cin % 4 == 0 && Cin >= 256 && g.vecA && g.vecB == (Cout == 4))
         return launch_small_cout(g, kpx_stream(stream));
     if (g.vecA && g.vecB && !g.merge && Cin % 4 == 0) {        // small-M / long-K layers (the discriminator's 10x10 .. 4x4 maps): split K over workgroups
         const int S = conv_splitk_plan((long)N * Ho * Wo, Cout, (long)KH * KW * ((Cin + 31) / 32));
@@ -603,7 +631,7 @@ extern "C" int kpx_act_bwd_f32(const float* dy, const float* y, float* dz, size_
 // value, same shape as dx).  Fused into the epilogue where the layer runs on the gather kernels; a second pass over dx otherwise.
 static int dgrad_impl(const float* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
                       float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, int arith,
-                      const float* y_in, int ld_y_in, int act_in, void* workspace, size_t workspace_bytes, void* stream);
+                      const float* y_in, int ld_y_in, int act_in, void* workspace, size_t workspace_bytes, void* stream, int io16 = 0);
 
 extern "C" int kpx_conv2d_dgrad_f32(const float* dy, int N, int Ho, int Wo, int Cout, int lddy,
                                     const float* w, int KH, int KW,
@@ -623,6 +651,18 @@ extern "C" int kpx_conv2d_dgrad_act_f32(const float* dy, int N, int Ho, int Wo, 
                       workspace, workspace_bytes, stream);
 }
 
+// bf16 configuration: dy bf16, dx bf16 (dx_f32 = 0) or fp32 (the gradient towards an fp32 tensor); y_in (optional, with act_in): the bf16
+// ACTIVATED tensor dx is the gradient of -- its activation backward is applied in the epilogue.  KPX_EINVAL for shapes the bf16-pipe gather
+// kernel does not take.
+extern "C" int kpx_conv2d_dgrad_bf16(const void* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
+                                     void* dx, int dx_f32, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l,
+                                     const void* y_in, int ld_y_in, int act_in, void* workspace, size_t workspace_bytes, void* stream) {
+    if (lddy % 8 || !aligned16(dy) || !aligned16(dx) || (!dx_f32 && lddx % 4)) return KPX_EINVAL;
+    if (y_in && (ld_y_in < Cin || (act_in != KPX_ACT_RELU && act_in != KPX_ACT_LRELU))) return KPX_EINVAL;
+    return dgrad_impl((const float*)dy, N, Ho, Wo, Cout, lddy, w, KH, KW, (float*)dx, Hi, Wi, Cin, lddx, stride, pad_t, pad_l, KPX_ARITH_BF16,
+                      (const float*)y_in, ld_y_in, y_in ? act_in : KPX_ACT_NONE, workspace, workspace_bytes, stream, 1 | (dx_f32 ? 0 : 2) | (y_in ? 4 : 0));
+}
+
 // the specialised data-gradient kernels have no factor in their epilogues: one pass over dx afterwards (contiguous tensors only)
 static int dgrad_act_pass(int rc, float* dx, int N, int Hi, int Wi, int Cin, int lddx, const float* y_in, int ld_y_in, int act_in, void* stream) {
     if (rc || !y_in) return rc;
@@ -632,11 +672,12 @@ static int dgrad_act_pass(int rc, float* dx, int N, int Hi, int Wi, int Cin, int
 
 static int dgrad_impl(const float* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
                       float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, int arith,
-                      const float* y_in, int ld_y_in, int act_in, void* workspace, size_t workspace_bytes, void* stream) {
+                      const float* y_in, int ld_y_in, int act_in, void* workspace, size_t workspace_bytes, void* stream, int io16) {
     if (!dy || !w || !dx || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 ||
         KH <= 0 || KW <= 0 || stride <= 0 || lddy < Cout || lddx < Cin || arith < 0 || arith > 1)
         return KPX_EINVAL;
     if (stride > 2) return KPX_EINVAL;             // at most 4 parity classes per launch (the path has strides 1 and 2)
+    if (io16) goto gather;                         // bf16 tensors: only the bf16-pipe gather kernel reads them
     if (KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi &&
         kpx_conv3x3_c16_eligible(N, Hi, Wi, Cout, Cin, lddy, lddx, dy))
         return dgrad_act_pass(kpx_conv3x3_c16_f32(dy, N, Hi, Wi, Cout, lddy, w, 1, nullptr, dx, lddx, KPX_ACT_NONE, nullptr, stream),
@@ -649,8 +690,9 @@ static int dgrad_impl(const float* dy, int N, int Ho, int Wo, int Cout, int lddy
         workspace && workspace_bytes >= wino_ws_bytes(Cin, Cout) && kpx_wino_eligible(N, Hi, Wi, Cout, Cin, lddy, dy))
         return dgrad_act_pass(kpx_wino_conv3x3(dy, N, Hi, Wi, Cout, lddy, w, Cin, Cout, 1, nullptr, KPX_ACT_NONE, dx, Cin, lddx, (float*)workspace, kpx_stream(stream)),
                               dx, N, Hi, Wi, Cin, lddx, y_in, ld_y_in, act_in, stream);
+gather:
     ConvGeom g{};
-    g.x = dy; g.y = dx; g.w = w; g.bias = nullptr;
+    g.x = dy; g.y = dx; g.w = w; g.bias = nullptr; g.io16 = io16;
     g.mul_y = y_in; g.ld_mul = ld_y_in; g.mul_act = act_in;
     g.N = N; g.Hi = Ho; g.Wi = Wo; g.Cin = Cout; g.ldx = lddy;       // "input" of the gather = dy
     g.Ho = Hi; g.Wo = Wi; g.Cout = Cin; g.ldy = lddx;                // "output" = dx
@@ -677,6 +719,7 @@ static int dgrad_impl(const float* dy, int N, int Ho, int Wo, int Cout, int lddy
             g.cls[g.ncls++] = c;
         }
     }
+    if (io16 && !kpx_gemm3_eligible(&g)) return KPX_EINVAL;
     if (g.vecA && g.vecB && Cout % 4 == 0) {
         const int S = dgrad_splitk_plan(N, Hi, Wi, Cin, Cout, KH, KW, stride);
         g.ws_slab = (size_t)N * Hi * Wi * Cin;
@@ -1342,6 +1385,36 @@ static int wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW
     if ((size_t)S * slab_bytes > cap) S = (long)(cap / slab_bytes);
     if (S < 1) S = 1;
     return (int)S;
+}
+
+// bf16 configuration: x and dy bf16 (pixel strides multiples of 8 elements), dw fp32; the bf16-pipe weight-gradient kernel of conv_gemm3.hip
+// with the generic split plan (workspace: kpx_conv2d_wgrad_workspace_bytes).  KPX_EINVAL for shapes it does not take.
+extern "C" int kpx_conv2d_wgrad_bf16(const void* x, int N, int Hi, int Wi, int Cin, int ldx, const void* dy, int Ho, int Wo, int Cout, int lddy,
+                                     float* dw, int KH, int KW, int stride, int pad_t, int pad_l, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || Ho <= 0 || Wo <= 0 || KH <= 0 || KW <= 0 || stride <= 0 ||
+        ldx < Cin || lddy < Cout || ldx % 8 || lddy % 8 || !aligned16(x) || !aligned16(dy))
+        return KPX_EINVAL;
+    WgradGeom g{};
+    g.x = (const float*)x; g.dy = (const float*)dy; g.io16 = 1;
+    g.N = N; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.ldx = ldx;
+    g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.lddy = lddy;
+    g.KH = KH; g.KW = KW; g.stride = stride; g.pad_t = pad_t; g.pad_l = pad_l;
+    g.P = N * Ho * Wo;
+    g.S = wgrad_splits(N, Ho, Wo, Cin, Cout, KH, KW);
+    g.slab = (size_t)KH * KW * Cin * Cout;
+    if (g.S > 1 && (!workspace || workspace_bytes < (size_t)g.S * g.slab * 4)) return KPX_EINVAL;
+    g.pps = ((g.P + g.S - 1) / g.S + 31) / 32 * 32;
+    g.out = g.S > 1 ? (float*)workspace : dw;
+    int bm, bn;
+    wgrad_tiles(Cin, Cout, bm, bn);
+    g.ct = (Cin + bm - 1) / bm; g.kt = (Cout + bn - 1) / bn;
+    g.vecA = 1; g.vecB = 1; g.terms = 1;
+    if (!kpx_wgrad3_eligible(&g)) return KPX_EINVAL;
+    hipStream_t s = kpx_stream(stream);
+    int rc = kpx_wgrad3_launch(g, bm, 1, s);
+    if (rc) return rc;
+    if (g.S > 1) { launch_wgrad_reduce((const float*)workspace, dw, g.slab, g.S, s); rc = kpx_launch_status(); }
+    return rc;
 }
 
 extern "C" size_t kpx_conv2d_wgrad_workspace_bytes(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {

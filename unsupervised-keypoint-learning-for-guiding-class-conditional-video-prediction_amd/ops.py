@@ -578,6 +578,16 @@ def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act, want_s
             r = _bf16s_conv(x, ldx, cin, w, bias, y, ldy, cout, act, False, want_stats=want_stats)
             if r:
                 return r if isinstance(r, tuple) else None
+        if x.dtype == BF16 and act != ACT_TANH:
+            # strided / 4x4 / 1x1 layers: the gather kernel of the bf16 matrix pipe on bf16 tensors
+            nbytes = lib.kpx_conv2d_fwd_workspace_bytes(n, y.shape[1], y.shape[2], cin, cout, kh, kw)
+            ws = scratch.get('splitk', nbytes, x.device) if nbytes else None
+            rc = lib.kpx_conv2d_fwd_bf16(x.data_ptr(), n, hi, wi, cin, ldx, w.data_ptr(), kh, kw, bias.data_ptr() if bias is not None else None,
+                                         y.data_ptr(), 1 if y.dtype == torch.float32 else 0, y.shape[1], y.shape[2], cout, ldy, stride, pad_t, pad_l, act,
+                                         ws.data_ptr() if ws is not None else None, nbytes, _stream())
+            if rc != -1:
+                check(rc, 'kpx_conv2d_fwd_bf16')
+                return None
         if x.dtype == BF16:
             fallback_uses['conv_fwd'] += 1
             x, ldx = _slice_f32(x, ldx, cin), cin
@@ -618,6 +628,16 @@ def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l, bn_src=None
         if (dy.dtype == BF16 and mul is None and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and dx.shape[1] == ho and dx.shape[2] == wo
                 and _bf16s_conv(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True)):
             return None
+        if dy.dtype == BF16 and (mul is None or mul[0].dtype == BF16):
+            nbytes = lib.kpx_conv2d_dgrad_workspace_bytes(n, dx.shape[1], dx.shape[2], cin, cout, kh, kw, stride)
+            ws = scratch.get('splitk', nbytes, dy.device) if nbytes else None
+            rc = lib.kpx_conv2d_dgrad_bf16(dy.data_ptr(), n, ho, wo, cout, lddy, w.data_ptr(), kh, kw, dx.data_ptr(), 1 if dx.dtype == torch.float32 else 0,
+                                           dx.shape[1], dx.shape[2], cin, lddx, stride, pad_t, pad_l,
+                                           mul[0].data_ptr() if mul is not None else None, mul[0].shape[3] if mul is not None else 0, mul[1] if mul is not None else 0,
+                                           ws.data_ptr() if ws is not None else None, nbytes, _stream())
+            if rc != -1:
+                check(rc, 'kpx_conv2d_dgrad_bf16')
+                return None
         if dy.dtype == BF16:
             fallback_uses['conv_dgrad'] += 1
             dy, lddy = _slice_f32(dy, lddy, cout), cout
@@ -665,6 +685,14 @@ def conv_wgrad_raw(x, ldx, cin, dy, lddy, dw, stride, pad_t, pad_l):
         check(lib.kpx_conv3x3_wgrad_bf16(x.data_ptr(), n, hi, wi, cin, ldx, dy.data_ptr(), cout, lddy, dw.data_ptr(), ws.data_ptr(), nbytes, _stream()),
               'kpx_conv3x3_wgrad_bf16')
         return
+    if x.dtype == BF16 and dy.dtype == BF16:
+        nbytes = lib.kpx_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, cout, kh, kw)
+        ws = scratch.get('wgrad', nbytes, x.device) if nbytes else None
+        rc = lib.kpx_conv2d_wgrad_bf16(x.data_ptr(), n, hi, wi, cin, ldx, dy.data_ptr(), ho, wo, cout, lddy, dw.data_ptr(), kh, kw, stride, pad_t, pad_l,
+                                       ws.data_ptr() if ws is not None else None, nbytes, _stream())
+        if rc != -1:
+            check(rc, 'kpx_conv2d_wgrad_bf16')
+            return
     if x.dtype == BF16 or dy.dtype == BF16:
         fallback_uses['conv_wgrad'] += 1
         if x.dtype == BF16:
