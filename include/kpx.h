@@ -104,6 +104,11 @@ int kpx_conv3x3_bf16s_prepare_f32(const float* w_hwio, int Cin, int Cout, int dg
 int kpx_conv3x3_bf16s_prepare_batch_f32(const void* table, int ndesc, void* stream);
 int kpx_conv3x3_bf16s(const void* in, int N, int H, int W, int K, int ldin, const void* wf, const float* bias,
                       void* out, int Nn, int ldout, int out_f32, int act, const void* mask, int ldmask, float* stats, void* stream);
+/* Data gradient towards bn_y = relu(batch_norm(.)) (bf16 [N,H,W,Nn]) with that batch norm's backward sums reduced in the epilogue: out = conv3x3(in, wf)
+ * gated by bn_y > 0, stats[tile][2][Nn] = sum(dz), sum(dz * (bn_y - beta)) per workgroup -- kpx_bn_train_bwd_bf16 takes them as tile_stats and skips
+ * its reduction pass over (dz, x) (the fp32 configuration's kpx_conv3x3_wino43_bnbwd_stats_f32). */
+int kpx_conv3x3_bf16s_bnbwd(const void* in, int N, int H, int W, int K, int ldin, const void* wf, void* out, int Nn, int ldout,
+                            const void* bn_y, int ld_bn_y, const float* beta, float* stats, void* stream);
 
 /* dx = d(loss)/dx given dy (gradient of the conv output BEFORE activation).  Writes every element of dx.
  * stride <= 2.  `workspace`: optional split-K scratch, see kpx_conv2d_fwd_f32. */
@@ -397,7 +402,8 @@ int kpx_bn_train_fwd_bf16(const void* x, size_t P, int groups, int C, int ldx, c
                           float* moving_mean, float* moving_var, float decay, void* y, int ldy, int y_f32, int act, void* scratch, void* stream);
 int kpx_bn_train_bwd_bf16(const void* dy, int lddy, int dy_f32, const void* x, int ldx, size_t P, int groups, int C,
                           const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
-                          void* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* scratch, void* stream);
+                          void* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
+                          const float* tile_stats, size_t tiles_per_group, void* scratch, void* stream);
 int kpx_act_bwd_bf16(const void* dy, const void* y, void* dz, size_t n, int act, void* stream);
 int kpx_resize2x_fwd_bf16(const void* x, int N, int H, int W, int C, int ldx, void* y, int ldy, void* stream);
 int kpx_resize2x_bwd_bf16(const void* dy, int N, int H, int W, int C, int lddy, void* dx, int lddx, void* stream);

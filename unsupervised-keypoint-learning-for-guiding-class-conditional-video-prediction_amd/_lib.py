@@ -76,10 +76,11 @@ SIGNATURES = {
     'kpx_conv3x3_wgrad_bf16_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     'kpx_conv3x3_wgrad_bf16_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv3x3_wgrad_bf16': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, c_size_t, P]),
+    'kpx_conv3x3_bf16s_bnbwd': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int, P, c_int, P, P, P]),
     'kpx_cast_channels': (c_int, [P, c_int, P, c_int, c_size_t, c_int, c_int, P]),
     'kpx_chan_sum_bf16': (c_int, [P, c_size_t, c_int, c_int, P, P, P]),
     'kpx_bn_train_fwd_bf16': (c_int, [P, c_size_t, c_int, c_int, c_int, P, c_size_t, c_float, P, P, P, P, P, P, c_float, P, c_int, c_int, c_int, P, P]),
-    'kpx_bn_train_bwd_bf16': (c_int, [P, c_int, c_int, P, c_int, c_size_t, c_int, c_int, P, P, P, P, c_int, P, c_int, P, P, c_int, P, P]),
+    'kpx_bn_train_bwd_bf16': (c_int, [P, c_int, c_int, P, c_int, c_size_t, c_int, c_int, P, P, P, P, c_int, P, c_int, P, P, c_int, P, c_size_t, P, P]),
     'kpx_act_bwd_bf16': (c_int, [P, P, P, c_size_t, c_int, P]),
     'kpx_resize2x_fwd_bf16': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),
     'kpx_resize2x_bwd_bf16': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P]),

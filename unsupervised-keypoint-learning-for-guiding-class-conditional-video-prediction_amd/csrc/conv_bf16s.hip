@@ -98,7 +98,10 @@ struct S16Tile {
     static constexpr int PW = BW + 2;
 };
 
-// STATS: 0 none, 1 per-workgroup channel sums of the accumulators (before bias / activation) -> stats[tile][2][Nn]
+// STATS: 0 none; 1 per-workgroup channel sums and sums of squares of the fp32 outputs before the activation -> stats[tile][2][Nn] (the batch
+// norm BEHIND a forward convolution); 2 (data gradient towards y = relu(batch norm)): `mask` is y, `bias` is the batch norm's beta -- the
+// gradient is gated by y > 0 and the workgroup writes sum(dz), sum(dz * (y - beta)) per channel: the batch norm's backward sums
+// (x_hat = (y - beta) / gamma wherever dz != 0), as kpx_conv3x3_wino43_bnbwd_stats_f32 does in the fp32 configuration
 template <int WN, int Q, int P, int BW, int STATS>
 __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, const int TH, const int G) {
     using T = S16Tile<WN, Q, P, BW>;
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
     }
 
     // ---- epilogue.  acc[p][q][e]: pixel = lane li of block p, output channel = c0 + 32 (wn Q + q) + 8 (e >> 2) + 4 lh + (e & 3)
-    if (g.bias) {
+    if (STATS != 2 && g.bias) {
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
@@ -258,6 +261,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
                 for (int p = 0; p < P; ++p) acc[p][q][e] += b;
             }
     }
+    size_t pix_off[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int mb = wm * P + p;
+        const int tr0 = mb * R + li / BW;
+        const int gi = tr0 / TH, row = tr0 - gi * TH;
+        const int j = li % BW;
+        const int rot = (BW == 16 && (li / BW) == 1) ? 2 : (BW == 8 && (li / BW) == 3) ? 2 : 0;
+        const int col = (j - rot) & (BW - 1);
+        pix_off[p] = (((size_t)(n0 + gi) * g.H + oy0 + row) * g.W + ox0 + col);
+    }
     if (STATS) {
         // per-channel sums over the workgroup's pixels, from the fp32 (biased, not yet activated) outputs: per lane over its P blocks, then a halving butterfly over
         // the 32 lanes of a half-wave (16 values -> 1 per lane), then over the WM wavefronts through LDS
@@ -265,12 +279,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             float s1[16], s2[16];
+            if (STATS == 2) {
+                const int cbq = c0 + 32 * (wn * Q + q);
+                float be[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float a = 0.f, b = 0.f;
+                for (int e = 0; e < 16; ++e) {
+                    const int ch = cbq + 8 * (e >> 2) + 4 * lh + (e & 3);
+                    be[e] = ch < g.Nn ? g.bias[ch] : 0.f;
+                    s1[e] = 0.f; s2[e] = 0.f;
+                }
 #pragma unroll
-                for (int p = 0; p < P; ++p) { const float v = acc[p][q][e]; a += v; b = fmaf(v, v, b); }
-                s1[e] = a; s2[e] = b;
+                for (int p = 0; p < P; ++p) {
+                    const unsigned short* const yo = reinterpret_cast<const unsigned short*>(g.mask) + pix_off[p] * g.ldm;
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int ch = cbq + 8 * gq + 4 * lh;
+                        const u32x2 yy = ch < g.Nn ? *reinterpret_cast<const u32x2*>(yo + ch) : u32x2{0u, 0u};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float yv = (j & 1) ? s16_hi(yy[j >> 1]) : s16_lo(yy[j >> 1]);
+                            const int e = 4 * gq + j;
+                            const float v = yv > 0.f ? acc[p][q][e] : 0.f;
+                            acc[p][q][e] = v;
+                            s1[e] += v; s2[e] = fmaf(v, yv - be[e], s2[e]);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float a = 0.f, b = 0.f;
+#pragma unroll
+                    for (int p = 0; p < P; ++p) { const float v = acc[p][q][e]; a += v; b = fmaf(v, v, b); }
+                    s1[e] = a; s2[e] = b;
+                }
             }
             // butterfly: after the step with distance d a lane keeps half of its values
 #pragma unroll
@@ -306,17 +348,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
         }
     }
 
-    size_t pix_off[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const int mb = wm * P + p;
-        const int tr0 = mb * R + li / BW;
-        const int gi = tr0 / TH, row = tr0 - gi * TH;
-        const int j = li % BW;
-        const int rot = (BW == 16 && (li / BW) == 1) ? 2 : (BW == 8 && (li / BW) == 3) ? 2 : 0;
-        const int col = (j - rot) & (BW - 1);
-        pix_off[p] = (((size_t)(n0 + gi) * g.H + oy0 + row) * g.W + ox0 + col);
-    }
     const bool img_ok = true;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -340,7 +371,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
                 }
             } else {
                 unsigned short* const yo = reinterpret_cast<unsigned short*>(g.y) + pix_off[p] * g.ldy;
-                const unsigned short* const mo = g.mask ? reinterpret_cast<const unsigned short*>(g.mask) + pix_off[p] * g.ldm : nullptr;
+                const unsigned short* const mo = (STATS != 2 && g.mask) ? reinterpret_cast<const unsigned short*>(g.mask) + pix_off[p] * g.ldm : nullptr;
 #pragma unroll
                 for (int k = 0; k < 4; k += 2) {
                     // groups k, k+1 (channels 8k + 4lh .. and 8(k+1) + 4lh ..): after the half exchange lanes 0-31 hold channels 8k .. 8k+7,
@@ -470,6 +501,20 @@ static void s16_go(const S16Geom& g, const S16Plan& pl, unsigned blocks, hipStre
     }
 }
 
+static int kpx_conv3x3_bf16s_attrs() {
+    if (kpx_first_use_on_device(&s16_attr_mask)) {
+        hipError_t e = hipSuccess;
+#define S16_ATTR(wn, q, p) \
+        if (e == hipSuccess) e = s16_attr<wn, q, p, 32, 0>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 16, 0>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 8, 0>(); \
+        if (e == hipSuccess) e = s16_attr<wn, q, p, 32, 1>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 16, 1>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 8, 1>(); \
+        if (e == hipSuccess) e = s16_attr<wn, q, p, 32, 2>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 16, 2>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 8, 2>();
+        S16_ATTR(2, 2, 4) S16_ATTR(2, 2, 2) S16_ATTR(1, 2, 2) S16_ATTR(1, 1, 2) S16_ATTR(2, 2, 1) S16_ATTR(2, 1, 1)
+#undef S16_ATTR
+        if (e != hipSuccess) return -(int)e;
+    }
+    return 0;
+}
+
 // in [N,H,W,K] bf16 (pixel stride ldin elements), Wf prepared for (K gathered, Nn produced), out [N,H,W,Nn] bf16 (out_f32 = 0) or fp32
 // (pixel stride ldout elements).  mask (optional, bf16 [N,H,W,Nn], pixel stride ldmask): the output is zeroed where mask <= 0.
 // stats (optional): [tiles][2][Nn] fp32 per-workgroup sums / sums of squares of the fp32 outputs before the activation (kpx_conv3x3_bf16s_stats_tiles tiles).
@@ -479,15 +524,7 @@ extern "C" int kpx_conv3x3_bf16s(const void* in, int N, int H, int W, int K, int
     if (!in || !Wf || !out || !kpx_conv3x3_bf16s_eligible(N, H, W, K, Nn, ldin, in) || ldout < Nn || (mask && (out_f32 || ldmask % 8 || ldmask < Nn))) return KPX_EINVAL;
     if (out_f32 ? (Nn % 4 || ldout % 4 || (((uintptr_t)out) & 15)) : (Nn % 8 || ldout % 8 || (((uintptr_t)out) & 15))) return KPX_EINVAL;
     if (!s16_plan(N, H, W, K, Nn, &pl)) return KPX_EINVAL;
-    if (kpx_first_use_on_device(&s16_attr_mask)) {
-        hipError_t e = hipSuccess;
-#define S16_ATTR(wn, q, p) \
-        if (e == hipSuccess) e = s16_attr<wn, q, p, 32, 0>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 16, 0>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 8, 0>(); \
-        if (e == hipSuccess) e = s16_attr<wn, q, p, 32, 1>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 16, 1>(); if (e == hipSuccess) e = s16_attr<wn, q, p, 8, 1>();
-        S16_ATTR(2, 2, 4) S16_ATTR(2, 2, 2) S16_ATTR(1, 2, 2) S16_ATTR(1, 1, 2) S16_ATTR(2, 2, 1) S16_ATTR(2, 1, 1)
-#undef S16_ATTR
-        if (e != hipSuccess) return -(int)e;
-    }
+    { const int rc = kpx_conv3x3_bf16s_attrs(); if (rc) return rc; }
     S16Geom g{};
     g.x = in; g.y = out; g.Wf = Wf; g.bias = bias; g.mask = mask; g.stats = stats;
     g.N = N; g.H = H; g.W = W; g.K = K; g.ldx = ldin; g.Nn = Nn; g.ldy = ldout; g.ldm = ldmask; g.act = act; g.out_f32 = out_f32;
@@ -496,5 +533,26 @@ extern "C" int kpx_conv3x3_bf16s(const void* in, int N, int H, int W, int K, int
     const unsigned blocks = (unsigned)((size_t)g.ngrp * g.tiles_y * g.tiles_x * g.ntc);
     hipStream_t s = kpx_stream(stream);
     if (stats) s16_go<1>(g, pl, blocks, s); else s16_go<0>(g, pl, blocks, s);
+    return kpx_launch_status();
+}
+
+// Data gradient towards y = relu(batch norm(.)) with that batch norm's backward sums from the epilogue (STATS 2 above): dz = conv(dy, wf) gated
+// by bn_y > 0, stored bf16; stats[tile][2][Nn] = sum(dz), sum(dz * (bn_y - beta)) per workgroup (kpx_conv3x3_bf16s_stats_tiles tiles).
+extern "C" int kpx_conv3x3_bf16s_bnbwd(const void* in, int N, int H, int W, int K, int ldin, const void* Wf, void* out, int Nn, int ldout,
+                                       const void* bn_y, int ld_bn_y, const float* beta, float* stats, void* stream) {
+    S16Plan pl;
+    if (!in || !Wf || !out || !bn_y || !beta || !stats || !kpx_conv3x3_bf16s_eligible(N, H, W, K, Nn, ldin, in) || ldout < Nn || Nn % 8 || ldout % 8 || ld_bn_y % 8 ||
+        ld_bn_y < Nn || ((((uintptr_t)out) | ((uintptr_t)bn_y)) & 15))
+        return KPX_EINVAL;
+    if (!s16_plan(N, H, W, K, Nn, &pl)) return KPX_EINVAL;
+    int rc = kpx_conv3x3_bf16s_attrs();
+    if (rc) return rc;
+    S16Geom g{};
+    g.x = in; g.y = out; g.Wf = Wf; g.bias = beta; g.mask = bn_y; g.stats = stats;
+    g.N = N; g.H = H; g.W = W; g.K = K; g.ldx = ldin; g.Nn = Nn; g.ldy = ldout; g.ldm = ld_bn_y; g.act = KPX_ACT_NONE; g.out_f32 = 0;
+    g.KC = (K + 31) / 32; g.NB = ((Nn + 127) / 128) * 4;
+    g.tiles_y = H / pl.TH; g.tiles_x = W / pl.BW; g.ngrp = N / pl.G; g.ntc = (Nn + pl.NBT * 32 - 1) / (pl.NBT * 32);
+    const unsigned blocks = (unsigned)((size_t)g.ngrp * g.tiles_y * g.tiles_x * g.ntc);
+    s16_go<2>(g, pl, blocks, kpx_stream(stream));
     return kpx_launch_status();
 }

@@ -455,19 +455,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad3_kernel(const Wgra
 
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x), 0, (int)((size_t)g.N * g.Hi * g.Wi * g.ldx * ESZ), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.dy), 0, (int)((size_t)g.P * g.lddy * ESZ), 0x00020000);
-    // bf16 tensors: a unit's four channels of one pixel are 8 bytes = two dword loads (raw_buffer_load_b64 is mis-lowered, see above), widened
-    // to fp32 in registers -- the one-term split below then packs the very same bf16 values
-    auto load4 = [&](const __amdgpu_buffer_rsrc_t& rs, int voff) -> f32x4 {
-        if (!IO16) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
-        const unsigned lo = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, 0, 0), hi = __builtin_amdgcn_raw_buffer_load_b32(rs, voff == G3_OOB ? G3_OOB : voff + 4, 0, 0);
-        return f32x4{g3_float(lo << 16), g3_float(lo & 0xffff0000u), g3_float(hi << 16), g3_float(hi & 0xffff0000u)};
-    };
-
     // this thread's unit: pixel pair kp of the 32-pixel chunk, channel quad cq (kp fastest: conflict-free ds_write_b32 at pitch 80)
-    const int kp = t & 15, cq = t >> 4;
-    const int ac = cbase + cq * 4, bc = kbase + cq * 4;
-    const bool a_cok = ac < g.Cin, b_cok = bc < g.Cout;            // (Cin, Cout multiples of 4: a quad is all in or all out)
-    const int a_st = (cq * 4) * G3_PITCH + kp * 4, b_st = a_st;
+    // bf16 tensors (IO16): a unit is two pixels x EIGHT channels (one 16-byte load per pixel) of ONE operand -- the first half of the
+    // workgroup's threads stage x, the second half dy
+    const bool isB16 = IO16 && t >= NT / 2;
+    const int tt = IO16 ? (isB16 ? t - NT / 2 : t) : t;
+    const int kp = tt & 15, cq = tt >> 4;
+    const int ac = cbase + cq * (IO16 ? 8 : 4), bc = kbase + cq * (IO16 ? 8 : 4);
+    const bool a_cok = ac < g.Cin, b_cok = bc < g.Cout;            // (Cin, Cout multiples of 4 / 8: a unit is all in or all out)
+    const int a_st = (cq * (IO16 ? 8 : 4)) * G3_PITCH + kp * 4, b_st = a_st;
     // pixel coordinates of the unit's two pixels, advanced by 32 pixels per chunk
     int pn[2], pho[2], pwo[2];
 #pragma unroll
@@ -501,10 +497,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad3_kernel(const Wgra
             const int ih = pho[j] * g.stride + r - g.pad_t, iw = pwo[j] * g.stride + q - g.pad_l;
             const bool va = a_cok & (p0 + j < pend) & ((unsigned)ih < (unsigned)g.Hi) & ((unsigned)iw < (unsigned)g.Wi);
             const int av = va ? (((pn[j] * g.Hi + ih) * g.Wi + iw) * g.ldx + ac) * ESZ : G3_OOB;
-            ra[j] = load4(rs_a, av);
             const bool vb = b_cok & (p0 + j < pend);
             const int bv = vb ? ((p0 + j) * g.lddy + bc) * ESZ : G3_OOB;
-            rb[j] = load4(rs_b, bv);
+            if (IO16) {                                    // one operand per thread: ra[j] = eight bf16 channels of pixel j
+                ra[j] = __builtin_bit_cast(f32x4, isB16 ? __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs_a, av, 0, 0));
+            } else {
+                ra[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, av, 0, 0));
+                rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, bv, 0, 0));
+            }
             // advance this pixel by one chunk (32 pixels): at most a few row wraps for narrow images
             pwo[j] += BKP;
             while (pwo[j] >= g.Wo) {
@@ -517,6 +517,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad3_kernel(const Wgra
     auto store_ab = [&]() {
         unsigned char* const Ab = Asm + a_st;
         unsigned char* const Bb = Bsm + b_st;
+        if (IO16) {
+            // channel c of the unit: (pixel 0, pixel 1) as one bf16 pair in LDS row c of the thread's operand
+            unsigned char* const Ob = isB16 ? Bb : Ab;
+            const u32x4 v0 = __builtin_bit_cast(u32x4, ra[0]), v1 = __builtin_bit_cast(u32x4, ra[1]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const unsigned pr = (c & 1) ? __builtin_amdgcn_perm(v1[c >> 1], v0[c >> 1], 0x07060302u) : __builtin_amdgcn_perm(v1[c >> 1], v0[c >> 1], 0x05040100u);
+                *reinterpret_cast<unsigned*>(Ob + c * G3_PITCH) = pr;
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             unsigned pa[3], pb[3];

@@ -1367,19 +1367,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_strip_bf16_kernel(const void
 // dy bf16 (dy_f32 = 0) or fp32 (dy_f32 = 1: the batch norm whose output stayed fp32), x bf16 (the batch norm's input) -> dx bf16
 extern "C" int kpx_bn_train_bwd_bf16(const void* dy, int lddy, int dy_f32, const void* x, int ldx, size_t P, int groups, int C,
                                      const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
-                                     void* dx, int lddx, float* dgamma, float* dbeta, int accumulate, void* scratch, void* stream) {
+                                     void* dx, int lddx, float* dgamma, float* dbeta, int accumulate,
+                                     const float* tile_stats, size_t tiles_per_group, void* scratch, void* stream) {
     if (!dy || !x || !mean || !invstd || !gamma || !beta || !dx || !dgamma || !dbeta || !scratch || groups <= 0 || groups > 65535 || C <= 0 || C % 8 ||
-        ldx % 8 || lddy % 8 || lddx % 8 || ldx < C || lddy < C || lddx < C || act < 0 || act > 1 || P == 0 || !pw_al16(dy, x, dx))
+        ldx % 8 || lddy % 8 || lddx % 8 || ldx < C || lddy < C || lddx < C || act < 0 || act > 1 || P == 0 || !pw_al16(dy, x, dx) ||
+        (tile_stats && (act != KPX_ACT_RELU || tiles_per_group == 0)))
         return KPX_EINVAL;
     hipStream_t s = kpx_stream(stream);
     const size_t gstride = (size_t)KPX_RED_BLOCKS * 2 * C;
     int nb = 0, rc = 0;
     RedArgs a{}; a.x = (const float*)x; a.ldx = ldx; a.dy = (const float*)dy; a.lddy = lddy; a.P = P; a.C = C;
     a.mean = mean; a.invstd = invstd; a.gamma = gamma; a.beta = beta; a.act = act; a.part = (double*)scratch; a.part_gstride = gstride;
-    rc = launch_chan_reduce_bf16(2, dy_f32 != 0, a, &nb, s, groups);
-    if (rc) return rc;
+    if (!tile_stats) {                                   // (with tile_stats the data-gradient epilogue that produced dy already reduced the two sums)
+        rc = launch_chan_reduce_bf16(2, dy_f32 != 0, a, &nb, s, groups);
+        if (rc) return rc;
+    }
     float* sums = reinterpret_cast<float*>((double*)scratch + (size_t)groups * gstride);
-    hipLaunchKernelGGL(bn_bwd_finalize_groups_kernel, dim3(C), dim3(256 * (groups < 4 ? groups : 4)), 0, s, (const double*)scratch, gstride, nb, (const float*)nullptr, (size_t)0,
+    hipLaunchKernelGGL(bn_bwd_finalize_groups_kernel, dim3(C), dim3(256 * (groups < 4 ? groups : 4)), 0, s, (const double*)scratch, gstride, nb, tile_stats, tiles_per_group,
                        gamma, groups, C, dgamma, dbeta, sums, accumulate);
     if ((rc = kpx_launch_status())) return rc;
     const float inv_count = (float)(1.0 / (double)P);

@@ -262,6 +262,24 @@ def _slice_f32(x, ldx, cin):
     return out
 
 
+def _bf16s_bnbwd(dy, lddy, k, w, dx, lddx, nn, bn_y, beta):
+    """(slab, tiles per image) or False: data gradient + the backward sums of the batch norm whose ReLU'd output ``bn_y`` the convolution read."""
+    n, h, wd = dy.shape[0], dy.shape[1], dy.shape[2]
+    if (bn_y.dtype != BF16 or not bn_y.is_contiguous() or bn_y.shape[3] != nn or nn % 8 or lddx % 8 or not (k % 32 == 0 or k in (8, 16))
+            or not lib.kpx_conv3x3_bf16s_eligible(n, h, wd, k, nn, lddy, dy.data_ptr())):
+        return False
+    wf = _bf16s_prepared(w, True)
+    tiles = lib.kpx_conv3x3_bf16s_stats_tiles(n, h, wd, k, nn)
+    slab = torch.empty(tiles * 2 * nn, dtype=torch.float32, device=dy.device)
+    rc = lib.kpx_conv3x3_bf16s_bnbwd(dy.data_ptr(), n, h, wd, k, lddy, wf.data_ptr(), dx.data_ptr(), nn, lddx, bn_y.data_ptr(), nn, beta.data_ptr(), slab.data_ptr(), _stream())
+    if rc == -1:
+        return False
+    check(rc, 'kpx_conv3x3_bf16s_bnbwd')
+    conv_kernel_uses_bf16s[0] += 1
+    from fractions import Fraction
+    return slab, Fraction(tiles, n)
+
+
 # prepared (fragment-ordered bf16) filters of the bf16-storage 3x3 kernel: (filter data_ptr, dgrad) -> (Wf, owning FilterBank or None, weak ref, (Cin, Cout))
 _bf16s_w = {}
 conv_kernel_uses_bf16s = [0]
@@ -625,9 +643,14 @@ def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l, bn_src=None
     n, ho, wo = dy.shape[0], dy.shape[1], dy.shape[2]
     kh, kw, _, cout = w.shape
     if dy.dtype == BF16 or dx.dtype == BF16:
-        if (dy.dtype == BF16 and mul is None and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and dx.shape[1] == ho and dx.shape[2] == wo
-                and _bf16s_conv(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True)):
-            return None
+        if dy.dtype == BF16 and mul is None and kh == 3 and kw == 3 and stride == 1 and pad_t == 1 and pad_l == 1 and dx.shape[1] == ho and dx.shape[2] == wo:
+            if bn_src is not None and dx.dtype == BF16:
+                # towards a ReLU'd batch norm's output: the epilogue gates the gradient and reduces that batch norm's backward sums
+                r = _bf16s_bnbwd(dy, lddy, cout, w, dx, lddx, cin, bn_src[0], bn_src[1])
+                if r:
+                    return r
+            if _bf16s_conv(dy, lddy, cout, w, None, dx, lddx, cin, ACT_NONE, True):
+                return None
         if dy.dtype == BF16 and (mul is None or mul[0].dtype == BF16):
             nbytes = lib.kpx_conv2d_dgrad_workspace_bytes(n, dx.shape[1], dx.shape[2], cin, cout, kh, kw, stride)
             ws = scratch.get('splitk', nbytes, dy.device) if nbytes else None
@@ -980,8 +1003,11 @@ class BatchNormFn(torch.autograd.Function):
         # kernel that produced dy (per-tile sums, ng * tiles-per-image tiles per group)
         sc = scratch.get('bn%d' % groups, lib.kpx_bn_train_scratch_bytes(c, groups), dev)
         if ctx.x16:
+            if ent is not None:
+                fused_bn_uses['backward_sums_from_dgrad_epilogue'] += groups
             check(lib.kpx_bn_train_bwd_bf16(dy.data_ptr(), c, 1 if dy.dtype == torch.float32 else 0, x.data_ptr(), c, pix, groups, c, mean.data_ptr(), invstd.data_ptr(),
                                             gamma.data_ptr(), beta.data_ptr(), ctx.act, dx.data_ptr(), c, dg.data_ptr(), db.data_ptr(), 0 if fresh else 1,
+                                            ent[0].data_ptr() if ent is not None else None, int(ng * ent[1]) if ent is not None else 0,
                                             sc.data_ptr(), _stream()), 'kpx_bn_train_bwd_bf16')
             return (dx, None if ctx.g_grad_out is not None else dg, None if ctx.b_grad_out is not None else db,
                     None, None, None, None, None, None, None, None, None, None, None)
