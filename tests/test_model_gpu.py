@@ -927,12 +927,12 @@ def test_configs4_rollout_128_lstm1024_matches_oracle():
 
 
 def test_bf16_mode_forward_and_train_step_tolerance():
-    """BASELINE configs[2] arithmetic (bf16 operands on the 3x3 stride-1 convs, fp32 everything else) against the fp32 oracle at
-    128x128, K=15, B=2: the tolerance of THIS mode (stated, not the fp32 parity bar): key-points abs 2e-2 of the [-1,1] range,
-    frame rel-L2 1e-1 (ten stacked bf16 conv + batch-norm layers), losses 2e-2 relative.  Measured on MI355X: key-points 1e-3, frame
-    5.4e-2, losses 5e-4, cosine of the generator gradient with the fp32 oracle's ~0.6 -- on these synthetic inputs (noise images,
-    random VGG19) the loss gradient is chaotic: a 1e-7 perturbation already moves it by 1 % (float64-arbiter tests), so bf16's 4e-3
-    saturates it; only the direction is checked."""
+    """BASELINE configs[2] (bf16 activation tensors in HBM, bf16 x bf16 products accumulated in fp32; fp32 statistics, master weights, Adam)
+    against the fp32 oracle at 128x128, K=15, B=2: the tolerance of THIS configuration (stated, not the fp32 parity bar): key-points abs 2e-2
+    of the [-1,1] range, frame rel-L2 1e-1 (ten stacked bf16 conv + batch-norm layers), losses 2e-2 relative.  The cosine of the generator
+    gradient with the fp32 oracle's is ~0.6 on these synthetic inputs (noise images, random VGG19): the loss gradient is chaotic -- a 1e-7
+    perturbation already moves it by 1 % (float64-arbiter tests), so bf16's 4e-3 saturates it; only the direction is checked.  The step may
+    route at most the documented handful of layers through fp32 kernels (D_logit, image-input layers, the 4-channel head)."""
     from kpx_amd import ops
     dev = torch.device('cuda:0')
     res, k, b = 128, 15, 2
@@ -942,8 +942,12 @@ def test_bf16_mode_forward_and_train_step_tolerance():
     want = R.train_step(st, im, fut)
     ops.set_compute_dtype('bf16')
     try:
+        for key in ops.fallback_uses:
+            ops.fallback_uses[key] = 0
         model = make_model(res, k, b, dev, width_div=4)
         model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, 0, b)
+        # D_logit (2048 -> 1, 6x6) forward and data gradient in both discriminator passes; weight gradients of D_logit, the fp32 4-channel head and the three image-input layers
+        assert ops.fallback_uses == {'conv_fwd': 2, 'conv_dgrad': 2, 'conv_wgrad': 5, 'other': 0}, ops.fallback_uses
         got = model.loss_values()
         fwd = model.last['fwd']
         kp_err = float(np.abs(fwd['current_points'].cpu().numpy() - want['current_points'].numpy()).max())
@@ -1157,9 +1161,42 @@ def smooth_pair(bsz, res, seed):
     return ims[0], ims[1]
 
 
+def test_bf16_configuration_tracks_the_fp32_configuration_over_ten_steps():
+    """Ten train steps of the bf16 configuration beside ten of the fp32 configuration from the same seeded state on the same structured
+    batches (B=8, 128x128, K=15, full-width VGG19; graph replay from the third step on).  The two weight trajectories separate by +-lr per
+    step and the GAN dynamics amplify that (ANY two roundings of this model are 10-30 % apart after ten steps), so the bound
+    widens with the step: the first four steps within 2.5 % on every term (measured 3e-4 .. 1.7e-2), all ten within 1 % on loss_D, 5 % on the
+    perceptual term and 15 % on the adversarial term (measured 2.4e-3 / 2.2e-2 / 6.5e-2), the perceptual loss falling alike in both."""
+    from kpx_amd import ops
+    dev = torch.device('cuda:0')
+    res, k, b = 128, 15, 8
+
+    def run(dtype):
+        ops.set_compute_dtype(dtype)
+        try:
+            m = make_model(res, k, b, dev, width_div=1)
+            out = []
+            for s in range(10):
+                im, fut = smooth_pair(b, res, 500 + s)
+                m.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, s, b)
+                lv = m.loss_values()
+                out.append([lv['loss_D'], lv['loss_G_recon'], lv['loss_G_adv']])
+            return np.asarray(out)
+        finally:
+            ops.set_compute_dtype('f32')
+    f32, bf16 = run('f32'), run('bf16')
+    dev_rel = np.abs(bf16 - f32) / np.abs(f32)
+    print('bf16 vs fp32 over ten steps: max relative loss deviation per term (D, recon, adv) %s; recon %s -> %s (fp32 %s -> %s)'
+          % (dev_rel.max(0).round(5).tolist(), round(bf16[0, 1], 3), round(bf16[-1, 1], 3), round(f32[0, 1], 3), round(f32[-1, 1], 3)))
+    assert dev_rel[:4].max() < 2.5e-2, dev_rel[:4]
+    assert (dev_rel.max(0) < np.asarray([1e-2, 5e-2, 1.5e-1])).all(), dev_rel.max(0)
+    assert abs(bf16[-1, 1] - f32[-1, 1]) < 0.02 * f32[-1, 1]
+    assert bf16[-1, 1] < bf16[0, 1] and f32[-1, 1] < f32[0, 1]
+
+
 @pytest.mark.parametrize('b', [8, 32], ids=['batch_8', 'per_gpu_batch_32'])
 def test_bf16_configuration_tracks_the_fp32_configuration_on_structured_frames(b):
-    """BASELINE configs[2] arithmetic against the fp32 configuration of the same HIP path on STRUCTURED inputs (smooth frames with moving
+    """BASELINE configs[2] (bf16 activation storage) against the fp32 configuration of the same HIP path on STRUCTURED inputs (smooth frames with moving
     blobs, 128x128, K=15, full-width VGG19; B=8, and B=32 = the batch the configuration runs per GPU, i.e. the launch sizes of
     `bench.py --dtype bf16`), three train steps from the seeded initial state.  On uniform-noise frames the generator
     gradient is chaotic (cosine ~0.6 between ANY two roundings); here it is meaningful: the first step's generator gradient must point the
