@@ -733,10 +733,10 @@ def test_bf16_storage_conv_batch_norm_relu_forward_and_backward(kpx, dev, monkey
     yo.backward(gy.float())
     want = [t2n(t) for t in (yo, xo.grad, po[0].grad, po[1].grad, po[2].grad, po[3].grad)]
     for name, got in (('fused', fused), ('plain', plain)):
-        for i, tol in enumerate((8e-3, 2e-2, 1e-2, 8e-3, 1e-2, 1e-2)):            # y, dx, dw1, dw2, dgamma, dbeta: bf16 storage through 2-3 stacked layers
+        for i, tol in enumerate((8e-3, 3e-2, 3e-2, 8e-3, 2e-2, 2e-2)):            # y, dx, dw1, dw2, dgamma, dbeta: ~4e-3 of bf16 storage per stage, 2-4 stacked stages
             assert rel_l2(got[i], want[i]) < tol, (name, i, rel_l2(got[i], want[i]))
     for i in range(8):                                                          # fused epilogue sums vs reduction passes: the same numbers up to storage rounding
-        assert rel_l2(fused[i], plain[i]) < (4e-3 if i < 6 else 1e-5), (i, rel_l2(fused[i], plain[i]))
+        assert rel_l2(fused[i], plain[i]) < (4e-3 if i < 6 else 1e-3), (i, rel_l2(fused[i], plain[i]))      # (moving statistics: sums of the fp32 accumulators vs of the rounded tensor)
 
 
 def test_bf16_storage_pointwise_kernels_against_torch_on_the_rounded_inputs(kpx, dev):
