@@ -926,6 +926,56 @@ def test_configs4_rollout_128_lstm1024_matches_oracle():
     assert rel_l2(out['mask'].cpu().numpy(), want['mask'].numpy()) < 1e-4
 
 
+def _rollout_arrays(k, res, cells, vdim, seed=77):
+    arrays = {**R.init_variables(k, res=res, seed=seed), **R.init_stage2_decoder(k, cell_info=cells, vae_dim=vdim, seed=seed + 1)}
+    rs = np.random.RandomState(5)
+    for n in list(arrays):
+        if n.endswith('moving_mean') or n.endswith('/beta'):
+            arrays[n] = (rs.randn(*arrays[n].shape) * 0.1).astype(np.float32)
+        elif n.endswith('moving_variance') or n.endswith('/gamma'):
+            arrays[n] = (rs.uniform(0.5, 1.5, arrays[n].shape)).astype(np.float32)
+        elif n.endswith('/bias') or n.endswith('/biases') or n.endswith('/b'):
+            arrays[n] = (rs.randn(*arrays[n].shape) * 0.05).astype(np.float32)
+    return {n: a for n, a in arrays.items() if not n.startswith('img_discr')}
+
+
+def test_configs4_rollout_at_the_benched_launch_geometry():
+    """The rollout exactly as `bench.py --config c4` launches it (reference models/final_model.py:94-99 runs the translator on all B*32
+    frames at once; here in slabs of frames_per_launch = 256 frames): (1) B=8 -> 256 frames = ONE full slab against the oracle at the
+    frame bar (rel-L2 1e-4); (2) B=64 -> 2 048 frames = eight slabs, the bench's run: its first eight samples are the inputs of (1); their
+    256 frames must match the oracle at the same bar and (1) to rounding (rel-L2 1e-6 -- NOT bit for bit: the sample-level layers in front
+    of the translator -- key-point detector, image encoder, the LSTM's GEMMs -- choose their tiles / split-K plan from the batch size, so the
+    key-points of a sample differ in the last bit between a batch of 8 and a batch of 64; measured 2e-7)."""
+    import kpx_amd
+    dev = torch.device('cuda:0')
+    res, k, cells, vdim = 128, 15, (1024, 1024), 64
+    cfg = {'model': {'n_pts': k, 'cell_info': list(cells), 'vae_dim': vdim, 'n_action': 9}, 'paths': {'log_dir': '/tmp/kpx_final'}}
+    arrays = _rollout_arrays(k, res, cells, vdim)
+    rs = np.random.RandomState(9)
+    im = (rs.randint(0, 256, size=(64, res, res, 3)).astype(np.float32) / 255.0 * 2 - 1).astype(np.float32)
+    act = np.eye(9, dtype=np.float32)[rs.randint(0, 9, size=64)]
+    z = rs.randn(64, vdim).astype(np.float32)
+    outs = {}
+    for b in (8, 64):
+        fm = kpx_amd.FinalModel(cfg, device=dev, image_size=res, frames_per_launch=256)
+        fm.build()
+        fm.store.load_numpy(arrays, strict=True)
+        feed = {'image': torch.from_numpy(im[:b]).to(dev), 'action_code': torch.from_numpy(act[:b]).to(dev)}
+        for _ in range(2):                       # the second run replays the captured graph, as the bench's timed runs do
+            out = fm.run(None, feed, z=torch.from_numpy(z[:b]).to(dev))
+        outs[b] = out['pred_im_seq'].cpu().numpy().copy()
+        assert outs[b].shape == (b, 32, res, res, 3)
+        del fm
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    with torch.no_grad():
+        want = R.final_model_forward({n: torch.from_numpy(a) for n, a in arrays.items()}, torch.from_numpy(im[:8]), torch.from_numpy(act[:8]),
+                                     torch.from_numpy(z[:8]), k, cell_info=cells)
+    assert rel_l2(outs[8], want['pred_im_seq'].numpy()) < 1e-4
+    assert rel_l2(outs[64][:8], want['pred_im_seq'].numpy()) < 1e-4
+    assert rel_l2(outs[64][:8], outs[8]) < 1e-6
+    assert np.isfinite(outs[64]).all()
+
+
 def test_bf16_mode_forward_and_train_step_tolerance():
     """BASELINE configs[2] (bf16 activation tensors in HBM, bf16 x bf16 products accumulated in fp32; fp32 statistics, master weights, Adam)
     against the fp32 oracle at 128x128, K=15, B=2: the tolerance of THIS configuration (stated, not the fp32 parity bar): key-points abs 2e-2
