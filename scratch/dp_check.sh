@@ -8,7 +8,6 @@ timeout 200 $B 2>/dev/null | tail -1 > $O/single_graph.json
 KPX_GRAPH=0 timeout 200 $B 2>/dev/null | tail -1 > $O/single_eager.json
 KPX_DP_FORCE_EXCHANGE=1 timeout 200 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 4 --no-cpu-baseline --no-roofline 2>$O/nccl1_one.err | tail -1 > $O/nccl1_one.json
 KPX_DP_GRAPH=segments KPX_DP_FORCE_EXCHANGE=1 timeout 200 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29521 bench.py --gpus 1 --steps 20 --warmup 4 --no-cpu-baseline --no-roofline 2>$O/nccl1_segments.err | tail -1 > $O/nccl1_segments.json
-KPX_DP_GRAPH=segments KPX_DP_NO_COLLECTIVES=1 KPX_DP_FORCE_EXCHANGE=1 timeout 200 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29520 bench.py --gpus 1 --steps 20 --warmup 4 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/nccl1_segments_nocoll.json
 KPX_GRAPH=0 KPX_DP_GRAPH=segments KPX_DP_FORCE_EXCHANGE=1 timeout 200 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --steps 20 --warmup 4 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/nccl1_eager_segments.json
 KPX_GRAPH=0 KPX_DP_GRAPH=inline KPX_DP_FORCE_EXCHANGE=1 timeout 200 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29519 bench.py --gpus 1 --steps 20 --warmup 4 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/nccl1_inline.json
 KPX_DIST_BACKEND=gloo timeout 200 python3 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 > $O/gloo2_segments.json

@@ -138,7 +138,6 @@ static std::atomic<unsigned long long> c16_attr_mask{0};
 // in [N,H,W,K] (pixel stride ldin) -> out [N,H,W,16] (pixel stride ldout).  forward: w = [3][3][K][16]; dgrad: w = [3][3][16][K] (the layer's
 // own HWIO filter, produced channels = its Cin = 16).  tile_stats (or NULL): [N * H/16 * W/16][2][16] sums of the output.
 extern "C" int kpx_conv3x3_c16_eligible(int N, int H, int W, int K, int Nn, int ldin, int ldout, const void* in_ptr) {
-    if (kpx_env()->no_c16) return 0;
     return N > 0 && Nn == 16 && K >= 16 && K % 16 == 0 && H % 16 == 0 && W % 16 == 0 && ldin % 4 == 0 && ldout >= 16 && (((uintptr_t)in_ptr) & 15) == 0;
 }
 extern "C" int kpx_conv3x3_c16_f32(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int dgrad, const float* bias,

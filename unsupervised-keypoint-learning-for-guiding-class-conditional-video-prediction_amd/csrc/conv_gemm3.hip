@@ -604,7 +604,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad3_kernel(const Wgra
 
 extern "C" __attribute__((visibility("hidden"))) int kpx_wgrad3_eligible(const WgradGeom* g) {
     const KpxEnv* e = kpx_env();
-    if (e->no_gemm3 || e->no_wgrad3 || g->merge || !g->vecA || !g->vecB) return 0;
+    if (e->no_gemm3 || g->merge || !g->vecA || !g->vecB) return 0;
     if (g->Cin % 4 != 0 || g->Cout % 4 != 0 || g->Cin < 16 || g->Cout < 16) return 0;
     if ((size_t)g->N * g->Hi * g->Wi * g->ldx * 4 >= 0x7fffffffu || (size_t)g->P * g->lddy * 4 >= 0x7fffffffu) return 0;     // 32-bit buffer offsets
     if (g->io16 && g->terms != 1) return 0;

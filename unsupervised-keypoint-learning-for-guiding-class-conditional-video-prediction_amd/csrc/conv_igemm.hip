@@ -354,9 +354,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // Split-K plan (shape only): used when the 128x128 tiling would leave most CUs idle (small M, long K).
 static int conv_splitk_plan(long M, int Cout, long nchunks_total) {
-    if (kpx_env()->no_splitk || Cout % 4 != 0 || Cout < 64) return 1;
+    if (Cout % 4 != 0 || Cout < 64) return 1;
     const long tiles = ((M + 127) / 128) * ((Cout + 127) / 128);
-    const long max_tiles = kpx_env()->splitk_maxtiles;   // a full round of 128x128 tiles: splitting only adds the reduce pass
+    const long max_tiles = 256;                          // a full round of 128x128 tiles: splitting only adds the reduce pass
     if (tiles >= max_tiles) return 1;
     long S = 512 / tiles;
     if (S > 8) S = 8;
@@ -415,12 +415,6 @@ static int launch_gather_conv_v(ConvGeom g, hipStream_t s) {
             const double score = cs[i].eff * (double)nb / (double)(rounds * slots);
             if (score > best) { best = score; BM = cs[i].bm; BN = cs[i].bn; }
         }
-    }
-    if (kpx_env()->tile_bm) {                             // debug / tuning override KPX_TILE="BM,BN" among the instantiated tiles
-        const int obm = kpx_env()->tile_bm, obn = kpx_env()->tile_bn;
-        if (BN != 32 && (obm == 128 || obm == 64) && (obn == 128 || obn == 64) &&
-            (obn == 64 || g.Cout > 64))
-            { BM = obm; BN = obn; }
     }
     g.nt = (g.Cout + BN - 1) / BN;
     int mtmax = 0;
@@ -611,11 +605,11 @@ gather:
     g.wts = Cin * Cout; g.ldw = Cout; g.act = act; g.terms = arith == KPX_ARITH_BF16 ? 1 : 3;
     g.vecA = (ldx % 4 == 0) && aligned16(x);
     g.vecB = (Cout % 4 == 0) && aligned16(w);
-    if (!(kpx_env()->no_merge_kh && kpx_env()->no_merge_kh == KH) && Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64) {      // image inputs (Cin = 3): merge each filter row
+    if (Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64) {      // image inputs (Cin = 3): merge each filter row
         g.merge = Cin; g.Tq = 1; g.KW = 1; g.Cin = KW * Cin; g.wts = KW * Cin * Cout; g.vecA = 0;
     }
     if (io16 && !kpx_gemm3_eligible(&g)) return KPX_EINVAL;
-    if (!io16 && !kpx_env()->no_smallcout && Cout <= 4 && Cin % 4 == 0 && Cin >= 256 && g.vecA && g.vecB == (Cout == 4))
+    if (!io16 && Cout <= 4 && Cin % 4 == 0 && Cin >= 256 && g.vecA && g.vecB == (Cout == 4))
         return launch_small_cout(g, kpx_stream(stream));
     if (g.vecA && g.vecB && !g.merge && Cin % 4 == 0) {        // small-M / long-K layers (the discriminator's 10x10 .. 4x4 maps): split K over workgroups
         const int S = conv_splitk_plan((long)N * Ho * Wo, Cout, (long)KH * KW * ((Cin + 31) / 32));
@@ -1332,7 +1326,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_merged_kernel(const Wgrad
 }
 
 static bool wgrad_rows_merged_plan(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int* S, int* cpb) {
-    if (kpx_env()->no_wrows) return false;
     if (Cin % 4 == 0 || KW * Cin > 32 || (32 + KW - 1) * Cin > 128 || KH > 8 || KW < 2 || Wo % 32 != 0 || Cout > 32 ||
         (long)N * Ho * Wo < 65536)
         return false;
@@ -1345,7 +1338,6 @@ static bool wgrad_rows_merged_plan(int N, int Ho, int Wo, int Cin, int Cout, int
 
 // shape-only eligibility + split plan of the rows kernel (alignment / stride are checked by the caller)
 static bool wgrad_rows_plan(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW, int* S, int* cpb, int* CT) {
-    if (kpx_env()->no_wrows) return false;
     if (KH > 3 || KW > 3 || KH * KW < 2 || Wo % 32 != 0 || Cout > 32 || Cin > 128 || (long)N * Ho * Wo < 65536) return false;
     *CT = Cin > 32 ? 2 : 1;
     const int ct = (Cin + 32 * *CT - 1) / (32 * *CT);
@@ -1368,7 +1360,7 @@ static void wgrad_tiles(int Cin, int Cout, int& bm, int& bn) {
     if (bm != bn) { bm = 64; bn = 64; }   // only the square tiles are instantiated
 }
 
-static inline bool wgrad_merge(int Cin, int ldx, int KW) { return !kpx_env()->no_wmerge && Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64; }
+static inline bool wgrad_merge(int Cin, int ldx, int KW) { return Cin % 4 != 0 && ldx == Cin && KW > 1 && KW * Cin <= 64; }
 
 static int wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
     int bm, bn;
@@ -1376,7 +1368,7 @@ static int wgrad_splits(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW
     long tiles = (long)KH * KW * ((Cin + bm - 1) / bm) * ((Cout + bn - 1) / bn);
     if (wgrad_merge(Cin, Cin, KW)) tiles = (long)KH * ((Cout + bn - 1) / bn);
     const long P = (long)N * Ho * Wo;
-    const long target = kpx_env()->wgrad_target ? kpx_env()->wgrad_target : (bm == 128 ? 2560 : 4096);   // measured optimum: several short rounds balance better than one long one
+    const long target = bm == 128 ? 2560 : 4096;   // measured optimum: several short rounds balance better than one long one
     long S = target / tiles;                            // floor: never split a layer that already has enough tiles
     const long maxS_pix = P / 512 > 0 ? P / 512 : 1;   // >= 16 chunks of 32 pixels per split
     if (S > maxS_pix) S = maxS_pix;
@@ -1464,10 +1456,9 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
             return rc;
         }
     }
-    // KPX_WGRAD3_FIRST (tuning): 1 = the bf16x3 kernel (conv_gemm3.hip) ahead of the specialised fp32 kernels below except the Winograd
-    // weight gradient; 2 = ahead of that one too.  Default 0: only where the generic fp32 kernel would run.
-    const int g3_first = (kpx_env()->no_gemm3 || kpx_env()->no_wgrad3 || Cin % 4 || Cout % 4 || Cin < 16 || Cout < 16 || ldx % 4 || lddy % 4 ||
-                          !aligned16(x) || !aligned16(dy)) ? 0 : kpx_env()->wgrad3_first;
+    // (the bf16x3 weight gradient of conv_gemm3.hip runs where the generic fp32 kernel would, and on the strided layers: measured ahead of the
+    //  specialised fp32 kernels it loses -- 18.65 vs 17.9 ms per step in round 3)
+    const int g3_first = 0;
     if (g3_first < 2 && KH == 3 && KW == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && Ho == Hi && Wo == Wi && ldx % 4 == 0 && lddy % 4 == 0 &&
         ldx >= ((Cin + 3) & ~3) && aligned16(x) && aligned16(dy) &&
         (size_t)N * Hi * Wi * (size_t)(ldx > lddy ? ldx : lddy) * 4 < 0x60000000ull) {       // (the kernel addresses x / dy with 32-bit byte offsets)
@@ -1547,7 +1538,7 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
     // (strided layers: the bf16x3 kernel below beats the fp32 tap-rows kernel -- encoder conv_3 at N = 64: 0.152 vs 0.198 ms; the stride-1
     //  layers that reach this point are faster on tap-rows / rows, and the 3x3 stride-1 layers on the Winograd weight gradient)
     const bool g3_strided = stride > 1 && g.vecA && g.vecB && kpx_wgrad3_eligible(&g);
-    if (!g3_first && !g3_strided && !kpx_env()->no_wtaprows && g.vecA && g.vecB && Cin % 4 == 0 && Cout % 4 == 0 && Wo % 32 == 0 && !wgrad_merge(Cin, ldx, KW)) {
+    if (!g3_first && !g3_strided && g.vecA && g.vecB && Cin % 4 == 0 && Cout % 4 == 0 && Wo % 32 == 0 && !wgrad_merge(Cin, ldx, KW)) {
         // chunk-aligned split: same S as the generic plan, but in units of 32-pixel row chunks
         WgradTapGeom r{};
         r.x = x; r.dy = dy;
@@ -1561,8 +1552,7 @@ extern "C" int kpx_conv2d_wgrad_f32(const float* x, int N, int Hi, int Wi, int C
         r.out = r.S > 1 ? (float*)workspace : dw;
         hipStream_t s = kpx_stream(stream);
         const dim3 grid((unsigned)(r.S * KH * KW * r.ct * r.kt));
-        if (bm == 128 && kpx_env()->wgrad_4w) hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, r);
-        else if (bm == 128) hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<128, 128, 2, 4>), grid, dim3(512), 0, s, r);
+        if (bm == 128) hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<128, 128, 2, 4>), grid, dim3(512), 0, s, r);
         else hipLaunchKernelGGL((conv_wgrad_tap_rows_kernel<64, 64, 2, 2>), grid, dim3(256), 0, s, r);
         int rc = kpx_launch_status();
         if (rc) return rc;

@@ -120,7 +120,7 @@ static std::atomic<unsigned long long> rgb_attr_mask{0};
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW,
                                                                   const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
                                                                   int stride, int pad_t, int pad_l, int act, hipStream_t s) {
-    if (Cin > 4 || Cout > 64 || KH > 7 || KW > 7 || stride < 1 || stride > 2 || kpx_env()->no_rgb) return -2;
+    if (Cin > 4 || Cout > 64 || KH > 7 || KW > 7 || stride < 1 || stride > 2) return -2;
     RgbGeom g{};
     g.x = x; g.w = w; g.bias = bias; g.y = y;
     g.N = N; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
@@ -253,7 +253,7 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_dgrad(const fl
                                                                     float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, hipStream_t s) {
     const bool k3 = KH == 3 && KW == 3 && stride == 1, k4 = KH == 4 && KW == 4 && stride == 2;
     if (!(k3 || k4) || (Cin != 3 && Cin != 4) || Cout % 16 || lddy % 4 || (((uintptr_t)dy) & 15) || (((uintptr_t)w) & 15) || pad_t < 0 || pad_l < 0 ||
-        pad_t >= KH || pad_l >= KW || kpx_env()->no_rgb)
+        pad_t >= KH || pad_l >= KW)
         return -2;
     // every input pixel's taps must land inside the 18-pixel patch: true for Ho = ceil-type SAME / explicit pads of this path (checked per launch)
     RgbDgradGeom g{};
@@ -274,7 +274,7 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_few_fwd(const floa
                                                                   const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
                                                                   int stride, int pad_t, int pad_l, int act, hipStream_t s) {
     if (KH != 3 || KW != 3 || stride != 1 || (Cout != 3 && Cout != 4) || Cin % 16 || ldx % 4 || (((uintptr_t)x) & 15) || (((uintptr_t)w) & 15) ||
-        pad_t < 0 || pad_l < 0 || pad_t > 2 || pad_l > 2 || Ho != Hi + 2 * pad_t - 2 || Wo != Wi + 2 * pad_l - 2 || kpx_env()->no_rgb)
+        pad_t < 0 || pad_l < 0 || pad_t > 2 || pad_l > 2 || Ho != Hi + 2 * pad_t - 2 || Wo != Wi + 2 * pad_l - 2)
         return -2;
     RgbDgradGeom g{};
     g.dy = x; g.w = w; g.dx = y; g.bias = bias; g.act = act;

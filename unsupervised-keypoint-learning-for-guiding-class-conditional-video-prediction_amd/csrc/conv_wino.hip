@@ -398,7 +398,7 @@ extern "C" int kpx_conv3x3_wino_eligible(int N, int H, int W, int K, int Nn, int
     if (kpx_env()->no_wino || N <= 0 || K <= 0 || Nn <= 0) return 0;       // (bench.py flips KPX_NO_WINO and calls kpx_reload_env() to time the direct kernel)
     // K is padded to a multiple of 8 (the pad channels must exist in the row: ldin >= Kp) and Nn to a multiple of 32
     const bool shape = (H % 16 == 0 && W % 16 == 0) || (H == 8 && W == 8 && N % 4 == 0);      // 8x8 images are packed four to a workgroup
-    const int kmin = kpx_env()->wino_kmin, nmin = kpx_env()->wino_nmin;
+    const int kmin = 4, nmin = 4;
     const bool kfit = ldin >= ((K + 7) & ~7) || K == 4;          // K = 4: only the lower 16-B half of the chunk is ever loaded
     return shape && K >= kmin && Nn >= nmin && (K >= 16 || K == 4 || K == 8) && kfit && (ldin % 4 == 0) && (((uintptr_t)in_ptr) & 15) == 0;
 }
@@ -512,10 +512,8 @@ static int wino_launch(const float* in, int N, int H, int W, int K, int ldin, co
     g.tiles_y = g.pack ? 1 : H / 16; g.tiles_x = g.pack ? 1 : W / 16; g.nt = g.Np / 32;
     const unsigned blocks = (unsigned)((size_t)(g.pack ? N / 4 : N) * g.tiles_y * g.tiles_x * g.nt);
     // 64 output channels per workgroup when that still fills the 256 CUs, else 32
-    const int force_ct = kpx_env()->wino_ct;
-    const bool wide = (force_ct ? force_ct == 2 : (blocks / 2 >= 256)) && g.Np % 64 == 0;
-    const int stagger = kpx_env()->wino_stagger;
-    g.stagger = stagger;
+    const bool wide = blocks / 2 >= 256 && g.Np % 64 == 0;
+    g.stagger = 1;                                       // wavefronts 4-7 run the MFMA half of a chunk first (worth 1-2 %, A/B in round 2)
     const int st = !tile_stats ? 0 : (mask_y ? 2 : 1);
 #define W2_GO(M, S) hipLaunchKernelGGL((conv_wino_v2_kernel<M, S>), dim3(M == 2 ? blocks / 2 : blocks), dim3(512), w2_lds_bytes(M), s, g)
     if (wide) { if (st == 0) W2_GO(2, 0); else if (st == 1) W2_GO(2, 1); else W2_GO(2, 2); }
@@ -744,13 +742,13 @@ static inline int ww_tile(int C) { return (C % 64 == 0 || C > 96) ? 2 : 1; }
 
 // splits for the Winograd wgrad (0 = shape not handled): ~256 workgroups (one per CU; measured best of 128..1024), >= 8 chunks per split, slabs <= 128 MB
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
-    if (kpx_env()->no_wino || kpx_env()->no_wino_wgrad) return 0;
-    const int comin = kpx_env()->ww_comin;
+    if (kpx_env()->no_wino) return 0;
+    const int comin = 4;
     if (H % 4 || W % 8 || Cout % 4 || Cin < 32 || Cout < comin) return 0;         // (a Cin that is not a multiple of 4 needs ldx >= Cin rounded up, checked by the caller)
     const int ti = ww_tile(Cin), to = ww_tile(Cout);
     if (ti == 1 && to == 1) return 0;                     // 32 x 32 blocks: too few MFMAs per barrier, the direct kernels do better
     const long tc = (long)N * (H / 4) * (W / 8), tiles = (long)((Cin + 32 * ti - 1) / (32 * ti)) * ((Cout + 32 * to - 1) / (32 * to));
-    const long target = kpx_env()->ww_target;
+    const long target = 256;
     long S = target / tiles;                              // floor: tiles * S workgroups must fit ONE round of the chip (158 -> 256 channels: 12 tiles,
     if (S < 1) S = 1;                                     // 22 splits = 264 workgroups ran as two rounds, 0.309 ms; 21 splits = 252: one round)
     if (S > tc / 8) S = tc / 8;

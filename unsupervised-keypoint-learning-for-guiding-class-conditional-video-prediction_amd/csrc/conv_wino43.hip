@@ -502,7 +502,7 @@ static std::atomic<unsigned long long> w43_attr_mask{0};
 static inline int w43_lds_bytes() { return (W4_MAIN > W4_EPI ? W4_MAIN : W4_EPI) * 4; }
 
 extern "C" int kpx_conv3x3_wino43_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
-    if (kpx_env()->no_wino43 || kpx_env()->no_wino || N <= 0) return 0;
+    if (kpx_env()->no_wino || N <= 0) return 0;
     const bool shape = (H % 16 == 0 && W % 32 == 0) || (H == 16 && W == 16 && N % 2 == 0);      // 16 x 16 images are packed two to a workgroup
     return shape && K >= 16 && Nn >= 33 && ldin >= ((K + 7) & ~7) && ldin % 4 == 0 && (((uintptr_t)in_ptr) & 15) == 0 &&
            (size_t)H * W * ldin * 8 < 0x7fffffffu;

@@ -189,12 +189,11 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_small_kernel(const Wsma
 // variant: 0 = none; 1 = Cin 16, 3x3, Cout <= 16; 2 = Cin 3, 7x7, Cout <= 32; 3 = Cin 3, 4x4 stride 2, Cout <= 64; 4 = Cin 64, 3x3, Cout <= 16;
 // 5 = Cin 32, 3x3, Cout <= 32
 static int wsmall_variant(int Cin, int Cout, int KH, int KW, int stride) {
-    if (kpx_env()->no_wsmall) return 0;
     if (Cin == 16 && KH == 3 && KW == 3 && stride == 1 && Cout <= 16) return 1;
     if (Cin == 3 && KH == 7 && KW == 7 && stride == 1 && Cout <= 32) return 2;
     if (Cin == 3 && KH == 4 && KW == 4 && stride == 2 && Cout <= 64) return 3;
-    if (Cin == 64 && KH == 3 && KW == 3 && stride == 1 && Cout <= kpx_env()->wsmall_c64_max) return 4;
-    if (Cin == 32 && KH == 3 && KW == 3 && stride == 1 && Cout <= 32 && !kpx_env()->no_wsmall32) return 5;
+    if (Cin == 64 && KH == 3 && KW == 3 && stride == 1 && Cout <= 4) return 4;
+    if (Cin == 32 && KH == 3 && KW == 3 && stride == 1 && Cout <= 32) return 5;
     return 0;
 }
 

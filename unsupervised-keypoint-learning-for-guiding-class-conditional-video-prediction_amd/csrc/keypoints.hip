@@ -555,18 +555,13 @@ extern "C" int kpx_gaussian_maps_fwd_f32(const float* mu, int B, int K, int H, i
         const int T = K * m, n4 = (int)(((size_t)H * W * K) >> 2);
         // Stores per thread: ~11 on the fixed-column path, ~6 on the general one (twice the VALU per element needs twice the wavefronts to
         // keep HBM fed), never fewer than ~512 workgroups.  Measured (nine / three rotating outputs): [64,128,128,15] 0.67 of the 8 TB/s spec at
-        // 512-768 workgroups, 0.35 at 12 288; [32,256,256,40] 0.57 at 768, 0.72 at 12 288, 0.68 at 16 384.  KPX_GAUSS_BLOCKS overrides.
-        const int target = kpx_env()->gauss_blocks;
-        int G;
-        if (target > 0) G = target / B;
-        else {
-            G = (n4 + T * (wfix ? 11 : 6) - 1) / (T * (wfix ? 11 : 6));
-            if (G * B < 512) G = (512 + B - 1) / B;
-        }
+        // 512-768 workgroups, 0.35 at 12 288; [32,256,256,40] 0.57 at 768, 0.72 at 12 288, 0.68 at 16 384.
+        int G = (n4 + T * (wfix ? 11 : 6) - 1) / (T * (wfix ? 11 : 6));
+        if (G * B < 512) G = (512 + B - 1) / B;
         if (G < 1) G = 1;
         int iters = (n4 + T * G - 1) / (T * G); if (iters < 1) iters = 1;
         G = (n4 + T * iters - 1) / (T * iters);
-        const int nt = kpx_env()->gauss_nt;
+        const int nt = 1;                                 // non-temporal stores
         const dim3 grid((unsigned)G, (unsigned)B), block((unsigned)T);
         if (wfix) {
             if (nt) hipLaunchKernelGGL((gauss_fwd_reg_kernel<true, true>), grid, block, 0, s, mu, K, H, W, inv2, maps, iters);

@@ -21,13 +21,12 @@ from .base_model import BaseModel
 from .variables import Sym
 from .vgg import Vgg19
 
-# the discriminator update on an auxiliary HIP stream beside the VGG19 forward of the G run (KPX_AUX_STREAM=0: one stream)
-AUX_STREAM = os.environ.get('KPX_AUX_STREAM', '1') != '0'
-AUX_STREAM_FWD = os.environ.get('KPX_AUX_STREAM_FWD', '1') != '0'      # the image encoder (forward and backward) beside the key-point detector
-AUX_STREAM_ADV = os.environ.get('KPX_AUX_STREAM_ADV', '1') != '0'
-# which half of the middle of the step runs on the auxiliary stream: the discriminator update (default) or the perceptual VGG19 chain
-# (KPX_VGG_ON_AUX=1; lets the update's weight gradients use a side stream under graph capture, but measured +0.9 ms: 25.1-25.5 vs 24.2-24.7 ms)
-VGG_ON_AUX = os.environ.get('KPX_VGG_ON_AUX', '0') != '0'      # the G run's adversarial branch on that stream as well
+# the discriminator update on an auxiliary HIP stream beside the VGG19 forward of the G run; the image encoder (forward and backward) beside the
+# key-point detector; the G run's adversarial branch on that stream as well.  Module constants: the three-stream == one-stream bit-identity
+# test sets them to False.  (Measured alternative, deleted: the perceptual VGG19 chain on the auxiliary stream instead, +0.9 ms.)
+AUX_STREAM = True
+AUX_STREAM_FWD = True
+AUX_STREAM_ADV = True
 
 # The whole step -- ~700 launches on three streams -- as ONE HIP graph, captured from the second call on a given input shape and replayed
 # afterwards (KPX_GRAPH=0: every step is enqueued from Python).  Single-process steps on the shared batch only; see _train_step_graphed.
@@ -62,8 +61,6 @@ class _Bf16Exchange:
 #              a capture that HANGS is bench.py's supervisor's business (fresh processes with the next form);
 #   'inline'   round 3's form: one eager pass with the collectives inline (also taken by separate-batch steps and with KPX_GRAPH=0 + this value).
 DP_GRAPH = os.environ.get('KPX_DP_GRAPH', '')
-# measurement only, ONE rank only (refused otherwise: replicas would diverge silently): the data-parallel code path WITHOUT its two collectives
-DP_NO_COLLECTIVES = os.environ.get('KPX_DP_NO_COLLECTIVES', '0') != '0'
 GRAPH_WARMUP_STEPS = 1          # eager steps before the capture: they create every lazily allocated scratch buffer and kernel attribute
 
 log = logging.getLogger('kpx')
@@ -97,8 +94,6 @@ class DetectorTranslatorModel(BaseModel):
         if DP_GRAPH not in ('', 'one', 'segments', 'inline'):
             raise ValueError("KPX_DP_GRAPH must be 'one', 'segments' or 'inline' (got %r)" % DP_GRAPH)
         self.dp_graph = DP_GRAPH or ('one' if (backend == 'nccl' and self.world_size == 1) else 'segments')
-        if DP_NO_COLLECTIVES and self.world_size > 1:
-            raise ValueError('KPX_DP_NO_COLLECTIVES=1 is a one-rank measurement switch: with %d ranks the replicas would diverge' % self.world_size)
         self.store = variables.VariableStore(device=self.device, seed=seed)
         self.vgg = vgg
         # Adam state (two optimisers, reference :198 and :201): fp32 beta powers like TF's beta{1,2}_power variables
@@ -212,7 +207,7 @@ class DetectorTranslatorModel(BaseModel):
         178.9 MB discriminator exchange overlaps the VGG19 forward of the generator's perceptual loss."""
         bucket = self.store.buckets[which]
         ops.join_side_stream(self.device)       # weight gradients are written on the side stream
-        if self.distributed and not DP_NO_COLLECTIVES:
+        if self.distributed:
             if which in DP_BF16_BUCKETS:
                 bufs = self.__dict__.setdefault('_bf16_exchange_bufs', {})
                 buf = bufs.get(which)
@@ -595,74 +590,50 @@ class DetectorTranslatorModel(BaseModel):
             # G batch the generator forward below re-derives every Winograd filter form, the discriminator's included, so the D update must be
             # complete first: no overlap there.)
             aux = self._aux_stream() if (AUX_STREAM and not separate and self.device.type == 'cuda') else None
-            if aux is not None and AUX_STREAM_ADV and VGG_ON_AUX:
-                # WHICH half goes to the auxiliary stream is decided by the stream discipline (ops.py): the discriminator update needs its weight
-                # gradients back before Adam, and a side stream may only be joined into the MAIN stream -- so the update stays on the main
-                # stream (weight gradients on side(main), as everywhere) and the perceptual half, whose VGG19 weights are constants (no weight
-                # gradients, nothing to fork), moves to the auxiliary stream.  MEASURED SLOWER than the default below (eager 25.1-25.5 vs 24.2 ms,
-                # replayed 25.4 vs 24.7 ms, same box, alternating runs): the large VGG19 launches then share the chip with the update AND its
-                # weight-gradient stream.  Kept behind KPX_VGG_ON_AUX=1 for A/B.
-                main = torch.cuda.current_stream(self.device)
-                final = fwd['final_output']
-                aux.wait_stream(main)
-                with torch.cuda.stream(aux):
-                    recon = self._loss_G_recon(final, future_im)
-                    g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
+            if aux is not None:
+                aux.wait_stream(torch.cuda.current_stream(self.device))
+            with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
                 d_losses = self._loss_D(final_d, future_im)
                 ops.begin_backward()
-                torch.autograd.backward([d_losses], [self._e0])
-                pending = self.exchange_gradients('D', async_op=True)      # (data-parallel: the exchange runs beside the VGG19 chain)
-                self._apply_adam('D', lr, pending=pending, exchanged=True)
-                adv = self._loss_G_adv(final)                              # sees the UPDATED discriminator, like the reference's second sess.run
-                g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
-                main.wait_stream(aux)
+                # on the auxiliary stream the update continues right here (exchange, Adam), so its weight gradients run inline on this
+                # stream: a side stream forked from a forked stream must never be joined back into it (ops: stream discipline)
+                with (ops.inline_wgrad() if aux is not None else contextlib.nullcontext()):
+                    torch.autograd.backward([d_losses], [self._e0])
+                # (under capture the collective is issued synchronously: it then runs on THIS stream, see DP_GRAPH 'one')
+                pending = self.exchange_gradients('D', async_op=not self._capturing)
+                if aux is not None:
+                    self._apply_adam('D', lr, pending=pending, exchanged=True)
+            # ---- G run (:94): the perceptual forward does not involve the discriminator, so it runs first ...
+            if separate:
+                im, future_im = feed_dict['image_G'], feed_dict['future_image_G']
+                fwd = self._define_forward_pass(im, future_im)
+            final = fwd['final_output']
+            recon = self._loss_G_recon(final, future_im)
+            if aux is not None and AUX_STREAM_ADV:
+                g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
+                # CROSS-STREAM LIFETIME INVARIANT (no record_stream anywhere in this step): a tensor that crosses main <-> aux is produced
+                # BEFORE the fork whose wait_stream orders it and stays referenced from Python until AFTER the join that orders its last
+                # reader, so the caching allocator never recycles it under a kernel of the other stream:
+                #   main -> aux: `final`, `final_d`, `future_im` predate aux.wait_stream(main) above (the fork of the discriminator update) and
+                #                are locals of this frame until the join below;
+                #   aux -> main: `g_adv`, `d_losses`, `adv` are read on main only after main.wait_stream(aux) below.
+                # No fresh aux.wait_stream(main) here on purpose: it would order the adversarial branch behind the VGG19 chain just enqueued
+                # on main (g_recon) and serialise the two halves; `final` is already ordered by the earlier fork.
+                with torch.cuda.stream(aux):
+                    adv = self._loss_G_adv(final)
+                    g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
+                torch.cuda.current_stream(self.device).wait_stream(aux)
                 ops.begin_backward()
                 final.backward(g_recon + g_adv)
             else:
                 if aux is not None:
-                    aux.wait_stream(torch.cuda.current_stream(self.device))
-                with (torch.cuda.stream(aux) if aux is not None else contextlib.nullcontext()):
-                    d_losses = self._loss_D(final_d, future_im)
-                    ops.begin_backward()
-                    # on the auxiliary stream the update continues right here (exchange, Adam), so its weight gradients run inline on this
-                    # stream: a side stream forked from a forked stream must never be joined back into it (ops: stream discipline)
-                    with (ops.inline_wgrad() if aux is not None else contextlib.nullcontext()):
-                        torch.autograd.backward([d_losses], [self._e0])
-                    # (under capture the collective is issued synchronously: it then runs on THIS stream, see DP_GRAPH 'one')
-                    pending = self.exchange_gradients('D', async_op=not self._capturing)
-                    if aux is not None:
-                        self._apply_adam('D', lr, pending=pending, exchanged=True)
-                # ---- G run (:94): the perceptual forward does not involve the discriminator, so it runs first ...
-                if separate:
-                    im, future_im = feed_dict['image_G'], feed_dict['future_image_G']
-                    fwd = self._define_forward_pass(im, future_im)
-                final = fwd['final_output']
-                recon = self._loss_G_recon(final, future_im)
-                if aux is not None and AUX_STREAM_ADV:         # (KPX_VGG_ON_AUX=0: round 3's first structure, kept for A/B)
-                    g_recon = torch.autograd.grad([recon], [final], [self._one])[0]
-                    # CROSS-STREAM LIFETIME INVARIANT (no record_stream anywhere in this step): a tensor that crosses main <-> aux is produced
-                    # BEFORE the fork whose wait_stream orders it and stays referenced from Python until AFTER the join that orders its last
-                    # reader, so the caching allocator never recycles it under a kernel of the other stream:
-                    #   main -> aux: `final`, `final_d`, `future_im` predate aux.wait_stream(main) above (the fork of the discriminator update) and
-                    #                are locals of this frame until the join below;
-                    #   aux -> main: `g_adv`, `d_losses`, `adv` are read on main only after main.wait_stream(aux) below.
-                    # No fresh aux.wait_stream(main) here on purpose: it would order the adversarial branch behind the VGG19 chain just enqueued
-                    # on main (g_recon) and serialise the two halves; `final` is already ordered by the earlier fork.
-                    with torch.cuda.stream(aux):
-                        adv = self._loss_G_adv(final)
-                        g_adv = torch.autograd.grad([adv], [final], [self._e0])[0]
                     torch.cuda.current_stream(self.device).wait_stream(aux)
-                    ops.begin_backward()
-                    final.backward(g_recon + g_adv)
                 else:
-                    if aux is not None:
-                        torch.cuda.current_stream(self.device).wait_stream(aux)
-                    else:
-                        self._apply_adam('D', lr, pending=pending, exchanged=True)
-                    # ... and the adversarial term sees the UPDATED discriminator, exactly as the reference's second sess.run
-                    adv = self._loss_G_adv(final)
-                    ops.begin_backward()
-                    torch.autograd.backward([recon, adv], [self._one, self._e0])
+                    self._apply_adam('D', lr, pending=pending, exchanged=True)
+                # ... and the adversarial term sees the UPDATED discriminator, exactly as the reference's second sess.run
+                adv = self._loss_G_adv(final)
+                ops.begin_backward()
+                torch.autograd.backward([recon, adv], [self._one, self._e0])
             if self.device.type == 'cuda' and getattr(self, '_aux', None) is not None:
                 # backward nodes recorded on the auxiliary stream ran there (their weight gradients on the side stream forked from it):
                 # the main stream joins the auxiliary stream here and every side stream in exchange_gradients('G') (ops: stream discipline)

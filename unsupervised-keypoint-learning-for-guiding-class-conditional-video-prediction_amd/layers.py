@@ -13,7 +13,7 @@ from .variables import Sym, default_store, is_sym
 ACT_NONE, ACT_RELU, ACT_LRELU = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LRELU
 EXACT_ZERO_BIAS_GRAD = True      # see conv_bn_relu
 import os as _os
-FOLD_BN_INFERENCE = _os.environ.get('KPX_FOLD_BN_INFERENCE', '1') != '0'      # see conv_bn_relu
+FOLD_BN_INFERENCE = True      # see conv_bn_relu
 
 
 def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', act=ACT_NONE, cin=None, head31=False, bias_grad=True, bn_stats=False,

@@ -13,8 +13,8 @@ import os as _os
 from .variables import Sym, default_store, is_sym
 
 # pose_encoder's 1x1 head and the two get_coord reductions as ONE op that never writes the [B,H,W,K] logits (ops.KeypointHeadProjFn);
-# KPX_FUSE_KP_HEAD=0 keeps the conv + head pair (also used whenever the caller asks for the logits)
-FUSE_KEYPOINT_HEAD = _os.environ.get('KPX_FUSE_KP_HEAD', '1') != '0'
+# False keeps the conv + head pair (also used whenever the caller asks for the logits); a module constant the tests flip
+FUSE_KEYPOINT_HEAD = True
 
 
 def _upsample_concat(x, skip):

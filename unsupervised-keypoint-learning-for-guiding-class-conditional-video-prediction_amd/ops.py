@@ -82,19 +82,21 @@ scratch = _Scratch()
 
 # Weight gradients are off the backward critical path (only the optimiser consumes them), so they are launched on a second
 # HIP stream where they fill the ramp-up / tail gaps of the dgrad chain on the main stream.  join_side_stream() is called
-# before the gradient exchange / Adam update.  KPX_SIDE_WGRAD=0 disables it.
-SIDE_WGRAD = _os.environ.get('KPX_SIDE_WGRAD', '1') != '0'
-FUSE_BN_STATS = _os.environ.get('KPX_FUSE_BN_STATS', '1') != '0'     # batch statistics from the conv epilogue
+# before the gradient exchange / Adam update.
+# (The switches below are module constants, not environment variables: the tests that compare a fused path with its separate passes
+#  monkeypatch them; DESIGN.md lists the environment variables the repo does read.)
+SIDE_WGRAD = True
+FUSE_BN_STATS = True     # batch statistics from the conv epilogue
 # the discriminator's leaky-ReLU backward in the epilogue of the data gradient above it (kpx_conv2d_dgrad_act_f32) instead of a pass of its own
-FUSE_ACT_BWD = _os.environ.get('KPX_FUSE_ACT_BWD', '1') != '0' 
+FUSE_ACT_BWD = True
 # batch-norm backward sums (and the ReLU mask of the gradient) from the epilogue of the data gradient that produces it, F(4x4,3x3) and
 # F(2x2,3x3) kernels: the reduction pass over (dz, y) of kpx_bn_train_bwd_f32 is then skipped.  Round 2 measured the F(2x2,3x3)-only version a
 # wash (31.4-31.7 vs 31.3 ms); with the F(4x4,3x3) epilogue and the batched finalize it is -0.15 ms (23.05 vs 23.20, A/B in one session)
-FUSE_BN_BWD = _os.environ.get('KPX_FUSE_BN_BWD', '1') != '0'
+FUSE_BN_BWD = True
 # where a layer's weight gradient forks from its stream: 'after' its data gradient has been enqueued, 'before' it, or 'capture' (default):
 # before it while the step is being captured into a HIP graph, after it in eager mode -- measured on MI355X at B=32: eager 26.57 ms (after) /
 # 27.22 ms (before); graph replay 27.44 ms (after) / 26.96 ms (before)
-FORK_BEFORE_DGRAD = _os.environ.get('KPX_FORK_BEFORE_DGRAD', 'capture')
+FORK_BEFORE_DGRAD = 'capture'
 _side_streams = {}       # (device, raw handle of the stream the weight gradients were forked from) -> side stream
 _side_dirty = {}         # the same keys -> True while un-joined kernels are pending on that side stream
 _side_keep = []          # tensors read by kernels on a side stream: kept alive until join_side_stream() (cheaper than
@@ -169,8 +171,7 @@ def reset_after_failed_capture():
 def graph_knobs():
     """Everything besides the input shape that a captured step freezes: the compute dtype and the module-level kernel-selection
     switches.  Part of the graph cache keys, so that flipping one re-captures instead of replaying the old arithmetic."""
-    return (_compute_dtype[0], SIDE_WGRAD, FUSE_BN_STATS, FUSE_BN_BWD, FUSE_ACT_BWD, FORK_BEFORE_DGRAD, WINO43, WINO43_FWD_ALL, WINO43_EXCLUDE_FWD, WINO43_EXCLUDE_DGRAD,
-            WINO43_MIN_WORKGROUPS, WINO43_NMIN)
+    return (_compute_dtype[0], SIDE_WGRAD, FUSE_BN_STATS, FUSE_BN_BWD, FUSE_ACT_BWD, FORK_BEFORE_DGRAD, WINO43, WINO43_MIN_WORKGROUPS, WINO43_NMIN)
 
 
 def normalize_device(device):
@@ -373,26 +374,22 @@ conv_kernel_uses = {'wino43': 0}      # diagnostics / tests: launches of the F(4
 #     generated frame moves 3e-5 instead of 1.7e-5 from the oracle's and the discriminator gradient 4.6x instead of 1.2x as far from the
 #     float64 gradient as the fp32 oracle's own.
 # The attribute lives with the layer's filter variable (VariableStore.layer_attrs), not in its name: renaming a scope changes no kernel.
-# Policy experiments: KPX_WINO43_FWD_ALL=1 ignores the attribute; KPX_WINO43_EXCLUDE_FWD / _DGRAD take extra name prefixes to exclude.
+# (Round 4 measured the alternative -- F(4x4,3x3) on every forward layer: -0.13..-0.2 ms per step for a generated frame 3.6e-5 instead of
+#  1.7e-5 from the oracle's; the margin was kept and the experiment switches are gone.)  KPX_WINO43=0: F(2x2,3x3) everywhere (tests).
 WINO43 = _os.environ.get('KPX_WINO43', '1') != '0'
-WINO43_FWD_ALL = _os.environ.get('KPX_WINO43_FWD_ALL', '0') != '0'
-WINO43_EXCLUDE_FWD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_FWD', '').split(',') if p)
 # launches of at most this many F(4x4,3x3) workgroups stay on F(2x2,3x3).  Round 2 set 128 from a kernel measured ALONE (128 workgroups: 0.187 vs
 # 0.158 ms -- one F(4x4) workgroup owns its CU); inside the step, where the other streams fill the idle CUs, F(4x4,3x3) wins on those layers too:
 # 23.73-23.83 ms per step at 0 / 32 / 64 against 24.01-24.16 at 128 (three repetitions each, B=32) -- so no threshold
-WINO43_MIN_WORKGROUPS = int(_os.environ.get('KPX_WINO43_MIN_WGS', '0'))
-WINO43_NMIN = int(_os.environ.get('KPX_WINO43_NMIN', '33'))      # produced channels from which a layer takes the 64-cout F(4x4,3x3) workgroups
-WINO43_EXCLUDE_DGRAD = tuple(p for p in _os.environ.get('KPX_WINO43_EXCLUDE_DGRAD', '').split(',') if p)
+WINO43_MIN_WORKGROUPS = 0          # (a module constant the model-level parity tests set to 128 and back)
+WINO43_NMIN = 33                   # produced channels from which a layer takes the 64-cout F(4x4,3x3) workgroups (32 / 16 measured: no change)
 
 
 def _wino43_wanted(name, cin, cout, dgrad, f43_fwd=True):
-    """f43_fwd: the layer's attribute (layers.conv(..., f43_fwd=)); name: only for the experiment prefixes of the environment."""
+    """f43_fwd: the layer's attribute (layers.conv(..., f43_fwd=)); name: unused (kept for the callers' signatures)."""
     k, nn = (cout, cin) if dgrad else (cin, cout)
     if not (WINO43 and k >= 16 and nn >= WINO43_NMIN):
         return False
-    if not dgrad and not (f43_fwd or WINO43_FWD_ALL):
-        return False
-    return not any(name.startswith(p) for p in (WINO43_EXCLUDE_DGRAD if dgrad else WINO43_EXCLUDE_FWD))
+    return bool(dgrad or f43_fwd)
 
 
 class FilterBank:

@@ -188,7 +188,7 @@ class VariableStore:
             #  ten batch norms -- does not apply: the batch norm is a constant folded into this filter, and a layer's own F(4x4,3x3) error is
             #  2.5e-6 with the double-precision filter transform.  KPX_INFER_F43=0 keeps the training attribute.)
             import os
-            f43 = True if os.environ.get('KPX_INFER_F43', '1') != '0' else self.layer_attrs.get(kname, {}).get('f43_fwd', True)
+            f43 = True                                    # (inference: the training-accuracy policy does not apply to a folded batch norm)
             ent = folded[kname] = (wf, bf, ops.register_constant_filter(wf, kname, f43_fwd=f43))
         return ent[0], ent[1]
 

@@ -113,9 +113,9 @@ def _vgg_forward(vgg, images):
 
 
 import os as _os
-FUSE_FEAT_BWD = _os.environ.get('KPX_FUSE_FEAT_BWD', '1') != '0'      # feature gradient (pool bwd + L1 bwd + ReLU bwd) in one pass
-FUSE_POOL_FWD = _os.environ.get('KPX_FUSE_POOL_FWD', '1') != '0'      # 2x2 max-pool written by the producing conv's epilogue
-FUSE_RELU_BWD = _os.environ.get('KPX_FUSE_RELU_BWD', '1') != '0'      # ReLU backward applied in the epilogue of the data gradient above it
+FUSE_FEAT_BWD = True      # feature gradient (pool bwd + L1 bwd + ReLU bwd) in one pass
+FUSE_POOL_FWD = True      # 2x2 max-pool written by the producing conv's epilogue
+FUSE_RELU_BWD = True      # ReLU backward applied in the epilogue of the data gradient above it
 
 
 class _PerceptualLossFn(torch.autograd.Function):
@@ -170,7 +170,7 @@ class _PerceptualLossFn(torch.autograd.Function):
                 done.add(id(y))
             elif k is not None and id(y) not in done:                 # y is a returned feature: add its L1 gradient
                 if y.dtype == ops.BF16:
-                    raise ops._lib.KpxError('bf16 configuration: the separate feature-L1 gradient pass is not built (KPX_FUSE_FEAT_BWD=0 / odd channel counts)')
+                    raise ops._lib.KpxError('bf16 configuration: the separate feature-L1 gradient pass is not built (vgg.FUSE_FEAT_BWD off / odd channel counts)')
                 half = y.numel() // 2
                 dl = torch.empty((b,) + tuple(y.shape[1:]), dtype=torch.float32, device=y.device)
                 check(lib.kpx_l1_pair_bwd_f32(y.data_ptr(), half, g.data_ptr(), 1.0 / (nfeat * half), dl.data_ptr(), ops._stream()),
