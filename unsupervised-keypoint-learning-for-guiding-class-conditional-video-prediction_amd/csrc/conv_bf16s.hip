@@ -35,6 +35,7 @@ struct S16Geom {
     int N, H, W, K, ldx, Nn, ldy, ldm, act;
     int KC, NB;                          // 32-channel chunks of K, 32-cout blocks of the prepared filters (Nn rounded up to the tile)
     int tiles_y, tiles_x, ngrp, ntc;     // ngrp: image groups (G images per tile), ntc: cout tiles
+    int total_tiles;                     // ngrp * tiles_y * tiles_x * ntc: walked by persistent workgroups
     int out_f32;
 };
 
@@ -89,6 +90,38 @@ __device__ __forceinline__ unsigned s16_pack2(float a, float b) {
 __device__ __forceinline__ float s16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float s16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
 
+// outstanding vector-memory operations allowed to remain (s_waitcnt takes an immediate)
+__device__ __forceinline__ void s16_wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        default: if (n > 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;       // (n < 0: no wait; more than 20: waiting for more is safe)
+    }
+}
+// depth of the filter-row ring by tile variant (LDS budget: s16_plan adds it up)
+// (Measured: rings of 3 / 4 rows on the small tiles change nothing -- 0.112 vs 0.116 ms on VGG19 conv1_2 -- those launches are bound by the
+//  per-tile instruction overhead, not by the filter rows' latency; every variant keeps two.)
+template <int NBT, int P> struct S16Ring { static constexpr int nbb = 2; };
+
 // geometry of a tile at compile time
 template <int WN, int Q, int P, int BW>
 struct S16Tile {
@@ -112,21 +145,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
     const int APIECES = (NPX * 5 + 63) >> 6;                // 1-KB LDS-DMA pieces of one patch
     const int ABYTES = APIECES << 10;
     constexpr int BPIECES = 6 * NBT, BBYTES = BPIECES << 10;
+    // filter-row ring: a row is requested D = NBB - 1 phases ahead (S16Ring: two rows everywhere, deeper rings measured no gain)
+    constexpr int NBB = S16Ring<NBT, P>::nbb, D = NBB - 1;
     constexpr int BPW = (BPIECES + 7) / 8;                  // filter pieces per wavefront and phase
     constexpr int APW = 9;                                  // patch pieces per wavefront and chunk (host: APIECES <= 72), up to three per phase
     unsigned char* const Asm = smem;                        // [2][ABYTES]
-    unsigned char* const Bsm = smem + 2 * ABYTES;           // [2][BBYTES]
+    unsigned char* const Bsm = smem + 2 * ABYTES;           // [NBB][BBYTES]
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int li = lane & 31, lh = lane >> 5;
     const int wm = wave % WM, wn = wave / WM;
-    int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
-    const int nti = L % g.ntc; L /= g.ntc;
-    const int bx = L % g.tiles_x; L /= g.tiles_x;
-    const int by = L % g.tiles_y;
-    const int grp = L / g.tiles_y;
-    const int oy0 = by * TH, ox0 = bx * BW, n0 = grp * G, c0 = nti * NBT * 32;
+    // PERSISTENT workgroups: tile L, L + gridDim.x, ..  The next tile's first patch and filter row are requested BEFORE the current tile's
+    // epilogue (its stores then drain beside the next tile's loads); tiles of one XCD's workgroups are neighbours (shared halo / the cout tiles
+    // of one input tile hit the same L2)
+    struct Tile { int nti, bx, by, grp; };
+    auto decode = [&](int L) {
+        Tile tl;
+        tl.nti = L % g.ntc; L /= g.ntc;
+        tl.bx = L % g.tiles_x; L /= g.tiles_x;
+        tl.by = L % g.tiles_y;
+        tl.grp = L / g.tiles_y;
+        return tl;
+    };
+    unsigned char* const Rsm = smem + 2 * ABYTES + NBB * BBYTES;     // [bias NBT * 32 floats][statistics 2 x WM x NBT * 32 floats]
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, (int)((size_t)g.N * g.H * g.W * g.ldx * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.Wf), 0, (int)((size_t)g.KC * 18 * g.NB * 1024), 0x00020000);
@@ -135,16 +177,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
     int a_voff[APW];
     unsigned a_tail = 0;                                    // bit i: the unit exists in the LAST chunk too (channel tail)
     const int ktail = g.K - 32 * (g.KC - 1);
+    int a_pos[APW];                                         // patch position of this lane's slot of piece i (tile independent), packed
+                                                            // row | column << 8 | image << 16 | unit << 24; -1: no slot
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
         const int piece = wave + 8 * i;
         const int S = piece * 64 + lane, q = S / 5, u = S - 5 * q;
         const int gi = q / (PH * PW), rem = q - gi * (PH * PW), pr = rem / PW, pc = rem - pr * PW;
-        const int n = n0 + gi, iy = oy0 - 1 + pr, ix = ox0 - 1 + pc;
-        const bool ok = piece < APIECES && u < 4 && q < NPX && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W && n < g.N;
-        a_voff[i] = ok ? (int)((((size_t)n * g.H + iy) * g.W + ix) * g.ldx * 2 + u * 16) : S16_OOB;
-        if (ok && u * 8 < ktail) a_tail |= 1u << i;
+        a_pos[i] = (piece < APIECES && u < 4 && q < NPX) ? (pr | (pc << 8) | (gi << 16) | (u << 24)) : -1;
     }
+    auto set_tile = [&](const Tile& tl) {                   // buffer offsets of this lane's patch slots for tile tl
+        const int oy0 = tl.by * TH, ox0 = tl.bx * BW, n0 = tl.grp * G;
+        a_tail = 0;
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int pos = a_pos[i], u = (pos >> 24) & 3;
+            const int n = n0 + ((pos >> 16) & 255), iy = oy0 - 1 + (pos & 255), ix = ox0 - 1 + ((pos >> 8) & 255);
+            const bool ok = pos >= 0 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W && n < g.N;
+            a_voff[i] = ok ? (int)((((size_t)n * g.H + iy) * g.W + ix) * g.ldx * 2 + u * 16) : S16_OOB;
+            if (ok && u * 8 < ktail) a_tail |= 1u << i;
+        }
+    };
     // ---- fragment read bases
     int pb[P];                                              // pixel block p of this wavefront: LDS byte offset of (lane's pixel, tap (0,0), unit lh)
 #pragma unroll
@@ -160,14 +213,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
     const int wb = (wn * Q) * 1024 + lane * 16;
 
     f32x16 acc[P][Q];
-#pragma unroll
-    for (int p = 0; p < P; ++p)
-#pragma unroll
-        for (int q = 0; q < Q; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
 
-    auto issue_b = [&](int kc, int r, int buf) {           // filter row r of chunk kc -> Bsm[buf]
+    auto issue_b = [&](int nti, int kc, int r, int buf) {  // filter row r of chunk kc, cout tile nti -> Bsm[buf]
 #pragma unroll
         for (int i = 0; i < BPW; ++i) {
             const int piece = wave * BPW + i;               // = (s * 2 + ks) * NBT + nb
@@ -178,11 +225,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
             }
         }
     };
-    auto issue_a = [&](int kc, int part, int buf) {        // pieces part, part + 3, part + 6 of this wavefront, chunk kc -> Asm[buf]
+    auto issue_a = [&](int kc, int part, int buf) {        // pieces part, part + 2, .. of this wavefront (part 0 / 1), chunk kc -> Asm[buf]
         const bool last = kc == g.KC - 1;
 #pragma unroll
-        for (int ii = 0; ii < 3; ++ii) {
-            const int i = part + 3 * ii;
+        for (int ii = 0; ii < 5; ++ii) {
+            const int i = part + 2 * ii;
+            if (i >= APW) continue;
             const int piece = wave + 8 * i;
             if (piece < APIECES) {
                 const int vo = (last && !((a_tail >> i) & 1u)) ? S16_OOB : a_voff[i];
@@ -191,24 +239,58 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
         }
     };
 
-    // ---- prologue: chunk 0's patch and filter row 0
-    issue_b(0, 0, 0);
-    issue_a(0, 0, 0); issue_a(0, 1, 0); issue_a(0, 2, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // bias (forward) / beta (STATS 2) of a tile's output channels travel through LDS: [2 slots by tile parity][NBT * 32] floats at Rsm.  The
+    // value is loaded BEFORE the tile's LDS-DMA requests (vector-memory results return in order) and parked in LDS after the previous tile's epilogue.
+    float bias_next = 0.f;
+    auto issue_first = [&](const Tile& tl) {               // a tile's first operands: chunk 0's patch and filter row 0, its bias values
+        const int ch = tl.nti * NBT * 32 + t;
+        bias_next = (g.bias && t < NBT * 32 && ch < g.Nn) ? g.bias[ch] : 0.f;
+        set_tile(tl);
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            if (j < 3 * g.KC) issue_b(tl.nti, j / 3, j % 3, j);
+        issue_a(0, 0, 0); issue_a(0, 1, 0);
+        if (g.KC > 1) { issue_a(1, 0, 1); issue_a(1, 1, 1); }     // both patch buffers are free at a tile boundary: two chunks ahead
+    };
+    float* const Bias = reinterpret_cast<float*>(Rsm);      // [2][NBT * 32]
+    int Lcur = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    Tile cur = decode(Lcur);
+    int it = 0;
+    issue_first(cur);
+    if (t < NBT * 32) Bias[t] = bias_next;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    int phase = 0;
+  for (;;) {
+    const int nti = cur.nti, bx = cur.bx, by = cur.by, grp = cur.grp;
+    const int oy0 = by * TH, ox0 = bx * BW, n0 = grp * G, c0 = nti * NBT * 32;
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][q][r] = 0.f;
+    int phase = 0, hist_a1 = 0, hist_a2 = 0, hist_b1 = 0;
+    const int nphases = 3 * g.KC;
     for (int kc = 0; kc < g.KC; ++kc) {
         const int abuf = (kc & 1) * ABYTES;
         const bool more = kc + 1 < g.KC;
 #pragma unroll
         for (int r = 0; r < 3; ++r, ++phase) {
-            const int bbuf = (phase & 1) * BBYTES;
-            // prefetch: the next phase's filter row, a third of the next chunk's patch
-            if (r < 2) issue_b(kc, r + 1, (phase + 1) & 1);
-            else if (more) issue_b(kc + 1, 0, (phase + 1) & 1);
-            int na = 0;                                      // patch pieces this wavefront issues in this phase (wave-uniform)
-            if (more) { issue_a(kc + 1, r, (kc + 1) & 1); na = (wave + 8 * r < APIECES) + (wave + 8 * (r + 3) < APIECES) + (wave + 8 * (r + 6) < APIECES); }
+            const int bbuf = (phase % NBB) * BBYTES;
+            // prefetch: the filter row of phase + D; the next chunk's patch in the first two phases of a chunk (never in the third: the wait
+            // before a new chunk then leaves this phase's filter request in flight)
+            int nbi = 0, na = 0;                             // LDS-DMA instructions this wavefront issues in this phase (wave-uniform)
+            if (phase + D < nphases) {
+                const int pp = phase + D;
+                issue_b(nti, pp / 3, pp % 3, pp % NBB);
+                nbi = BPIECES % 8 == 0 ? BPW : max(0, min(BPW, BPIECES - wave * BPW));
+            }
+            if (more && kc >= 1 && r < 2) {
+                issue_a(kc + 1, r, (kc + 1) & 1);
+#pragma unroll
+                for (int ii = 0; ii < 5; ++ii) na += (r + 2 * ii < APW && wave + 8 * (r + 2 * ii) < APIECES) ? 1 : 0;
+            }
             const unsigned char* const Ab = Asm + abuf;
             const unsigned char* const Bb = Bsm + bbuf + wb;
             // six (tap, k16) steps; the fragments of step i+1 are read before the MFMAs of step i (two register sets)
@@ -240,25 +322,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
                 mm(xb, wc);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // the next phase's operands have landed (the patch pieces issued in this phase may still be in flight, except before a new chunk)
-            if (r < 2 && na == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if (r < 2 && na == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (r < 2 && na == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // Everything the NEXT phase reads must have landed: its filter row (requested D - 1 phases ago) and, before a new chunk, the
+            // chunk's patch (requested in the first two phases of this chunk or at the tile boundary).  Vector-memory operations retire in
+            // order: wait until at most `young` = the requests issued AFTER the youngest required one are outstanding.
+            int young;
+            if (r == 2) young = D >= 2 ? nbi : 0;
+            else young = D == 1 ? na : D == 2 ? hist_a1 + nbi + na : hist_a2 + hist_b1 + hist_a1 + nbi + na;
+            if (phase + 1 >= nphases) young = -1;            // last phase of the tile: nothing to wait for here
+            hist_a2 = hist_a1; hist_b1 = nbi; hist_a1 = na;
+            s16_wait_vmcnt(young);
             __builtin_amdgcn_s_barrier();
         }
     }
 
+    // ---- the next tile's first operands are requested before this tile's epilogue -- unless the epilogue has loads of its own (mask / batch
+    // norm output): vector-memory operations complete in order, so those loads would wait for the whole prologue
+    const int Lnext = Lcur + (int)gridDim.x;
+    const bool has_next = Lnext < g.total_tiles;
+    Tile nxt = cur;
+    const bool early = has_next && !g.mask;
+    if (has_next) nxt = decode(Lnext);
+    if (early) issue_first(nxt);
+
     // ---- epilogue.  acc[p][q][e]: pixel = lane li of block p, output channel = c0 + 32 (wn Q + q) + 8 (e >> 2) + 4 lh + (e & 3)
+    const float* const bias_cur = Bias + (it & 1) * (NBT * 32);
     if (STATS != 2 && g.bias) {
 #pragma unroll
         for (int q = 0; q < Q; ++q)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ch = c0 + 32 * (wn * Q + q) + 8 * (e >> 2) + 4 * lh + (e & 3);
-                const float b = ch < g.Nn ? g.bias[ch] : 0.f;
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bias_cur + 32 * (wn * Q + q) + 8 * gq + 4 * lh);
 #pragma unroll
-                for (int p = 0; p < P; ++p) acc[p][q][e] += b;
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) acc[p][q][4 * gq + j] += b[j];
             }
     }
     size_t pix_off[P];
@@ -275,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
     if (STATS) {
         // per-channel sums over the workgroup's pixels, from the fp32 (biased, not yet activated) outputs: per lane over its P blocks, then a halving butterfly over
         // the 32 lanes of a half-wave (16 values -> 1 per lane), then over the WM wavefronts through LDS
-        float* const red = reinterpret_cast<float*>(smem);                 // [2 (sum, sumsq)][WM][NBT * 32]
+        float* const red = reinterpret_cast<float*>(Rsm) + 2 * NBT * 32;   // [2 (sum, sumsq)][WM][NBT * 32] behind the two bias slots
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             float s1[16], s2[16];
@@ -283,10 +380,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
                 const int cbq = c0 + 32 * (wn * Q + q);
                 float be[16];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int ch = cbq + 8 * (e >> 2) + 4 * lh + (e & 3);
-                    be[e] = ch < g.Nn ? g.bias[ch] : 0.f;
-                    s1[e] = 0.f; s2[e] = 0.f;
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(bias_cur + 32 * (wn * Q + q) + 8 * gq + 4 * lh);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { be[4 * gq + j] = b[j]; s1[4 * gq + j] = 0.f; s2[4 * gq + j] = 0.f; }
                 }
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
@@ -337,7 +434,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
                 red[(WM + wm) * (NBT * 32) + ch] = t2;
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (a raw barrier: __syncthreads() would also wait for the LDS-DMA in flight)
+        __builtin_amdgcn_s_barrier();
         if (t < 2 * NBT * 32) {
             const int which = t / (NBT * 32), ch = t - which * (NBT * 32);
             float a = 0.f;
@@ -399,6 +497,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16s_kernel(const S16Geom g, 
             }
         }
     }
+    if (!has_next) break;
+    if (!early) issue_first(nxt);
+    ++it;
+    if (t < NBT * 32) Bias[(it & 1) * (NBT * 32) + t] = bias_next;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    cur = nxt; Lcur = Lnext;
+  }
 }
 
 static std::atomic<unsigned long long> s16_attr_mask{0};
@@ -437,7 +543,8 @@ static bool s16_plan(int N, int H, int W, int K, int Nn, S16Plan* pl) {
     const int apieces = (NPX * 5 + 63) / 64;
     if (apieces > 72) return false;
     pl->variant = variant; pl->BW = BW; pl->TH = TH; pl->G = G; pl->MB = MB; pl->NBT = NBT;
-    pl->lds = 2 * apieces * 1024 + 2 * 6 * NBT * 1024;
+    const int nbb = 2;                                       // filter-row ring depth (S16Ring)
+    pl->lds = 2 * apieces * 1024 + nbb * 6 * NBT * 1024 + 8192;        // + bias / statistics staging
     if (pl->lds > 160 * 1024) return false;
     return true;
 }
@@ -501,6 +608,13 @@ static void s16_go(const S16Geom& g, const S16Plan& pl, unsigned blocks, hipStre
     }
 }
 
+// persistent grid: one workgroup per CU (147 KB of LDS each), every workgroup the same number of tiles where that divides
+static unsigned s16_grid(int total) {
+    if (total <= 256) return (unsigned)total;
+    const int per = (total + 255) / 256;
+    return (unsigned)((total + per - 1) / per);
+}
+
 static int kpx_conv3x3_bf16s_attrs() {
     if (kpx_first_use_on_device(&s16_attr_mask)) {
         hipError_t e = hipSuccess;
@@ -530,7 +644,8 @@ extern "C" int kpx_conv3x3_bf16s(const void* in, int N, int H, int W, int K, int
     g.N = N; g.H = H; g.W = W; g.K = K; g.ldx = ldin; g.Nn = Nn; g.ldy = ldout; g.ldm = ldmask; g.act = act; g.out_f32 = out_f32;
     g.KC = (K + 31) / 32; g.NB = ((Nn + 127) / 128) * 4;
     g.tiles_y = H / pl.TH; g.tiles_x = W / pl.BW; g.ngrp = N / pl.G; g.ntc = (Nn + pl.NBT * 32 - 1) / (pl.NBT * 32);
-    const unsigned blocks = (unsigned)((size_t)g.ngrp * g.tiles_y * g.tiles_x * g.ntc);
+    g.total_tiles = g.ngrp * g.tiles_y * g.tiles_x * g.ntc;
+    const unsigned blocks = s16_grid(g.total_tiles);
     hipStream_t s = kpx_stream(stream);
     if (stats) s16_go<1>(g, pl, blocks, s); else s16_go<0>(g, pl, blocks, s);
     return kpx_launch_status();
@@ -552,7 +667,8 @@ extern "C" int kpx_conv3x3_bf16s_bnbwd(const void* in, int N, int H, int W, int 
     g.N = N; g.H = H; g.W = W; g.K = K; g.ldx = ldin; g.Nn = Nn; g.ldy = ldout; g.ldm = ld_bn_y; g.act = KPX_ACT_NONE; g.out_f32 = 0;
     g.KC = (K + 31) / 32; g.NB = ((Nn + 127) / 128) * 4;
     g.tiles_y = H / pl.TH; g.tiles_x = W / pl.BW; g.ngrp = N / pl.G; g.ntc = (Nn + pl.NBT * 32 - 1) / (pl.NBT * 32);
-    const unsigned blocks = (unsigned)((size_t)g.ngrp * g.tiles_y * g.tiles_x * g.ntc);
+    g.total_tiles = g.ngrp * g.tiles_y * g.tiles_x * g.ntc;
+    const unsigned blocks = s16_grid(g.total_tiles);
     s16_go<2>(g, pl, blocks, kpx_stream(stream));
     return kpx_launch_status();
 }
