@@ -74,7 +74,7 @@ def _time_conv_3_1(dev, pretransformed=False, name='translator/conv_3_1', f43_fw
     return ms, 2.0 * 9 * c * c * h * h * n
 
 
-PROFILE = 'r04'          # prefix of the committed rocprofv3 summaries under profiles/ the lines below point at (profiles/collect_r04.sh)
+PROFILE = 'r05'          # prefix of the committed rocprofv3 summaries under profiles/ the lines below point at (profiles/collect_r05.sh)
 
 
 def _rocprof_avg_ms(kernel_substr, csv_name=PROFILE + '_roofline_only_kernel_stats.csv'):
@@ -109,6 +109,7 @@ def _pmc_traffic(name):
 
 WINO43_PMC, WINO_PMC, DIRECT_PMC, RENDER_PMC = PROFILE + '_wino43_pmc.json', PROFILE + '_wino_pmc.json', PROFILE + '_direct_pmc.json', PROFILE + '_render_pmc.json'
 GEMM3_PMC, BF16_PMC, WGRAD_PMC = PROFILE + '_gemm3_pmc.json', PROFILE + '_bf16_pmc.json', PROFILE + '_wgrad_pmc.json'
+WGRAD16_PMC = PROFILE + '_wgrad_bf16_pmc.json'
 
 
 def _roofline_wino(dev, name, kernel_substr, kernel_desc, reduction, pmc, f43_fwd=True, csv_name=None, **shape):
@@ -220,7 +221,7 @@ def roofline_conv_bf16(dev, n=BATCH, h=64, c=128):
     nbytes = 2 * n * h * h * c * 2 + 9 * c * c * 2
     ach = flops / (ms * 1e-3) / 1e12
     traffic, src = _pmc_traffic(BF16_PMC)
-    rp_ms, rp_src = _rocprof_avg_ms('conv3x3_bf16s_kernel<2, 2, 4, 32, 0>')
+    rp_ms, rp_src = _rocprof_avg_ms('conv3x3_bf16s_kernel<2, 2, 4, 32, 0>', PROFILE + '_roofline_only_bf16_kernel_stats.csv')
     return {'committed_profile': {'note': 'from files committed under profiles/, NOT measured in this run', 'collected_at_commit': _profile_stamp(),
                                   'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'traffic_source': src},
             'bound': 'mfma', 'kernel': 'conv3x3_bf16s_kernel<2,2,4,32,0> (512 pixels x 128 couts per workgroup, LDS-DMA operands, filters prepared once) fwd 3x3 s1 '
@@ -228,6 +229,32 @@ def roofline_conv_bf16(dev, n=BATCH, h=64, c=128):
             'achieved': round(ach, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(ach / 2500.0, 4), 'traffic': traffic, 'traffic_source': src,
             'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops, 'bytes_per_launch_algorithmic': nbytes,
             'hbm_gbps_algorithmic': round(nbytes / (ms * 1e-3) / 1e9, 1), 'hbm_frac_algorithmic': round(nbytes / (ms * 1e-3) / 8e12, 4)}
+
+
+def roofline_wgrad_bf16(dev):
+    """The bf16 configuration's weight gradient of the same layer as roofline_wgrad (translator conv_3_0, 256 -> 128 at 64x64, batch 32):
+    conv3x3_wgrad_bf16_kernel (bf16 x and dy, transposed LDS reads, fp32 accumulate) + the fixed-tree reduce of its split slabs, against the
+    dense bf16 matrix peak.  The slabs (one round of 256 workgroups x 9 x 64 x 128 fp32) are traffic beyond the algorithmic bytes."""
+    from kpx_amd import ops
+    from kpx_amd._lib import lib, check
+    n, h, ci, co = BATCH, 64, 256, 128
+    x = torch.randn(n, h, h, ci, device=dev).bfloat16()
+    dy = torch.randn(n, h, h, co, device=dev).bfloat16()
+    dw = torch.empty(3, 3, ci, co, device=dev)
+    nbytes = lib.kpx_conv3x3_wgrad_bf16_workspace_bytes(n, h, h, ci, co)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ms = time_kernel(lambda: check(lib.kpx_conv3x3_wgrad_bf16(x.data_ptr(), n, h, h, ci, ci, dy.data_ptr(), co, co, dw.data_ptr(), ws.data_ptr(), nbytes, ops._stream()), 'wgrad'),
+                     iters=50, warm=10)
+    flops = 2.0 * 9 * ci * co * h * h * n
+    ach = flops / (ms * 1e-3) / 1e12
+    alg = n * h * h * (ci + co) * 2 + 9 * ci * co * 4
+    traffic, src = _pmc_traffic(WGRAD16_PMC)
+    rp_ms, rp_src = _rocprof_avg_ms('conv3x3_wgrad_bf16_kernel<2, 4, 1, 1>', PROFILE + '_roofline_only_bf16_kernel_stats.csv')
+    return {'committed_profile': {'note': 'from files committed under profiles/, NOT measured in this run', 'collected_at_commit': _profile_stamp(),
+                                  'rocprof_avg_launch_ms_main_kernel': rp_ms, 'rocprof_source': rp_src, 'traffic_source': src},
+            'bound': 'mfma', 'kernel': 'conv3x3_wgrad_bf16_kernel<2,4,1,1> (+ wgrad16_reduce_kernel) wgrad 3x3 s1 256->128 @64x64 B=32 (translator conv_3_0), bf16 tensors',
+            'achieved': round(ach, 1), 'peak': 2500.0, 'unit': 'TFLOP/s', 'frac': round(ach / 2500.0, 4), 'traffic': traffic, 'traffic_source': src,
+            'avg_launch_ms': round(ms, 4), 'flops_per_launch': flops, 'bytes_per_launch_algorithmic': alg, 'slab_bytes_per_launch': nbytes}
 
 
 def roofline_conv_bf16x3(dev):
@@ -607,10 +634,13 @@ def main():
     if args.roofline_only and args.config == 'c3':
         print(json.dumps({'roofline': roofline_conv_c3(dev, args.batch), 'roofline_hbm_render': roofline_render(dev, RES, K_PTS, args.batch)}), flush=True)
         return
+    if args.roofline_only and args.dtype == 'bf16':
+        print(json.dumps({'roofline': roofline_conv_bf16(dev), 'roofline_wgrad': roofline_wgrad_bf16(dev)}), flush=True)
+        return
     if args.roofline_only:
         kops.set_compute_dtype('f32')
         print(json.dumps({'roofline': roofline_conv(dev), 'roofline_wgrad': roofline_wgrad(dev), 'roofline_wino_f23': roofline_conv_f23(dev), 'roofline_direct_conv': roofline_conv_direct(dev), 'roofline_bf16x3_conv': roofline_conv_bf16x3(dev),
-                          'roofline_hbm_render': roofline_render(dev), 'roofline_bf16_conv': roofline_conv_bf16(dev)}), flush=True)
+                          'roofline_hbm_render': roofline_render(dev)}), flush=True)
         return
     cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': args.batch},
            'model': {'n_pts': K_PTS}, 'paths': {'log_dir': '/tmp/kpx_bench', 'vggnet': None}}
@@ -683,6 +713,7 @@ def main():
                'step_algorithmic_frac_of_f32_peak': round(2 * gmac * 1e9 * value / world / 157.3e12, 4),
                # the chip's fp32-EQUIVALENT ceiling is the six-product bf16x3 bound (2.5 PFLOP/s / 6 = 417 TFLOP/s), not the fp32-MFMA pipe
                'step_algorithmic_frac_of_bf16x3_bound': round(2 * gmac * 1e9 * value / world / 416.7e12, 4),
+               'step_algorithmic_frac_of_bf16_peak': round(2 * gmac * 1e9 * value / world / 2.5e15, 4),
                'n_ranks_seen': n_ranks_seen, 'dist_backend': backend if launched else None,
                'ms_per_step_by_rank': [round(x, 3) for x in ms_by_rank],
                'host_call_wall_ms_per_step': round(max(enq), 3), 'host_call_wall_ms_per_step_by_rank': [round(x, 3) for x in enq],
@@ -700,15 +731,19 @@ def main():
             out['dp_fallbacks'] = json.loads(os.environ.get('KPX_BENCH_FALLBACKS', '[]'))
         if world == 1 and not args.no_roofline:
             if args.dtype == 'bf16':
+                # the bf16 configuration's own dominant kernels (its fp32 legs are the fp32 line's)
                 out['fp32_kernel_fallbacks'] = dict(kops.fallback_uses)       # bf16 tensors routed through an fp32 kernel between two conversions (whole run)
-                out['roofline_bf16_conv'] = roofline_conv_bf16(dev)
-            kops.set_compute_dtype('f32')
-            out['roofline'] = roofline_conv(dev) if args.config == 'c1' else roofline_conv_c3(dev, args.batch)
-            out['roofline_wgrad'] = roofline_wgrad(dev)
-            out['roofline_wino_f23'] = roofline_conv_f23(dev)
-            out['roofline_direct_conv'] = roofline_conv_direct(dev)
-            out['roofline_bf16x3_conv'] = roofline_conv_bf16x3(dev)
-            out['roofline_hbm_render'] = roofline_render(dev, RES, K_PTS, args.batch)
+                out['roofline'] = roofline_conv_bf16(dev)
+                out['roofline_wgrad'] = roofline_wgrad_bf16(dev)
+                kops.set_compute_dtype('f32')
+                out['roofline_hbm_render'] = roofline_render(dev, RES, K_PTS, args.batch)
+            else:
+                out['roofline'] = roofline_conv(dev) if args.config == 'c1' else roofline_conv_c3(dev, args.batch)
+                out['roofline_wgrad'] = roofline_wgrad(dev)
+                out['roofline_wino_f23'] = roofline_conv_f23(dev)
+                out['roofline_direct_conv'] = roofline_conv_direct(dev)
+                out['roofline_bf16x3_conv'] = roofline_conv_bf16x3(dev)
+                out['roofline_hbm_render'] = roofline_render(dev, RES, K_PTS, args.batch)
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -3,7 +3,10 @@
 (B=32, 128x128, K=15).  Prints time, TFLOP/s and fraction of the 157.3 TF fp32-MFMA peak for
 forward / dgrad / wgrad of every distinct layer, weighted by how often the step runs it.
 
-    python bench_layers.py [--batch 32]
+    python bench_layers.py [--batch 32] [--dtype bf16]
+
+--dtype bf16: the same table for the bf16 configuration (bf16 activation tensors; image-input layers take fp32 images and produce bf16, the
+translator's 4-channel head and D_logit produce fp32) -- each layer on the kernel `ops` picks for it there, fraction against the bf16 peak.
 """
 import argparse
 import os
@@ -73,26 +76,37 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--filter', default='', help='comma-separated substrings of layer names')
     ap.add_argument('--unregistered', action='store_true', help='3x3 layers through the plain C entry (filter transformed inside the call, F(2x2,3x3) only)')
+    ap.add_argument('--dtype', choices=['f32', 'bf16'], default='f32')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
+    ops.set_compute_dtype(args.dtype)
+    b16 = args.dtype == 'bf16'
+    peak = 2500.0 if b16 else PEAK
     tot = {'fwd': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
     flops_tot = 0.0
     print('%-36s %5s %4s %5s %5s k s | %9s %6s | %9s %6s | %9s %6s' % ('layer', 'N', 'H', 'Cin', 'Cout', 'fwd ms', 'TF', 'dgrad ms', 'TF', 'wgrad ms', 'TF'))
     for (name, n, h, ci, co, k, s, pad, ld, wf, wd, ww) in layers(args.batch):
         if args.filter and not any(f in name for f in args.filter.split(',')):
             continue
+        if b16 and ci > 4 and ld % 8:
+            ld = (ci + 31) // 32 * 32                     # (the bf16 joint buffer: 158 channels in a 160-wide pixel)
         x = torch.randn(n, h, h, ld, device=dev)
+        if ld > ci:
+            x[..., ci:] = 0
+        adt = torch.bfloat16 if (b16 and ci > 4) else torch.float32            # images stay fp32
+        ydt = torch.bfloat16 if (b16 and co > 4) else torch.float32            # the 4-channel head and D_logit stay fp32
+        x = x.to(adt)
         w = torch.randn(k, k, ci, co, device=dev) * 0.05
         if os.environ.get('KPX_BENCH_ZERO'):
             x.zero_(); w.zero_()
         b = torch.zeros(co, device=dev)
         pt, _, ho = ops.same_pad(h + 2 * pad, k, s)
         pad_t = pad + pt
-        y = torch.empty(n, ho, ho, co, device=dev)
-        dy = torch.randn(n, ho, ho, co, device=dev)
+        y = torch.empty(n, ho, ho, co, dtype=ydt, device=dev)
+        dy = torch.randn(n, ho, ho, co, device=dev).to(ydt)
         if os.environ.get('KPX_BENCH_ZERO'):
             dy.zero_()
-        dx = torch.empty(n, h, h, ld, device=dev)
+        dx = torch.empty(n, h, h, ld, dtype=adt, device=dev)
         dw = torch.empty_like(w)
         flops = 2.0 * n * ho * ho * co * k * k * ci
         # the filter is registered under the layer's variable name, so that the 3x3 layers run on the kernel the train step picks for
@@ -116,8 +130,9 @@ def main():
         f = lambda t: flops / (t * 1e-3) / 1e12 if t else 0.0
         print('%-36s %5d %4d %5d %5d %d %d | %9.3f %6.1f | %9.3f %6.1f | %9.3f %6.1f' % (name, n, h, ci, co, k, s, tf, f(tf), td, f(td), tw, f(tw)))
     t = sum(tot.values())
-    print('weighted per-step totals: fwd %.2f ms, dgrad %.2f ms, wgrad %.2f ms, all %.2f ms; %.1f TF = %.1f%% of fp32 MFMA peak'
-          % (tot['fwd'], tot['dgrad'], tot['wgrad'], t, flops_tot / (t * 1e-3) / 1e12, 100 * flops_tot / (t * 1e-3) / 1e12 / PEAK))
+    print('weighted per-step totals: fwd %.2f ms, dgrad %.2f ms, wgrad %.2f ms, all %.2f ms; %.1f TF = %.1f%% of the %s MFMA peak%s'
+          % (tot['fwd'], tot['dgrad'], tot['wgrad'], t, flops_tot / (t * 1e-3) / 1e12, 100 * flops_tot / (t * 1e-3) / 1e12 / peak, 'bf16' if b16 else 'fp32',
+             '; layers routed through fp32 kernels between conversions: %s' % dict(ops.fallback_uses) if b16 else ''))
 
 
 if __name__ == '__main__':

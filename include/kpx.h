@@ -381,6 +381,19 @@ int kpx_conv2d_dgrad_bf16(const void* dy, int N, int Ho, int Wo, int Cout, int l
 int kpx_conv2d_wgrad_bf16(const void* x, int N, int Hi, int Wi, int Cin, int ldx, const void* dy, int Ho, int Wo, int Cout, int lddy,
                           float* dw, int KH, int KW, int stride, int pad_t, int pad_l, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Image-input layers in the bf16 configuration (models/networks/pose_encoder.py conv_1 7x7x3 -> 32, img_discriminator.py conv_0 4x4/s2 3 -> 64,
+ * vgg.py:51 conv1_1 3x3x3 -> 64): the image stays fp32, what the layer produces / receives is bf16.  KPX_EINVAL (-1) for shapes the LDS-resident
+ * image kernels do not take (the caller converts and uses the fp32 entries).
+ *   fwd:   x fp32 [N,Hi,Wi,Cin<=4] contiguous -> y bf16 (pixel stride ldy elements), Cout <= 64
+ *   dgrad: dy bf16 (pixel stride lddy, a multiple of 8; Cout a multiple of 16) -> dx fp32 [N,Hi,Wi,Cin] (3x3/s1 and 4x4/s2 filters)
+ *   wgrad: x fp32, dy bf16 (pixel stride a multiple of 4) -> dw fp32 HWIO; workspace = kpx_conv2d_wgrad_workspace_bytes */
+int kpx_conv_image_fwd_bf16(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW, const float* bias,
+                            void* y, int Ho, int Wo, int Cout, int ldy, int stride, int pad_t, int pad_l, int act, void* stream);
+int kpx_conv_image_dgrad_bf16(const void* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
+                              float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, void* stream);
+int kpx_conv_image_wgrad_bf16(const float* x, int N, int Hi, int Wi, int Cin, int ldx, const void* dy, int Ho, int Wo, int Cout, int lddy,
+                              float* dw, int KH, int KW, int stride, int pad_t, int pad_l, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Weight gradient of a 3x3 stride-1 SAME layer in the bf16 configuration (gradient of layers.py:6-9): x bf16 [N,H,W,>=Cin] (pixel stride ldx;
  * the pad channels up to the next multiple of 8 must hold finite values), dy bf16 [N,H,W,>=Cout], dw fp32 HWIO [3,3,Cin,Cout], written.
  * W a multiple of 16; workspace = kpx_conv3x3_wgrad_bf16_workspace_bytes (partial slabs of the pixel splits, summed in fixed order). */
@@ -392,7 +405,8 @@ int kpx_conv3x3_wgrad_bf16(const void* x, int N, int H, int W, int Cin, int ldx,
 /* ---- bf16 STORAGE variants of the streaming kernels (BASELINE configs[2]): bf16 tensors in HBM, fp32 arithmetic, fp64 reductions, fp32
  *      statistics / parameter gradients.  C and the pixel strides (in ELEMENTS) are multiples of 8, pointers 16-byte aligned, unless an
  *      entry says otherwise.  Reference call sites as the fp32 entries of the same name above. */
-/* dst[p][0:C] = src[p][0:C] with conversion: kind 0 = f32 -> bf16, 1 = bf16 -> f32, 2 = bf16 -> bf16 (tf.concat channel slices); any C. */
+/* dst[p][0:C] = src[p][0:C] with conversion: kind 0 = f32 -> bf16, 1 = bf16 -> f32, 2 = bf16 -> bf16 (tf.concat channel slices); any C.
+ * kind 3 = f32 -> bf16 into a contiguous 8-channel tensor (lddst = 8, C <= 8) whose channels C .. 7 are written as zeros. */
 int kpx_cast_channels(const void* src, int ldsrc, void* dst, int lddst, size_t P, int C, int kind, void* stream);
 int kpx_chan_sum_bf16(const void* x, size_t P, int C, int ldx, float* sum_out, void* scratch, void* stream);
 /* layers.batch_norm, train mode, all weight-sharing groups in one launch per phase (kpx_bn_train_fwd_f32 / _bwd_f32): x bf16, y bf16

@@ -8,6 +8,10 @@ import csv
 import sys
 
 FAMILIES = [
+    ('bf16-storage 3x3 conv fwd/dgrad (conv3x3_bf16s)', ('conv3x3_bf16s_kernel',)),
+    ('bf16 3x3 weight gradient (conv3x3_wgrad_bf16 + slab reduce)', ('conv3x3_wgrad_bf16_kernel', 'wgrad16_reduce_kernel')),
+    ('bf16 filter preparation', ('conv_bf16s_prepare',)),
+    ('bf16 <-> fp32 conversions / bf16 channel copies', ('cast_channels_kernel',)),
     ('F(4x4,3x3) Winograd fwd/dgrad', ('conv_wino43_kernel',)),
     ('F(2x2,3x3) Winograd fwd/dgrad', ('conv_wino_v2_kernel',)),
     ('Winograd weight gradient', ('conv_wino_wgrad_kernel',)),
@@ -17,8 +21,8 @@ FAMILIES = [
     ('fp32-MFMA direct weight gradients', ('conv_wgrad_kernel', 'conv_wgrad_rows', 'conv_wgrad_tap_rows', 'conv_wgrad_rows_merged', 'conv_c16_wgrad', 'wgrad_small')),
     ('split-K / weight-gradient slab reductions', ('wgrad_reduce_kernel', 'splitk_reduce_kernel')),
     ('16-cout / image-input conv kernels', ('conv3x3_c16_kernel', 'conv_rgb', 'conv_few')),
-    ('batch norm', ('bn_', 'chan_reduce_kernel<1', 'chan_reduce_kernel<2')),
-    ('bias gradients (channel sums)', ('chan_reduce_kernel<0', 'chan_sum_finalize')),
+    ('batch norm', ('bn_', 'chan_reduce_kernel<1', 'chan_reduce_kernel<2', 'chan_reduce_bf16_kernel<1', 'chan_reduce_bf16_kernel<2')),
+    ('bias gradients (channel sums)', ('chan_reduce_kernel<0', 'chan_reduce_bf16_kernel<0', 'chan_sum_finalize')),
     ('Winograd filter transforms', ('filter_transform',)),
     ('key-point head / heat-map render', ('kp_', 'gauss_')),
     ('VGG19 pointwise (prep, pool, feature gradient, L1)', ('vgg_', 'maxpool2', 'l1_pair')),

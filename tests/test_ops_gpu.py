@@ -657,6 +657,79 @@ def test_bf16_storage_conv_reads_a_channel_slice_gates_by_a_mask_and_writes_a_st
 BF16_GATHER_CASES = [(4, 33, 64, 128, 4, 2, 1, 2), (4, 18, 256, 512, 4, 2, 1, 2), (2, 32, 32, 64, 3, 2, 0, 0), (8, 6, 1024, 2048, 4, 2, 1, 2), (2, 64, 64, 128, 3, 2, 0, 0)]
 
 
+BF16_IMAGE_CASES = [(2, 128, 3, 32, 7, 1, 0, 0, False), (8, 128, 3, 64, 4, 2, 1, 2, True), (2, 128, 3, 64, 3, 1, 0, 1, True)]
+
+
+@pytest.mark.parametrize('n,h,cin,cout,k,s,pad,act,xgrad', BF16_IMAGE_CASES)
+def test_bf16_storage_image_input_layers_read_fp32_images_and_exchange_bf16(kpx, dev, n, h, cin, cout, k, s, pad, act, xgrad):
+    """pose_encoder conv_1 (7x7x3 -> 32), img_discriminator conv_0 (4x4/s2, 3 -> 64) and a VGG19 conv1_1-shaped layer in the bf16
+    configuration: the image stays fp32, the produced tensor and the incoming gradient are bf16 (kpx_conv_image_{fwd,dgrad,wgrad}_bf16: the
+    LDS-resident image kernels with a bf16 store / load) -- against the oracle: outputs at the storage bound, the fp32 image and parameter
+    gradients at the fp32 bar, and no detour through an fp32 kernel (the 3x3 layer's filter is a constant in the model: its weight gradient
+    is the one allowed detour)."""
+    ops = kpx.ops
+    ops.set_compute_dtype('bf16')
+    try:
+        for key in ops.fallback_uses:
+            ops.fallback_uses[key] = 0
+        g = torch.Generator().manual_seed(k * 100 + cout)
+        x = torch.randn(n, h, h, cin, generator=g)
+        w = torch.randn(k, k, cin, cout, generator=g) / (k * k * cin) ** 0.5
+        b = torch.randn(cout, generator=g)
+        xg = x.to(dev).requires_grad_(xgrad); wg = w.to(dev).requires_grad_(True); bg = b.to(dev).requires_grad_(True)
+        y = ops.conv2d(xg, wg, bg, stride=s, pad=pad, act=act)
+        assert y.dtype == torch.bfloat16
+        gy = torch.randn(*y.shape, generator=g).bfloat16()
+        y.backward(gy.to(dev))
+        ops.join_side_stream()
+        assert ops.fallback_uses == {'conv_fwd': 0, 'conv_dgrad': 0, 'conv_wgrad': 1 if k == 3 else 0, 'other': 0}, ops.fallback_uses
+    finally:
+        ops.set_compute_dtype('f32')
+    xo = x.clone().requires_grad_(xgrad); wo = w.clone().requires_grad_(True); bo = b.clone().requires_grad_(True)
+    zo = R.conv(xo, wo, bo, s, pad)
+    yo = torch.relu(zo) if act == 1 else torch.nn.functional.leaky_relu(zo, 0.01) if act == 2 else zo
+    yk = y.detach().float().cpu()
+    fac = torch.where(yk > 0, torch.tensor(1.0), torch.tensor(0.01 if act == 2 else 0.0)) if act else torch.ones_like(zo)
+    zo.backward((gy.float() * fac).bfloat16().float() if act else gy.float())          # (the HIP path stores the gated gradient as bf16 too)
+    assert rel_l2(t2n(y.float()), t2n(yo.detach().bfloat16().float())) < 1e-3           # fp32 arithmetic, ONE rounding at the store (boundary ties aside)
+    if xgrad:
+        assert xg.grad.dtype == torch.float32
+        assert rel_l2(t2n(xg.grad), t2n(xo.grad)) < 1e-5
+    assert rel_l2(t2n(wg.grad), t2n(wo.grad)) < 1e-5
+    assert rel_l2(t2n(bg.grad), t2n(bo.grad)) < 1e-5
+
+
+def test_bf16_storage_four_channel_head_takes_its_fp32_gradient_through_the_bf16_kernels(kpx, dev):
+    """The translator's head (3x3, 64 -> 4, fp32 output feeding the mask / crude image): its fp32 gradient is cast into a zero-padded
+    8-channel bf16 operand (kpx_cast_channels kind 3) and both gradients run on the bf16 3x3 kernels -- no fp32 detour."""
+    ops = kpx.ops
+    n, h, cin, cout = 2, 64, 64, 4
+    ops.set_compute_dtype('bf16')
+    try:
+        for key in ops.fallback_uses:
+            ops.fallback_uses[key] = 0
+        g = torch.Generator().manual_seed(64004)
+        x = torch.randn(n, h, h, cin, generator=g).bfloat16()
+        w = (torch.randn(3, 3, cin, cout, generator=g) / (9 * cin) ** 0.5).bfloat16().float()
+        b = torch.randn(cout, generator=g)
+        xg = x.to(dev).requires_grad_(True); wg = w.to(dev).requires_grad_(True); bg = b.to(dev).requires_grad_(True)
+        y = ops.conv2d(xg, wg, bg, stride=1, pad=0, act=0, out_dtype=torch.float32)
+        assert y.dtype == torch.float32
+        gy = torch.randn(*y.shape, generator=g).bfloat16().float()
+        y.backward(gy.to(dev))
+        ops.join_side_stream()
+        assert sum(ops.fallback_uses.values()) == 0, ops.fallback_uses
+    finally:
+        ops.set_compute_dtype('f32')
+    xo = x.float().requires_grad_(True); wo = w.clone().requires_grad_(True); bo = b.clone().requires_grad_(True)
+    yo = R.conv(xo, wo, bo, 1, 0)
+    yo.backward(gy)
+    assert rel_l2(t2n(y), t2n(yo.detach())) < 1e-5
+    assert rel_l2(t2n(xg.grad.float()), t2n(xo.grad.bfloat16().float())) < 4e-3
+    assert rel_l2(t2n(wg.grad), t2n(wo.grad)) < 1e-5
+    assert rel_l2(t2n(bg.grad), t2n(bo.grad)) < 1e-5
+
+
 @pytest.mark.parametrize('n,h,cin,cout,k,s,pad,act', BF16_GATHER_CASES)
 def test_bf16_storage_strided_layers_through_autograd(kpx, dev, n, h, cin, cout, k, s, pad, act):
     """The discriminator's 4x4 stride-2 layers and the encoders' stride-2 layers on bf16 tensors (kpx_conv2d_{fwd,dgrad,wgrad}_bf16: the

@@ -73,6 +73,9 @@ SIGNATURES = {
     'kpx_conv2d_fwd_bf16': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'kpx_conv2d_dgrad_bf16': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_size_t, P]),
     'kpx_conv2d_wgrad_bf16': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    'kpx_conv_image_fwd_bf16': (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'kpx_conv_image_dgrad_bf16': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'kpx_conv_image_wgrad_bf16': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     'kpx_conv3x3_wgrad_bf16_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P]),
     'kpx_conv3x3_wgrad_bf16_workspace_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     'kpx_conv3x3_wgrad_bf16': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, P, P, c_size_t, P]),

@@ -519,9 +519,9 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wino_conv3x3(const floa
 // conv_rgb.hip: LDS-resident first-layer kernel (Cin <= 4, stride 1)
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW,
                                                                   const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
-                                                                  int stride, int pad_t, int pad_l, int act, hipStream_t s);
+                                                                  int stride, int pad_t, int pad_l, int act, hipStream_t s, int y16 = 0);
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
-                                                                    float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, hipStream_t s);
+                                                                    float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, hipStream_t s, int dy16 = 0);
 extern "C" int kpx_conv3x3_c16_eligible(int N, int H, int W, int K, int Nn, int ldin, int ldout, const void* in_ptr);
 extern "C" int kpx_conv3x3_c16_f32(const float* in, int N, int H, int W, int K, int ldin, const float* w_hwio, int dgrad, const float* bias,
                                    float* out, int ldout, int act, float* tile_stats, void* stream);
@@ -531,7 +531,7 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_few_fwd(const floa
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad_splits(int N, int H, int W, int Cin, int Cout);
 extern "C" __attribute__((visibility("hidden"))) int kpx_wsmall_splits(int N, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride);
 extern "C" __attribute__((visibility("hidden"))) int kpx_wsmall_launch(const float* x, int N, int Hi, int Wi, int Cin, int ldx, const float* dy, int Ho, int Wo, int Cout, int lddy,
-                                                                   int KH, int KW, int stride, int pad_t, int pad_l, float* slabs, int S, hipStream_t s);
+                                                                   int KH, int KW, int stride, int pad_t, int pad_l, float* slabs, int S, hipStream_t s, int dy16 = 0);
 extern "C" __attribute__((visibility("hidden"))) int kpx_wino_wgrad3x3(const float* x, int N, int H, int W, int Cin, int ldx, const float* dy, int Cout, int lddy,
                                                                    float* slabs, int S, hipStream_t s);
 static inline size_t wino_ws_bytes(int Cin, int Cout) {          // U[16][K padded to 8][Nn padded to 32] for either direction
@@ -643,6 +643,44 @@ extern "C" int kpx_conv2d_dgrad_act_f32(const float* dy, int N, int Ho, int Wo, 
     if (!y_in || ld_y_in < Cin || (act_in != KPX_ACT_RELU && act_in != KPX_ACT_LRELU)) return KPX_EINVAL;
     return dgrad_impl(dy, N, Ho, Wo, Cout, lddy, w, KH, KW, dx, Hi, Wi, Cin, lddx, stride, pad_t, pad_l, arith, y_in, ld_y_in, act_in,
                       workspace, workspace_bytes, stream);
+}
+
+static inline void launch_wgrad_reduce(const float* ws, float* dw, size_t n, int S, hipStream_t s);
+// bf16 configuration, image-input layers (the images stay fp32; what the layer produces / receives is bf16).  KPX_EINVAL for shapes the
+// LDS-resident image kernels (conv_rgb.hip, conv_wsmall.hip) do not take: the caller then converts and uses the fp32 entries.
+//   forward:  x fp32 [N, Hi, Wi, Cin <= 4] contiguous -> y bf16 (pixel stride ldy elements)
+extern "C" int kpx_conv_image_fwd_bf16(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW, const float* bias,
+                                       void* y, int Ho, int Wo, int Cout, int ldy, int stride, int pad_t, int pad_l, int act, void* stream) {
+    if (!x || !w || !y || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cin > 4 || Cout <= 0 || Cout > 64 || Ho * Wo < 256 || stride < 1 || stride > 2 ||
+        ldy < Cout || act < 0 || act > 3)
+        return KPX_EINVAL;
+    const int rc = kpx_conv_rgb_fwd(x, N, Hi, Wi, Cin, w, KH, KW, bias, (float*)y, Ho, Wo, Cout, ldy, stride, pad_t, pad_l, act, kpx_stream(stream), 1);
+    return rc == -2 ? KPX_EINVAL : rc;
+}
+//   data gradient:  dy bf16 (pixel stride lddy elements, a multiple of 8) -> dx fp32 [N, Hi, Wi, Cin] (pixel stride lddx)
+extern "C" int kpx_conv_image_dgrad_bf16(const void* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
+                                         float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, void* stream) {
+    if (!dy || !w || !dx || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cin > 4 || Cout <= 0 || Ho <= 0 || Wo <= 0 || lddy < Cout || lddx < Cin)
+        return KPX_EINVAL;
+    const int rc = kpx_conv_rgb_dgrad((const float*)dy, N, Ho, Wo, Cout, lddy, w, KH, KW, dx, Hi, Wi, Cin, lddx, stride, pad_t, pad_l, kpx_stream(stream), 1);
+    return rc == -2 ? KPX_EINVAL : rc;
+}
+//   weight gradient:  x fp32 image, dy bf16 (pixel stride lddy elements, a multiple of 4) -> dw fp32 [KH, KW, Cin, Cout]
+//   (workspace: kpx_conv2d_wgrad_workspace_bytes)
+extern "C" int kpx_conv_image_wgrad_bf16(const float* x, int N, int Hi, int Wi, int Cin, int ldx, const void* dy, int Ho, int Wo, int Cout, int lddy,
+                                         float* dw, int KH, int KW, int stride, int pad_t, int pad_l, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!x || !dy || !dw || N <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cin > 4 || Cout <= 0 || Ho <= 0 || Wo <= 0 || ldx < Cin || lddy < Cout)
+        return KPX_EINVAL;
+    const bool off32_ok = (size_t)N * Hi * Wi * (size_t)ldx * 4 < 0x60000000ull && (size_t)N * Ho * Wo * (size_t)lddy * 4 < 0x60000000ull;
+    if (!off32_ok || Cout % 4 || lddy % 4 || !aligned16(dy)) return KPX_EINVAL;
+    const int Ss = kpx_wsmall_splits(N, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride);
+    const size_t slab = (size_t)KH * KW * Cin * Cout;
+    if (Ss < 1 || (Ss > 1 && (!workspace || workspace_bytes < (size_t)Ss * slab * 4))) return KPX_EINVAL;
+    hipStream_t s = kpx_stream(stream);
+    int rc = kpx_wsmall_launch(x, N, Hi, Wi, Cin, ldx, (const float*)dy, Ho, Wo, Cout, lddy, KH, KW, stride, pad_t, pad_l, Ss > 1 ? (float*)workspace : dw, Ss, s, 1);
+    if (rc) return rc;
+    if (Ss > 1) { launch_wgrad_reduce((const float*)workspace, dw, slab, Ss, s); rc = kpx_launch_status(); }
+    return rc;
 }
 
 // bf16 configuration: dy bf16, dx bf16 (dx_f32 = 0) or fp32 (the gradient towards an fp32 tensor); y_in (optional, with act_in): the bf16

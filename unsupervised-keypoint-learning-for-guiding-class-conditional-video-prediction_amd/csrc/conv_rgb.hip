@@ -11,6 +11,7 @@ struct RgbGeom {
     const float* x; const float* w; const float* bias; float* y;
     int N, Hi, Wi, Cin, Ho, Wo, Cout, ldy;
     int KH, KW, pad_t, pad_l, act, stride;
+    int y16;                         // bf16 configuration: y is a bf16 tensor (ldy in elements)
     int tiles_y, tiles_x, total_tiles, tpb;
     int PH, PWC, KWC, KWCp;          // patch rows, floats per patch row (+ slack), floats per filter row, padded to even
 };
@@ -94,7 +95,9 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const RgbGeom g) {
         }
         // ---- epilogue: accumulator register r of M-tile mt is output row 2 * (2 * wave + mt) + (r >> 3), column ((r >> 2) & 1) * 8 + 4 * lh + (r & 3)
         const bool full = oy0 + 16 <= g.Ho && ox0 + 16 <= g.Wo;            // tile-uniform
-        float* const ybase = g.y + (((size_t)n * g.Ho + oy0 + 4 * wave) * g.Wo + ox0 + 4 * lh) * g.ldy + li;
+        const size_t ybase_off = (((size_t)n * g.Ho + oy0 + 4 * wave) * g.Wo + ox0 + 4 * lh) * g.ldy + li;
+        float* const ybase = g.y + ybase_off;
+        unsigned short* const ybase16 = reinterpret_cast<unsigned short*>(g.y) + ybase_off;
         const size_t rstep = (size_t)g.Wo * g.ldy;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -107,8 +110,10 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const RgbGeom g) {
                     float v = acc[mt][nt][r] + bv[nt];
                     if (g.act == KPX_ACT_TANH) v = tanhf(v);
                     else { v = fmaxf(v, lo); v = v > 0.f ? v : v * slope; }
-                    if (full || (oy0 + 4 * wave + row < g.Ho && ox0 + 4 * lh + col < g.Wo))
-                        ybase[row * rstep + (size_t)col * g.ldy + nt * 32] = v;
+                    if (full || (oy0 + 4 * wave + row < g.Ho && ox0 + 4 * lh + col < g.Wo)) {
+                        if (g.y16) { const __bf16 hb = (__bf16)v; ybase16[row * rstep + (size_t)col * g.ldy + nt * 32] = __builtin_bit_cast(unsigned short, hb); }
+                        else ybase[row * rstep + (size_t)col * g.ldy + nt * 32] = v;
+                    }
                 }
         }
     }
@@ -119,10 +124,10 @@ static std::atomic<unsigned long long> rgb_attr_mask{0};
 // stride-1 / stride-2 convolutions of a dense (ldx == Cin) image with Cin <= 4 and Cout <= 64; returns -2 when the shape is not handled
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const float* x, int N, int Hi, int Wi, int Cin, const float* w, int KH, int KW,
                                                                   const float* bias, float* y, int Ho, int Wo, int Cout, int ldy,
-                                                                  int stride, int pad_t, int pad_l, int act, hipStream_t s) {
+                                                                  int stride, int pad_t, int pad_l, int act, hipStream_t s, int y16) {
     if (Cin > 4 || Cout > 64 || KH > 7 || KW > 7 || stride < 1 || stride > 2) return -2;
     RgbGeom g{};
-    g.x = x; g.w = w; g.bias = bias; g.y = y;
+    g.x = x; g.w = w; g.bias = bias; g.y = y; g.y16 = y16;
     g.N = N; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.ldy = ldy;
     g.KH = KH; g.KW = KW; g.pad_t = pad_t; g.pad_l = pad_l; g.act = act; g.stride = stride;
     g.tiles_y = (Ho + 15) / 16; g.tiles_x = (Wo + 15) / 16;
@@ -163,6 +168,7 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const floa
 struct RgbDgradGeom {
     const float* dy; const float* w; float* dx; const float* bias;
     int N, Ho, Wo, Cout, lddy, Hi, Wi, Cin, lddx, pad_t, pad_l, tiles_y, tiles_x, act;
+    int dy16;                        // bf16 configuration: the gathered tensor (dy, or x of the few-channel forward) is bf16 (lddy in elements)
 };
 
 template <int KS, int S, int CIN, bool FWD>
@@ -193,8 +199,14 @@ __global__ __launch_bounds__(256) void conv_rgb_dgrad_kernel(const RgbDgradGeom 
             const int px = i >> 2, q = i & 3, pr = px / PR, pc = px - pr * PR;
             const int oy = oy_min + pr, ox = ox_min + pc;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)oy < (unsigned)g.Ho && (unsigned)ox < (unsigned)g.Wo)
-                v = *reinterpret_cast<const f32x4*>(g.dy + (((size_t)n * g.Ho + oy) * g.Wo + ox) * g.lddy + c0 + 4 * q);
+            if ((unsigned)oy < (unsigned)g.Ho && (unsigned)ox < (unsigned)g.Wo) {
+                const size_t off = (((size_t)n * g.Ho + oy) * g.Wo + ox) * g.lddy + c0 + 4 * q;
+                if (g.dy16) {
+                    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+                    const u32x2_t h = *reinterpret_cast<const u32x2_t*>(reinterpret_cast<const unsigned short*>(g.dy) + off);
+                    v = f32x4{__builtin_bit_cast(float, h[0] << 16), __builtin_bit_cast(float, h[0] & 0xffff0000u), __builtin_bit_cast(float, h[1] << 16), __builtin_bit_cast(float, h[1] & 0xffff0000u)};
+                } else v = *reinterpret_cast<const f32x4*>(g.dy + off);
+            }
             *reinterpret_cast<f32x4*>(&patch[px * PS + 4 * q]) = v;
         }
         __syncthreads();
@@ -250,14 +262,14 @@ __global__ __launch_bounds__(256) void conv_rgb_dgrad_kernel(const RgbDgradGeom 
 
 // 3x3 stride-1 and 4x4 stride-2 data gradients towards Cin <= 4 channels, Cout a multiple of 16; returns -2 when the shape is not handled
 extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_dgrad(const float* dy, int N, int Ho, int Wo, int Cout, int lddy, const float* w, int KH, int KW,
-                                                                    float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, hipStream_t s) {
+                                                                    float* dx, int Hi, int Wi, int Cin, int lddx, int stride, int pad_t, int pad_l, hipStream_t s, int dy16) {
     const bool k3 = KH == 3 && KW == 3 && stride == 1, k4 = KH == 4 && KW == 4 && stride == 2;
-    if (!(k3 || k4) || (Cin != 3 && Cin != 4) || Cout % 16 || lddy % 4 || (((uintptr_t)dy) & 15) || (((uintptr_t)w) & 15) || pad_t < 0 || pad_l < 0 ||
+    if (!(k3 || k4) || (Cin != 3 && Cin != 4) || Cout % 16 || lddy % (dy16 ? 8 : 4) || (((uintptr_t)dy) & 15) || (((uintptr_t)w) & 15) || pad_t < 0 || pad_l < 0 ||
         pad_t >= KH || pad_l >= KW)
         return -2;
     // every input pixel's taps must land inside the 18-pixel patch: true for Ho = ceil-type SAME / explicit pads of this path (checked per launch)
     RgbDgradGeom g{};
-    g.dy = dy; g.w = w; g.dx = dx;
+    g.dy = dy; g.w = w; g.dx = dx; g.dy16 = dy16;
     g.N = N; g.Ho = Ho; g.Wo = Wo; g.Cout = Cout; g.lddy = lddy; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.lddx = lddx; g.pad_t = pad_t; g.pad_l = pad_l;
     const int TI = 16 * stride;
     g.tiles_y = (Hi + TI - 1) / TI; g.tiles_x = (Wi + TI - 1) / TI;

@@ -20,6 +20,7 @@ struct WsmallGeom {
     const float* x; const float* dy; float* out;
     int N, Hi, Wi, ldx, Ho, Wo, Cout, lddy;
     int KH, KW, stride, pad_t, pad_l;
+    int dy16;                   // bf16 configuration: dy is a bf16 tensor (lddy in elements), x stays fp32 (the image-input layers)
     int TH, TW;                 // output tile (TW a multiple of 4)
     int tiles_y, tiles_x, total_tiles, tpb;
     int in_rows, in_cols;       // staged patch
@@ -125,8 +126,13 @@ __global__ __launch_bounds__(WAVES * 64) void conv_wgrad_small_kernel(const Wsma
         for (int i = 0; i < DU; ++i) {
             const int oy = oy0 + (drc[i] >> 16), ox = ox0 + (drc[i] & 0xffff);
             const int vo = (oy < g.Ho && ox < g.Wo) ? dvo[i] : WS_OOB;
-            if constexpr (VD) dv[i] = __builtin_bit_cast(dunit, __builtin_amdgcn_raw_buffer_load_b128(rsd, vo, sd, 0));
-            else dv[i] = __builtin_bit_cast(dunit, __builtin_amdgcn_raw_buffer_load_b32(rsd, vo, sd, 0));
+            if constexpr (VD) {
+                if (g.dy16) {                                  // four bf16 channels = 8 bytes: two dword loads (raw_buffer_load_b64 is mis-lowered), widened
+                    const int v2 = vo == WS_OOB ? WS_OOB : vo >> 1;
+                    const unsigned lo = __builtin_amdgcn_raw_buffer_load_b32(rsd, v2, sd >> 1, 0), hi = __builtin_amdgcn_raw_buffer_load_b32(rsd, v2 == WS_OOB ? WS_OOB : v2 + 4, sd >> 1, 0);
+                    dv[i] = wf32x4{__builtin_bit_cast(float, lo << 16), __builtin_bit_cast(float, lo & 0xffff0000u), __builtin_bit_cast(float, hi << 16), __builtin_bit_cast(float, hi & 0xffff0000u)};
+                } else dv[i] = __builtin_bit_cast(dunit, __builtin_amdgcn_raw_buffer_load_b128(rsd, vo, sd, 0));
+            } else dv[i] = __builtin_bit_cast(dunit, __builtin_amdgcn_raw_buffer_load_b32(rsd, vo, sd, 0));
         }
         if (++ctx == g.tiles_x) { ctx = 0; if (++cty == g.tiles_y) { cty = 0; ++cn; } }
     };
@@ -239,13 +245,13 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_wsmall_splits(int N, in
 }
 
 extern "C" __attribute__((visibility("hidden"))) int kpx_wsmall_launch(const float* x, int N, int Hi, int Wi, int Cin, int ldx, const float* dy, int Ho, int Wo, int Cout, int lddy,
-                                                                   int KH, int KW, int stride, int pad_t, int pad_l, float* slabs, int S, hipStream_t s) {
+                                                                   int KH, int KW, int stride, int pad_t, int pad_l, float* slabs, int S, hipStream_t s, int dy16) {
     static std::atomic<unsigned long long> attr_mask{0};
     const int variant = wsmall_variant(Cin, Cout, KH, KW, stride);
     if (!variant) return KPX_EINVAL;
     WsmallGeom g{}; int lds, threads;
     wsmall_geom(variant, N, Hi, Wi, ldx, Ho, Wo, Cout, lddy, KH, KW, stride, pad_t, pad_l, Cin, &g, &lds, &threads);
-    g.x = x; g.dy = dy; g.out = slabs;
+    g.x = x; g.dy = dy; g.out = slabs; g.dy16 = dy16;
     g.tpb = (g.total_tiles + S - 1) / S;
 #define WS_K1 conv_wgrad_small_kernel<16, 3, 1, 64, 3, 1, 3, 9, 6, true, true>
 #define WS_K2 conv_wgrad_small_kernel<3, 7, 1, 64, 2, 2, 5, 6, 4, false, true>

@@ -1144,10 +1144,26 @@ __global__ __launch_bounds__(256) void cast_channels_kernel(const TS* __restrict
         if (sizeof(TD) == 2) reinterpret_cast<bf16_t*>(dst)[p * ldd + c] = pw_to_bf(v); else reinterpret_cast<float*>(dst)[p * ldd + c] = v;
     }
 }
-// kind: 0 = f32 -> bf16, 1 = bf16 -> f32, 2 = bf16 -> bf16 (channel-slice copy: tf.concat)
+// few fp32 channels (C <= 8) into a contiguous 8-channel bf16 tensor, the channels C .. 7 written as zeros: one 16-byte store per pixel
+__global__ __launch_bounds__(256) void cast_pad8_kernel(const float* __restrict__ src, int lds_, bf16_t* __restrict__ dst, size_t P, int C) {
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < P; p += (size_t)gridDim.x * 256) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = j < C ? src[p * lds_ + j] : 0.f;
+        pw_st8(dst + p * 8, v);
+    }
+}
+// kind: 0 = f32 -> bf16, 1 = bf16 -> f32, 2 = bf16 -> bf16 (channel-slice copy: tf.concat),
+//       3 = f32 -> bf16 with the destination's channels C .. 7 zeroed (C <= 8, lddst = 8: the 4-channel gradient of the translator's head as an
+//           operand of the bf16 3x3 kernels, which gather whole 8-channel groups)
 extern "C" int kpx_cast_channels(const void* src, int ldsrc, void* dst, int lddst, size_t P, int C, int kind, void* stream) {
-    if (!src || !dst || C <= 0 || ldsrc < C || lddst < C || kind < 0 || kind > 2) return KPX_EINVAL;
+    if (!src || !dst || C <= 0 || ldsrc < C || lddst < C || kind < 0 || kind > 3) return KPX_EINVAL;
     if (P == 0) return 0;
+    if (kind == 3) {
+        if (C > 8 || lddst != 8 || (((uintptr_t)dst) & 15)) return KPX_EINVAL;
+        hipLaunchKernelGGL(cast_pad8_kernel, dim3(grid_for(P)), dim3(256), 0, kpx_stream(stream), (const float*)src, ldsrc, (bf16_t*)dst, P, C);
+        return kpx_launch_status();
+    }
     const int sa = kind == 0 ? 4 : 2, da = kind == 1 ? 4 : 2;
     const int vec = (C % 8 == 0) && (((size_t)ldsrc * sa) % 16 == 0) && (((size_t)lddst * da) % 16 == 0) && pw_al16(src, dst);
     const unsigned nb = grid_for(vec ? P * (C / 8) : P * C);

@@ -231,7 +231,7 @@ def _arith():
 
 
 def cast_channels_raw(src_ptr, ldsrc, dst_ptr, lddst, pixels, c, kind):
-    """dst[p][0:c] = src[p][0:c]; kind 0: f32 -> bf16, 1: bf16 -> f32, 2: bf16 -> bf16."""
+    """dst[p][0:c] = src[p][0:c]; kind 0: f32 -> bf16, 1: bf16 -> f32, 2: bf16 -> bf16, 3: f32 -> bf16 into 8 channels, c .. 7 zeroed."""
     check(lib.kpx_cast_channels(src_ptr, ldsrc, dst_ptr, lddst, pixels, c, kind, _stream()), 'kpx_cast_channels')
 
 
@@ -266,7 +266,11 @@ def _slice_f32(x, ldx, cin):
 def _bf16s_bnbwd(dy, lddy, k, w, dx, lddx, nn, bn_y, beta):
     """(slab, tiles per image) or False: data gradient + the backward sums of the batch norm whose ReLU'd output ``bn_y`` the convolution read."""
     n, h, wd = dy.shape[0], dy.shape[1], dy.shape[2]
-    if (bn_y.dtype != BF16 or not bn_y.is_contiguous() or bn_y.shape[3] != nn or nn % 8 or lddx % 8 or not (k % 32 == 0 or k in (8, 16))
+    if not (k % 32 == 0 or k in (8, 16)):
+        k = 8 if k < 8 else 16 if k < 16 else (k + 31) // 32 * 32            # (as _bf16s_conv: the prepared filters are zero there)
+        if lddy < k:
+            return False
+    if (bn_y.dtype != BF16 or not bn_y.is_contiguous() or bn_y.shape[3] != nn or nn % 8 or lddx % 8
             or not lib.kpx_conv3x3_bf16s_eligible(n, h, wd, k, nn, lddy, dy.data_ptr())):
         return False
     wf = _bf16s_prepared(w, True)
@@ -311,7 +315,7 @@ def _bf16s_conv(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, want_stats=
     # prepared filters are zero there, so the extra gathered channels (zero-filled / finite by the producer's contract) contribute nothing
     # and the extra produced channels come out as zeros
     if not (k % 32 == 0 or k in (8, 16)):
-        k = (k + 31) // 32 * 32
+        k = 8 if k < 8 else 16 if k < 16 else (k + 31) // 32 * 32
         if ld_in < k:
             return False
     g = 4 if out_f32 else 8
@@ -593,6 +597,13 @@ def conv_fwd_raw(x, ldx, cin, w, bias, y, ldy, stride, pad_t, pad_l, act, want_s
             r = _bf16s_conv(x, ldx, cin, w, bias, y, ldy, cout, act, False, want_stats=want_stats)
             if r:
                 return r if isinstance(r, tuple) else None
+        if x.dtype == torch.float32 and y.dtype == BF16 and cin <= 4 and ldx == cin:
+            # image-input layers: the LDS-resident image kernel writes bf16
+            rc = lib.kpx_conv_image_fwd_bf16(x.data_ptr(), n, hi, wi, cin, w.data_ptr(), kh, kw, bias.data_ptr() if bias is not None else None,
+                                             y.data_ptr(), y.shape[1], y.shape[2], cout, ldy, stride, pad_t, pad_l, act, _stream())
+            if rc != -1:
+                check(rc, 'kpx_conv_image_fwd_bf16')
+                return None
         if x.dtype == BF16 and act != ACT_TANH:
             # strided / 4x4 / 1x1 layers: the gather kernel of the bf16 matrix pipe on bf16 tensors
             nbytes = lib.kpx_conv2d_fwd_workspace_bytes(n, y.shape[1], y.shape[2], cin, cout, kh, kw)
@@ -658,6 +669,13 @@ def conv_dgrad_raw(dy, lddy, w, dx, lddx, cin, stride, pad_t, pad_l, bn_src=None
             if rc != -1:
                 check(rc, 'kpx_conv2d_dgrad_bf16')
                 return None
+        if dy.dtype == BF16 and dx.dtype == torch.float32 and cin <= 4 and mul is None:
+            # gradient towards an image: the image kernel reads the bf16 gradient
+            rc = lib.kpx_conv_image_dgrad_bf16(dy.data_ptr(), n, ho, wo, cout, lddy, w.data_ptr(), kh, kw, dx.data_ptr(), dx.shape[1], dx.shape[2], cin, lddx,
+                                               stride, pad_t, pad_l, _stream())
+            if rc != -1:
+                check(rc, 'kpx_conv_image_dgrad_bf16')
+                return None
         if dy.dtype == BF16:
             fallback_uses['conv_dgrad'] += 1
             dy, lddy = _slice_f32(dy, lddy, cout), cout
@@ -712,6 +730,15 @@ def conv_wgrad_raw(x, ldx, cin, dy, lddy, dw, stride, pad_t, pad_l):
                                        ws.data_ptr() if ws is not None else None, nbytes, _stream())
         if rc != -1:
             check(rc, 'kpx_conv2d_wgrad_bf16')
+            return
+    if x.dtype == torch.float32 and dy.dtype == BF16 and cin <= 4:
+        # image-input layers: fp32 image, bf16 gradient
+        nbytes = lib.kpx_conv2d_wgrad_workspace_bytes(n, ho, wo, cin, cout, kh, kw)
+        ws = scratch.get('wgrad', nbytes, x.device) if nbytes else None
+        rc = lib.kpx_conv_image_wgrad_bf16(x.data_ptr(), n, hi, wi, cin, ldx, dy.data_ptr(), ho, wo, cout, lddy, dw.data_ptr(), kh, kw, stride, pad_t, pad_l,
+                                           ws.data_ptr() if ws is not None else None, nbytes, _stream())
+        if rc != -1:
+            check(rc, 'kpx_conv_image_wgrad_bf16')
             return
     if x.dtype == BF16 or dy.dtype == BF16:
         fallback_uses['conv_wgrad'] += 1
@@ -832,6 +859,14 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         want_w = ctx.needs_input_grad[1]
         want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        dy_sum = dy
+        if (dy.dtype == torch.float32 and x.dtype == BF16 and cout < 8 and w.shape[0] == 3 and w.shape[1] == 3 and stride == 1
+                and ctx.input_act == ACT_NONE):
+            # the translator's 4-channel head: its fp32 gradient as a zero-padded 8-channel bf16 operand of the bf16 3x3 kernels
+            dy16 = torch.empty((dy.shape[0], dy.shape[1], dy.shape[2], 8), dtype=BF16, device=dy.device)
+            cast_channels_raw(dy.data_ptr(), cout, dy16.data_ptr(), 8, dy.shape[0] * dy.shape[1] * dy.shape[2], cout, 3)
+            dy = dy16
+        lddy = dy.shape[3]
         # side stream only when the gradient goes straight into the flat bucket (nobody on the main stream reads it
         # before join_side_stream())
         side = (SIDE_WGRAD and not _inline_wgrad[0] and (want_w or want_b) and (not want_w or ctx.w_grad_out is not None)
@@ -848,7 +883,7 @@ class Conv2dFn(torch.autograd.Function):
             dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
             if cin < cx:
                 fill_raw_(dx, 0.0)
-            st = conv_dgrad_raw(dy, cout, w, dx, cx, cin, stride, pad_t, pad_l,
+            st = conv_dgrad_raw(dy, lddy, w, dx, cx, cin, stride, pad_t, pad_l,
                                 bn_src=(x, ctx.bn_src[0]) if ctx.bn_src is not None else None,
                                 mul=(x, ctx.input_act) if ctx.input_act != ACT_NONE else None)
             if st is not None:
@@ -863,7 +898,7 @@ class Conv2dFn(torch.autograd.Function):
                 st.wait_event(fork)                      # dy (and x) were ready when the fork point was recorded
             else:
                 st.wait_stream(main)                     # ... or wait for everything enqueued so far, the data gradient included
-            _side_keep.append((dy, x))                   # keep the allocator from recycling them under the side kernels
+            _side_keep.append((dy, dy_sum, x))                   # keep the allocator from recycling them under the side kernels
             _side_dirty[skey] = True
             stream_ctx = torch.cuda.stream(st)
         else:
@@ -873,14 +908,14 @@ class Conv2dFn(torch.autograd.Function):
             if want_w:
                 direct = ctx.w_grad_out is not None and _claim_grad(ctx.w_grad_out)
                 dw_buf = ctx.w_grad_out if direct else torch.empty_like(w)
-                conv_wgrad_raw(x, ldx, cin, dy, cout, dw_buf, stride, pad_t, pad_l)
+                conv_wgrad_raw(x, ldx, cin, dy, lddy, dw_buf, stride, pad_t, pad_l)
                 if ctx.w_grad_out is not None and not direct:
                     axpy_raw_(ctx.w_grad_out, dw_buf)                 # second use of this variable in one backward
                 dw = None if ctx.w_grad_out is not None else dw_buf
             if want_b:
                 direct = ctx.b_grad_out is not None and _claim_grad(ctx.b_grad_out)
                 db_buf = ctx.b_grad_out if direct else torch.empty(cout, dtype=torch.float32, device=x.device)
-                chan_sum_raw(dy, cout, dy.shape[0] * dy.shape[1] * dy.shape[2], cout, db_buf)
+                chan_sum_raw(dy_sum, cout, dy.shape[0] * dy.shape[1] * dy.shape[2], cout, db_buf)
                 if ctx.b_grad_out is not None and not direct:
                     axpy_raw_(ctx.b_grad_out, db_buf)
                 db = None if ctx.b_grad_out is not None else db_buf
