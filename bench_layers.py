@@ -97,15 +97,11 @@ def main():
         ydt = torch.bfloat16 if (b16 and co > 4) else torch.float32            # the 4-channel head and D_logit stay fp32
         x = x.to(adt)
         w = torch.randn(k, k, ci, co, device=dev) * 0.05
-        if os.environ.get('KPX_BENCH_ZERO'):
-            x.zero_(); w.zero_()
         b = torch.zeros(co, device=dev)
         pt, _, ho = ops.same_pad(h + 2 * pad, k, s)
         pad_t = pad + pt
         y = torch.empty(n, ho, ho, co, dtype=ydt, device=dev)
         dy = torch.randn(n, ho, ho, co, device=dev).to(ydt)
-        if os.environ.get('KPX_BENCH_ZERO'):
-            dy.zero_()
         dx = torch.empty(n, h, h, ld, dtype=adt, device=dev)
         dw = torch.empty_like(w)
         flops = 2.0 * n * ho * ho * co * k * k * ci

@@ -71,7 +71,7 @@ for f in sorted(glob.glob(O + '/pmc_*/**/*counter_collection.csv', recursive=Tru
                     pmc[tag][r['Counter_Name']].append(float(r['Counter_Value']))
             continue
         for key, tag in (('conv_wino_wgrad_kernel<2, 2>', 'wgrad'), ('conv_wino43_kernel<0, false>', 'wino43'), ('conv_wino_v2_kernel<2, 0>', 'wino'), ('gauss_fwd', 'render'), ('conv_igemm_kernel<128, 128', 'direct'),
-                         ('conv_gemm3_kernel<128, 128, 2, 4, false, 3>', 'gemm3')):
+                         ('conv_gemm3_kernel<128, 128, 2, 4, false, 3,', 'gemm3')):
             if key in r['Kernel_Name']:
                 pmc[tag][r['Counter_Name']].append(float(r['Counter_Value']))
 mean = lambda v: sum(v) / len(v) if v else None
