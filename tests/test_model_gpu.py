@@ -997,8 +997,9 @@ def test_bf16_mode_forward_and_train_step_tolerance():
         model = make_model(res, k, b, dev, width_div=4)
         model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, 0, b)
         # only D_logit (2048 -> 1 over 6x6 logits): forward of both discriminator passes and its weight gradient; the image-input layers and
-        # the 4-channel head run on kernels that read / write bf16 directly
-        assert ops.fallback_uses == {'conv_fwd': 2, 'conv_dgrad': 0, 'conv_wgrad': 1, 'other': 0}, ops.fallback_uses
+        # the 4-channel head run on kernels that read / write bf16 directly -- except that at THIS batch (B=2) img_discr conv_0's weight gradient
+        # (4 x 64 x 64 = 16 384 output pixels) is below the tiny-filter kernel's launch threshold of 32 768 (1 at the bench batch: bench.py reports it)
+        assert ops.fallback_uses == {'conv_fwd': 2, 'conv_dgrad': 0, 'conv_wgrad': 2, 'other': 0}, ops.fallback_uses
         got = model.loss_values()
         fwd = model.last['fwd']
         kp_err = float(np.abs(fwd['current_points'].cpu().numpy() - want['current_points'].numpy()).max())
