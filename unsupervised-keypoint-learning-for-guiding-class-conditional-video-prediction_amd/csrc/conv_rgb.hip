@@ -21,7 +21,10 @@ struct RgbGeom {
 // speed: the first version spent 1 700-2 000 VALU per wavefront and tile (per-element index divisions while staging the filter and the patch,
 // 64 stores with their own bounds / address arithmetic) against 3 840-9 900 MFMA cycles -- PMC: matrix pipe busy 18-40 %.  Here the patch is
 // staged by rows (one division-free row per wavefront and trip), and the epilogue works from one base pointer with a tile-uniform fast path.
-template <int NT>
+// VEC (Cout a multiple of 8, 16-B aligned pixel rows): the MFMA roles are swapped -- A = filter value (rows = output channels), B = pixel value
+// (columns = pixels) -- so a lane holds 16 output channels of ONE pixel in groups of four consecutive ones and stores 16 bytes at a time (four
+// stores per 32 x 32 block instead of sixteen 4-byte ones; bf16 output: two, after a half-wave exchange as in conv_bf16s.hip).
+template <int NT, bool VEC>
 __global__ __launch_bounds__(256) void conv_rgb_kernel(const RgbGeom g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch = smem;                                   // [PH][PWC] (+4 zero floats)
@@ -44,6 +47,16 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const RgbGeom g) {
     float bv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bv[nt] = (g.bias && nt * 32 + li < g.Cout) ? g.bias[nt * 32 + li] : 0.f;
+    f32x4 bvv[VEC ? NT : 1][4];                           // VEC: bias of channels nt * 32 + 8 gq + 4 lh .. + 3
+    if (VEC) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int ch = nt * 32 + 8 * gq + 4 * lh;
+                bvv[nt][gq] = (g.bias && ch < g.Cout) ? *reinterpret_cast<const f32x4*>(g.bias + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
     const int rowlen = g.Wi * g.Cin;
     // lane's pixel inside M-tile mt: row 2*mt + li/16, column li%16
     const int a0 = g.stride * (2 * (2 * wave) + (li >> 4)) * g.PWC + g.stride * (li & 15) * g.Cin + lh;
@@ -88,13 +101,62 @@ __global__ __launch_bounds__(256) void conv_rgb_kernel(const RgbGeom g) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float vb = pb[2 * s * NC + nt * 32];
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, vb, acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, vb, acc[1][nt], 0, 0, 0);
+                    if (VEC) {
+                        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, va0, acc[0][nt], 0, 0, 0);
+                        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vb, va1, acc[1][nt], 0, 0, 0);
+                    } else {
+                        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, vb, acc[0][nt], 0, 0, 0);
+                        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, vb, acc[1][nt], 0, 0, 0);
+                    }
                 }
             }
         }
         // ---- epilogue: accumulator register r of M-tile mt is output row 2 * (2 * wave + mt) + (r >> 3), column ((r >> 2) & 1) * 8 + 4 * lh + (r & 3)
         const bool full = oy0 + 16 <= g.Ho && ox0 + 16 <= g.Wo;            // tile-uniform
+        if (VEC) {
+            // accumulator register e of (mt, nt): pixel = lane li of M-tile mt (row 4 wave + 2 mt + li / 16, column li % 16), channel
+            // nt * 32 + 8 (e >> 2) + 4 lh + (e & 3)
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int oy = oy0 + 4 * wave + 2 * mt + (li >> 4), ox = ox0 + (li & 15);
+                const bool ok = full || (oy < g.Ho && ox < g.Wo);
+                const size_t base = (((size_t)n * g.Ho + oy) * g.Wo + ox) * g.ldy;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float v[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float a = acc[mt][nt][e] + bvv[nt][e >> 2][e & 3];
+                        if (g.act == KPX_ACT_TANH) a = tanhf(a);
+                        else { a = fmaxf(a, lo); a = a > 0.f ? a : a * slope; }
+                        v[e] = a;
+                    }
+                    if (g.y16) {
+                        unsigned short* const yo = reinterpret_cast<unsigned short*>(g.y) + base;
+#pragma unroll
+                        for (int k = 0; k < 4; k += 2) {
+                            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                            auto pk = [](float p0, float p1) { const bf16x2_t h = {(__bf16)p0, (__bf16)p1}; return __builtin_bit_cast(unsigned, h); };
+                            const unsigned a0 = pk(v[4 * k], v[4 * k + 1]), a1 = pk(v[4 * k + 2], v[4 * k + 3]);
+                            const unsigned b0 = pk(v[4 * k + 4], v[4 * k + 5]), b1 = pk(v[4 * k + 6], v[4 * k + 7]);
+                            auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                            auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                            const int ch = nt * 32 + 8 * (k + lh);
+                            if (ok && ch < g.Cout) *reinterpret_cast<u32x4_t*>(yo + ch) = u32x4_t{r0[0], r1[0], r0[1], r1[1]};
+                        }
+                    } else {
+                        float* const yo = g.y + base;
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const int ch = nt * 32 + 8 * gq + 4 * lh;
+                            if (ok && ch < g.Cout) *reinterpret_cast<f32x4*>(yo + ch) = f32x4{v[4 * gq], v[4 * gq + 1], v[4 * gq + 2], v[4 * gq + 3]};
+                        }
+                    }
+                }
+            }
+            continue;
+        }
         const size_t ybase_off = (((size_t)n * g.Ho + oy0 + 4 * wave) * g.Wo + ox0 + 4 * lh) * g.ldy + li;
         float* const ybase = g.y + ybase_off;
         unsigned short* const ybase16 = reinterpret_cast<unsigned short*>(g.y) + ybase_off;
@@ -136,8 +198,10 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const floa
     const int nt = Cout <= 32 ? 1 : 2;
     const size_t lds = ((size_t)((g.PH * g.PWC + 4 + 3) & ~3) + (size_t)KH * g.KWCp * 32 * nt) * 4;
     if (kpx_first_use_on_device(&rgb_attr_mask)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rgb_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rgb_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rgb_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rgb_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rgb_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_rgb_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304);
         if (e != hipSuccess) return -(int)e;
     }
     if (lds > 98304) return -2;
@@ -147,8 +211,13 @@ extern "C" __attribute__((visibility("hidden"))) int kpx_conv_rgb_fwd(const floa
     int want = 256 * per_cu; if (want > g.total_tiles) want = g.total_tiles;
     g.tpb = (g.total_tiles + want - 1) / want;
     const unsigned blocks = (unsigned)((g.total_tiles + g.tpb - 1) / g.tpb);
-    if (nt == 1) hipLaunchKernelGGL(conv_rgb_kernel<1>, dim3(blocks), dim3(256), lds, s, g);
-    else hipLaunchKernelGGL(conv_rgb_kernel<2>, dim3(blocks), dim3(256), lds, s, g);
+    // 16-byte stores: whole 8-channel groups, aligned pixel rows (and a 16-B aligned bias: 4-channel groups are read as one)
+    const bool vec = Cout % 8 == 0 && ldy % 8 == 0 && ((((uintptr_t)y) | ((uintptr_t)bias)) & 15) == 0;
+    if (vec) {
+        if (nt == 1) hipLaunchKernelGGL((conv_rgb_kernel<1, true>), dim3(blocks), dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((conv_rgb_kernel<2, true>), dim3(blocks), dim3(256), lds, s, g);
+    } else if (nt == 1) hipLaunchKernelGGL((conv_rgb_kernel<1, false>), dim3(blocks), dim3(256), lds, s, g);
+    else hipLaunchKernelGGL((conv_rgb_kernel<2, false>), dim3(blocks), dim3(256), lds, s, g);
     return kpx_launch_status();
 }
 
