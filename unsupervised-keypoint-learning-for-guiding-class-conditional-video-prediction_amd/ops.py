@@ -300,7 +300,7 @@ def _bf16s_prepared(w, dgrad):
         check(lib.kpx_conv3x3_bf16s_prepare_f32(w.data_ptr(), cin, cout, 1 if dgrad else 0, wf.data_ptr(), _stream()), 'kpx_conv3x3_bf16s_prepare_f32')
         return wf
     if ent[1] is not None:
-        ent[1].ensure_fresh()
+        ent[1].ensure_fresh('bf16s')
     return ent[0]
 
 
@@ -448,13 +448,23 @@ class FilterBank:
         self.table16 = torch.frombuffer(bytearray(table), dtype=torch.uint8).to(self.device)
         self.n_desc16 = len(table) // 32
 
-    def ensure_fresh(self):
-        if (self.synced != self.version or getattr(self, 'synced_mode', None) != _compute_dtype[0]) and self.filters:
-            self.synced_mode = _compute_dtype[0]
-            if _compute_dtype[0] == 'bf16':
+    def ensure_fresh(self, form=None):
+        """Refresh the derived filter forms a convolution is about to read, if the filters changed since they were made.  form: 'wino' (the
+        Winograd forms of the fp32 kernels), 'bf16s' (the prepared bf16 fragments), None = the form the current configuration's kernels use
+        (the model calls this before it forks streams).  The other form stays stale until a kernel asks for it (an fp32 fall-back inside the bf16
+        configuration): a bf16 step does not pay for the Winograd transforms."""
+        if not self.filters:
+            return
+        if form is None:
+            form = 'bf16s' if _compute_dtype[0] == 'bf16' else 'wino'
+        if form == 'bf16s':
+            if getattr(self, 'synced16', -1) != self.version:
                 if getattr(self, 'table16', None) is None:
                     self._build_bf16s()
                 check(lib.kpx_conv3x3_bf16s_prepare_batch_f32(self.table16.data_ptr(), self.n_desc16, _stream()), 'kpx_conv3x3_bf16s_prepare_batch_f32')
+                self.synced16 = self.version
+            return
+        if self.synced != self.version:
             check(lib.kpx_wino_filter_transform_batch_f32(self.table.data_ptr(), self.n_desc, _stream()), 'kpx_wino_filter_transform_batch_f32')
             if self.n_desc43:
                 check(lib.kpx_wino43_filter_transform_batch_f32(self.table43.data_ptr(), self.n_desc43, _stream()), 'kpx_wino43_filter_transform_batch_f32')
@@ -512,7 +522,7 @@ def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, wa
         return False
     u, bank = ent[0], ent[1]
     if bank is not None:
-        bank.ensure_fresh()
+        bank.ensure_fresh('wino')
     bptr = bias.data_ptr() if bias is not None else None
     ent43 = _cached_u(_wino43_u, w, dgrad) if WINO43 else None
     tiles = lib.kpx_conv3x3_wino43_stats_tiles(n, h, wd) if want_stats else 1      # 0: no statistics from this kernel for the shape (16 x 16)
@@ -574,7 +584,7 @@ def conv3x3_wino43_ex(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, mask=
     if wgs43 <= WINO43_MIN_WORKGROUPS or not lib.kpx_conv3x3_wino43_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr()):
         return False
     if ent43[1] is not None:
-        ent43[1].ensure_fresh()
+        ent43[1].ensure_fresh('wino')
     rc = lib.kpx_conv3x3_wino43_ex_f32(inp.data_ptr(), n, h, wd, k, ld_in, ent43[0].data_ptr(), bias.data_ptr() if bias is not None else None,
                                        out.data_ptr(), nn, ld_out, act, mask.data_ptr() if mask is not None else None,
                                        mask.shape[3] if mask is not None else 0, pool_out.data_ptr() if pool_out is not None else None,
