@@ -38,6 +38,23 @@ struct W16Geom {
     size_t slab;                    // floats per slab = 9 * Cin * Cout
 };
 
+// One LDS-DMA instruction (16 B per lane to LDS address `lds` + 16 lane) issued from inline assembly: hipcc treats the transposed LDS reads
+// (an intrinsic without memory operands) as readers of everything an LDS-DMA it knows about may write and puts `s_waitcnt vmcnt(0)` in front
+// of the first read after a request -- the next stage's prefetch then completed before the current stage's first MFMA (found in the ISA of
+// round 5's first version).  The waits of this kernel are explicit (vmcnt(0) + barrier at the end of a stage), so the compiler need not know.
+typedef int w16_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ w16_i32x4 w16_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    w16_i32x4 r = {(int)(unsigned)a, (int)(unsigned)(a >> 32), (int)bytes, 0x00020000};
+    r[0] = __builtin_amdgcn_readfirstlane(r[0]); r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+    r[2] = __builtin_amdgcn_readfirstlane(r[2]); r[3] = __builtin_amdgcn_readfirstlane(r[3]);
+    return r;
+}
+__device__ __forceinline__ void w16_dma16(const w16_i32x4 rsrc, const void* lds, int voffset) {
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(lds_ptr_t)lds);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(l), "v"(voffset), "s"(rsrc) : "memory");       // (m0 is a reserved register to hipcc: it cannot be named as a clobber, and nothing else in this kernel uses it)
+}
+
 // XOR swizzle of the 64-B channel block `cb` of pixel q, for NBLK blocks per pixel (see the header)
 template <int NBLK>
 __device__ __forceinline__ int w16_swz(int cb, int q) { return NBLK == 4 ? (cb ^ (q & 3)) : NBLK == 2 ? (cb ^ ((q >> 1) & 1)) : cb; }
@@ -67,8 +84,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_kernel(const W16Geo
     const int cin8 = (g.Cin + 7) & ~7, cout8 = (g.Cout + 7) & ~7;
     const int t_beg = split * g.tps, t_end = min(g.tiles, t_beg + g.tps);
 
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.x), 0, (int)((size_t)g.N * g.H * g.W * g.ldx * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.dy), 0, (int)((size_t)g.N * g.H * g.W * g.lddy * 2), 0x00020000);
+    const w16_i32x4 rs_x = w16_rsrc(g.x, (unsigned)((size_t)g.N * g.H * g.W * g.ldx * 2));
+    const w16_i32x4 rs_y = w16_rsrc(g.dy, (unsigned)((size_t)g.N * g.H * g.W * g.lddy * 2));
 
     // ---- LDS-DMA pieces of this wavefront (piece = wave + 8 i): per lane the patch / tile position and the channel unit it fetches
     constexpr int XPW = 6, YPW = 9;                          // pieces per wavefront: host keeps XPIECES <= 48, YPIECES <= 72
@@ -100,13 +117,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_kernel(const W16Geo
             if (wave + 8 * i < XPIECES) {
                 const int iy = y0 - 1 + x_pr[i], ix = x0 - 1 + x_pc[i];
                 const bool ok = (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(Xs + buf * XBYTES + (wave + 8 * i) * 1024), 16, ok ? base_x + x_rel[i] : W16_OOB, 0, 0, 0);
+                w16_dma16(rs_x, Xs + buf * XBYTES + (wave + 8 * i) * 1024, ok ? base_x + x_rel[i] : W16_OOB);
             }
         }
 #pragma unroll
         for (int i = 0; i < YPW; ++i) {
             if (wave + 8 * i < YPIECES)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_y, (lds_ptr_t)(Ys + buf * YBYTES + (wave + 8 * i) * 1024), 16, y_rel[i] >= 0 ? base_y + y_rel[i] : W16_OOB, 0, 0, 0);
+                w16_dma16(rs_y, Ys + buf * YBYTES + (wave + 8 * i) * 1024, y_rel[i] >= 0 ? base_y + y_rel[i] : W16_OOB);
         }
     };
 
@@ -120,6 +137,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_kernel(const W16Geo
     const int rq = i16 >> 2, rp = i16 & 3;
     const int xch = (16 * g16 + 4 * rp) * 2, ych = xch;       // byte offset inside the 64-B channel block
     constexpr int XPB = 64 * AB, YPB = 64 * BB;                // bytes per pixel
+    // Every transposed read addresses pixel q = (multiple of 4) + rq: the patch / tile widths, the k-step columns and the lane's 8 lh + 4 n
+    // are multiples of 4, so the XOR swizzle of q is a constant of the lane, and an address is (lane constant) + (wave-uniform offset of the
+    // k-step) + (immediate of the read) -- one v_add per filter row and k-step instead of the index arithmetic of eleven reads.
+    const int swx = AB == 4 ? (ai ^ rq) : AB == 2 ? (ai ^ ((rq >> 1) & 1)) : ai;
+    const int swy = BB == 4 ? (bi ^ rq) : BB == 2 ? (bi ^ ((rq >> 1) & 1)) : bi;
+    const int x_lane = (8 * lh + rq) * XPB + swx * 64 + xch;
+    const int y_lane = (8 * lh + rq) * YPB + swy * 64 + ych;
+    const int rowstep = __builtin_amdgcn_readfirstlane(PWX * XPB);
 
     if (t_beg < t_end) {
         // zero the slack behind the patches once (reads past the last patch row's end must stay finite: they meet no accumulator, but NaN bits would)
@@ -136,31 +161,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_kernel(const W16Geo
         if (tile + 1 < t_end) issue(tile + 1, buf ^ 1);
         const unsigned char* const Xb = Xs + buf * XBYTES;
         const unsigned char* const Yb = Ys + buf * YBYTES;
-#pragma unroll 1
-        for (int kk = 0; kk < 8 * M / WS; ++kk) {
-            const int ks = wsi + WS * kk;                      // this wavefront's k-step of the stage: 16 consecutive pixels of one tile row
+        // k-steps of this wavefront: ks = wsi + WS kk (16 consecutive pixels of one tile row each).  The fragments of step kk + 1 are read
+        // before the MFMAs of step kk (two register sets; sched_barrier keeps hipcc from sinking the reads to their use).
+        struct Frag { unsigned bq[4]; unsigned d[3][6]; };
+        auto rd = [&](int kk, Frag& f) {
+            const int ks = __builtin_amdgcn_readfirstlane(wsi + WS * kk);
             const int row = TW == 32 ? ks >> 1 : ks, col = TW == 32 ? (ks & 1) << 4 : 0;
+            const unsigned char* const Yk = Yb + (row * TW + col) * YPB + y_lane;
+            const unsigned char* const Xk = Xb + (row * PWX + col) * XPB + x_lane;
             // dy fragment: pixels (row, col + 8 lh + 0..7), output channel 32 bi + li
-            unsigned bq[4];
 #pragma unroll
             for (int n2 = 0; n2 < 2; ++n2) {
-                const int q = row * TW + col + 8 * lh + 4 * n2 + rq;
-                const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Yb + q * YPB + w16_swz<BB>(bi, q) * 64 + ych));
+                const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Yk + 4 * n2 * YPB));
                 const u32x2 vv = __builtin_bit_cast(u32x2, v);
-                bq[2 * n2] = vv[0]; bq[2 * n2 + 1] = vv[1];
+                f.bq[2 * n2] = vv[0]; f.bq[2 * n2 + 1] = vv[1];
             }
-            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, u32x4{bq[0], bq[1], bq[2], bq[3]});
+            // x: patch row (row + r), patch columns col + 8 lh + 0..11 (patch column 0 = image column x0 - 1), input channel 32 ai + li
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                // x: patch row (row + r), patch columns col + 8 lh + 0..11 (patch column 0 = image column x0 - 1), input channel 32 ai + li
-                unsigned d[6];
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int n3 = 0; n3 < 3; ++n3) {
-                    const int q = (row + r) * PWX + col + 8 * lh + 4 * n3 + rq;
-                    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Xb + q * XPB + w16_swz<AB>(ai, q) * 64 + xch));
+                    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Xk + r * rowstep + 4 * n3 * XPB));
                     const u32x2 vv = __builtin_bit_cast(u32x2, v);
-                    d[2 * n3] = vv[0]; d[2 * n3 + 1] = vv[1];
+                    f.d[r][2 * n3] = vv[0]; f.d[r][2 * n3 + 1] = vv[1];
                 }
+        };
+        auto mm = [&](const Frag& f) {
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, u32x4{f.bq[0], f.bq[1], f.bq[2], f.bq[3]});
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const unsigned* const d = f.d[r];
+                // the three column taps are the same 12 pixels shifted by 0 / 1 / 2
                 const bf16x8 a0 = __builtin_bit_cast(bf16x8, u32x4{d[0], d[1], d[2], d[3]});
                 const bf16x8 a1 = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(d[1], d[0], 16), __builtin_amdgcn_alignbit(d[2], d[1], 16),
                                                                   __builtin_amdgcn_alignbit(d[3], d[2], 16), __builtin_amdgcn_alignbit(d[4], d[3], 16)});
@@ -169,6 +200,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_kernel(const W16Geo
                 acc[3 * r + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfrag, acc[3 * r + 1], 0, 0, 0);
                 acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bfrag, acc[3 * r + 2], 0, 0, 0);
             }
+        };
+        constexpr int KSTEPS = 8 * M / WS;
+        static_assert(KSTEPS % 2 == 0, "k-steps come in pairs");
+        Frag fa, fb;
+        rd(0, fa);
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; kk += 2) {
+            rd(kk + 1, fb);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(fa);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk + 2 < KSTEPS) rd(kk + 2, fa);
+            __builtin_amdgcn_sched_barrier(0);
+            mm(fb);
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
