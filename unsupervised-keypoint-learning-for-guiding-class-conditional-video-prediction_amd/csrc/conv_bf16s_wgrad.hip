@@ -9,9 +9,9 @@
 //     taps of its block: 9 accumulators of 32 x 32;
 //   * a stage = 128 M output pixels (TR rows x TW columns, 8 M k-steps of 16 consecutive pixels of a row): the dy tile and the (TR+2) x (TW+4)
 //     x patch, double buffered, one barrier per stage;
-//   * per k-step a wavefront reads 2 quads of dy and, per filter ROW, three consecutive quads of x (12 pixels): the three column taps are
-//     the same 12 pixels shifted by 0 / 1 / 2 -- a register funnel shift (v_alignbit) instead of two more LDS reads: 11 transposed reads
-//     (5.6 KB) per 9 MFMAs;
+//   * per k-step a wavefront needs 2 quads of dy and, per filter ROW, three consecutive quads of x (12 pixels): the three column taps are
+//     the same 12 pixels shifted by 0 / 1 / 2 -- a register funnel shift (v_alignbit) instead of two more LDS reads -- and a wavefront walks
+//     consecutive rows, so two of the three patch rows are the previous k-step's: 5 transposed reads (2.5 KB) per 9 MFMAs;
 //   * bank conflicts: the four pixel rows of a transposed read must fall in four different 64-B quarters of the 256-B bank row: the 64-B
 //     channel blocks of a pixel are XOR-swizzled with the pixel index (on the SOURCE side of the LDS-DMA, the LDS image stays lane-linear);
 //   * the K range (all pixels) is split over workgroups into partial slabs [splits][9][Cin][Cout] fp32 (the WS wavefronts of a block are summed
@@ -55,6 +55,7 @@ __device__ __forceinline__ void w16_dma16(const w16_i32x4 rsrc, const void* lds,
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(l), "v"(voffset), "s"(rsrc) : "memory");       // (m0 is a reserved register to hipcc: it cannot be named as a clobber, and nothing else in this kernel uses it)
 }
 
+template <int V> struct w16_ic { static constexpr int value = V; };
 // XOR swizzle of the 64-B channel block `cb` of pixel q, for NBLK blocks per pixel (see the header)
 template <int NBLK>
 __device__ __forceinline__ int w16_swz(int cb, int q) { return NBLK == 4 ? (cb ^ (q & 3)) : NBLK == 2 ? (cb ^ ((q >> 1) & 1)) : cb; }
@@ -161,36 +162,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_kernel(const W16Geo
         if (tile + 1 < t_end) issue(tile + 1, buf ^ 1);
         const unsigned char* const Xb = Xs + buf * XBYTES;
         const unsigned char* const Yb = Ys + buf * YBYTES;
-        // k-steps of this wavefront: ks = wsi + WS kk (16 consecutive pixels of one tile row each).  The fragments of step kk + 1 are read
-        // before the MFMAs of step kk (two register sets; sched_barrier keeps hipcc from sinking the reads to their use).
-        struct Frag { unsigned bq[4]; unsigned d[3][6]; };
-        auto rd = [&](int kk, Frag& f) {
-            const int ks = __builtin_amdgcn_readfirstlane(wsi + WS * kk);
-            const int row = TW == 32 ? ks >> 1 : ks, col = TW == 32 ? (ks & 1) << 4 : 0;
-            const unsigned char* const Yk = Yb + (row * TW + col) * YPB + y_lane;
-            const unsigned char* const Xk = Xb + (row * PWX + col) * XPB + x_lane;
-            // dy fragment: pixels (row, col + 8 lh + 0..7), output channel 32 bi + li
+        // A k-step = 16 consecutive pixels of one tile row: patch rows row .. row + 2 against the dy row.  A wavefront walks a RUN of consecutive
+        // rows at one 16-column position, so that two of a k-step's three patch-row fragments are the previous k-step's: a ring of four
+        // patch-row fragments (three in use, one being read) and two dy fragments -- ONE new patch row (3 transposed reads) + the dy fragment
+        // (2) per 9 MFMAs instead of 11 reads (the kernel was bound by the LDS reads: 54 % LDS against 39 % matrix-pipe activity).  The reads of
+        // k-step j + 1 are issued before the MFMAs of k-step j (sched_barrier keeps hipcc from sinking them to their use).
+        constexpr int KSTEPS = 8 * M / WS;
+        unsigned xr[4][6], bq[2][4];
+        auto rd_x = [&](const unsigned char* Xrow, int slot) {   // patch columns col + 8 lh + 0..11 of one patch row, input channel 32 ai + li
+#pragma unroll
+            for (int n3 = 0; n3 < 3; ++n3) {
+                const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Xrow + 4 * n3 * XPB));
+                const u32x2 vv = __builtin_bit_cast(u32x2, v);
+                xr[slot][2 * n3] = vv[0]; xr[slot][2 * n3 + 1] = vv[1];
+            }
+        };
+        auto rd_y = [&](const unsigned char* Yk, int slot) {     // pixels (row, col + 8 lh + 0..7), output channel 32 bi + li
 #pragma unroll
             for (int n2 = 0; n2 < 2; ++n2) {
                 const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Yk + 4 * n2 * YPB));
                 const u32x2 vv = __builtin_bit_cast(u32x2, v);
-                f.bq[2 * n2] = vv[0]; f.bq[2 * n2 + 1] = vv[1];
+                bq[slot][2 * n2] = vv[0]; bq[slot][2 * n2 + 1] = vv[1];
             }
-            // x: patch row (row + r), patch columns col + 8 lh + 0..11 (patch column 0 = image column x0 - 1), input channel 32 ai + li
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int n3 = 0; n3 < 3; ++n3) {
-                    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(Xk + r * rowstep + 4 * n3 * XPB));
-                    const u32x2 vv = __builtin_bit_cast(u32x2, v);
-                    f.d[r][2 * n3] = vv[0]; f.d[r][2 * n3 + 1] = vv[1];
-                }
         };
-        auto mm = [&](const Frag& f) {
-            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, u32x4{f.bq[0], f.bq[1], f.bq[2], f.bq[3]});
+        auto mm = [&](int s0, int ys) {                         // patch rows in ring slots s0, s0 + 1, s0 + 2 (mod 4) = filter rows 0, 1, 2
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, u32x4{bq[ys][0], bq[ys][1], bq[ys][2], bq[ys][3]});
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const unsigned* const d = f.d[r];
+                const unsigned* const d = xr[(s0 + r) & 3];
                 // the three column taps are the same 12 pixels shifted by 0 / 1 / 2
                 const bf16x8 a0 = __builtin_bit_cast(bf16x8, u32x4{d[0], d[1], d[2], d[3]});
                 const bf16x8 a1 = __builtin_bit_cast(bf16x8, u32x4{__builtin_amdgcn_alignbit(d[1], d[0], 16), __builtin_amdgcn_alignbit(d[2], d[1], 16),
@@ -201,20 +200,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16_kernel(const W16Geo
                 acc[3 * r + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, bfrag, acc[3 * r + 2], 0, 0, 0);
             }
         };
-        constexpr int KSTEPS = 8 * M / WS;
-        static_assert(KSTEPS % 2 == 0, "k-steps come in pairs");
-        Frag fa, fb;
-        rd(0, fa);
+        const int ystep = __builtin_amdgcn_readfirstlane(TW * YPB);
+        auto run = [&](auto rl, int row0, int col) {            // RL k-steps: tile rows row0 .. row0 + RL - 1 at columns col .. col + 15
+            constexpr int RL = decltype(rl)::value;
+            const unsigned char* const Xk = Xb + (row0 * PWX + col) * XPB + x_lane;
+            const unsigned char* const Yk = Yb + (row0 * TW + col) * YPB + y_lane;
+            rd_x(Xk, 0); rd_x(Xk + rowstep, 1); rd_x(Xk + 2 * rowstep, 2); rd_y(Yk, 0);
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; kk += 2) {
-            rd(kk + 1, fb);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(fa);
-            __builtin_amdgcn_sched_barrier(0);
-            if (kk + 2 < KSTEPS) rd(kk + 2, fa);
-            __builtin_amdgcn_sched_barrier(0);
-            mm(fb);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int j = 0; j < RL; ++j) {
+                if (j + 1 < RL) { rd_x(Xk + (j + 3) * rowstep, (j + 3) & 3); rd_y(Yk + (j + 1) * ystep, (j + 1) & 1); }
+                __builtin_amdgcn_sched_barrier(0);
+                mm(j & 3, j & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // this wavefront's KSTEPS consecutive (column half, row) units of the stage, column half major, in runs of RL rows (a lone wavefront
+        // owns the whole stage: both column halves of a 32-wide tile / both row halves of a 16-wide one -- two runs, one loop body)
+        constexpr int NRUN = WS == 1 ? 2 : 1, RL = KSTEPS / NRUN;
+#pragma unroll 1
+        for (int h = 0; h < NRUN; ++h) {
+            const int u0 = __builtin_amdgcn_readfirstlane(wsi * KSTEPS + h * RL);
+            const int colh = TW == 32 ? u0 / TR : 0, row0 = TW == 32 ? u0 - colh * TR : u0;
+            run(w16_ic<RL>{}, row0, colh * 16);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
