@@ -1,4 +1,4 @@
-"""In-kernel s_memtime stamps of conv3x3_bf16s_kernel (diagnostic build scratch/exp/libkpx_stamp.so via KPX_LIB): per phase and wavefront the cycles
+"""In-kernel s_memtime stamps of conv3x3_bf16s_kernel (diagnostic build: csrc/conv_bf16s.hip with scratch/exp/conv_bf16s_stamps.patch applied, built to scratch/exp/libkpx_stamp.so, selected with KPX_LIB): per phase and wavefront the cycles
 spent in the request block, the fragment reads + MFMAs, the counted wait and the barrier.   KPX_LIB=... python scratch/bf16s_stamps.py N H Cin Cout"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
