@@ -576,6 +576,8 @@ BF16S_CASES = [
     (2, 16, 16, 256, 64, 2),         # leaky relu, 64-cout variant on 16x16 images
     (16, 8, 8, 32, 32, 0),
     (32, 64, 64, 128, 128, 1),       # THE roofline launch of the configuration (bench.py roofline_bf16_conv): 256 workgroups
+    (16, 128, 128, 64, 64, 1),       # 512 tiles on 256 persistent workgroups: the tile boundary (next tile requested before the epilogue), 512 x 64 variant
+    (12, 64, 64, 128, 256, 0),       # 256-pixel tiles x 2 cout tiles = 384 tiles, two per persistent workgroup (cout tile fastest)
 ]
 
 
