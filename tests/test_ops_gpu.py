@@ -814,6 +814,44 @@ def test_bf16_storage_conv_batch_norm_relu_forward_and_backward(kpx, dev, monkey
         assert rel_l2(fused[i], plain[i]) < (4e-3 if i < 6 else 1e-3), (i, rel_l2(fused[i], plain[i]))      # (moving statistics: sums of the fp32 accumulators vs of the rounded tensor)
 
 
+@pytest.mark.parametrize('n,h,cin,cout,groups', [(6, 8, 128, 128, 2), (2, 8, 128, 128, 2), (6, 16, 32, 64, 2), (8, 8, 64, 64, 2), (4, 8, 128, 128, 2)])
+def test_bf16_storage_batch_norm_groups_with_packed_conv_tiles(kpx, dev, n, h, cin, cout, groups):
+    """The bf16 3x3 kernel packs G images into one statistics tile on 8x8 (and narrow 16x16) layers.  With n / groups not a multiple of G a
+    tile straddles two batch-norm groups: the tile sums must then be dropped for the separate reduction pass (round-5 advisor finding:
+    int(ng * tiles_per_image) truncated and the group statistics were silently wrong, mean = var = 0 at n / groups = 1).  Forward output and
+    all gradients against the fp32 oracle with per-group statistics, whichever path runs."""
+    ops = kpx.ops
+    g = torch.Generator().manual_seed(n * 100 + h + cin)
+    x = torch.randn(n, h, h, cin, generator=g).bfloat16()
+    x[n // 2:] += 0.75                                                        # the two groups have different statistics
+    w1 = (torch.randn(3, 3, cin, cout, generator=g) / (9 * cin) ** 0.5).bfloat16().float()
+    w2 = (torch.randn(3, 3, cout, cout, generator=g) / (9 * cout) ** 0.5).bfloat16().float()
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    gy = torch.randn(n, h, h, cout, generator=g).bfloat16()
+    ops.set_compute_dtype('bf16')
+    try:
+        xg = x.to(dev).requires_grad_(True)
+        p = [t.to(dev).requires_grad_(True) for t in (w1, w2, gamma, beta)]
+        mm, mv = torch.zeros(cout, device=dev), torch.ones(cout, device=dev)
+        z = ops.conv2d(xg, p[0], None, stride=1, pad=0, bn_stats=True)
+        a = ops.batch_norm(z, p[2], p[3], mm, mv, train=True, act=ops.ACT_RELU, groups=groups)
+        y = ops.conv2d(a, p[1], None, stride=1, pad=0)
+        y.backward(gy.to(dev))
+        got = [t2n(t.float()) for t in (y, xg.grad, p[0].grad, p[1].grad, p[2].grad, p[3].grad)]
+    finally:
+        ops.set_compute_dtype('f32')
+    xo = x.float().requires_grad_(True)
+    po = [t.clone().requires_grad_(True) for t in (w1, w2, gamma, beta)]
+    zo = R.conv(xo, po[0], None, 1, 0)
+    ng = n // groups
+    ao = torch.cat([torch.relu(R.batch_norm_train(zo[i * ng:(i + 1) * ng], po[2], po[3])[0]) for i in range(groups)], 0)
+    yo = R.conv(ao, po[1], None, 1, 0)
+    yo.backward(gy.float())
+    want = [t2n(t) for t in (yo, xo.grad, po[0].grad, po[1].grad, po[2].grad, po[3].grad)]
+    for i, tol in enumerate((8e-3, 3e-2, 3e-2, 8e-3, 2e-2, 2e-2)):
+        assert rel_l2(got[i], want[i]) < tol, (i, rel_l2(got[i], want[i]))
+
+
 def test_bf16_storage_pointwise_kernels_against_torch_on_the_rounded_inputs(kpx, dev):
     """cast, channel-slice copy, bilinear x2 (+ backward), 2x2 max-pool, the one-pass VGG19 feature gradient, feature L1, bias-gradient sum:
     fp32 arithmetic on bf16 tensors -- the bf16 results must be the rounding of the fp32 oracle's on the same inputs (<= 1 ulp: rel-L2 1e-3)."""

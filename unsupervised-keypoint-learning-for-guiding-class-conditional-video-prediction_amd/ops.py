@@ -956,6 +956,14 @@ def conv2d(x, w, b=None, stride=1, pad=0, act=ACT_NONE, cin=None, w_grad_out=Non
 
 
 # ----------------------------------------------------------------------------------------------- batch norm
+def _whole_tiles_per_group(n, groups, tiles_per_image):
+    """True when every statistics tile of a producing convolution lies inside ONE batch-norm group.  The bf16 3x3 kernel packs G images into a
+    tile on 8x8 / narrow 16x16 layers (tiles per image = 1/G, a Fraction): with n / groups not a multiple of G a tile would straddle two
+    groups, and int(ng * tpi) would silently drop or misattribute images."""
+    from fractions import Fraction
+    return n % groups == 0 and (Fraction(tiles_per_image) * (n // groups)).denominator == 1
+
+
 class BatchNormFn(torch.autograd.Function):
     """layers.batch_norm (+ fused ReLU) -- tf.contrib.layers.batch_norm(eps=1e-5) (reference layers.py:13-14).
 
@@ -1039,7 +1047,7 @@ class BatchNormFn(torch.autograd.Function):
             fresh = _claim_grad(ctx.g_grad_out)
             _claim_grad(ctx.b_grad_out)
         ent = _pending_bwd_stats.pop(dy.data_ptr(), None)        # sums reduced by the epilogue of the dgrad kernel that produced dy
-        if ent is not None and (ent[2] != ctx.bn_id or ctx.act != ACT_RELU or tuple(ent[0].shape) != (n * ent[1] * 2 * c,)):
+        if ent is not None and (ent[2] != ctx.bn_id or ctx.act != ACT_RELU or tuple(ent[0].shape) != (n * ent[1] * 2 * c,) or not _whole_tiles_per_group(n, groups, ent[1])):
             ent = None
         # (reduction,) finalize, apply: one launch each for all groups; with `ent` the reduction was done by the epilogue of the data-gradient
         # kernel that produced dy (per-tile sums, ng * tiles-per-image tiles per group)
@@ -1068,8 +1076,8 @@ class BatchNormFn(torch.autograd.Function):
 def batch_norm(x, gamma, beta, moving_mean, moving_var, train=True, act=ACT_RELU, groups=1, update_moving=True,
                g_grad_out=None, b_grad_out=None, out_f32=False):
     ts = getattr(x, '_kpx_tile_stats', None) if train else None
-    if ts is not None and (x.shape[0] % groups or tuple(ts[0].shape) != (x.shape[0] * ts[1] * 2 * x.shape[3],)):
-        ts = None
+    if ts is not None and (x.shape[0] % groups or tuple(ts[0].shape) != (x.shape[0] * ts[1] * 2 * x.shape[3],) or not _whole_tiles_per_group(x.shape[0], groups, ts[1])):
+        ts = None                                        # (a tile that packs images of two groups cannot be split: the separate reduction pass runs)
     _bn_counter[0] += 1
     y = BatchNormFn.apply(x, gamma, beta, moving_mean, moving_var, g_grad_out, b_grad_out, train, act, groups, update_moving, ts, _bn_counter[0], out_f32)
     if train and act == ACT_RELU:
