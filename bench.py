@@ -350,6 +350,104 @@ def cpu_baseline():
             'sec_per_step': round(med, 3)}
 
 
+def _timed_train_leg(dev, config, dtype, steps, warmup):
+    """ms per step / pairs per second of one more train configuration on a FRESH model in this process (the `also` legs: BASELINE configs[2]
+    and [3] under the driver's clock, after the headline's timed region and roofline legs)."""
+    import gc
+    import kpx_amd
+    from kpx_amd import ops as kops
+    from kpx_amd.synthetic import synthetic_pair
+    conf = CONFIGS[config]
+    res, k, batch = conf['res'], conf['k'], conf['batch']
+    kops.set_compute_dtype(dtype)
+    try:
+        cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': batch},
+               'model': {'n_pts': k}, 'paths': {'log_dir': '/tmp/kpx_bench', 'vggnet': None}}
+        vgg = kpx_amd.Vgg19(weights=kpx_amd.synthetic_vgg19_weights(seed=19), device=dev)
+        model = kpx_amd.DetectorTranslatorModel(cfg, device=dev, vgg=vgg, image_size=res)
+        model.build()
+        feed = {kk: torch.from_numpy(v).to(dev) for kk, v in synthetic_pair(batch, res=res, seed0=0, seed1=1).items()}
+        for i in range(warmup):
+            model.train_step(None, feed, i, batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            model.train_step(None, feed, warmup + i, batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        losses = model.loss_values()
+        ok = bool(np.isfinite(losses['loss_D']) and np.isfinite(losses['loss_G']))
+        leg = {'workload': 'Penn %dx%d K=%d detector_translator %s, batch=%d (BASELINE configs[%d])' % (res, res, k, 'fp32' if dtype == 'f32' else 'bf16 + VGG19 perceptual loss',
+                                                                                               batch, conf['idx'] if dtype == 'f32' else 2),
+               'ms_per_step': round(dt / steps * 1e3, 3), 'value': round(batch * steps / dt, 2), 'unit': 'image pairs/sec', 'steps': steps, 'warmup': warmup,
+               'dtype': dtype, 'launch_mode': model.LAUNCH_MODES[model.launch_mode()].split(':')[0], 'losses_finite': ok}
+        if dtype == 'bf16':
+            leg['fp32_kernel_fallbacks'] = dict(kops.fallback_uses)
+        del model, vgg, feed
+        gc.collect()
+        torch.cuda.empty_cache()
+        if dtype == 'bf16':
+            leg['roofline'] = roofline_conv_bf16(dev)
+        else:
+            kops.set_compute_dtype('f32')
+            leg['roofline'] = roofline_conv_c3(dev, batch)
+        return leg
+    finally:
+        kops.set_compute_dtype('f32')
+
+
+def _timed_rollout_leg(dev, runs, warmup=1):
+    """BASELINE configs[4] (bench_rollout's workload) on a fresh FinalModel in this process."""
+    import gc
+    import kpx_amd
+    conf = CONFIGS['c4']
+    res, k, b = conf['res'], conf['k'], conf['batch']
+    cfg = {'model': {'n_pts': k, 'cell_info': [1024, 1024], 'vae_dim': 64, 'n_action': 9}, 'paths': {'log_dir': '/tmp/kpx_bench'}}
+    fm = kpx_amd.FinalModel(cfg, device=dev, image_size=res, frames_per_launch=256)
+    fm.build()
+    rs = np.random.RandomState(7)
+    im = torch.from_numpy((rs.randint(0, 256, size=(b, res, res, 3)).astype(np.float32) / 255.0 * 2 - 1).astype(np.float32)).to(dev)
+    act = torch.from_numpy(np.eye(9, dtype=np.float32)[rs.randint(0, 9, size=b)]).to(dev)
+    z = torch.from_numpy(rs.randn(b, 64).astype(np.float32)).to(dev)
+    feed = {'image': im, 'action_code': act}
+    for _ in range(warmup):
+        out = fm.run(None, feed, z=z)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(runs):
+        out = fm.run(None, feed, z=z)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = bool(torch.isfinite(out['pred_im_seq']).all())
+    leg = {'workload': 'evaluate.py rollout 128x128 K=15: %d source images -> %d frames per run (BASELINE configs[4])' % (b, b * 32),
+           'ms_per_step': round(dt / runs * 1e3, 3), 'value': round(b * 32 * runs / dt, 1), 'unit': 'predicted frames/sec', 'steps': runs, 'warmup': warmup,
+           'dtype': 'f32', 'outputs_finite': ok}
+    del fm, out, feed
+    gc.collect()
+    torch.cuda.empty_cache()
+    leg['roofline'] = roofline_conv_c4(dev)
+    return leg
+
+
+def also_legs(dev):
+    """The other BASELINE configurations under the same clock as the headline (N = 1 only, after everything the headline line needs has been
+    measured): configs[2] (bf16), configs[3] (256x256, K=40) and configs[4] (the rollout).  A leg that fails reports its error; it can never
+    change or suppress the headline fields."""
+    also = {}
+    for name, fn in (('bf16', lambda: _timed_train_leg(dev, 'c1', 'bf16', 10, 3)), ('c3', lambda: _timed_train_leg(dev, 'c3', 'f32', 5, 2)),
+                     ('c4', lambda: _timed_rollout_leg(dev, 3))):
+        t0 = time.perf_counter()
+        try:
+            also[name] = fn()
+        except Exception as e:                             # noqa: BLE001 -- reported, never raised: the headline stands on its own
+            also[name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
+        also[name]['leg_wall_s'] = round(time.perf_counter() - t0, 1)
+        only = {kk: v for kk, v in also[name].get('roofline', {}).items() if kk in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'avg_launch_ms')}
+        if only:
+            also[name]['roofline'] = only
+    return also
+
+
 # ---------------------------------------------------------------------------------------------- N > 1: ranks under a supervisor
 # `bench.py --gpus N` must not be able to hang: a data-parallel step that deadlocks inside a collective (a captured graph with RCCL nodes that
 # never completes, a rank that dies in the rendezvous) would leave the driver without a number.  So for N > 1 the ranks that do the work are
@@ -589,6 +687,7 @@ def main():
                          'HBM, fp32 accumulate / batch-norm statistics / master weights / Adam; a SEPARATE configuration, never the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true', help='skip the kernel microbenchmarks after the timed steps (clean per-step rocprofv3 kernel statistics)')
+    ap.add_argument('--no-also', action='store_true', help='skip the `also` legs (bf16 / c3 / c4 on fresh models after the headline; N = 1, --config c1 --dtype f32 only)')
     ap.add_argument('--roofline-only', action='store_true', help='only the two kernel microbenchmarks (used for the rocprofv3 cross-check)')
     args = ap.parse_args()
 
@@ -744,6 +843,13 @@ def main():
                 out['roofline_direct_conv'] = roofline_conv_direct(dev)
                 out['roofline_bf16x3_conv'] = roofline_conv_bf16x3(dev)
                 out['roofline_hbm_render'] = roofline_render(dev, RES, K_PTS, args.batch)
+            if args.config == 'c1' and args.dtype == 'f32' and not args.no_also:
+                # every other configuration's number under the same (driver's) clock: after the timed region and the roofline legs, fresh models
+                del model, vgg
+                import gc
+                gc.collect()
+                torch.cuda.empty_cache()
+                out['also'] = also_legs(dev)
             if not args.no_cpu_baseline:
                 out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -89,7 +89,7 @@ def main(argv=None):
     parser.add_argument('--synthetic', action='store_true', help='synthetic Penn-shaped pairs instead of the JPEG pipeline')
     parser.add_argument('--synthetic-vgg', action='store_true', help='He-normal VGG19 weights when paths.vggnet is absent')
     parser.add_argument('--steps', type=int, default=None, help='override training.n_steps')
-    parser.add_argument('--ckpt-format', choices=['npz', 'tf'], default=os.environ.get('KPX_CKPT_FORMAT', 'npz'),
+    parser.add_argument('--ckpt-format', choices=['npz', 'tf', 'bundle'], default=os.environ.get('KPX_CKPT_FORMAT', 'npz'),
                         help="checkpoint container: 'tf' = TensorFlow V2 bundle (model.ckpt-N.index / .data-00000-of-00001 + `checkpoint`, the "
                              "layout tf.train.Saver writes and the reference restores, models/base_model.py:74-91); 'npz' (default) = one "
                              "numpy archive with the same variable names -- readable by this repo only")

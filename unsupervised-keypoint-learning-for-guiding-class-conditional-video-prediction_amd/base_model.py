@@ -2,7 +2,8 @@
 
 ``sess`` arguments are kept for signature parity and ignored (there is no session: kernels are launched eagerly on the
 current HIP stream).  Checkpoints keep the reference's location ``<log_dir>/<name>/model.ckpt-<step>`` and variable
-names in an ``.npz`` container; the TF-V2 bundle byte format is a later row.
+names (SURVEY Appendix B), in an ``.npz`` container (default) or as a TensorFlow V2 checkpoint bundle (``tf_bundle.py``, SURVEY 8f-2;
+``KPX_CKPT_FORMAT=tf``).
 """
 import os
 from abc import ABC, abstractmethod
@@ -50,8 +51,10 @@ class BaseModel(ABC):
         """reference :77-81 -> <log_dir>/<name>/model.ckpt-<step>.  ``fmt`` (or $KPX_CKPT_FORMAT): 'npz' (default, one file) or
         'tf' = a TensorFlow V2 bundle (.index + .data-00000-of-00001 + ``checkpoint``) that tf.train.Saver can restore."""
         fmt = fmt or os.environ.get('KPX_CKPT_FORMAT', 'npz')
+        if fmt not in ('npz', 'tf', 'bundle'):           # ('bundle' = 'tf'; anything else is a typo that must not silently write the other container)
+            raise ValueError("checkpoint format %r: expected 'npz', 'tf' or 'bundle' (KPX_CKPT_FORMAT / --ckpt-format)" % (fmt,))
         prefix = osp.join(self.log_dir, self.__class__.name, 'model.ckpt-%d' % step)
-        if fmt == 'tf':
+        if fmt in ('tf', 'bundle'):
             from . import tf_bundle
             tf_bundle.write_bundle(prefix, self.checkpoint_arrays())
             return prefix
