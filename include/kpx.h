@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 #define KPX_EINVAL (-1)
-#define KPX_ABI_VERSION 2
+#define KPX_ABI_VERSION 3
 
 enum { KPX_ACT_NONE = 0, KPX_ACT_RELU = 1, KPX_ACT_LRELU = 2 /* slope 0.01 */, KPX_ACT_TANH = 3 /* forward only */ };
 
@@ -183,6 +183,22 @@ int kpx_conv3x3_wino43_ex_f32(const float* in, int N, int H, int W, int K, int l
 size_t kpx_conv3x3_wino43_stats_tiles(int N, int H, int W);
 int kpx_conv3x3_wino43_stats_f32(const float* in, int N, int H, int W, int K, int ldin, const float* u, const float* bias,
                                  float* out, int Nn, int ldout, int act, float* tile_stats, void* stream);
+/* The same F(4x4,3x3) layers FP32-EQUIVALENT ON THE BF16 MATRIX PIPE (csrc/conv_wino43b.hip): U pre-split into three exact bf16 terms in
+ * fragment order by kpx_wino43b_filter_transform(_batch)_f32 (kpx_wino43b_u_bytes bytes; descriptors as for
+ * kpx_wino_filter_transform_batch_f32), V split in registers after the input transform, six v_mfma_f32_32x32x16_bf16 products per block,
+ * fp32 accumulate: the fp32 configuration's arithmetic (error vs float64 as the fp32-MFMA kernel's), not the bf16 mode.  Eligible when
+ * H % 16 == 0, W % 32 == 0, K >= 16, K % 4 == 0, Nn > 32, ldin >= K, 16-B alignment.  One entry for every form of the launch: tile_stats
+ * alone = kpx_conv3x3_wino43_stats_f32's statistics strips (kpx_conv3x3_wino43_stats_tiles); tile_stats + bn_y + bn_beta =
+ * kpx_conv3x3_wino43_bnbwd_stats_f32 (no bias / act); mask_y / pool_y = kpx_conv3x3_wino43_ex_f32's options (Nn % 64 == 0); all NULL = the
+ * plain convolution.  Replaces the same tf.layers.conv2d call sites (reference models/networks/layers.py:4-10 on
+ * models/networks/__init__.py:13,22,80-97; models/networks/vgg.py:51). */
+int kpx_conv3x3_wino43b_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr);
+size_t kpx_wino43b_u_bytes(int Cin, int Cout);
+int kpx_wino43b_filter_transform_f32(const float* w_hwio, int Cin, int Cout, int dgrad, void* u, void* stream);
+int kpx_wino43b_filter_transform_batch_f32(const void* descs_dev, int n, void* stream);
+int kpx_conv3x3_wino43b_f32(const float* in, int N, int H, int W, int K, int ldin, const void* u, const float* bias,
+                            float* out, int Nn, int ldout, int act, const float* mask_y, int ld_mask, float* pool_y, int ld_pool,
+                            float* tile_stats, const float* bn_y, int ld_bn_y, const float* bn_beta, void* stream);
 /* 3x3 stride-1 SAME convolution PRODUCING exactly 16 channels on 16x16x4 MFMA blocks (no cout padding): the forward of the key-point
  * detector's last decoder block (64 -> 16, 16 -> 16 at full resolution, reference models/networks/__init__.py:50-54) and the data gradient
  * of its 16 -> 16 layer.  w_hwio is the layer's own filter: [3][3][K][16] forward, [3][3][16][K] for dgrad (K = gathered channels, a

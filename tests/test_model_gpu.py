@@ -567,7 +567,8 @@ def test_final_model_rollout_matches_oracle():
 F43_LAUNCHES_PER_STEP = {'configs0': 17 + 36, 'configs3': 18 + 36}
 
 
-@pytest.mark.parametrize('force_f43', [False, True], ids=['f23_for_launches_up_to_128_workgroups', 'bench_policy_f43_on_every_policy_layer'])
+@pytest.mark.parametrize('force_f43', [False, True, 'f32mfma'], ids=['f23_for_launches_up_to_128_workgroups', 'bench_policy_f43_on_every_policy_layer',
+                                                                         'bench_policy_with_the_fp32_mfma_f43_kernel'])
 def test_configs0_train_step_128_k15_b4_matches_oracle(monkeypatch, force_f43):
     """BASELINE configs[0]: Penn 128x128 K=15, batch 4, full-width VGG19 (synthetic weights): one complete train step
     (D update + G update) against the CPU restatement -- all six loss terms, key-points, frame, and the norm-weighted
@@ -576,18 +577,24 @@ def test_configs0_train_step_128_k15_b4_matches_oracle(monkeypatch, force_f43):
     ``force_f43``: with ops.WINO43_MIN_WORKGROUPS = 0 (the default since the threshold was measured inside the step: 23.8 vs 24.1 ms at
     B=32) every policy layer takes the F(4x4,3x3) kernel -- the kernel selection of the bench under the float64-arbitrated bounds -- and the
     launch counter must show it.  The other variant sets the threshold to 128 workgroups (round 2's policy): at B=4 most policy layers then
-    fall back to F(2x2,3x3), which keeps that path covered at model level."""
+    fall back to F(2x2,3x3), which keeps that path covered at model level.  'f32mfma': the bench policy with ops.WINO43B off -- every F(4x4,3x3)
+    launch on the fp32-MFMA kernel (csrc/conv_wino43.hip) instead of the bf16x3 form (csrc/conv_wino43b.hip) that the default takes wherever
+    the shape allows: both kernels under the same model-level bounds."""
     from kpx_amd import ops
     dev = torch.device('cuda:0')
     res, k, b = 128, 15, 4
     monkeypatch.setattr(ops, 'WINO43_MIN_WORKGROUPS', 0 if force_f43 else 128)
+    if force_f43 == 'f32mfma':
+        monkeypatch.setattr(ops, 'WINO43B', False)
     model = make_model(res, k, b, dev, width_div=1)
-    used = ops.conv_kernel_uses['wino43']
+    used, usedb = ops.conv_kernel_uses['wino43'], ops.conv_kernel_uses['wino43b']
     im, fut, want, want64 = oracle_first_step(res, k, b, 1)
     model.train_step(None, {'image': torch.from_numpy(im).to(dev), 'future_image': torch.from_numpy(fut).to(dev)}, 0, b)
     if ops.WINO43:
         launched = ops.conv_kernel_uses['wino43'] - used
         assert (launched == F43_LAUNCHES_PER_STEP['configs0']) if force_f43 else (0 < launched < F43_LAUNCHES_PER_STEP['configs0']), launched
+        launched_b = ops.conv_kernel_uses['wino43b'] - usedb
+        assert (launched_b == 0) if (force_f43 == 'f32mfma' or not ops.WINO43B) else (launched_b > 0), launched_b
     got = model.loss_values()
     for key in ('loss_D', 'loss_D_real', 'loss_D_fake', 'loss_G_recon', 'loss_G_adv', 'loss_G'):
         assert abs(got[key] - want[key]) <= 1e-4 * max(1.0, abs(want[key])), (key, got[key], want[key])

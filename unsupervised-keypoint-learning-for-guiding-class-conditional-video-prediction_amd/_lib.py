@@ -29,7 +29,7 @@ lib = ctypes.CDLL(LIB_PATH)
 
 P = c_void_p
 # name -> (restype, argtypes); mirrors include/kpx.h one to one (tests/test_abi.py checks header vs this table)
-ABI_VERSION = 2        # = KPX_ABI_VERSION of include/kpx.h (tests/test_abi.py holds the two equal); bumped whenever a signature changes
+ABI_VERSION = 3        # = KPX_ABI_VERSION of include/kpx.h (tests/test_abi.py holds the two equal); bumped whenever a signature changes
 SIGNATURES = {
     'kpx_abi_version': (c_int, []),
     'kpx_reload_env': (c_int, []),
@@ -57,6 +57,11 @@ SIGNATURES = {
     'kpx_wino43_filter_transform_batch_f32': (c_int, [P, c_int, P]),
     'kpx_conv3x3_wino43_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P]),
     'kpx_conv3x3_wino43_ex_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P, c_int, P, c_int, P]),
+    'kpx_conv3x3_wino43b_eligible': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    'kpx_wino43b_u_bytes': (c_size_t, [c_int, c_int]),
+    'kpx_wino43b_filter_transform_f32': (c_int, [P, c_int, c_int, c_int, P, P]),
+    'kpx_wino43b_filter_transform_batch_f32': (c_int, [P, c_int, P]),
+    'kpx_conv3x3_wino43b_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P, c_int, P, c_int, P, P, c_int, P, P]),
     'kpx_conv3x3_wino43_stats_tiles': (c_size_t, [c_int, c_int, c_int]),
     'kpx_conv3x3_wino43_stats_f32': (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_int, c_int, P, P]),
     'kpx_conv3x3_wino_stats_tiles': (c_size_t, [c_int, c_int, c_int]),

@@ -1,0 +1,692 @@
+// Fused Winograd F(4x4, 3x3) convolution whose 36 transform-domain GEMMs run FP32-EQUIVALENT ON THE BF16 MATRIX PIPE of gfx950
+// (v_mfma_f32_32x32x16_bf16, six products of exact three-term operands), for the 3x3 stride-1 SAME layers of the fp32 configuration
+// (reference models/networks/layers.py:4-10 on models/networks/__init__.py:13-24,50-62,80-97 and models/networks/vgg.py:20-40):
+// forward, and the data gradient on dgrad-transformed filters.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      as in conv_wino43.hip (points 0, +-1, +-2, inf), but
+//   U = G g G^T (fp64, rounded once to fp32) is stored PRE-SPLIT as u = u0 + u1 + u2 (three bf16 planes, exact: trunc16 twice, the rest fits)
+//   V = B^T d B (fp32 VALU) is split the same way in registers right after the input transform, and each point-wise product is
+//   v.u ~ v1u1 + v0u2 + v2u0 + v0u1 + v1u0 + v0u0  (smallest first, fp32 accumulate; the dropped terms are < 2^-23 |vu|: conv_gemm3.hip).
+// Cost per 32 x 32 x 16 block: 6 x 32 cycles instead of 8 x 64 of v_mfma_f32_32x32x2_f32, and -- the point of the exercise, DESIGN.md 4.1 --
+// a bf16 MFMA lets the other instructions of its SIMD issue beside it.
+//
+// Why the structure differs from conv_wino43_kernel: with the multiplies 2.7x cheaper the kernel is bound by everything else -- V through LDS
+// (110 KB per 16 channels as three bf16 planes: it cannot even be double buffered), the transform on two of four SIMDs, 20 k cycles of
+// prologue / epilogue per tile.  Here V NEVER TOUCHES LDS:
+//   * one workgroup = 4 wavefronts (one per SIMD, up to 512 registers each) = 16 x 32 output pixels (4 x 8 tiles = the 32 rows of the MFMA)
+//     x 64 output channels x all 36 points; wavefront (rh, ch) owns the 3 x 3 block of points {rows 3rh..3rh+2} x {cols 3ch..3ch+2} for BOTH
+//     32-channel halves: 18 accumulator blocks = 288 registers;
+//   * lane (tile = lane & 31, channel octet = lane >> 5) is exactly the lane of the MFMA's A operand that needs V[point][tile][8 channels], so
+//     every wavefront transforms ITS nine points for its own lanes: B^T d B restricted to a 3 x 3 block needs 5 x 5 of the 6 x 6 patch and
+//     48 instead of 36 FMAs per channel (the separable passes share less) -- 1/3 more transform arithmetic buys no V traffic, no V
+//     barriers and no transform / multiply role split;
+//   * the raw patch (18 x 34 pixels x 16 channels per K step, fp32) reaches LDS by LDS-DMA (no staging registers), pixel-major (the four
+//     channel quads of a pixel are consecutive lanes of a request: 64 contiguous bytes) with one skew slot per four pixels (conflict-free
+//     transform reads), double buffered: ONE barrier per 16-channel K step;
+//   * the filter fragments come straight from L2 in fragment order through a buffer descriptor with scalar offsets, a ring of six
+//     (point, cout half) units = 72 registers, refilled in place five units (~960 MFMA cycles) ahead;
+//   * per K step: transform the `single` point row (rows 0 / 5 of B^T: three-term sums), multiply its three points; transform the two `pair`
+//     rows (rows 1,2 / 3,4: they share their partial sums), multiply their six points.  The split of point p+1 (44 VALU) is independent of
+//     the twelve MFMAs of point p and issues beside them;
+//   * the epilogue runs in two passes of ALL 36 points x 32 output channels through LDS (147 KB): every wavefront deposits nine blocks in
+//     both passes, every thread owns (tile, 4 couts), reads its 36 values as ds_read_b128 and finishes the 4 x 4 output pixels in one go.
+// STATS / mask / pool epilogue options are those of conv_wino43_kernel (same statistics strips: kpx_conv3x3_wino43_stats_tiles).
+#include "kpx_common.h"
+#include "kpx_env.h"
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+#define W4B_OOB 0x7ffffff0                 // voffset beyond any buffer: the load returns / lands as zeros
+#define W4B_ROWSLOTS 146                   // 16-B slots per patch row: pixel column c at slot 4 c + (c >> 2) (four channel quads per pixel, one skew slot per
+                                           // four pixels), 34 columns = 144 slots, padded to 146 so that four rows are 8 (mod 16) slots
+#define W4B_NPIECES 44                     // LDS-DMA pieces of 1 KB per buffer (18 x 146 = 2628 slots, rounded up to 11 pieces per wavefront)
+#define W4B_RAW_BYTES (W4B_NPIECES * 1024) // one raw buffer
+#define W4B_TAB_OFF (2 * W4B_RAW_BYTES)    // [4 wavefronts][3][64 lanes][4] buffer offsets of the DMA slots (tile constants: they would otherwise be spilled)
+#define W4B_ACC_OFF (W4B_TAB_OFF + 4 * 3072)   // [4 wavefronts][3 blocks][4][64 lanes] x 16 B: three of a wavefront's 18 accumulator blocks (cout block 1 of
+                                           // local points 2, 5, 8) live here between K steps and pass through ONE transient block: 18 blocks are 288
+                                           // registers, the accumulator file has 256, and hipcc otherwise spills two blocks to scratch every K step
+                                           // (vector-memory operations in the middle of a counted-vmcnt pipeline) and shuffles a third through VGPRs
+#define W4B_MAIN_BYTES (W4B_ACC_OFF + 4 * 12288)
+#define W4B_EPI_BYTES (36 * 32 * 32 * 4)   // P[point][tile][32 couts] fp32
+
+struct Wino43bGeom {
+    const float* x; float* y; const void* U; const float* bias;
+    int N, H, W, Cin, ldx, Cout, ldy, act;
+    int Kp, Np;                              // U is [36][Kp/16][Np/32][3 terms][64 lanes][8] bf16
+    int tiles_y, tiles_x;                    // 16 x 32-pixel regions per image
+    const float* mask_y; int ld_mask;        // optional: zero the output where mask_y <= 0
+    float* pool_y; int ld_pool;              // optional: also write the 2x2 max-pool of the (activated) output
+    float* stats;                            // STATS 1 / 2: as conv_wino43_kernel
+    const float* bn_beta;
+};
+
+__device__ __forceinline__ unsigned w4b_bits(float v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ float w4b_float(unsigned v) { return __builtin_bit_cast(float, v); }
+// {hi16(b), hi16(a)}: two truncated bf16 values in one dword, a in the low half
+__device__ __forceinline__ unsigned w4b_pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// ---------------------------------------------------------------------------------------------- filter transform (once per optimiser update)
+// U[p = 6 i + j] = (G g G^T)[i][j] in double precision, rounded once (conv_wino43.hip says why), then split into three bf16 terms and stored
+// as the B operand of v_mfma_f32_32x32x16_bf16: Ub[p][ks][nb][term][lane = r + 32 h][e] = term of U[p][c = 16 ks + 8 h + e][n = 32 nb + r].
+// One thread = (channel pair c, c+1; n): one dword per (point, term).
+struct KpxWino43bDesc { const float* w; unsigned* u; int cin, cout, dgrad, reserved; };
+
+__device__ __forceinline__ void w4b_ggt(const float* __restrict__ w, int Cin, int Cout, bool dg, int c, int n, bool real, float* __restrict__ out36) {
+    double g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            g[r][q] = !real ? 0.0 : (double)(dg ? w[((size_t)((2 - r) * 3 + (2 - q)) * Cin + n) * Cout + c] : w[((size_t)(r * 3 + q) * Cin + c) * Cout + n]);
+    // rows of G: [1/4,0,0], [-1/6,-1/6,-1/6], [-1/6,1/6,-1/6], [1/24,1/12,1/6], [1/24,-1/12,1/6], [0,0,1]
+    double t[6][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const double a = g[0][q], b = g[1][q], c2 = g[2][q];
+        t[0][q] = 0.25 * a;
+        t[1][q] = (-1.0 / 6.0) * (a + b + c2);
+        t[2][q] = (-1.0 / 6.0) * (a - b + c2);
+        t[3][q] = (1.0 / 24.0) * a + (1.0 / 12.0) * b + (1.0 / 6.0) * c2;
+        t[4][q] = (1.0 / 24.0) * a - (1.0 / 12.0) * b + (1.0 / 6.0) * c2;
+        t[5][q] = c2;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double a = t[i][0], b = t[i][1], c2 = t[i][2];
+        out36[i * 6 + 0] = (float)(0.25 * a);
+        out36[i * 6 + 1] = (float)((-1.0 / 6.0) * (a + b + c2));
+        out36[i * 6 + 2] = (float)((-1.0 / 6.0) * (a - b + c2));
+        out36[i * 6 + 3] = (float)((1.0 / 24.0) * a + (1.0 / 12.0) * b + (1.0 / 6.0) * c2);
+        out36[i * 6 + 4] = (float)((1.0 / 24.0) * a - (1.0 / 12.0) * b + (1.0 / 6.0) * c2);
+        out36[i * 6 + 5] = (float)c2;
+    }
+}
+
+__device__ __forceinline__ void w4b_transform_filter(const float* __restrict__ w, int Cin, int Cout, bool dg, size_t idx, int Kp, int Np, unsigned* __restrict__ Ub) {
+    const int K = dg ? Cout : Cin, Nn = dg ? Cin : Cout;
+    const int KS = Kp >> 4, NB = Np >> 5;
+    const int n = (int)(idx % (size_t)Np), cp = (int)(idx / (size_t)Np);       // consecutive threads: consecutive n (the filter's fastest index forward)
+    const int c = 2 * cp;
+    float ua[36], ub[36];
+    w4b_ggt(w, Cin, Cout, dg, c, n, c < K && n < Nn, ua);
+    w4b_ggt(w, Cin, Cout, dg, c + 1, n, c + 1 < K && n < Nn, ub);
+    const int ks = c >> 4, h = (c >> 3) & 1, e = c & 7, nb = n >> 5, r = n & 31;
+    const size_t pstride = (size_t)KS * NB * 768;                               // dwords per point
+    unsigned* o = Ub + ((size_t)ks * NB + nb) * 768 + (r + 32 * h) * 4 + (e >> 1);
+#pragma unroll
+    for (int p = 0; p < 36; ++p) {
+        const float a = ua[p], b = ub[p];
+        const unsigned a0 = w4b_bits(a), b0 = w4b_bits(b);
+        const float ra = a - w4b_float(a0 & 0xffff0000u), rb = b - w4b_float(b0 & 0xffff0000u);
+        const unsigned a1 = w4b_bits(ra), b1 = w4b_bits(rb);
+        const float sa = ra - w4b_float(a1 & 0xffff0000u), sb = rb - w4b_float(b1 & 0xffff0000u);
+        o[p * pstride] = w4b_pack_hi(a0, b0);
+        o[p * pstride + 256] = w4b_pack_hi(a1, b1);
+        o[p * pstride + 512] = w4b_pack_hi(w4b_bits(sa), w4b_bits(sb));
+    }
+}
+__global__ __launch_bounds__(256) void wino43b_filter_transform_batch_kernel(const KpxWino43bDesc* __restrict__ descs) {
+    const KpxWino43bDesc d = descs[blockIdx.y];
+    const bool dg = d.dgrad != 0;
+    const int K = dg ? d.cout : d.cin, Nn = dg ? d.cin : d.cout;
+    const int Kp = (K + 15) & ~15, Np = (Nn + 63) & ~63;
+    const size_t total = (size_t)(Kp / 2) * Np;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256)
+        w4b_transform_filter(d.w, d.cin, d.cout, dg, idx, Kp, Np, d.u);
+}
+__global__ __launch_bounds__(256) void wino43b_filter_transform_kernel(const float* __restrict__ w, int Cin, int Cout, int dgrad, int Kp, int Np, unsigned* __restrict__ Ub) {
+    const size_t total = (size_t)(Kp / 2) * Np;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256)
+        w4b_transform_filter(w, Cin, Cout, dgrad != 0, idx, Kp, Np, Ub);
+}
+
+// ---------------------------------------------------------------------------------------------- the convolution
+// exact three-way split of eight floats into the three A-operand fragments of one point (element e of a fragment = channel e of the lane's octet)
+__device__ __forceinline__ void w4b_split8(const float* __restrict__ v, u32x4* __restrict__ f) {
+#if defined(W4B_EXP) && (W4B_EXP & 1)      // timing experiment (numerically meaningless): no split arithmetic
+#pragma unroll
+    for (int m = 0; m < 4; ++m) { f[0][m] = w4b_bits(v[2 * m]); f[1][m] = w4b_bits(v[2 * m + 1]); f[2][m] = w4b_bits(v[m]); }
+    return;
+#endif
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float a = v[2 * m], b = v[2 * m + 1];
+        const unsigned a0 = w4b_bits(a), b0 = w4b_bits(b);
+        f[0][m] = w4b_pack_hi(a0, b0);
+        const float ra = a - w4b_float(a0 & 0xffff0000u), rb = b - w4b_float(b0 & 0xffff0000u);
+        const unsigned a1 = w4b_bits(ra), b1 = w4b_bits(rb);
+        f[1][m] = w4b_pack_hi(a1, b1);
+        const float sa = ra - w4b_float(a1 & 0xffff0000u), sb = rb - w4b_float(b1 & 0xffff0000u);
+        f[2][m] = w4b_pack_hi(w4b_bits(sa), w4b_bits(sb));
+    }
+}
+
+__constant__ float w4b_AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
+
+// global row / column of the 6 x 6 point grid of a wavefront's local kind (0: the `single` one, 1 / 2: the pair) for block half hf (0: rows 0-2)
+__device__ __forceinline__ constexpr int w4b_grid(int hf, int kind) { return kind == 0 ? (hf ? 5 : 0) : (hf ? 2 + kind : kind); }
+
+#ifdef KPX_W4B_STAMP      // diagnostic build only (scratch/w43b_stamps.py): s_memtime stamps of every wavefront of the first 64 workgroups
+static __device__ unsigned long long* w4b_dbg = nullptr;
+extern "C" int kpx_debug_w4b_stamps(unsigned long long* buf) { return -(int)hipMemcpyToSymbol(HIP_SYMBOL(w4b_dbg), &buf, sizeof(buf)); }
+#define W4B_STAMP(slot) do { if (dbgp) dbgp[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define W4B_KSTAMP(k, j) do { if (dbgp && (k) >= 1 && (k) < 5) dbgp[16 + ((k) - 1) * 8 + (j)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define W4B_USTAMP(k, u) do { if (dbgp && (k) == 2) dbgp[256 + (u)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W4B_STAMP(slot) do { } while (0)
+#define W4B_KSTAMP(k, j) do { } while (0)
+#define W4B_USTAMP(k, u) do { } while (0)
+#endif
+
+// The K loop of one wavefront role.  RH / CH: which half of the point rows / columns (compile time: the second transform pass selects
+// REGISTERS by column, the first one patch rows).  acc[lp = 3 rk + ck][nb]: local point (row kind rk, column kind ck), 32-cout block nb.
+template <int RH, int CH>
+__device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&acc0)[9], f32x16 (&acc1)[6], unsigned char* const smem, const int lane, const int wave,
+                                         const int n, const int oy0, const int ox0, const int nti, unsigned long long* const dbgp) {
+    const int KS = g.Kp >> 4, NB = g.Np >> 5;
+    // ---- LDS-DMA of the raw patch: piece wave * 12 + i covers slots 64 (wave * 12 + i) .. + 63 of the buffer
+    const unsigned img_bytes = (unsigned)g.H * g.W * g.ldx * 4u;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x) + (size_t)n * g.H * g.W * g.ldx, 0, img_bytes, 0x00020000);
+    // slot S of row r = S / 146: within the row, slot 17 g + 4 k + q is channel quad q of pixel column 4 g + k (slot 17 g + 16: the skew slot; slots
+    // 144, 145: row padding).  Consecutive lanes = the four quads of a pixel (64 contiguous bytes of the tensor) and four consecutive pixels.
+    unsigned dtail = 0;                                  // bit i: piece i's channel quad exists in the LAST K step (channel tail; K % 4 == 0)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4* const dtab = reinterpret_cast<i32x4*>(smem + W4B_TAB_OFF) + wave * 3 * 64 + lane;      // [3][64 lanes] x 4 offsets: three reads per K step
+    i32x4 dv[3] = {{W4B_OOB, W4B_OOB, W4B_OOB, W4B_OOB}, {W4B_OOB, W4B_OOB, W4B_OOB, W4B_OOB}, {W4B_OOB, W4B_OOB, W4B_OOB, W4B_OOB}};
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int S = (wave * 11 + i) * 64 + lane;
+        const int row = S / W4B_ROWSLOTS, rs = S - row * W4B_ROWSLOTS, grp = rs / 17, r17 = rs - grp * 17;
+        const int col = 4 * grp + (r17 >> 2), q = r17 & 3;
+        const int iy = oy0 - 1 + row, ix = ox0 - 1 + col;
+        const bool ok = r17 < 16 && rs < 144 && row < 18 && col < 34 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        dv[i >> 2][i & 3] = ok ? ((iy * g.W + ix) * g.ldx + q * 4) * 4 : W4B_OOB;
+        if ((KS - 1) * 16 + q * 4 < g.Cin) dtail |= 1u << i;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dtab[i * 64] = dv[i];
+    auto dma = [&](int s, int buf) {                     // K step s -> raw buffer buf
+        unsigned char* const dst = smem + buf * W4B_RAW_BYTES + wave * 11 * 1024;
+        const bool last = s == KS - 1;
+        const i32x4 t0 = dtab[0], t1 = dtab[64], t2 = dtab[128];
+#pragma unroll
+        for (int i = 0; i < 11; ++i) {
+            const int v = i < 4 ? t0[i & 3] : i < 8 ? t1[i & 3] : t2[i & 3];
+            const int vo = (last && !((dtail >> i) & 1u)) ? W4B_OOB : v;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(dst + i * 1024), 16, vo, s * 64, 0, 0);
+        }
+    };
+    // ---- filter fragments: unit u = 2 lp + nb of a K step; ring slot u % 6
+    const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.U), 0, 36u * (unsigned)(KS * NB) * 3072u, 0x00020000);
+    const int ulane = lane * 16;
+    const int ustep = NB * 3072;                         // bytes per K step
+    int ubase[9];
+#pragma unroll
+    for (int lp = 0; lp < 9; ++lp)
+        ubase[lp] = __builtin_amdgcn_readfirstlane(((6 * w4b_grid(RH, lp / 3) + w4b_grid(CH, lp % 3)) * KS * NB + 2 * nti) * 3072);
+    u32x4 ub[6][3];
+    auto uload = [&](int slot, int unit, int koff) {     // unit of the K step at byte offset koff -> ring slot
+#if defined(W4B_EXP) && (W4B_EXP & 2)      // timing experiment: the ring is loaded once (prologue) and never refilled
+        if (unit >= 6) return;
+#endif
+        const int so = ubase[unit >> 1] + (unit & 1) * 3072 + koff;
+#pragma unroll
+        for (int tm = 0; tm < 3; ++tm)
+            ub[slot][tm] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, so + tm * 1024, 0));
+    };
+
+    // ---- transform read base of this lane: pixel (4 ty + RH, 4 tx + CH) of the patch, channel quad 2 * octet.  Tile origins are 17 slots apart
+    // in x and 4 x 146 = 8 (mod 16) slots in y, so the sixteen lanes of every ds_read_b128 group (tiles {0-3, 12-15, 20-27} /
+    // {4-11, 16-19, 28-31} of one octet) hit sixteen different 16-B columns of the 256-B bank row: {0..3}, {12..15}, {4..7}, {8..11}.
+    const int tile = lane & 31, oct = lane >> 5, ty = tile >> 3, tx = tile & 7;
+    const int rbase = ((4 * ty + RH) * W4B_ROWSLOTS + 17 * tx + 2 * oct) * 16;
+    // patch column CH + m of the tile: slot 4 (CH + m) + ((CH + m) >> 2)
+#define W4B_RD(buf, j, a, m) (*reinterpret_cast<const f32x4*>(smem + (buf) * W4B_RAW_BYTES + rbase + ((a) * W4B_ROWSLOTS + 4 * (CH + (m)) + ((CH + (m)) >> 2) + (j)) * 16))
+
+    // the LDS-resident accumulator blocks (this lane's 16 registers of block lp / 3 as 4 x 16 B)
+    unsigned char* const accsp = smem + W4B_ACC_OFF + wave * 12288 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) *reinterpret_cast<f32x4*>(accsp + i * 1024) = f32x4{0.f, 0.f, 0.f, 0.f};
+    // one unit's six products, smallest first
+    auto mma = [&](f32x16& c, const u32x4* a, const u32x4* b) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[1]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[2]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[2]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[1]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
+    };
+    f32x16 ct;                                           // the transient block: zero = the first K step's block 0
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ct[r] = 0.f;
+    // one unit: six products into the unit's accumulator block -- a register block, or (nb = 1 of local points 2, 5, 8) LDS -> transient -> LDS
+    auto unit = [&](int lp, int nb, const u32x4* a, const u32x4* b) {
+#if defined(W4B_EXP) && (W4B_EXP & 16)
+        if (nb == 1 && lp % 3 == 2) { mma(acc1[lp - lp / 3 - 1], a, b); return; }
+#endif
+        if (nb == 1 && lp % 3 == 2) {
+            // the transient `ct` already holds this block (read right after the previous LDS-resident block was written back: a whole
+            // third of a K step earlier); write it back and fetch the next one
+            mma(ct, a, b);
+            unsigned char* const sp = accsp + (lp / 3) * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(sp + i * 1024) = f32x4{ct[4 * i], ct[4 * i + 1], ct[4 * i + 2], ct[4 * i + 3]};
+            const unsigned char* const sq = accsp + ((lp / 3 + 1) % 3) * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(sq + i * 1024);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) ct[4 * i + q] = v[q];
+            }
+        } else if (nb == 0) mma(acc0[lp], a, b);
+        else mma(acc1[lp - lp / 3], a, b);
+    };
+    // second transform pass over the five column sums t[m] (column CH + m) of one point row: the three points of this wavefront's column half
+    //   single (B^T row 0 / 5): 4 t0 - 5 t2 + t4 ;  pair, CH = 0 (rows 1, 2 of B^T on columns 1..4): (t4 - 4 t2) +- (t3 - 4 t1)
+    //                                               pair, CH = 1 (rows 3, 4 on columns 1..4 = t0..t3): (t3 - t1) +- 2 (t2 - t0)
+    auto second = [&](const f32x4* t, f32x4* o) {
+        o[0] = 4.f * t[0] - 5.f * t[2] + t[4];
+        if (CH == 0) {
+            const f32x4 u = t[4] - 4.f * t[2], v = t[3] - 4.f * t[1];
+            o[1] = u + v; o[2] = u - v;
+        } else {
+            const f32x4 u = t[3] - t[1], v = t[2] - t[0];
+            o[1] = u + 2.f * v; o[2] = u - 2.f * v;
+        }
+    };
+
+
+    // (Walking the K steps in an order rotated from tile to tile, so that the workgroups of a round do not all read the same few KB of U at
+    //  the same time, was measured: no change -- the L2 channels are not the limit.  Every tile sums its channels in the same order.)
+    //
+    // Schedule of a K step: T single, M single, T pair, M pair, counted wait + barrier (the next step's patch was requested at the top of the
+    // step).  The filter stream is latency bound (six units of look-ahead against ~2 k cycles of loaded L2 latency), so the transforms would
+    // ideally issue BESIDE the multiplies of the previous point group; the rotated loop that does this (M single, T pair | barrier | M pair ||
+    // T single of the next step) was built and spills 11-36 registers per iteration to scratch -- vector-memory operations with vmcnt(0) waits
+    // in the middle of the counted pipeline -- because V of two point groups, the fragment ring and the transform's temporaries are live
+    // together.  Not kept.
+    auto t_single = [&](int buf, float (&vs)[3][8]) {    // patch rows RH + 0, 2, 4
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 t[5];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) t[m] = 4.f * W4B_RD(buf, j, 0, m) - 5.f * W4B_RD(buf, j, 2, m) + W4B_RD(buf, j, 4, m);
+            f32x4 o[3];
+            second(t, o);
+#pragma unroll
+            for (int ck = 0; ck < 3; ++ck)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vs[ck][4 * j + q] = o[ck][q];
+        }
+    };
+    auto t_pair = [&](int buf, float (&vp)[6][8]) {      // patch rows 1..4 (= RH-relative rows 1-RH .. 4-RH)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 t1[5], t2[5];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                const f32x4 d1 = W4B_RD(buf, j, 1 - RH, m), d2 = W4B_RD(buf, j, 2 - RH, m), d3 = W4B_RD(buf, j, 3 - RH, m), d4 = W4B_RD(buf, j, 4 - RH, m);
+                if (RH == 0) {
+                    const f32x4 u = d4 - 4.f * d2, v = d3 - 4.f * d1;
+                    t1[m] = u + v; t2[m] = u - v;
+                } else {
+                    const f32x4 u = d4 - d2, v = d3 - d1;
+                    t1[m] = u + 2.f * v; t2[m] = u - 2.f * v;
+                }
+            }
+            f32x4 o1[3], o2[3];
+            second(t1, o1);
+            second(t2, o2);
+#pragma unroll
+            for (int ck = 0; ck < 3; ++ck)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { vp[ck][4 * j + q] = o1[ck][q]; vp[3 + ck][4 * j + q] = o2[ck][q]; }
+        }
+    };
+
+    // prologue: the first K step's patch, the first six filter units
+    dma(0, 0);
+#pragma unroll
+    for (int u = 0; u < 6; ++u) uload(u, u, 0);
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");     // the 11 DMA pieces are older than the 18 fragment loads
+    __builtin_amdgcn_s_barrier();
+    W4B_STAMP(1);
+
+    for (int it = 0; it < KS; ++it) {
+        const int buf = it & 1;
+        const int koff = it * ustep;
+        W4B_KSTAMP(it, 0);
+#if defined(W4B_EXP) && (W4B_EXP & 8)
+#else
+        if (it + 1 < KS) dma(it + 1, buf ^ 1);
+#endif
+        W4B_KSTAMP(it, 1);
+        float vs[3][8];                                  // V of the `single` row's three points, this lane's 8 channels
+        t_single(buf, vs);
+        W4B_KSTAMP(it, 2);
+        // ---- its three points: units 0..5
+        {
+            u32x4 af[2][3];
+            w4b_split8(vs[0], af[0]);
+#pragma unroll
+            for (int ck = 0; ck < 3; ++ck) {
+                if (ck < 2) w4b_split8(vs[ck + 1], af[(ck + 1) & 1]);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int u = 2 * ck + nb;
+                    unit(ck, nb, af[ck & 1], ub[u]);
+                    uload(u, u + 6, koff);
+                    W4B_USTAMP(it, u);
+                }
+            }
+        }
+        W4B_KSTAMP(it, 3);
+        float vp[6][8];
+        t_pair(buf, vp);
+        W4B_KSTAMP(it, 4);
+        // ---- the pair rows' six points: units 6..17 (local points 3..8)
+        {
+            u32x4 af[2][3];
+            w4b_split8(vp[0], af[0]);
+#pragma unroll
+            for (int pp = 0; pp < 6; ++pp) {
+                if (pp < 5) w4b_split8(vp[pp + 1], af[(pp + 1) & 1]);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int u = 6 + 2 * pp + nb;
+                    unit(3 + pp, nb, af[pp & 1], ub[u % 6]);
+                    if (u < 12) uload(u % 6, u + 6, koff);
+                    else uload(u % 6, u - 12, koff + ustep);          // next K step (after the last one: a harmless read of the next point / zeros)
+                    W4B_USTAMP(it, u);
+                }
+            }
+        }
+        W4B_KSTAMP(it, 5);
+        if (it + 1 < KS) {
+            asm volatile("s_waitcnt vmcnt(18)" ::: "memory");         // the next patch has landed: only the 18 fragment loads issued after its DMA may be in flight
+            W4B_KSTAMP(it, 6);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    W4B_STAMP(2);
+#undef W4B_RD
+}
+
+template <int STATS>
+__global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
+    const int ntc = g.Np / 64;
+    const int nti = L % ntc; L /= ntc;
+    const int bx = L % g.tiles_x; L /= g.tiles_x;
+    const int by = L % g.tiles_y;
+    const int n = L / g.tiles_y;
+    const int oy0 = by * 16, ox0 = bx * 32, n0 = nti * 64;
+
+    f32x16 acc0[9], acc1[6];                             // cout block 0 of all nine local points; cout block 1 of local points 0, 1, 3, 4, 6, 7
+#pragma unroll
+    for (int b = 0; b < 9; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[b][r] = 0.f;
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[b][r] = 0.f;
+
+#ifdef KPX_W4B_STAMP
+    unsigned long long* const dbgp = (w4b_dbg && lane == 0 && blockIdx.x < 64) ? w4b_dbg + ((size_t)blockIdx.x * 4 + wave) * 512 : nullptr;
+    if (dbgp) { dbgp[0] = __builtin_amdgcn_s_memtime(); dbgp[8] = __builtin_amdgcn_s_memrealtime(); }
+#else
+    unsigned long long* const dbgp = nullptr;
+#endif
+    const int rh = wave >> 1, ch = wave & 1;
+    if (wave == 0) w4b_kloop<0, 0>(g, acc0, acc1, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+    else if (wave == 1) w4b_kloop<0, 1>(g, acc0, acc1, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+    else if (wave == 2) w4b_kloop<1, 0>(g, acc0, acc1, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+    else w4b_kloop<1, 1>(g, acc0, acc1, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+
+    // ---- epilogue: two passes (one per 32-cout block) of all 36 points through LDS; thread = (tile, 4 couts)
+    f32x16 accl[3];                                      // the LDS-resident blocks, before the passes overwrite them
+    {
+        const unsigned char* const accsp = smem + W4B_ACC_OFF + wave * 12288 + lane * 16;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(accsp + (b * 4 + i) * 1024);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) accl[b][4 * i + q] = v[q];
+            }
+    }
+    float* const P = reinterpret_cast<float*>(smem);
+    const int li = lane & 31, lh = lane >> 5;
+    const int otile = t >> 3, ocq = t & 7;
+    const float* const Pr = P + otile * 32 + ocq * 4;
+    const float lo = g.act == KPX_ACT_RELU ? 0.f : -__builtin_inff();
+    const float slope = g.act == KPX_ACT_LRELU ? 0.01f : 1.f;
+    const int oy = oy0 + 4 * (otile >> 3), ox = ox0 + 4 * (otile & 7);
+    const size_t cstr = (size_t)g.ldy, rstr = (size_t)g.W * g.ldy;
+#pragma unroll 1
+    for (int nb = 0; nb < 2; ++nb) {
+        __syncthreads();                                 // main-loop LDS reads (nb = 0) / the first pass's P reads (nb = 1) are done
+        if (nb == 0) W4B_STAMP(3);
+#pragma unroll
+        for (int lp = 0; lp < 9; ++lp) {
+            const int p = 6 * w4b_grid(rh, lp / 3) + w4b_grid(ch, lp % 3);
+            float* const Pw = P + (p * 32 + 4 * lh) * 32 + li;
+            if (nb == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Pw[((r & 3) + 8 * (r >> 2)) * 32] = acc0[lp][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Pw[((r & 3) + 8 * (r >> 2)) * 32] = lp % 3 == 2 ? accl[lp / 3][r] : acc1[lp - lp / 3][r];
+            }
+        }
+        if (nb == 0) W4B_STAMP(4);
+        __syncthreads();
+        if (nb == 0) W4B_STAMP(5);
+        // Q[a][jj] = sum_b M[a][b] A[b][jj], then Y[ii][jj] = sum_a A^T[ii][a] Q[a][jj]
+        f32x4 Q[6][4];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            f32x4 m[6];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) m[b] = *reinterpret_cast<const f32x4*>(&Pr[(a * 6 + b) * 1024]);
+            const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+            Q[a][0] = m[0] + s12 + s34;
+            Q[a][1] = d12 + 2.f * d34;
+            Q[a][2] = s12 + 4.f * s34;
+            Q[a][3] = d12 + 8.f * d34 + m[5];
+        }
+        f32x4 Y[4][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const f32x4 s12 = Q[1][jj] + Q[2][jj], d12 = Q[1][jj] - Q[2][jj], s34 = Q[3][jj] + Q[4][jj], d34 = Q[3][jj] - Q[4][jj];
+            Y[0][jj] = Q[0][jj] + s12 + s34;
+            Y[1][jj] = d12 + 2.f * d34;
+            Y[2][jj] = s12 + 4.f * s34;
+            Y[3][jj] = d12 + 8.f * d34 + Q[5][jj];
+        }
+        if (nb == 0) W4B_STAMP(6);
+        const int c0o = n0 + 32 * nb + ocq * 4;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (c0o + q < g.Cout) bv[q] = g.bias[c0o + q];
+        }
+        float* const obase = g.y + ((size_t)(n * g.H + oy) * g.W + ox) * g.ldy + c0o;
+        const bool fast = (g.ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.y) & 15) == 0) && n0 + 32 * nb + 32 <= g.Cout;     // block-uniform
+        f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
+        if (STATS == 2) {
+            // data gradient dz of a ReLU'd batch norm's output z (= mask_y): store dz * [z > 0] and reduce sum(dz), sum(dz * (z - beta))
+            // (launch preconditions checked by the entry: fast stores, no bias / act)
+            const float* const mbase = g.mask_y + ((size_t)(n * g.H + oy) * g.W + ox) * g.ld_mask + c0o;
+            const size_t mc = (size_t)g.ld_mask, mr = (size_t)g.W * g.ld_mask;
+            const f32x4 be = *reinterpret_cast<const f32x4*>(g.bn_beta + c0o);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 zm[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) zm[j] = *reinterpret_cast<const f32x4*>(mbase + i * mr + j * mc);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float dz = zm[j][q] > 0.f ? Y[i][j][q] : 0.f;
+                        v[q] = dz; st_s[q] += dz; st_q[q] += dz * (zm[j][q] - be[q]);
+                    }
+                    *reinterpret_cast<f32x4*>(obase + i * rstr + j * cstr) = v;
+                }
+            }
+        } else if (fast && !STATS && (g.mask_y || g.pool_y)) {       // block-uniform: VGG19's fused ReLU backward / max-pool forward
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = Y[i][j] + bv;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float z = fmaxf(v[q], lo); v[q] = z > 0.f ? z : z * slope; }
+                    Y[i][j] = v;
+                }
+            if (g.mask_y) {
+                const float* const mbase = g.mask_y + ((size_t)(n * g.H + oy) * g.W + ox) * g.ld_mask + c0o;
+                const size_t mc = (size_t)g.ld_mask, mr = (size_t)g.W * g.ld_mask;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 ym = *reinterpret_cast<const f32x4*>(mbase + i * mr + j * mc);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) Y[i][j][q] = ym[q] > 0.f ? Y[i][j][q] : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(obase + i * rstr + j * cstr) = Y[i][j];
+            if (g.pool_y) {
+                const int Hp = g.H >> 1, Wp = g.W >> 1;
+                float* const pbase = g.pool_y + ((size_t)(n * Hp + (oy >> 1)) * Wp + (ox >> 1)) * g.ld_pool + c0o;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 pv;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            pv[q] = fmaxf(fmaxf(Y[2 * i][2 * j][q], Y[2 * i][2 * j + 1][q]), fmaxf(Y[2 * i + 1][2 * j][q], Y[2 * i + 1][2 * j + 1][q]));
+                        *reinterpret_cast<f32x4*>(pbase + ((size_t)i * Wp + j) * g.ld_pool) = pv;
+                    }
+            }
+        } else if (fast) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = Y[i][j] + bv;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float z = fmaxf(v[q], lo); v[q] = z > 0.f ? z : z * slope; }
+                    if (STATS) { st_s += v; st_q += v * v; }
+                    *reinterpret_cast<f32x4*>(obase + i * rstr + j * cstr) = v;
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = Y[i][j] + bv;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const float z = fmaxf(v[q], lo); v[q] = z > 0.f ? z : z * slope; }
+                    if (STATS) { st_s += v; st_q += v * v; }
+                    float* o = obase + i * rstr + j * cstr;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (c0o + q < g.Cout) o[q] = v[q];
+                }
+        }
+        if (STATS != 0) {
+            // batch-norm statistics per 4 x 16-pixel strip (4 tiles: lane bits 3-4), fixed butterfly order: bitwise reproducible.
+            // A wavefront's 64 threads = 8 tiles x 8 cout quads = two strips (2 wave + (lane >> 5)) x 32 couts.
+#pragma unroll
+            for (int sh = 8; sh <= 16; sh <<= 1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { st_s[q] += __shfl_xor(st_s[q], sh); st_q[q] += __shfl_xor(st_q[q], sh); }
+            if ((lane & 24) == 0) {
+                const size_t strip = (((size_t)n * g.tiles_y + by) * g.tiles_x + bx) * 8 + 2 * wave + lh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c0o + q < g.Cout) { g.stats[(strip * 2) * g.Cout + c0o + q] = st_s[q]; g.stats[(strip * 2 + 1) * g.Cout + c0o + q] = st_q[q]; }
+            }
+        }
+        if (nb == 0) W4B_STAMP(10);
+    }
+    W4B_STAMP(7);
+#ifdef KPX_W4B_STAMP
+    if (dbgp) dbgp[9] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+static std::atomic<unsigned long long> w4b_attr_mask{0};
+static inline int w4b_lds_bytes() { return W4B_EPI_BYTES > W4B_MAIN_BYTES ? W4B_EPI_BYTES : W4B_MAIN_BYTES; }
+
+extern "C" int kpx_conv3x3_wino43b_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
+    if (kpx_env()->no_wino || N <= 0) return 0;
+    return H % 16 == 0 && W % 32 == 0 && K >= 16 && K % 4 == 0 && Nn >= 33 && ldin >= K && ldin % 4 == 0 && (((uintptr_t)in_ptr) & 15) == 0 &&
+           (size_t)H * W * ldin * 4 < 0x7fffff00u && (size_t)36 * ((K + 15) & ~15) * ((Nn + 63) & ~63) * 6 < 0x7fffff00u;
+}
+extern "C" size_t kpx_wino43b_u_bytes(int Cin, int Cout) {
+    const size_t a = (size_t)((Cin + 15) & ~15) * ((Cout + 63) & ~63), b = (size_t)((Cout + 15) & ~15) * ((Cin + 63) & ~63);
+    return 36 * 6 * (a > b ? a : b);
+}
+extern "C" int kpx_wino43b_filter_transform_f32(const float* w_hwio, int Cin, int Cout, int dgrad, void* U, void* stream) {
+    if (!w_hwio || !U || Cin <= 0 || Cout <= 0) return KPX_EINVAL;
+    const int K = dgrad ? Cout : Cin, Nn = dgrad ? Cin : Cout;
+    const int Kp = (K + 15) & ~15, Np = (Nn + 63) & ~63;
+    size_t nb = ((size_t)(Kp / 2) * Np + 255) / 256; if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(wino43b_filter_transform_kernel, dim3((unsigned)nb), dim3(256), 0, kpx_stream(stream), w_hwio, Cin, Cout, dgrad, Kp, Np, (unsigned*)U);
+    return kpx_launch_status();
+}
+extern "C" int kpx_wino43b_filter_transform_batch_f32(const void* descs_dev, int n, void* stream) {
+    if (!descs_dev || n <= 0 || n > 65535) return KPX_EINVAL;
+    hipLaunchKernelGGL(wino43b_filter_transform_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, kpx_stream(stream), (const KpxWino43bDesc*)descs_dev);
+    return kpx_launch_status();
+}
+
+// One entry for every form of the launch (the options are those of kpx_conv3x3_wino43_f32 / _stats_f32 / _ex_f32 / _bnbwd_stats_f32):
+//   tile_stats alone: batch-norm sums of the output per 4 x 16-pixel strip;  tile_stats + bn_y + bn_beta: data gradient towards a ReLU'd batch
+//   norm's output, masked, with that batch norm's backward sums;  mask_y / pool_y: VGG19's fused ReLU backward / 2x2 max-pool.
+extern "C" int kpx_conv3x3_wino43b_f32(const float* in, int N, int H, int W, int K, int ldin, const void* U, const float* bias,
+                                       float* out, int Nn, int ldout, int act, const float* mask_y, int ld_mask, float* pool_y, int ld_pool,
+                                       float* tile_stats, const float* bn_y, int ld_bn_y, const float* bn_beta, void* stream) {
+    if (!in || !U || !out || ldin < K || ldout < Nn || act < 0 || act > 2 || !kpx_conv3x3_wino43b_eligible(N, H, W, K, Nn, ldin, in)) return KPX_EINVAL;
+    const bool bnbwd = bn_y != nullptr || bn_beta != nullptr;
+    if (bnbwd && (!tile_stats || !bn_y || !bn_beta || mask_y || pool_y || bias || act != KPX_ACT_NONE || Nn % 64 || ldout % 4 || (((uintptr_t)out) & 15) ||
+                  ld_bn_y % 4 || ld_bn_y < Nn || (((uintptr_t)bn_y) & 15) || (((uintptr_t)bn_beta) & 15)))
+        return KPX_EINVAL;
+    if ((mask_y || pool_y) && (tile_stats || Nn % 64 || ldout % 4 || (((uintptr_t)out) & 15) ||
+                               (mask_y && (ld_mask % 4 || ld_mask < Nn || (((uintptr_t)mask_y) & 15))) ||
+                               (pool_y && (ld_pool % 4 || ld_pool < Nn || (((uintptr_t)pool_y) & 15) || (H & 1) || (W & 1)))))
+        return KPX_EINVAL;
+    if (kpx_first_use_on_device(&w4b_attr_mask)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43b_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, w4b_lds_bytes());
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43b_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, w4b_lds_bytes());
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43b_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, w4b_lds_bytes());
+        if (e != hipSuccess) return -(int)e;
+    }
+    Wino43bGeom g{};
+    g.x = in; g.y = out; g.U = U; g.bias = bias;
+    g.N = N; g.H = H; g.W = W; g.Cin = K; g.ldx = ldin; g.Cout = Nn; g.ldy = ldout; g.act = act;
+    g.Kp = (K + 15) & ~15; g.Np = (Nn + 63) & ~63;
+    g.tiles_y = H / 16; g.tiles_x = W / 32;
+    g.stats = tile_stats;
+    g.mask_y = bnbwd ? bn_y : mask_y; g.ld_mask = bnbwd ? ld_bn_y : ld_mask; g.pool_y = pool_y; g.ld_pool = ld_pool; g.bn_beta = bn_beta;
+    const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x * (g.Np / 64));
+    if (bnbwd) hipLaunchKernelGGL((conv_wino43b_kernel<2>), dim3(blocks), dim3(256), w4b_lds_bytes(), kpx_stream(stream), g);
+    else if (tile_stats) hipLaunchKernelGGL((conv_wino43b_kernel<1>), dim3(blocks), dim3(256), w4b_lds_bytes(), kpx_stream(stream), g);
+    else hipLaunchKernelGGL((conv_wino43b_kernel<0>), dim3(blocks), dim3(256), w4b_lds_bytes(), kpx_stream(stream), g);
+    return kpx_launch_status();
+}

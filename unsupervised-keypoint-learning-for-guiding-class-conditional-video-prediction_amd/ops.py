@@ -351,6 +351,7 @@ import struct as _struct
 
 _wino_u = {}          # (filter data_ptr, dgrad) -> (U tensor, owning FilterBank or None, weak reference to the filter tensor, (Cin, Cout))
 _wino43_u = {}        # the same for the F(4x4,3x3) form of the filters whose layers may use it
+_wino43b_u = {}       # ... and its bf16x3 form (three exact bf16 planes in fragment order) for csrc/conv_wino43b.hip
 import weakref as _weakref
 
 
@@ -366,7 +367,7 @@ def _cached_u(table, w, dgrad):
         table.pop(key, None)
         return None
     return ent
-conv_kernel_uses = {'wino43': 0}      # diagnostics / tests: launches of the F(4x4,3x3) kernel
+conv_kernel_uses = {'wino43': 0, 'wino43b': 0}      # diagnostics / tests: launches of the F(4x4,3x3) kernels (fp32-MFMA form / bf16x3 form; 'wino43' counts both)
 
 # F(4x4,3x3) (csrc/conv_wino43.hip) does 2.25x fewer multiplies than F(2x2,3x3) at ~6x its rounding error (2-3e-6 rel-L2 per layer, still
 # inside the 1e-5 bar of one layer).  Where it runs is a PER-LAYER ATTRIBUTE and a direction, from the measured effect on a whole train
@@ -386,6 +387,20 @@ WINO43 = _os.environ.get('KPX_WINO43', '1') != '0'
 # 23.73-23.83 ms per step at 0 / 32 / 64 against 24.01-24.16 at 128 (three repetitions each, B=32) -- so no threshold
 WINO43_MIN_WORKGROUPS = 0          # (a module constant the model-level parity tests set to 128 and back)
 WINO43_NMIN = 33                   # produced channels from which a layer takes the 64-cout F(4x4,3x3) workgroups (32 / 16 measured: no change)
+# F(4x4,3x3) with the transform-domain GEMMs fp32-EQUIVALENT on the bf16 matrix pipe (csrc/conv_wino43b.hip: exact three-term operands, six
+# products): the same layers and directions as WINO43, same per-layer policy; the shapes it takes (no packed 16x16 images, K % 4 == 0) and
+# where it is preferred over the fp32-MFMA kernel: _wino43b_preferred.  KPX_WINO43B=0: the fp32-MFMA F(4x4,3x3) kernel everywhere (A/B, tests).
+WINO43B = _os.environ.get('KPX_WINO43B', '1') != '0'
+WINO43B_MAX_CHANNELS = 512         # gathered x produced channels up to which the bf16x3 form is prepared (its U is 1.5x the fp32 U: L2 traffic)
+
+
+def _wino43b_form_wanted(k, nn):
+    return WINO43B and k >= 16 and k % 4 == 0 and nn >= WINO43_NMIN and max(k, nn) <= WINO43B_MAX_CHANNELS
+
+
+def _wino43b_preferred(n, h, wd, k, nn):
+    """Launch shapes on which the bf16x3 kernel is the faster F(4x4,3x3) form (profiles/r06_wino43b_layers.txt)."""
+    return True
 
 
 def _wino43_wanted(name, cin, cout, dgrad, f43_fwd=True):
@@ -427,6 +442,21 @@ class FilterBank:
         self.table = torch.frombuffer(bytearray(table), dtype=torch.uint8).to(device)
         self.n_desc43 = len(table43) // 32
         self.table43 = torch.frombuffer(bytearray(table43), dtype=torch.uint8).to(device) if table43 else None
+        # the bf16x3 form of the same (filter, direction) pairs where the kernel can take the layer
+        want43b = [[wt[d] and _wino43b_form_wanted(*((int(w.shape[3]), int(w.shape[2])) if d else (int(w.shape[2]), int(w.shape[3])))) for d in (0, 1)]
+                   for (_, w), wt in zip(self.filters, want43)]
+        sizes43b = [lib.kpx_wino43b_u_bytes(int(w.shape[2]), int(w.shape[3])) for _, w in self.filters]
+        self.arena43b = torch.empty(sum(nb * sum(wb) for nb, wb in zip(sizes43b, want43b)) or 1, dtype=torch.uint8, device=device)
+        table43b, off = b'', 0
+        for (_, w), nb, wb in zip(self.filters, sizes43b, want43b):
+            for dgrad in (0, 1):
+                if wb[dgrad]:
+                    u = self.arena43b[off:off + nb]
+                    off += nb
+                    _wino43b_u[(w.data_ptr(), dgrad)] = (u, self, None, (int(w.shape[2]), int(w.shape[3])))
+                    table43b += _struct.pack('<QQiiii', w.data_ptr(), u.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, 0)
+        self.n_desc43b = len(table43b) // 32
+        self.table43b = torch.frombuffer(bytearray(table43b), dtype=torch.uint8).to(device) if table43b else None
 
     def touch(self):
         self.version += 1
@@ -468,6 +498,8 @@ class FilterBank:
             check(lib.kpx_wino_filter_transform_batch_f32(self.table.data_ptr(), self.n_desc, _stream()), 'kpx_wino_filter_transform_batch_f32')
             if self.n_desc43:
                 check(lib.kpx_wino43_filter_transform_batch_f32(self.table43.data_ptr(), self.n_desc43, _stream()), 'kpx_wino43_filter_transform_batch_f32')
+            if self.n_desc43b:
+                check(lib.kpx_wino43b_filter_transform_batch_f32(self.table43b.data_ptr(), self.n_desc43b, _stream()), 'kpx_wino43b_filter_transform_batch_f32')
             self.synced = self.version
 
     def keys(self):
@@ -494,6 +526,11 @@ def register_constant_filter(w, name='', f43_fwd=True):
             u = torch.empty(lib.kpx_wino43_u_bytes(int(w.shape[2]), int(w.shape[3])) // 4, dtype=torch.float32, device=w.device)
             check(lib.kpx_wino43_filter_transform_f32(w.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, u.data_ptr(), _stream()), 'kpx_wino43_filter_transform_f32')
             _wino43_u[(w.data_ptr(), dgrad)] = (u, None, _weakref.ref(w.untyped_storage()), (int(w.shape[2]), int(w.shape[3])))
+            kk, nn_ = (int(w.shape[3]), int(w.shape[2])) if dgrad else (int(w.shape[2]), int(w.shape[3]))
+            if _wino43b_form_wanted(kk, nn_):
+                ub = torch.empty(lib.kpx_wino43b_u_bytes(int(w.shape[2]), int(w.shape[3])), dtype=torch.uint8, device=w.device)
+                check(lib.kpx_wino43b_filter_transform_f32(w.data_ptr(), int(w.shape[2]), int(w.shape[3]), dgrad, ub.data_ptr(), _stream()), 'kpx_wino43b_filter_transform_f32')
+                _wino43b_u[(w.data_ptr(), dgrad)] = (ub, None, _weakref.ref(w.untyped_storage()), (int(w.shape[2]), int(w.shape[3])))
         if _compute_dtype[0] == 'bf16' and int(w.shape[2]) % 8 == 0:
             cin, cout = int(w.shape[2]), int(w.shape[3])
             k, nn = (cout, cin) if dgrad else (cin, cout)
@@ -508,6 +545,7 @@ def release_filters(keys):
     for k in keys:
         _wino_u.pop(k, None)
         _wino43_u.pop(k, None)
+        _wino43b_u.pop(k, None)
         _bf16s_w.pop(k, None)
 
 
@@ -528,6 +566,22 @@ def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, wa
     tiles = lib.kpx_conv3x3_wino43_stats_tiles(n, h, wd) if want_stats else 1      # 0: no statistics from this kernel for the shape (16 x 16)
     # (WINO43_MIN_WORKGROUPS: see its definition -- 0 by default)
     wgs43 = (n // 2 if wd == 16 else n * (h // 16) * (wd // 32)) * ((nn + 63) // 64)
+    # the bf16x3 form of F(4x4,3x3) (same policy, same epilogue options) where it is prepared, eligible and the faster one
+    ent43b = _cached_u(_wino43b_u, w, dgrad) if (WINO43B and ent43 is not None) else None
+    if (ent43b is not None and tiles and wgs43 > WINO43_MIN_WORKGROUPS and _wino43b_preferred(n, h, wd, k, nn)
+            and lib.kpx_conv3x3_wino43b_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr())):
+        bnbwd = bn_src is not None and dgrad and nn % 64 == 0
+        slab = None
+        if bnbwd or want_stats:
+            slab = torch.empty(lib.kpx_conv3x3_wino43_stats_tiles(n, h, wd) * 2 * nn, dtype=torch.float32, device=inp.device)
+        rc = lib.kpx_conv3x3_wino43b_f32(inp.data_ptr(), n, h, wd, k, ld_in, ent43b[0].data_ptr(), None if bnbwd else bptr, out.data_ptr(), nn, ld_out,
+                                         ACT_NONE if bnbwd else act, None, 0, None, 0, slab.data_ptr() if slab is not None else None,
+                                         bn_src[0].data_ptr() if bnbwd else None, bn_src[0].shape[3] if bnbwd else 0, bn_src[1].data_ptr() if bnbwd else None, _stream())
+        if rc != -1:
+            check(rc, 'kpx_conv3x3_wino43b_f32')
+            conv_kernel_uses['wino43'] += 1
+            conv_kernel_uses['wino43b'] += 1
+            return (slab, lib.kpx_conv3x3_wino43_stats_tiles(n, h, wd) // n) if slab is not None else True
     if (ent43 is not None and bn_src is not None and dgrad and wd != 16 and nn % 64 == 0 and wgs43 > WINO43_MIN_WORKGROUPS
             and lib.kpx_conv3x3_wino43_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr())):
         # data gradient towards a ReLU'd batch norm's output on F(4x4,3x3): its epilogue masks the gradient and reduces the batch norm's backward sums
@@ -585,6 +639,17 @@ def conv3x3_wino43_ex(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, mask=
         return False
     if ent43[1] is not None:
         ent43[1].ensure_fresh('wino')
+    ent43b = _cached_u(_wino43b_u, w, dgrad) if WINO43B else None
+    if (ent43b is not None and _wino43b_preferred(n, h, wd, k, nn) and lib.kpx_conv3x3_wino43b_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr())):
+        rc = lib.kpx_conv3x3_wino43b_f32(inp.data_ptr(), n, h, wd, k, ld_in, ent43b[0].data_ptr(), bias.data_ptr() if bias is not None else None,
+                                         out.data_ptr(), nn, ld_out, act, mask.data_ptr() if mask is not None else None,
+                                         mask.shape[3] if mask is not None else 0, pool_out.data_ptr() if pool_out is not None else None,
+                                         pool_out.shape[3] if pool_out is not None else 0, None, None, 0, None, _stream())
+        if rc != -1:
+            check(rc, 'kpx_conv3x3_wino43b_f32')
+            conv_kernel_uses['wino43'] += 1
+            conv_kernel_uses['wino43b'] += 1
+            return True
     rc = lib.kpx_conv3x3_wino43_ex_f32(inp.data_ptr(), n, h, wd, k, ld_in, ent43[0].data_ptr(), bias.data_ptr() if bias is not None else None,
                                        out.data_ptr(), nn, ld_out, act, mask.data_ptr() if mask is not None else None,
                                        mask.shape[3] if mask is not None else 0, pool_out.data_ptr() if pool_out is not None else None,
