@@ -74,7 +74,7 @@ def _time_conv_3_1(dev, pretransformed=False, name='translator/conv_3_1', f43_fw
     return ms, 2.0 * 9 * c * c * h * h * n
 
 
-PROFILE = 'r05'          # prefix of the committed rocprofv3 summaries under profiles/ the lines below point at (profiles/collect_r05.sh)
+PROFILE = 'r06'          # prefix of the committed rocprofv3 summaries under profiles/ the lines below point at (profiles/collect_r06.sh)
 
 
 def _rocprof_avg_ms(kernel_substr, csv_name=PROFILE + '_roofline_only_kernel_stats.csv'):
@@ -112,20 +112,43 @@ GEMM3_PMC, BF16_PMC, WGRAD_PMC = PROFILE + '_gemm3_pmc.json', PROFILE + '_bf16_p
 WGRAD16_PMC = PROFILE + '_wgrad_bf16_pmc.json'
 
 
-def _roofline_wino(dev, name, kernel_substr, kernel_desc, reduction, pmc, f43_fwd=True, csv_name=None, **shape):
-    ms, flops = _time_conv_3_1(dev, pretransformed=True, name=name, f43_fwd=f43_fwd, **shape)
+def _roofline_wino(dev, name, kernel_substr, kernel_desc, reduction, pmc, f43_fwd=True, csv_name=None, bf16x3=None, **shape):
+    """bf16x3: None = the kernel the train step uses for this launch (ops.WINO43B: the bf16x3 form of F(4x4,3x3) where it takes the shape);
+    False = the fp32-MFMA F(4x4,3x3) kernel (ops.WINO43B off for this leg).  The bound is the pipe the kernel's multiplies run on: the fp32
+    MFMA peak (157.3 TFLOP/s), or for the bf16x3 form the six-product bound of the bf16 pipe, 2 500 / 6 = 416.7 TFLOP/s of fp32-equivalent
+    work -- `achieved` counts the multiplies the kernel EXECUTES (algorithmic / the Winograd reduction, stated separately) in both cases."""
+    from kpx_amd import ops
+    keep = ops.WINO43B
+    if bf16x3 is False:
+        ops.WINO43B = False
+    try:
+        used_b = ops.conv_kernel_uses['wino43b']
+        ms, flops = _time_conv_3_1(dev, pretransformed=True, name=name, f43_fwd=f43_fwd, **shape)
+        ran_b = ops.conv_kernel_uses['wino43b'] > used_b
+    finally:
+        ops.WINO43B = keep
     alg = flops / (ms * 1e-3) / 1e12
     ach = alg / reduction
+    if ran_b:
+        kernel_substr = 'conv_wino43b_kernel<0>'
+        kernel_desc = kernel_desc.replace('conv_wino43_kernel<0, false> F(4x4,3x3)', 'conv_wino43b_kernel<0> F(4x4,3x3), transform-domain GEMMs as bf16x3 = fp32-equivalent on the bf16 pipe,')
+        pmc = pmc.replace('_wino43_', '_wino43b_')
+    peak = 416.7 if ran_b else 157.3
     traffic, src = _pmc_traffic(pmc)
     rp_ms, rp_src = _rocprof_avg_ms(kernel_substr, csv_name) if csv_name else _rocprof_avg_ms(kernel_substr)
-    return {'committed_profile': {'note': 'from files committed under profiles/, NOT measured in this run', 'collected_at_commit': _profile_stamp(),
-                                  'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'traffic_source': src,
-                                  'frac_at_rocprof_avg': round(flops / reduction / (rp_ms * 1e-3) / 157.3e12, 4) if rp_ms else None},
-            'bound': 'mfma', 'kernel': kernel_desc,
-            'achieved': round(ach, 2), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(ach / 157.3, 4),
-            'traffic': traffic, 'traffic_source': src, 'avg_launch_ms': round(ms, 4),
-            'flops_per_launch_executed': flops / reduction, 'flops_per_launch_algorithmic': flops,
-            'algorithmic_tflops': round(alg, 2), 'algorithmic_frac': round(alg / 157.3, 4)}
+    out = {'committed_profile': {'note': 'from files committed under profiles/, NOT measured in this run', 'collected_at_commit': _profile_stamp(),
+                                 'rocprof_avg_launch_ms': rp_ms, 'rocprof_source': rp_src, 'traffic_source': src,
+                                 'frac_at_rocprof_avg': round(flops / reduction / (rp_ms * 1e-3) / (peak * 1e12), 4) if rp_ms else None},
+           'bound': 'mfma', 'kernel': kernel_desc,
+           'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s' + (' (fp32-equivalent executed multiplies; bf16 dense peak 2500 / 6 products)' if ran_b else ''),
+           'frac': round(ach / peak, 4),
+           'traffic': traffic, 'traffic_source': src, 'avg_launch_ms': round(ms, 4),
+           'flops_per_launch_executed': flops / reduction, 'flops_per_launch_algorithmic': flops, 'winograd_reduction': reduction,
+           'algorithmic_tflops': round(alg, 2), 'algorithmic_frac': round(alg / peak, 4)}
+    if ran_b:
+        out['bf16_mfma_tflops_issued'] = round(6 * ach, 1)                 # six bf16 products per fp32-equivalent multiply
+        out['frac_of_fp32_mfma_peak'] = round(ach / 157.3, 4)              # (what rounds 2-5 reported for the fp32-MFMA kernel on this launch: 0.47-0.48)
+    return out
 
 
 def roofline_conv(dev):
@@ -136,6 +159,14 @@ def roofline_conv(dev):
     return _roofline_wino(dev, 'translator/conv_3_1', 'conv_wino43_kernel<0, false>',
                           'conv_wino43_kernel<0, false> F(4x4,3x3) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), filter pre-transformed as in the train step',
                           4.0, WINO43_PMC)
+
+
+def roofline_conv_f32mfma(dev):
+    """The same launch on the fp32-MFMA F(4x4,3x3) kernel (csrc/conv_wino43.hip; the headline kernel of rounds 2-5, still the kernel of the
+    packed 16x16 and ragged-channel launches): executed FLOPs against the fp32 MFMA peak."""
+    return _roofline_wino(dev, 'translator/conv_3_1', 'conv_wino43_kernel<0, false>',
+                          'conv_wino43_kernel<0, false> F(4x4,3x3) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), fp32 MFMA, filter pre-transformed',
+                          4.0, WINO43_PMC, bf16x3=False)
 
 
 def roofline_conv_c3(dev, batch=16):
@@ -583,11 +614,21 @@ def supervise(my_ranks, world, child_argv, key, plan=None, warm_deadline=None, r
                 p.wait(timeout=max(0.0, t_end - time.time()))
             except subprocess.TimeoutExpired:
                 p.kill()
-                p.wait()
+                try:
+                    p.wait(timeout=30)                           # (a rank stuck in an uninterruptible GPU wait must not block the supervisor for ever)
+                except subprocess.TimeoutExpired:
+                    say('a child survived SIGKILL for 30 s: giving up')
+                    return 1, attempts + [{'form': form, 'failed': why + '; child unkillable'}]
         for r in my_ranks:
             _touch(mark(r, 'killed'))
         for r in range(world):                                   # every rank's child is gone before the GPUs are used again
             wait_for(mark(r, 'killed'), settle)
+        if os.path.exists(mark(0, 'done')):                      # the abort raced with rank 0 printing its line: the result stands
+            say('rank 0 reported its result while this attempt was being aborted: done')
+            for r in my_ranks:
+                _touch(mark(r, 'ack'))
+            rc = 0
+            break
         attempts.append({'form': form, 'failed': why})
     if lead and rc == 0:
         for r in range(world):                                   # the other supervisors read rank 0's marker: leave the directory until they have
@@ -738,7 +779,7 @@ def main():
         return
     if args.roofline_only:
         kops.set_compute_dtype('f32')
-        print(json.dumps({'roofline': roofline_conv(dev), 'roofline_wgrad': roofline_wgrad(dev), 'roofline_wino_f23': roofline_conv_f23(dev), 'roofline_direct_conv': roofline_conv_direct(dev), 'roofline_bf16x3_conv': roofline_conv_bf16x3(dev),
+        print(json.dumps({'roofline': roofline_conv(dev), 'roofline_wino43_f32mfma': roofline_conv_f32mfma(dev), 'roofline_wgrad': roofline_wgrad(dev), 'roofline_wino_f23': roofline_conv_f23(dev), 'roofline_direct_conv': roofline_conv_direct(dev), 'roofline_bf16x3_conv': roofline_conv_bf16x3(dev),
                           'roofline_hbm_render': roofline_render(dev)}), flush=True)
         return
     cfg = {'training': {'lr': {'start_val': 1e-4, 'step': 20000, 'decay': 0.95}, 'batch_size': args.batch},
@@ -838,6 +879,8 @@ def main():
                 out['roofline_hbm_render'] = roofline_render(dev, RES, K_PTS, args.batch)
             else:
                 out['roofline'] = roofline_conv(dev) if args.config == 'c1' else roofline_conv_c3(dev, args.batch)
+                if args.config == 'c1':
+                    out['roofline_wino43_f32mfma'] = roofline_conv_f32mfma(dev)
                 out['roofline_wgrad'] = roofline_wgrad(dev)
                 out['roofline_wino_f23'] = roofline_conv_f23(dev)
                 out['roofline_direct_conv'] = roofline_conv_direct(dev)

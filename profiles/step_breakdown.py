@@ -12,7 +12,8 @@ FAMILIES = [
     ('bf16 3x3 weight gradient (conv3x3_wgrad_bf16 + slab reduce)', ('conv3x3_wgrad_bf16_kernel', 'wgrad16_reduce_kernel')),
     ('bf16 filter preparation', ('conv_bf16s_prepare',)),
     ('bf16 <-> fp32 conversions / bf16 channel copies', ('cast_channels_kernel',)),
-    ('F(4x4,3x3) Winograd fwd/dgrad', ('conv_wino43_kernel',)),
+    ('F(4x4,3x3) Winograd fwd/dgrad, bf16x3 form (conv_wino43b)', ('conv_wino43b_kernel',)),
+    ('F(4x4,3x3) Winograd fwd/dgrad, fp32 MFMA (conv_wino43)', ('conv_wino43_kernel',)),
     ('F(2x2,3x3) Winograd fwd/dgrad', ('conv_wino_v2_kernel',)),
     ('Winograd weight gradient', ('conv_wino_wgrad_kernel',)),
     ('bf16x3 gather conv fwd/dgrad (conv_gemm3)', ('conv_gemm3_kernel',)),

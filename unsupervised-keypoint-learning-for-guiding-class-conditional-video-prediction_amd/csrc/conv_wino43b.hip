@@ -44,13 +44,14 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
                                            // four pixels), 34 columns = 144 slots, padded to 146 so that four rows are 8 (mod 16) slots
 #define W4B_NPIECES 44                     // LDS-DMA pieces of 1 KB per buffer (18 x 146 = 2628 slots, rounded up to 11 pieces per wavefront)
 #define W4B_RAW_BYTES (W4B_NPIECES * 1024) // one raw buffer
-#define W4B_TAB_OFF (2 * W4B_RAW_BYTES)    // [4 wavefronts][3][64 lanes][4] buffer offsets of the DMA slots (tile constants: they would otherwise be spilled)
-#define W4B_ACC_OFF (W4B_TAB_OFF + 4 * 3072)   // [4 wavefronts][3 blocks][4][64 lanes] x 16 B: three of a wavefront's 18 accumulator blocks (cout block 1 of
-                                           // local points 2, 5, 8) live here between K steps and pass through ONE transient block: 18 blocks are 288
-                                           // registers, the accumulator file has 256, and hipcc otherwise spills two blocks to scratch every K step
-                                           // (vector-memory operations in the middle of a counted-vmcnt pipeline) and shuffles a third through VGPRs
-#define W4B_MAIN_BYTES (W4B_ACC_OFF + 4 * 12288)
+#define W4B_ACC_OFF (2 * W4B_RAW_BYTES)    // [4 wavefronts][4 blocks][4][64 lanes] x 16 B: four of a wavefront's 18 accumulator blocks (units 3, 8, 13, 17 of a K
+                                           // step) live here between K steps and pass through ONE transient block.  18 blocks are 288 registers, the
+                                           // accumulator file has 256: with all of them in registers hipcc spills two blocks to scratch every K step
+                                           // (vector-memory operations in the middle of a counted-vmcnt pipeline) and shuffles a third through VGPRs;
+                                           // with four in LDS 16 accumulator registers are left over for the compiler to park vector registers in
+#define W4B_NLDS 4
 #define W4B_EPI_BYTES (36 * 32 * 32 * 4)   // P[point][tile][32 couts] fp32
+#define W4B_MAIN_BYTES (W4B_ACC_OFF + 4 * W4B_NLDS * 4096)
 
 struct Wino43bGeom {
     const float* x; float* y; const void* U; const float* bias;
@@ -166,6 +167,10 @@ __device__ __forceinline__ void w4b_split8(const float* __restrict__ v, u32x4* _
 
 __constant__ float w4b_AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
 
+// unit u = 2 lp + nb of a K step: LDS-resident accumulator slot (0..3) or -1; register block index (0..13) of the others
+__device__ __forceinline__ constexpr int w4b_lds_slot(int u) { return u == 3 ? 0 : u == 8 ? 1 : u == 13 ? 2 : u == 17 ? 3 : -1; }
+__device__ __forceinline__ constexpr int w4b_reg_block(int u) { return u - (u > 3) - (u > 8) - (u > 13); }
+
 // global row / column of the 6 x 6 point grid of a wavefront's local kind (0: the `single` one, 1 / 2: the pair) for block half hf (0: rows 0-2)
 __device__ __forceinline__ constexpr int w4b_grid(int hf, int kind) { return kind == 0 ? (hf ? 5 : 0) : (hf ? 2 + kind : kind); }
 
@@ -184,7 +189,7 @@ extern "C" int kpx_debug_w4b_stamps(unsigned long long* buf) { return -(int)hipM
 // The K loop of one wavefront role.  RH / CH: which half of the point rows / columns (compile time: the second transform pass selects
 // REGISTERS by column, the first one patch rows).  acc[lp = 3 rk + ck][nb]: local point (row kind rk, column kind ck), 32-cout block nb.
 template <int RH, int CH>
-__device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&acc0)[9], f32x16 (&acc1)[6], unsigned char* const smem, const int lane, const int wave,
+__device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[14], unsigned char* const smem, const int lane, const int wave,
                                          const int n, const int oy0, const int ox0, const int nti, unsigned long long* const dbgp) {
     const int KS = g.Kp >> 4, NB = g.Np >> 5;
     // ---- LDS-DMA of the raw patch: piece wave * 12 + i covers slots 64 (wave * 12 + i) .. + 63 of the buffer
@@ -193,9 +198,7 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&acc0)[9
     // slot S of row r = S / 146: within the row, slot 17 g + 4 k + q is channel quad q of pixel column 4 g + k (slot 17 g + 16: the skew slot; slots
     // 144, 145: row padding).  Consecutive lanes = the four quads of a pixel (64 contiguous bytes of the tensor) and four consecutive pixels.
     unsigned dtail = 0;                                  // bit i: piece i's channel quad exists in the LAST K step (channel tail; K % 4 == 0)
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    i32x4* const dtab = reinterpret_cast<i32x4*>(smem + W4B_TAB_OFF) + wave * 3 * 64 + lane;      // [3][64 lanes] x 4 offsets: three reads per K step
-    i32x4 dv[3] = {{W4B_OOB, W4B_OOB, W4B_OOB, W4B_OOB}, {W4B_OOB, W4B_OOB, W4B_OOB, W4B_OOB}, {W4B_OOB, W4B_OOB, W4B_OOB, W4B_OOB}};
+    int dv[11];                                          // buffer offsets of this lane's slots (tile constants; the compiler parks them in spare accumulator registers)
 #pragma unroll
     for (int i = 0; i < 11; ++i) {
         const int S = (wave * 11 + i) * 64 + lane;
@@ -203,19 +206,15 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&acc0)[9
         const int col = 4 * grp + (r17 >> 2), q = r17 & 3;
         const int iy = oy0 - 1 + row, ix = ox0 - 1 + col;
         const bool ok = r17 < 16 && rs < 144 && row < 18 && col < 34 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-        dv[i >> 2][i & 3] = ok ? ((iy * g.W + ix) * g.ldx + q * 4) * 4 : W4B_OOB;
+        dv[i] = ok ? ((iy * g.W + ix) * g.ldx + q * 4) * 4 : W4B_OOB;
         if ((KS - 1) * 16 + q * 4 < g.Cin) dtail |= 1u << i;
     }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) dtab[i * 64] = dv[i];
     auto dma = [&](int s, int buf) {                     // K step s -> raw buffer buf
         unsigned char* const dst = smem + buf * W4B_RAW_BYTES + wave * 11 * 1024;
         const bool last = s == KS - 1;
-        const i32x4 t0 = dtab[0], t1 = dtab[64], t2 = dtab[128];
 #pragma unroll
         for (int i = 0; i < 11; ++i) {
-            const int v = i < 4 ? t0[i & 3] : i < 8 ? t1[i & 3] : t2[i & 3];
-            const int vo = (last && !((dtail >> i) & 1u)) ? W4B_OOB : v;
+            const int vo = (last && !((dtail >> i) & 1u)) ? W4B_OOB : dv[i];
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(dst + i * 1024), 16, vo, s * 64, 0, 0);
         }
     };
@@ -246,10 +245,10 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&acc0)[9
     // patch column CH + m of the tile: slot 4 (CH + m) + ((CH + m) >> 2)
 #define W4B_RD(buf, j, a, m) (*reinterpret_cast<const f32x4*>(smem + (buf) * W4B_RAW_BYTES + rbase + ((a) * W4B_ROWSLOTS + 4 * (CH + (m)) + ((CH + (m)) >> 2) + (j)) * 16))
 
-    // the LDS-resident accumulator blocks (this lane's 16 registers of block lp / 3 as 4 x 16 B)
-    unsigned char* const accsp = smem + W4B_ACC_OFF + wave * 12288 + lane * 16;
+    // the LDS-resident accumulator blocks (this lane's 16 registers of slot k as 4 x 16 B)
+    unsigned char* const accsp = smem + W4B_ACC_OFF + wave * (W4B_NLDS * 4096) + lane * 16;
 #pragma unroll
-    for (int i = 0; i < 12; ++i) *reinterpret_cast<f32x4*>(accsp + i * 1024) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4 * W4B_NLDS; ++i) *reinterpret_cast<f32x4*>(accsp + i * 1024) = f32x4{0.f, 0.f, 0.f, 0.f};
     // one unit's six products, smallest first
     auto mma = [&](f32x16& c, const u32x4* a, const u32x4* b) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[1]), c, 0, 0, 0);
@@ -259,30 +258,27 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&acc0)[9
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
     };
-    f32x16 ct;                                           // the transient block: zero = the first K step's block 0
+    f32x16 ct;                                           // the transient block: zero = the first K step's slot 0
 #pragma unroll
     for (int r = 0; r < 16; ++r) ct[r] = 0.f;
-    // one unit: six products into the unit's accumulator block -- a register block, or (nb = 1 of local points 2, 5, 8) LDS -> transient -> LDS
-    auto unit = [&](int lp, int nb, const u32x4* a, const u32x4* b) {
-#if defined(W4B_EXP) && (W4B_EXP & 16)
-        if (nb == 1 && lp % 3 == 2) { mma(acc1[lp - lp / 3 - 1], a, b); return; }
-#endif
-        if (nb == 1 && lp % 3 == 2) {
-            // the transient `ct` already holds this block (read right after the previous LDS-resident block was written back: a whole
-            // third of a K step earlier); write it back and fetch the next one
+    // one unit: six products into the unit's accumulator block -- a register block, or (units 3, 8, 13, 17) LDS -> transient -> LDS
+    auto unit = [&](int u, const u32x4* a, const u32x4* b) {
+        const int slot = w4b_lds_slot(u);
+        if (slot >= 0) {
+            // the transient `ct` already holds this block (read right after the previous LDS-resident block was written back: a quarter of a
+            // K step earlier); write it back and fetch the next one
             mma(ct, a, b);
-            unsigned char* const sp = accsp + (lp / 3) * 4096;
+            unsigned char* const sp = accsp + slot * 4096;
 #pragma unroll
             for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(sp + i * 1024) = f32x4{ct[4 * i], ct[4 * i + 1], ct[4 * i + 2], ct[4 * i + 3]};
-            const unsigned char* const sq = accsp + ((lp / 3 + 1) % 3) * 4096;
+            const unsigned char* const sq = accsp + ((slot + 1) % W4B_NLDS) * 4096;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(sq + i * 1024);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) ct[4 * i + q] = v[q];
             }
-        } else if (nb == 0) mma(acc0[lp], a, b);
-        else mma(acc1[lp - lp / 3], a, b);
+        } else mma(accr[w4b_reg_block(u)], a, b);
     };
     // second transform pass over the five column sums t[m] (column CH + m) of one point row: the three points of this wavefront's column half
     //   single (B^T row 0 / 5): 4 t0 - 5 t2 + t4 ;  pair, CH = 0 (rows 1, 2 of B^T on columns 1..4): (t4 - 4 t2) +- (t3 - 4 t1)
@@ -377,7 +373,7 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&acc0)[9
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
                     const int u = 2 * ck + nb;
-                    unit(ck, nb, af[ck & 1], ub[u]);
+                    unit(u, af[ck & 1], ub[u]);
                     uload(u, u + 6, koff);
                     W4B_USTAMP(it, u);
                 }
@@ -397,7 +393,7 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&acc0)[9
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
                     const int u = 6 + 2 * pp + nb;
-                    unit(3 + pp, nb, af[pp & 1], ub[u % 6]);
+                    unit(u, af[pp & 1], ub[u % 6]);
                     if (u < 12) uload(u % 6, u + 6, koff);
                     else uload(u % 6, u - 12, koff + ustep);          // next K step (after the last one: a harmless read of the next point / zeros)
                     W4B_USTAMP(it, u);
@@ -427,15 +423,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
     const int n = L / g.tiles_y;
     const int oy0 = by * 16, ox0 = bx * 32, n0 = nti * 64;
 
-    f32x16 acc0[9], acc1[6];                             // cout block 0 of all nine local points; cout block 1 of local points 0, 1, 3, 4, 6, 7
+    f32x16 accr[14];                                     // the register-resident accumulator blocks (w4b_reg_block)
 #pragma unroll
-    for (int b = 0; b < 9; ++b)
+    for (int b = 0; b < 14; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[b][r] = 0.f;
-#pragma unroll
-    for (int b = 0; b < 6; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[b][r] = 0.f;
+        for (int r = 0; r < 16; ++r) accr[b][r] = 0.f;
 
 #ifdef KPX_W4B_STAMP
     unsigned long long* const dbgp = (w4b_dbg && lane == 0 && blockIdx.x < 64) ? w4b_dbg + ((size_t)blockIdx.x * 4 + wave) * 512 : nullptr;
@@ -444,17 +436,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
     unsigned long long* const dbgp = nullptr;
 #endif
     const int rh = wave >> 1, ch = wave & 1;
-    if (wave == 0) w4b_kloop<0, 0>(g, acc0, acc1, smem, lane, wave, n, oy0, ox0, nti, dbgp);
-    else if (wave == 1) w4b_kloop<0, 1>(g, acc0, acc1, smem, lane, wave, n, oy0, ox0, nti, dbgp);
-    else if (wave == 2) w4b_kloop<1, 0>(g, acc0, acc1, smem, lane, wave, n, oy0, ox0, nti, dbgp);
-    else w4b_kloop<1, 1>(g, acc0, acc1, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+    if (wave == 0) w4b_kloop<0, 0>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+    else if (wave == 1) w4b_kloop<0, 1>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+    else if (wave == 2) w4b_kloop<1, 0>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+    else w4b_kloop<1, 1>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
 
     // ---- epilogue: two passes (one per 32-cout block) of all 36 points through LDS; thread = (tile, 4 couts)
-    f32x16 accl[3];                                      // the LDS-resident blocks, before the passes overwrite them
+    f32x16 accl[W4B_NLDS];                               // the LDS-resident blocks, before the passes overwrite them
     {
-        const unsigned char* const accsp = smem + W4B_ACC_OFF + wave * 12288 + lane * 16;
+        const unsigned char* const accsp = smem + W4B_ACC_OFF + wave * (W4B_NLDS * 4096) + lane * 16;
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+        for (int b = 0; b < W4B_NLDS; ++b)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(accsp + (b * 4 + i) * 1024);
@@ -480,10 +472,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
             float* const Pw = P + (p * 32 + 4 * lh) * 32 + li;
             if (nb == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Pw[((r & 3) + 8 * (r >> 2)) * 32] = acc0[lp][r];
+                for (int r = 0; r < 16; ++r) Pw[((r & 3) + 8 * (r >> 2)) * 32] = w4b_lds_slot(2 * lp) >= 0 ? accl[w4b_lds_slot(2 * lp) & 3][r] : accr[w4b_reg_block(2 * lp)][r];
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Pw[((r & 3) + 8 * (r >> 2)) * 32] = lp % 3 == 2 ? accl[lp / 3][r] : acc1[lp - lp / 3][r];
+                for (int r = 0; r < 16; ++r) Pw[((r & 3) + 8 * (r >> 2)) * 32] = w4b_lds_slot(2 * lp + 1) >= 0 ? accl[w4b_lds_slot(2 * lp + 1) & 3][r] : accr[w4b_reg_block(2 * lp + 1)][r];
             }
         }
         if (nb == 0) W4B_STAMP(4);

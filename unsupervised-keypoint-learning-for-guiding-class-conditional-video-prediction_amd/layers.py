@@ -14,6 +14,11 @@ ACT_NONE, ACT_RELU, ACT_LRELU = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LRELU
 EXACT_ZERO_BIAS_GRAD = True      # see conv_bn_relu
 import os as _os
 FOLD_BN_INFERENCE = True      # see conv_bn_relu
+# Diagnostics of the bf16 configuration (tests/test_model_gpu.py::test_bf16_error_budget, scratch/bf16_error_budget.py; nothing in the product
+# sets them): TRACE, a list that receives (scope of the layer's filter, output tensor) for every conv_bn_relu unit; F32_OUT_SCOPES, scopes whose
+# output stays fp32 in the bf16 configuration (what networks.py declares with out_f32=True, extended for what-if runs).
+TRACE = None
+F32_OUT_SCOPES = set()
 
 
 def conv(x, channels, kernel=4, stride=2, pad=0, use_bias=True, scope='conv_0', act=ACT_NONE, cin=None, head31=False, bias_grad=True, bn_stats=False,
@@ -98,6 +103,14 @@ def conv_bn_relu(x, channels, kernel, stride, train_mode, conv_scope, bn_scope, 
             return ops.conv2d(x, wf, bf, stride=stride, pad=0, act=ACT_RELU, cin=cin)
     x = conv(x, channels, kernel=kernel, stride=stride, scope=conv_scope, cin=cin, bias_grad=not (EXACT_ZERO_BIAS_GRAD and train_mode),
              bn_stats=bool(train_mode), f43_fwd=f43_fwd)       # the conv epilogue delivers the batch statistics when it can
+    if (TRACE is not None or F32_OUT_SCOPES) and not is_sym(x):
+        st = default_store()
+        with st.variable_scope(conv_scope):
+            full = st.scoped('')
+        y = batch_norm(x, train_mode, scope=bn_scope, act=ACT_RELU, groups=groups, update_moving=update_moving, out_f32=out_f32 or full.rstrip('/') in F32_OUT_SCOPES)
+        if TRACE is not None:
+            TRACE.append((full.rstrip('/'), y.detach()))
+        return y
     return batch_norm(x, train_mode, scope=bn_scope, act=ACT_RELU, groups=groups, update_moving=update_moving, out_f32=out_f32)
 
 

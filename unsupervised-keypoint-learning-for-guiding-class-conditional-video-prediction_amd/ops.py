@@ -315,9 +315,15 @@ def _bf16s_conv(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, want_stats=
     # prepared filters are zero there, so the extra gathered channels (zero-filled / finite by the producer's contract) contribute nothing
     # and the extra produced channels come out as zeros
     if not (k % 32 == 0 or k in (8, 16)):
+        k0 = k
         k = 8 if k < 8 else 16 if k < 16 else (k + 31) // 32 * 32
         if ld_in < k:
             return False
+        # CONTRACT of the rounded-up gather: channels k0..k of the caller's buffer are multiplied by zero filter rows, so they must be FINITE
+        # (0 * inf = nan).  Every producer on the path zero-fills its pad channels (JointEmbeddingFn, the concat buffers); KPX_DEBUG_FINITE=1
+        # checks it on every call (a device synchronisation: diagnostics only).
+        if DEBUG_FINITE and not bool(torch.isfinite(inp.reshape(-1, inp.shape[-1])[:, k0:k].float()).all()):
+            raise _lib.KpxError('bf16 3x3 conv: non-finite values in the pad channels %d..%d of a %d-wide buffer' % (k0, k, inp.shape[-1]))
     g = 4 if out_f32 else 8
     if nn % g:
         nn = (nn + g - 1) // g * g
@@ -382,6 +388,7 @@ conv_kernel_uses = {'wino43': 0, 'wino43b': 0}      # diagnostics / tests: launc
 # (Round 4 measured the alternative -- F(4x4,3x3) on every forward layer: -0.13..-0.2 ms per step for a generated frame 3.6e-5 instead of
 #  1.7e-5 from the oracle's; the margin was kept and the experiment switches are gone.)  KPX_WINO43=0: F(2x2,3x3) everywhere (tests).
 WINO43 = _os.environ.get('KPX_WINO43', '1') != '0'
+DEBUG_FINITE = _os.environ.get('KPX_DEBUG_FINITE', '0') == '1'      # assert the finite-pad-channel contract of the rounded-up bf16 gathers (_bf16s_conv)
 # launches of at most this many F(4x4,3x3) workgroups stay on F(2x2,3x3).  Round 2 set 128 from a kernel measured ALONE (128 workgroups: 0.187 vs
 # 0.158 ms -- one F(4x4) workgroup owns its CU); inside the step, where the other streams fill the idle CUs, F(4x4,3x3) wins on those layers too:
 # 23.73-23.83 ms per step at 0 / 32 / 64 against 24.01-24.16 at 128 (three repetitions each, B=32) -- so no threshold
@@ -412,6 +419,8 @@ def _wino43_wanted(name, cin, cout, dgrad, f43_fwd=True):
 
 
 class FilterBank:
+    wino_needed_in_bf16 = False      # set by the first lazy Winograd refresh inside the bf16 configuration (ensure_fresh)
+
     def __init__(self, named_filters, device, attrs=None):
         """named_filters: iterable of (name, [3,3,Cin,Cout] tensor views whose storage never moves); attrs: {name: {'f43_fwd': bool}}."""
         attrs = attrs or {}
@@ -487,6 +496,8 @@ class FilterBank:
             return
         if form is None:
             form = 'bf16s' if _compute_dtype[0] == 'bf16' else 'wino'
+            if form == 'bf16s' and FilterBank.wino_needed_in_bf16:
+                self.ensure_fresh('wino')                # an earlier step fell back to an fp32 Winograd kernel: refresh that form before the fork too
         if form == 'bf16s':
             if getattr(self, 'synced16', -1) != self.version:
                 if getattr(self, 'table16', None) is None:
@@ -501,6 +512,16 @@ class FilterBank:
             if self.n_desc43b:
                 check(lib.kpx_wino43b_filter_transform_batch_f32(self.table43b.data_ptr(), self.n_desc43b, _stream()), 'kpx_wino43b_filter_transform_batch_f32')
             self.synced = self.version
+            # A LAZY refresh (an fp32 3x3 fall-back inside the bf16 configuration, whose pre-fork ensure_fresh() only refreshes the bf16
+            # fragments) runs on whichever stream reaches it first: later readers on OTHER streams must wait for these launches
+            self._wino_fresh_ev = None
+            if _compute_dtype[0] == 'bf16' and not torch.cuda.is_current_stream_capturing():
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self._wino_fresh_ev = (ev, torch.cuda.current_stream().cuda_stream)
+                FilterBank.wino_needed_in_bf16 = True      # from now on the model's pre-fork refresh covers the Winograd forms too
+        elif getattr(self, '_wino_fresh_ev', None) is not None and torch.cuda.current_stream().cuda_stream != self._wino_fresh_ev[1]:
+            torch.cuda.current_stream().wait_event(self._wino_fresh_ev[0])
 
     def keys(self):
         return [(w.data_ptr(), dgrad) for _, w in self.filters for dgrad in (0, 1)]

@@ -86,9 +86,17 @@ def _vgg_forward(vgg, images):
             nn_, hh, ww, cc = x.shape
             if pooled is not None:
                 y = pooled
-            elif x.dtype == ops.BF16:
+            elif x.dtype == ops.BF16 and hh % 2 == 0 and ww % 2 == 0:
                 y = torch.empty((nn_, hh // 2, ww // 2, cc), dtype=ops.BF16, device=dev)
                 check(lib.kpx_maxpool2_fwd_bf16(x.data_ptr(), nn_, hh, ww, cc, y.data_ptr(), ops._stream()), 'kpx_maxpool2_fwd_bf16')
+            elif x.dtype == ops.BF16:
+                # odd feature maps (tf 'SAME' pooling: ceil): the bf16 kernel takes even sizes only -- through the fp32 kernel between two
+                # conversions, counted like every other fp32 detour of the bf16 configuration
+                ops.fallback_uses['other'] += 1
+                xf = ops.cast(x, torch.float32)
+                yf = torch.empty((nn_, (hh + 1) // 2, (ww + 1) // 2, cc), dtype=torch.float32, device=dev)
+                check(lib.kpx_maxpool2_fwd_f32(xf.data_ptr(), nn_, hh, ww, cc, yf.data_ptr(), ops._stream()), 'kpx_maxpool2_fwd_f32')
+                y = ops.cast(yf, ops.BF16)
             else:
                 y = torch.empty((nn_, (hh + 1) // 2, (ww + 1) // 2, cc), dtype=torch.float32, device=dev)
                 check(lib.kpx_maxpool2_fwd_f32(x.data_ptr(), nn_, hh, ww, cc, y.data_ptr(), ops._stream()), 'kpx_maxpool2_fwd_f32')
