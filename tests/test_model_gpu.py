@@ -12,6 +12,7 @@ from gradproj import projection
 from oracle import restatement as R
 
 pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def rel_l2(a, b):
@@ -1032,6 +1033,57 @@ def test_bf16_mode_forward_and_train_step_tolerance():
         assert abs(got[key] - want[key]) <= 2e-2 * max(1.0, abs(want[key])), (key, got[key], want[key])
     assert g_cos > 0.3                      # direction check only (see the docstring)
     assert fr_err > 1e-5                    # the bf16 kernels really ran
+
+
+def test_bf16_error_budget_per_layer():
+    """Where the bf16 configuration's error comes from (round-5 verdict: "nobody has measured where it enters"): the fp32 and the bf16
+    forward from the same state, rel-L2 of every conv + batch-norm + ReLU output (layers.TRACE), written to gpurun_out/bf16_error_budget.txt
+    (the committed copy with the what-if runs: profiles/r06_bf16_error_budget.txt, scratch/bf16_error_budget.py).  What it pins:
+      * the first unit of each network carries one operand rounding (2.3e-3), and NO unit is a jump: every unit's error is 0.7 .. 1.6 x its
+        predecessor's inside a network (measured 1.15 .. 1.78 for the first three, 1.2 .. 1.3 afterwards; the resize + concat stages of the
+        decoders mix in a cleaner skip tensor: 0.74 .. 0.79) -- the error is the network's own amplification of operand roundings, not a
+        few tensors one could keep in fp32;
+      * keeping every translator output fp32 (layers.F32_OUT_SCOPES) moves the frame by less than 10 %: a bf16 convolution rounds its MFMA
+        operands whatever the storage type of its input."""
+    from kpx_amd import ops, layers
+    dev = torch.device('cuda:0')
+    res, k, b = 128, 15, 2
+    im, fut = R.synthetic_pair(b, res=res, seed0=0, seed1=1)
+    im, fut = torch.from_numpy(im).to(dev), torch.from_numpy(fut).to(dev)
+
+    def run(dtype, keep=()):
+        ops.set_compute_dtype(dtype)
+        layers.F32_OUT_SCOPES = set(keep)
+        layers.TRACE = []
+        try:
+            out = make_model(res, k, b, dev).forward(im, fut)
+            return {kk: v.float().cpu() for kk, v in out.items() if torch.is_tensor(v)}, [(n, t.float().cpu()) for n, t in layers.TRACE]
+        finally:
+            layers.TRACE = None
+            layers.F32_OUT_SCOPES = set()
+            ops.set_compute_dtype('f32')
+    o32, t32 = run('f32')
+    o16, t16 = run('bf16')
+    assert [n for n, _ in t32] == [n for n, _ in t16] and len(t32) == 8 + 22 + 10
+    rows = [(n, tuple(a.shape[1:]), rel_l2(c.numpy(), a.numpy())) for (n, a), (_, c) in zip(t32, t16)]
+    frame = rel_l2(o16['final_output'].numpy(), o32['final_output'].numpy())
+    kp = float((o16['current_points'] - o32['current_points']).abs().max())
+    os.makedirs(os.path.join(os.path.dirname(HERE), 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(os.path.dirname(HERE), 'gpurun_out', 'bf16_error_budget.txt'), 'w') as f:
+        f.write('bf16 vs fp32 configuration, same weights, B=%d %dx%d K=%d: rel-L2 per conv+BN+ReLU output\n' % (b, res, res, k))
+        for n, sh, e in rows:
+            f.write('%-44s %14s %10.2e\n' % (n, 'x'.join(map(str, sh)), e))
+        f.write('key-points max abs %.2e, frame rel-L2 %.2e\n' % (kp, frame))
+    for net in ('image_encoder', 'pose_encoder', 'translator'):
+        errs = [e for n, _, e in rows if n.startswith(net)]
+        if net != 'translator':
+            assert 1e-3 < errs[0] < 4e-3, (net, errs[0])          # one rounding of the image-input layer's output + its bf16 consumers
+        ratios = [b_ / a_ for a_, b_ in zip(errs, errs[1:])]
+        assert 0.7 < min(ratios) and max(ratios) < 2.0, (net, ratios)
+    assert 1e-2 < frame < 1.2e-1 and kp < 5e-3, (frame, kp)
+    o16k, _ = run('bf16', [n for n, _ in t32 if n.startswith('translator')])
+    frame_k = rel_l2(o16k['final_output'].numpy(), o32['final_output'].numpy())
+    assert abs(frame_k - frame) < 0.1 * frame, (frame_k, frame)
 
 
 def test_exact_zero_bias_grad_switch_both_ways():
