@@ -69,82 +69,6 @@ __device__ __forceinline__ float w4b_float(unsigned v) { return __builtin_bit_ca
 // {hi16(b), hi16(a)}: two truncated bf16 values in one dword, a in the low half
 __device__ __forceinline__ unsigned w4b_pack_hi(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
-// ---------------------------------------------------------------------------------------------- filter transform (once per optimiser update)
-// U[p = 6 i + j] = (G g G^T)[i][j] in double precision, rounded once (conv_wino43.hip says why), then split into three bf16 terms and stored
-// as the B operand of v_mfma_f32_32x32x16_bf16: Ub[p][ks][nb][term][lane = r + 32 h][e] = term of U[p][c = 16 ks + 8 h + e][n = 32 nb + r].
-// One thread = (channel pair c, c+1; n): one dword per (point, term).
-struct KpxWino43bDesc { const float* w; unsigned* u; int cin, cout, dgrad, reserved; };
-
-__device__ __forceinline__ void w4b_ggt(const float* __restrict__ w, int Cin, int Cout, bool dg, int c, int n, bool real, float* __restrict__ out36) {
-    double g[3][3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-            g[r][q] = !real ? 0.0 : (double)(dg ? w[((size_t)((2 - r) * 3 + (2 - q)) * Cin + n) * Cout + c] : w[((size_t)(r * 3 + q) * Cin + c) * Cout + n]);
-    // rows of G: [1/4,0,0], [-1/6,-1/6,-1/6], [-1/6,1/6,-1/6], [1/24,1/12,1/6], [1/24,-1/12,1/6], [0,0,1]
-    double t[6][3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const double a = g[0][q], b = g[1][q], c2 = g[2][q];
-        t[0][q] = 0.25 * a;
-        t[1][q] = (-1.0 / 6.0) * (a + b + c2);
-        t[2][q] = (-1.0 / 6.0) * (a - b + c2);
-        t[3][q] = (1.0 / 24.0) * a + (1.0 / 12.0) * b + (1.0 / 6.0) * c2;
-        t[4][q] = (1.0 / 24.0) * a - (1.0 / 12.0) * b + (1.0 / 6.0) * c2;
-        t[5][q] = c2;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double a = t[i][0], b = t[i][1], c2 = t[i][2];
-        out36[i * 6 + 0] = (float)(0.25 * a);
-        out36[i * 6 + 1] = (float)((-1.0 / 6.0) * (a + b + c2));
-        out36[i * 6 + 2] = (float)((-1.0 / 6.0) * (a - b + c2));
-        out36[i * 6 + 3] = (float)((1.0 / 24.0) * a + (1.0 / 12.0) * b + (1.0 / 6.0) * c2);
-        out36[i * 6 + 4] = (float)((1.0 / 24.0) * a - (1.0 / 12.0) * b + (1.0 / 6.0) * c2);
-        out36[i * 6 + 5] = (float)c2;
-    }
-}
-
-__device__ __forceinline__ void w4b_transform_filter(const float* __restrict__ w, int Cin, int Cout, bool dg, size_t idx, int Kp, int Np, unsigned* __restrict__ Ub) {
-    const int K = dg ? Cout : Cin, Nn = dg ? Cin : Cout;
-    const int KS = Kp >> 4, NB = Np >> 5;
-    const int n = (int)(idx % (size_t)Np), cp = (int)(idx / (size_t)Np);       // consecutive threads: consecutive n (the filter's fastest index forward)
-    const int c = 2 * cp;
-    float ua[36], ub[36];
-    w4b_ggt(w, Cin, Cout, dg, c, n, c < K && n < Nn, ua);
-    w4b_ggt(w, Cin, Cout, dg, c + 1, n, c + 1 < K && n < Nn, ub);
-    const int ks = c >> 4, h = (c >> 3) & 1, e = c & 7, nb = n >> 5, r = n & 31;
-    const size_t pstride = (size_t)KS * NB * 768;                               // dwords per point
-    unsigned* o = Ub + ((size_t)ks * NB + nb) * 768 + (r + 32 * h) * 4 + (e >> 1);
-#pragma unroll
-    for (int p = 0; p < 36; ++p) {
-        const float a = ua[p], b = ub[p];
-        const unsigned a0 = w4b_bits(a), b0 = w4b_bits(b);
-        const float ra = a - w4b_float(a0 & 0xffff0000u), rb = b - w4b_float(b0 & 0xffff0000u);
-        const unsigned a1 = w4b_bits(ra), b1 = w4b_bits(rb);
-        const float sa = ra - w4b_float(a1 & 0xffff0000u), sb = rb - w4b_float(b1 & 0xffff0000u);
-        o[p * pstride] = w4b_pack_hi(a0, b0);
-        o[p * pstride + 256] = w4b_pack_hi(a1, b1);
-        o[p * pstride + 512] = w4b_pack_hi(w4b_bits(sa), w4b_bits(sb));
-    }
-}
-__global__ __launch_bounds__(256) void wino43b_filter_transform_batch_kernel(const KpxWino43bDesc* __restrict__ descs) {
-    const KpxWino43bDesc d = descs[blockIdx.y];
-    const bool dg = d.dgrad != 0;
-    const int K = dg ? d.cout : d.cin, Nn = dg ? d.cin : d.cout;
-    const int Kp = (K + 15) & ~15, Np = (Nn + 63) & ~63;
-    const size_t total = (size_t)(Kp / 2) * Np;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256)
-        w4b_transform_filter(d.w, d.cin, d.cout, dg, idx, Kp, Np, d.u);
-}
-__global__ __launch_bounds__(256) void wino43b_filter_transform_kernel(const float* __restrict__ w, int Cin, int Cout, int dgrad, int Kp, int Np, unsigned* __restrict__ Ub) {
-    const size_t total = (size_t)(Kp / 2) * Np;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256)
-        w4b_transform_filter(w, Cin, Cout, dgrad != 0, idx, Kp, Np, Ub);
-}
-
-// ---------------------------------------------------------------------------------------------- the convolution
 // exact three-way split of eight floats into the three A-operand fragments of one point (element e of a fragment = channel e of the lane's octet)
 __device__ __forceinline__ void w4b_split8(const float* __restrict__ v, u32x4* __restrict__ f) {
 #if defined(W4B_EXP) && (W4B_EXP & 1)      // timing experiment (numerically meaningless): no split arithmetic
@@ -165,6 +89,79 @@ __device__ __forceinline__ void w4b_split8(const float* __restrict__ v, u32x4* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------- filter transform (once per optimiser update)
+// U[p = 6 i + j] = (G g G^T)[i][j] in double precision, rounded once (conv_wino43.hip says why), then split into three bf16 terms and stored
+// as the B operand of v_mfma_f32_32x32x16_bf16: Ub[p][ks][nb][term][lane = r + 32 h][e] = term of U[p][c = 16 ks + 8 h + e][n = 32 nb + r].
+// One thread = (point row i, channel octet c8 = 2 ks + h, n): it reads the 3 x 3 taps of its eight channels (consecutive threads =
+// consecutive n: coalesced forward; eight contiguous channels per thread for the transposed dgrad read), forms the six points of row i and
+// writes ONE 16-byte fragment element group per (point, term) -- a wavefront stores 1 KB contiguous.  (Measured alternatives: a thread with
+// all 36 points of a channel pair stores 108 dwords at a 16-byte lane stride, 0.39 ms per step for the batch of trainable filters; a thread
+// per point re-reads the taps 36 times, 0.93 ms.  The fp32 form's transform is 0.03 ms.)
+struct KpxWino43bDesc { const float* w; unsigned* u; int cin, cout, dgrad, reserved; };
+
+__constant__ double w4b_G[6][3] = {{0.25, 0.0, 0.0}, {-1.0 / 6.0, -1.0 / 6.0, -1.0 / 6.0}, {-1.0 / 6.0, 1.0 / 6.0, -1.0 / 6.0},
+                                   {1.0 / 24.0, 1.0 / 12.0, 1.0 / 6.0}, {1.0 / 24.0, -1.0 / 12.0, 1.0 / 6.0}, {0.0, 0.0, 1.0}};
+
+__device__ __forceinline__ void w4b_transform_filter(const float* __restrict__ w, int Cin, int Cout, bool dg, size_t idx, int Kp, int Np, unsigned* __restrict__ Ub) {
+    const int K = dg ? Cout : Cin, Nn = dg ? Cin : Cout;
+    const int KS = Kp >> 4, NB = Np >> 5, C8 = Kp >> 3;
+    const int n = (int)(idx % (size_t)Np);
+    const int c8 = (int)((idx / (size_t)Np) % (size_t)C8), i = (int)(idx / ((size_t)Np * C8));
+    const double gi0 = w4b_G[i][0], gi1 = w4b_G[i][1], gi2 = w4b_G[i][2];
+    float u[6][8];
+    // taps of the eight channels: g[tap (r, q) of the flipped / transposed filter][e]
+    float g[9][8];
+    const bool vec = dg && 8 * c8 + 8 <= K && n < Nn && (Cout & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+    if (vec) {                                           // dgrad: the eight channels are contiguous in memory -- two 16-byte loads per tap
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(w + ((size_t)(8 - tp) * Cin + n) * Cout + 8 * c8);
+            const f32x4 a = src[0], b = src[1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g[tp][e] = a[e]; g[tp][4 + e] = b[e]; }
+        }
+    } else {
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = 8 * c8 + e;
+                g[tp][e] = !(c < K && n < Nn) ? 0.f : dg ? w[((size_t)(8 - tp) * Cin + n) * Cout + c] : w[((size_t)tp * Cin + c) * Cout + n];
+            }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        double t[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) t[q] = gi0 * (double)g[q][e] + gi1 * (double)g[3 + q][e] + gi2 * (double)g[6 + q][e];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) u[j][e] = (float)(t[0] * w4b_G[j][0] + t[1] * w4b_G[j][1] + t[2] * w4b_G[j][2]);
+    }
+    const int ks = c8 >> 1, h = c8 & 1, nb = n >> 5, r = n & 31;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        u32x4 f[3];
+        w4b_split8(u[j], f);
+        u32x4* const o = reinterpret_cast<u32x4*>(Ub + (((size_t)(6 * i + j) * KS + ks) * NB + nb) * 768) + (r + 32 * h);
+        o[0] = f[0]; o[64] = f[1]; o[128] = f[2];
+    }
+}
+__global__ __launch_bounds__(256) void wino43b_filter_transform_batch_kernel(const KpxWino43bDesc* __restrict__ descs) {
+    const KpxWino43bDesc d = descs[blockIdx.y];
+    const bool dg = d.dgrad != 0;
+    const int K = dg ? d.cout : d.cin, Nn = dg ? d.cin : d.cout;
+    const int Kp = (K + 15) & ~15, Np = (Nn + 63) & ~63;
+    const size_t total = (size_t)6 * (Kp / 8) * Np;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256)
+        w4b_transform_filter(d.w, d.cin, d.cout, dg, idx, Kp, Np, d.u);
+}
+__global__ __launch_bounds__(256) void wino43b_filter_transform_kernel(const float* __restrict__ w, int Cin, int Cout, int dgrad, int Kp, int Np, unsigned* __restrict__ Ub) {
+    const size_t total = (size_t)6 * (Kp / 8) * Np;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256)
+        w4b_transform_filter(w, Cin, Cout, dgrad != 0, idx, Kp, Np, Ub);
+}
+
+// ---------------------------------------------------------------------------------------------- the convolution
 __constant__ float w4b_AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
 
 // unit u = 2 lp + nb of a K step: LDS-resident accumulator slot (0..3) or -1; register block index (0..13) of the others
@@ -638,13 +635,13 @@ extern "C" int kpx_wino43b_filter_transform_f32(const float* w_hwio, int Cin, in
     if (!w_hwio || !U || Cin <= 0 || Cout <= 0) return KPX_EINVAL;
     const int K = dgrad ? Cout : Cin, Nn = dgrad ? Cin : Cout;
     const int Kp = (K + 15) & ~15, Np = (Nn + 63) & ~63;
-    size_t nb = ((size_t)(Kp / 2) * Np + 255) / 256; if (nb > 1024) nb = 1024;
+    size_t nb = ((size_t)6 * (Kp / 8) * Np + 255) / 256; if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(wino43b_filter_transform_kernel, dim3((unsigned)nb), dim3(256), 0, kpx_stream(stream), w_hwio, Cin, Cout, dgrad, Kp, Np, (unsigned*)U);
     return kpx_launch_status();
 }
 extern "C" int kpx_wino43b_filter_transform_batch_f32(const void* descs_dev, int n, void* stream) {
     if (!descs_dev || n <= 0 || n > 65535) return KPX_EINVAL;
-    hipLaunchKernelGGL(wino43b_filter_transform_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, kpx_stream(stream), (const KpxWino43bDesc*)descs_dev);
+    hipLaunchKernelGGL(wino43b_filter_transform_batch_kernel, dim3(96, (unsigned)n), dim3(256), 0, kpx_stream(stream), (const KpxWino43bDesc*)descs_dev);
     return kpx_launch_status();
 }
 
