@@ -246,36 +246,35 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
     unsigned char* const accsp = smem + W4B_ACC_OFF + wave * (W4B_NLDS * 4096) + lane * 16;
 #pragma unroll
     for (int i = 0; i < 4 * W4B_NLDS; ++i) *reinterpret_cast<f32x4*>(accsp + i * 1024) = f32x4{0.f, 0.f, 0.f, 0.f};
-    // one unit's six products, smallest first
-    auto mma = [&](f32x16& c, const u32x4* a, const u32x4* b) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[1]), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[2]), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[2]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[1]), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[1]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[0]), __builtin_bit_cast(bf16x8, b[0]), c, 0, 0, 0);
-    };
     f32x16 ct;                                           // the transient block: zero = the first K step's slot 0
 #pragma unroll
     for (int r = 0; r < 16; ++r) ct[r] = 0.f;
-    // one unit: six products into the unit's accumulator block -- a register block, or (units 3, 8, 13, 17) LDS -> transient -> LDS
-    auto unit = [&](int u, const u32x4* a, const u32x4* b) {
-        const int slot = w4b_lds_slot(u);
-        if (slot >= 0) {
-            // the transient `ct` already holds this block (read right after the previous LDS-resident block was written back: a quarter of a
-            // K step earlier); write it back and fetch the next one
-            mma(ct, a, b);
-            unsigned char* const sp = accsp + slot * 4096;
+    // The two units of one point (cout blocks 0 and 1: same V fragments): six products each, smallest first, their twelve MFMAs ALTERNATING
+    // between the two accumulator blocks (an MFMA then never follows, a few VALU instructions later, the MFMA that wrote its accumulator)
+    auto mma2 = [&](f32x16& c0, f32x16& c1, const u32x4* a, const u32x4* b0, const u32x4* b1) {
+#define W4B_P(ai, bi) \
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ai]), __builtin_bit_cast(bf16x8, b0[bi]), c0, 0, 0, 0); \
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ai]), __builtin_bit_cast(bf16x8, b1[bi]), c1, 0, 0, 0);
+        W4B_P(1, 1) W4B_P(0, 2) W4B_P(2, 0) W4B_P(0, 1) W4B_P(1, 0) W4B_P(0, 0)
+#undef W4B_P
+    };
+    auto ct_store_load = [&](int slot) {
+        unsigned char* const sp = accsp + slot * 4096;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(sp + i * 1024) = f32x4{ct[4 * i], ct[4 * i + 1], ct[4 * i + 2], ct[4 * i + 3]};
-            const unsigned char* const sq = accsp + ((slot + 1) % W4B_NLDS) * 4096;
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(sp + i * 1024) = f32x4{ct[4 * i], ct[4 * i + 1], ct[4 * i + 2], ct[4 * i + 3]};
+        const unsigned char* const sq = accsp + ((slot + 1) % W4B_NLDS) * 4096;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(sq + i * 1024);
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(sq + i * 1024);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) ct[4 * i + q] = v[q];
-            }
-        } else mma(accr[w4b_reg_block(u)], a, b);
+            for (int q = 0; q < 4; ++q) ct[4 * i + q] = v[q];
+        }
+    };
+    auto unit2 = [&](int u, const u32x4* a, const u32x4* b0, const u32x4* b1) {      // units u (even) and u + 1
+        const int s0 = w4b_lds_slot(u), s1 = w4b_lds_slot(u + 1);
+        if (s0 >= 0) { mma2(ct, accr[w4b_reg_block(u + 1)], a, b0, b1); ct_store_load(s0); }
+        else if (s1 >= 0) { mma2(accr[w4b_reg_block(u)], ct, a, b0, b1); ct_store_load(s1); }
+        else mma2(accr[w4b_reg_block(u)], accr[w4b_reg_block(u + 1)], a, b0, b1);
     };
     // second transform pass over the five column sums t[m] (column CH + m) of one point row: the three points of this wavefront's column half
     //   single (B^T row 0 / 5): 4 t0 - 5 t2 + t4 ;  pair, CH = 0 (rows 1, 2 of B^T on columns 1..4): (t4 - 4 t2) +- (t3 - 4 t1)
@@ -367,13 +366,9 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
 #pragma unroll
             for (int ck = 0; ck < 3; ++ck) {
                 if (ck < 2) w4b_split8(vs[ck + 1], af[(ck + 1) & 1]);
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const int u = 2 * ck + nb;
-                    unit(u, af[ck & 1], ub[u]);
-                    uload(u, u + 6, koff);
-                    W4B_USTAMP(it, u);
-                }
+                unit2(2 * ck, af[ck & 1], ub[2 * ck], ub[2 * ck + 1]);
+                uload(2 * ck, 2 * ck + 6, koff);
+                uload(2 * ck + 1, 2 * ck + 7, koff);
             }
         }
         W4B_KSTAMP(it, 3);
@@ -387,13 +382,14 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
 #pragma unroll
             for (int pp = 0; pp < 6; ++pp) {
                 if (pp < 5) w4b_split8(vp[pp + 1], af[(pp + 1) & 1]);
+                {
+                    const int u = 6 + 2 * pp;
+                    unit2(u, af[pp & 1], ub[u % 6], ub[(u + 1) % 6]);
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const int u = 6 + 2 * pp + nb;
-                    unit(u, af[pp & 1], ub[u % 6]);
-                    if (u < 12) uload(u % 6, u + 6, koff);
-                    else uload(u % 6, u - 12, koff + ustep);          // next K step (after the last one: a harmless read of the next point / zeros)
-                    W4B_USTAMP(it, u);
+                    for (int nb = 0; nb < 2; ++nb) {
+                        if (u + nb < 12) uload((u + nb) % 6, u + nb + 6, koff);
+                        else uload((u + nb) % 6, u + nb - 12, koff + ustep);      // next K step (after the last one: a harmless read of the next point / zeros)
+                    }
                 }
             }
         }
