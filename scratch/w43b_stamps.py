@@ -42,10 +42,3 @@ for wv in range(4):
     whole = np.median(q[:, 1:, 0] - q[:, :-1, 0]) if nst > 1 else float('nan')
     print('  wave %d: %6.0f | %6.0f | %6.0f | %6.0f | %6.0f | %6.0f | %6.0f | %6.0f' % (wv, seg[0], seg[1], seg[2], seg[3], seg[4], seg[5], whole - sum(seg) if nst > 1 else float('nan'), whole))
 
-if ks > 2:
-    print(" K step 2, per filter unit (cycles from the step's stamp after T single / after T pair to the point after each unit's MFMAs and refill were issued):")
-    for wv in range(4):
-        u = dfull[:, wv, 256:274]
-        t2 = dfull[:, wv, 16 + 8 + 2]; t4 = dfull[:, wv, 16 + 8 + 4]
-        a = [np.median(u[:, i] - t2) for i in range(6)]; b = [np.median(u[:, i] - t4) for i in range(6, 18)]
-        print('  wave %d: M single ' % wv + ' '.join('%5.0f' % v for v in a) + ' | M pair ' + ' '.join('%5.0f' % v for v in b))
