@@ -9,7 +9,9 @@ from kpx_amd._lib import lib, check
 dev = torch.device('cuda:0')
 n, h, c = [int(v) for v in sys.argv[1:4]] if len(sys.argv) >= 4 else (32, 64, 128)
 co = int(sys.argv[4]) if len(sys.argv) >= 5 else c
-x = torch.randn(n, h, h, c, device=dev); w = torch.randn(3, 3, c, co, device=dev) * 0.05; y = torch.empty(n, h, h, co, device=dev)
+x = torch.randn(n, h, h, c, device=dev); w = torch.randn(3, 3, c, co, device=dev) * 0.05
+if os.environ.get('W4B_ZERO'): x.zero_(); w.zero_()        # (power experiment: all-zero operands)
+y = torch.empty(n, h, h, co, device=dev)
 u = torch.empty(lib.kpx_wino43b_u_bytes(c, co), dtype=torch.uint8, device=dev)
 check(lib.kpx_wino43b_filter_transform_f32(w.data_ptr(), c, co, 0, u.data_ptr(), ops._stream()), 'xf')
 s = ops._stream()

@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256) void wino43b_filter_transform_kernel(const flo
 __constant__ float w4b_AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
 
 // unit u = 2 lp + nb of a K step: LDS-resident accumulator slot (0..3) or -1; register block index (0..13) of the others
-__device__ __forceinline__ constexpr int w4b_lds_slot(int u) { return u == 3 ? 0 : u == 8 ? 1 : u == 13 ? 2 : u == 17 ? 3 : -1; }
-__device__ __forceinline__ constexpr int w4b_reg_block(int u) { return u - (u > 3) - (u > 8) - (u > 13); }
+__device__ __forceinline__ constexpr int w4b_lds_slot(int u) { return u == 3 ? 0 : u == 9 ? 1 : u == 13 ? 2 : u == 17 ? 3 : -1; }
+__device__ __forceinline__ constexpr int w4b_reg_block(int u) { return u - (u > 3) - (u > 9) - (u > 13); }
 
 // global row / column of the 6 x 6 point grid of a wavefront's local kind (0: the `single` one, 1 / 2: the pair) for block half hf (0: rows 0-2)
 __device__ __forceinline__ constexpr int w4b_grid(int hf, int kind) { return kind == 0 ? (hf ? 5 : 0) : (hf ? 2 + kind : kind); }
@@ -175,7 +175,7 @@ __device__ __forceinline__ constexpr int w4b_grid(int hf, int kind) { return kin
 static __device__ unsigned long long* w4b_dbg = nullptr;
 extern "C" int kpx_debug_w4b_stamps(unsigned long long* buf) { return -(int)hipMemcpyToSymbol(HIP_SYMBOL(w4b_dbg), &buf, sizeof(buf)); }
 #define W4B_STAMP(slot) do { if (dbgp) dbgp[(slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define W4B_KSTAMP(k, j) do { if (dbgp && (k) >= 1 && (k) < 5) dbgp[16 + ((k) - 1) * 8 + (j)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define W4B_KSTAMP(k, j) do { __builtin_amdgcn_sched_barrier(0); if (dbgp && (k) >= 1 && (k) < 5) dbgp[16 + ((k) - 1) * 8 + (j)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define W4B_USTAMP(k, u) do { if (dbgp && (k) == 2) dbgp[256 + (u)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define W4B_STAMP(slot) do { } while (0)
@@ -246,35 +246,95 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
     unsigned char* const accsp = smem + W4B_ACC_OFF + wave * (W4B_NLDS * 4096) + lane * 16;
 #pragma unroll
     for (int i = 0; i < 4 * W4B_NLDS; ++i) *reinterpret_cast<f32x4*>(accsp + i * 1024) = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x16 ct;                                           // the transient block: zero = the first K step's slot 0
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ct[r] = 0.f;
-    // The two units of one point (cout blocks 0 and 1: same V fragments): six products each, smallest first, their twelve MFMAs ALTERNATING
-    // between the two accumulator blocks (an MFMA then never follows, a few VALU instructions later, the MFMA that wrote its accumulator)
-    auto mma2 = [&](f32x16& c0, f32x16& c1, const u32x4* a, const u32x4* b0, const u32x4* b1) {
-#define W4B_P(ai, bi) \
-        c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ai]), __builtin_bit_cast(bf16x8, b0[bi]), c0, 0, 0, 0); \
-        c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ai]), __builtin_bit_cast(bf16x8, b1[bi]), c1, 0, 0, 0);
-        W4B_P(1, 1) W4B_P(0, 2) W4B_P(2, 0) W4B_P(0, 1) W4B_P(1, 0) W4B_P(0, 0)
-#undef W4B_P
+    f32x16 ctA, ctB, ctC, ctD;                           // the LDS-resident blocks (units 3, 9, 13, 17) while they are in registers
+    // ---- the multiply phase is HAND PLACED (sched_barrier after every MFMA): one wavefront per SIMD hides at most six single-issue vector
+    // instructions under a v_mfma_f32_32x32x16_bf16 and NO packed-fp32 one (v_pk_*_f32 beside an MFMA costs ~10 cycles each:
+    // scratch/micro/valu_fill.hip), and hipcc left to itself clumps the split's arithmetic between runs of back-to-back MFMAs and SLP-packs
+    // the subtractions.  A point = the two units (cout blocks 0 / 1) on the same V fragments: six products each, smallest first, the twelve
+    // MFMAs alternating between the two accumulator blocks.  Gap q (after MFMA q) carries
+    //   * ops [S(q), S(q+1)) of the 44-instruction split of the NEXT point's eight V values (level-major over the four channel pairs, so
+    //     consecutive instructions are independent),
+    //   * the refill of a filter fragment of THIS point as soon as its last MFMA has issued (term 2 after q = 2 / 3, term 1 after 6 / 7,
+    //     term 0 after 10 / 11),
+    //   * one LDS instruction of the PREVIOUS point's accumulator swap (its MFMAs have long finished: no dependency stall).
+#if defined(W4B_EXP) && (W4B_EXP & 32)
+    unsigned hmask;
+    asm volatile("s_mov_b32 %0, 0xffff0000" : "=s"(hmask));
+#endif
+    auto split_op = [&](const int idx, float (&x)[8], unsigned (&h)[8], u32x4* f) {
+        const int lvl = idx < 4 ? 0 : idx < 12 ? 1 : idx < 20 ? 2 : idx < 24 ? 3 : idx < 32 ? 4 : idx < 40 ? 5 : 6;
+        const int k = idx - (lvl == 0 ? 0 : lvl == 1 ? 4 : lvl == 2 ? 12 : lvl == 3 ? 20 : lvl == 4 ? 24 : lvl == 5 ? 32 : 40);
+        if (lvl == 0 || lvl == 3 || lvl == 6) f[lvl / 3][k] = w4b_pack_hi(w4b_bits(x[2 * k]), w4b_bits(x[2 * k + 1]));
+#if defined(W4B_EXP) && (W4B_EXP & 32)
+        else if (lvl == 1 || lvl == 4) h[k] = w4b_bits(x[k]) & hmask;
+#else
+        else if (lvl == 1 || lvl == 4) h[k] = w4b_bits(x[k]) & 0xffff0000u;
+#endif
+        else asm("v_sub_f32 %0, %1, %2" : "=v"(x[k]) : "v"(x[k]), "v"(h[k]));      // (asm: never SLP-packed; exact -- the difference fits)
     };
-    auto ct_store_load = [&](int slot) {
-        unsigned char* const sp = accsp + slot * 4096;
+    auto split_all = [&](const float* v, u32x4* f) {     // a split with no MFMAs to hide under (the first point of a row group)
+        float x[8]; unsigned h[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(sp + i * 1024) = f32x4{ct[4 * i], ct[4 * i + 1], ct[4 * i + 2], ct[4 * i + 3]};
-        const unsigned char* const sq = accsp + ((slot + 1) % W4B_NLDS) * 4096;
+        for (int e = 0; e < 8; ++e) x[e] = v[e];
+#if defined(W4B_EXP) && (W4B_EXP & 1)
+        w4b_split8(v, f); return;
+#endif
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(sq + i * 1024);
+        for (int i = 0; i < 44; ++i) split_op(i, x, h, f);
+    };
+    // u: the point's even unit (accumulators c0 / c1); a: its V fragments; xn / fn: the next point's V values and fragment buffer (or null);
+    // st / st_slot: an LDS-resident block to put back (the previous point's), ld / ld_slot: the one to fetch for the NEXT point -- each such block
+    // lives in registers for three points only, and never two of them at once (the stores ride in gaps 1-4, the loads in gaps 5-8)
+    auto point = [&](const int u, f32x16& c0, f32x16& c1, const u32x4* a, const float* xn, u32x4* fn,
+                     const f32x16* st, const int st_slot, f32x16* ld, const int ld_slot, const int koff) {
+        constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
+        constexpr int S[13] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 35, 38, 41, 44};
+        const int sl0 = u % 6, sl1 = (u + 1) % 6;
+        // refill sources: unit + 6 of this K step, or unit - 12 of the next one (scalar base; the term's 1 KB steps ride in the immediate offset)
+        const int un0 = u + 6 < 18 ? u + 6 : u - 12, un1 = u + 7 < 18 ? u + 7 : u - 11;
+        const int so0 = ubase[un0 >> 1] + (un0 & 1) * 3072 + (u + 6 < 18 ? koff : koff + ustep);
+        const int so1 = ubase[un1 >> 1] + (un1 & 1) * 3072 + (u + 7 < 18 ? koff : koff + ustep);
+        float x[8]; unsigned h[8];
+        if (xn) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) ct[4 * i + q] = v[q];
+            for (int e = 0; e < 8; ++e) x[e] = xn[e];
         }
-    };
-    auto unit2 = [&](int u, const u32x4* a, const u32x4* b0, const u32x4* b1) {      // units u (even) and u + 1
-        const int s0 = w4b_lds_slot(u), s1 = w4b_lds_slot(u + 1);
-        if (s0 >= 0) { mma2(ct, accr[w4b_reg_block(u + 1)], a, b0, b1); ct_store_load(s0); }
-        else if (s1 >= 0) { mma2(accr[w4b_reg_block(u)], ct, a, b0, b1); ct_store_load(s1); }
-        else mma2(accr[w4b_reg_block(u)], accr[w4b_reg_block(u + 1)], a, b0, b1);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const int pr = q >> 1;
+            if (q & 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[PA[pr]]), __builtin_bit_cast(bf16x8, ub[sl1][PB[pr]]), c1, 0, 0, 0);
+            else c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[PA[pr]]), __builtin_bit_cast(bf16x8, ub[sl0][PB[pr]]), c0, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#if defined(W4B_EXP) && (W4B_EXP & 1)
+#else
+            if (xn) {
+#pragma unroll
+                for (int i = S[q]; i < S[q + 1]; ++i) split_op(i, x, h, fn);
+            }
+#endif
+#if defined(W4B_EXP) && (W4B_EXP & 2)
+#else
+            if (q == 3) ub[sl0][2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane + 2048, so0, 0));
+            if (q == 4) ub[sl1][2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane + 2048, so1, 0));
+            if (q == 7) ub[sl0][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane + 1024, so0, 0));
+            if (q == 8) ub[sl1][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane + 1024, so1, 0));
+            if (q == 11) {
+                ub[sl0][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, so0, 0));
+                ub[sl1][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, so1, 0));
+            }
+#endif
+            if (st && q >= 1 && q <= 4) {
+                const int i = q - 1;
+                *reinterpret_cast<f32x4*>(accsp + st_slot * 4096 + i * 1024) = f32x4{(*st)[4 * i], (*st)[4 * i + 1], (*st)[4 * i + 2], (*st)[4 * i + 3]};
+            }
+            if (ld && q >= 5 && q <= 8) {
+                const int i = q - 5;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(accsp + ld_slot * 4096 + i * 1024);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) (*ld)[4 * i + e] = v[e];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     };
     // second transform pass over the five column sums t[m] (column CH + m) of one point row: the three points of this wavefront's column half
     //   single (B^T row 0 / 5): 4 t0 - 5 t2 + t4 ;  pair, CH = 0 (rows 1, 2 of B^T on columns 1..4): (t4 - 4 t2) +- (t3 - 4 t1)
@@ -336,6 +396,7 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
             for (int ck = 0; ck < 3; ++ck)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { vp[ck][4 * j + q] = o1[ck][q]; vp[3 + ck][4 * j + q] = o2[ck][q]; }
+            __builtin_amdgcn_sched_barrier(0);          // (one channel quad at a time: the second quad's temporaries reuse the first's registers)
         }
     };
 
@@ -356,43 +417,32 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
         if (it + 1 < KS) dma(it + 1, buf ^ 1);
 #endif
         W4B_KSTAMP(it, 1);
+        __builtin_amdgcn_sched_barrier(0);
         float vs[3][8];                                  // V of the `single` row's three points, this lane's 8 channels
         t_single(buf, vs);
         W4B_KSTAMP(it, 2);
+        u32x4 af[2][3];
+        split_all(vs[0], af[0]);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- its three points: units 0..5
-        {
-            u32x4 af[2][3];
-            w4b_split8(vs[0], af[0]);
-#pragma unroll
-            for (int ck = 0; ck < 3; ++ck) {
-                if (ck < 2) w4b_split8(vs[ck + 1], af[(ck + 1) & 1]);
-                unit2(2 * ck, af[ck & 1], ub[2 * ck], ub[2 * ck + 1]);
-                uload(2 * ck, 2 * ck + 6, koff);
-                uload(2 * ck + 1, 2 * ck + 7, koff);
-            }
-        }
+        point(0, accr[w4b_reg_block(0)], accr[w4b_reg_block(1)], af[0], vs[1], af[1], nullptr, 0, &ctA, 0, koff);
+        point(2, accr[w4b_reg_block(2)], ctA, af[1], vs[2], af[0], nullptr, 0, nullptr, 0, koff);
+        point(4, accr[w4b_reg_block(4)], accr[w4b_reg_block(5)], af[0], nullptr, nullptr, &ctA, 0, nullptr, 0, koff);
         W4B_KSTAMP(it, 3);
         float vp[6][8];
         t_pair(buf, vp);
         W4B_KSTAMP(it, 4);
+        split_all(vp[0], af[1]);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- the pair rows' six points: units 6..17 (local points 3..8)
-        {
-            u32x4 af[2][3];
-            w4b_split8(vp[0], af[0]);
+        point(6, accr[w4b_reg_block(6)], accr[w4b_reg_block(7)], af[1], vp[1], af[0], nullptr, 0, &ctB, 1, koff);
+        point(8, accr[w4b_reg_block(8)], ctB, af[0], vp[2], af[1], nullptr, 0, nullptr, 0, koff);
+        point(10, accr[w4b_reg_block(10)], accr[w4b_reg_block(11)], af[1], vp[3], af[0], &ctB, 1, &ctC, 2, koff);
+        point(12, accr[w4b_reg_block(12)], ctC, af[0], vp[4], af[1], nullptr, 0, nullptr, 0, koff);
+        point(14, accr[w4b_reg_block(14)], accr[w4b_reg_block(15)], af[1], vp[5], af[0], &ctC, 2, &ctD, 3, koff);
+        point(16, accr[w4b_reg_block(16)], ctD, af[0], nullptr, nullptr, nullptr, 0, nullptr, 0, koff);
 #pragma unroll
-            for (int pp = 0; pp < 6; ++pp) {
-                if (pp < 5) w4b_split8(vp[pp + 1], af[(pp + 1) & 1]);
-                {
-                    const int u = 6 + 2 * pp;
-                    unit2(u, af[pp & 1], ub[u % 6], ub[(u + 1) % 6]);
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
-                        if (u + nb < 12) uload((u + nb) % 6, u + nb + 6, koff);
-                        else uload((u + nb) % 6, u + nb - 12, koff + ustep);      // next K step (after the last one: a harmless read of the next point / zeros)
-                    }
-                }
-            }
-        }
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(accsp + 3 * 4096 + i * 1024) = f32x4{ctD[4 * i], ctD[4 * i + 1], ctD[4 * i + 2], ctD[4 * i + 3]};
         W4B_KSTAMP(it, 5);
         if (it + 1 < KS) {
             asm volatile("s_waitcnt vmcnt(18)" ::: "memory");         // the next patch has landed: only the 18 fragment loads issued after its DMA may be in flight
