@@ -400,6 +400,36 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
         }
     };
 
+    // both row groups in ONE pass over the patch (rows RH .. RH + 4 read once: 50 instead of 70 ds_read_b128 per K step -- the four wavefronts'
+    // transform phases coincide and run at the LDS read bandwidth): v[0..2] the `single` row's points, v[3..8] the pair rows'
+    auto t_all = [&](int buf, float (&v)[9][8]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            f32x4 ts[5], t1[5], t2[5];
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                const f32x4 e0 = W4B_RD(buf, j, 0, m), e1 = W4B_RD(buf, j, 1, m), e2 = W4B_RD(buf, j, 2, m), e3 = W4B_RD(buf, j, 3, m), e4 = W4B_RD(buf, j, 4, m);
+                ts[m] = 4.f * e0 - 5.f * e2 + e4;
+                if (RH == 0) {                           // pair rows on patch rows 1..4
+                    const f32x4 u = e4 - 4.f * e2, w = e3 - 4.f * e1;
+                    t1[m] = u + w; t2[m] = u - w;
+                } else {                                 // patch rows 1..4 = relative rows 0..3
+                    const f32x4 u = e3 - e1, w = e2 - e0;
+                    t1[m] = u + 2.f * w; t2[m] = u - 2.f * w;
+                }
+            }
+            f32x4 o0[3], o1[3], o2[3];
+            second(ts, o0);
+            second(t1, o1);
+            second(t2, o2);
+#pragma unroll
+            for (int ck = 0; ck < 3; ++ck)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[ck][4 * j + q] = o0[ck][q]; v[3 + ck][4 * j + q] = o1[ck][q]; v[6 + ck][4 * j + q] = o2[ck][q]; }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
     // prologue: the first K step's patch, the first six filter units
     dma(0, 0);
 #pragma unroll
@@ -418,28 +448,23 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
 #endif
         W4B_KSTAMP(it, 1);
         __builtin_amdgcn_sched_barrier(0);
-        float vs[3][8];                                  // V of the `single` row's three points, this lane's 8 channels
-        t_single(buf, vs);
+        float v[9][8];                                   // V of this wavefront's nine points, this lane's 8 channels
+        t_all(buf, v);
         W4B_KSTAMP(it, 2);
         u32x4 af[2][3];
-        split_all(vs[0], af[0]);
+        split_all(v[0], af[0]);
         __builtin_amdgcn_sched_barrier(0);
-        // ---- its three points: units 0..5
-        point(0, accr[w4b_reg_block(0)], accr[w4b_reg_block(1)], af[0], vs[1], af[1], nullptr, 0, &ctA, 0, koff);
-        point(2, accr[w4b_reg_block(2)], ctA, af[1], vs[2], af[0], nullptr, 0, nullptr, 0, koff);
-        point(4, accr[w4b_reg_block(4)], accr[w4b_reg_block(5)], af[0], nullptr, nullptr, &ctA, 0, nullptr, 0, koff);
         W4B_KSTAMP(it, 3);
-        float vp[6][8];
-        t_pair(buf, vp);
         W4B_KSTAMP(it, 4);
-        split_all(vp[0], af[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- the pair rows' six points: units 6..17 (local points 3..8)
-        point(6, accr[w4b_reg_block(6)], accr[w4b_reg_block(7)], af[1], vp[1], af[0], nullptr, 0, &ctB, 1, koff);
-        point(8, accr[w4b_reg_block(8)], ctB, af[0], vp[2], af[1], nullptr, 0, nullptr, 0, koff);
-        point(10, accr[w4b_reg_block(10)], accr[w4b_reg_block(11)], af[1], vp[3], af[0], &ctB, 1, &ctC, 2, koff);
-        point(12, accr[w4b_reg_block(12)], ctC, af[0], vp[4], af[1], nullptr, 0, nullptr, 0, koff);
-        point(14, accr[w4b_reg_block(14)], accr[w4b_reg_block(15)], af[1], vp[5], af[0], &ctC, 2, &ctD, 3, koff);
+        // ---- the nine points, units 0..17: every point's gaps carry the next point's split
+        point(0, accr[w4b_reg_block(0)], accr[w4b_reg_block(1)], af[0], v[1], af[1], nullptr, 0, &ctA, 0, koff);
+        point(2, accr[w4b_reg_block(2)], ctA, af[1], v[2], af[0], nullptr, 0, nullptr, 0, koff);
+        point(4, accr[w4b_reg_block(4)], accr[w4b_reg_block(5)], af[0], v[3], af[1], &ctA, 0, nullptr, 0, koff);
+        point(6, accr[w4b_reg_block(6)], accr[w4b_reg_block(7)], af[1], v[4], af[0], nullptr, 0, &ctB, 1, koff);
+        point(8, accr[w4b_reg_block(8)], ctB, af[0], v[5], af[1], nullptr, 0, nullptr, 0, koff);
+        point(10, accr[w4b_reg_block(10)], accr[w4b_reg_block(11)], af[1], v[6], af[0], &ctB, 1, &ctC, 2, koff);
+        point(12, accr[w4b_reg_block(12)], ctC, af[0], v[7], af[1], nullptr, 0, nullptr, 0, koff);
+        point(14, accr[w4b_reg_block(14)], accr[w4b_reg_block(15)], af[1], v[8], af[0], &ctC, 2, &ctD, 3, koff);
         point(16, accr[w4b_reg_block(16)], ctD, af[0], nullptr, nullptr, nullptr, 0, nullptr, 0, koff);
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(accsp + 3 * 4096 + i * 1024) = f32x4{ctD[4 * i], ctD[4 * i + 1], ctD[4 * i + 2], ctD[4 * i + 3]};
