@@ -24,10 +24,12 @@
 //     channel quads of a pixel are consecutive lanes of a request: 64 contiguous bytes) with one skew slot per four pixels (conflict-free
 //     transform reads), double buffered: ONE barrier per 16-channel K step;
 //   * the filter fragments come straight from L2 in fragment order through a buffer descriptor with scalar offsets, a ring of six
-//     (point, cout half) units = 72 registers, refilled in place five units (~960 MFMA cycles) ahead;
-//   * per K step: transform the `single` point row (rows 0 / 5 of B^T: three-term sums), multiply its three points; transform the two `pair`
-//     rows (rows 1,2 / 3,4: they share their partial sums), multiply their six points.  The split of point p+1 (44 VALU) is independent of
-//     the twelve MFMAs of point p and issues beside them;
+//     (point, cout half) units = 72 registers, each fragment refilled in place as soon as its last MFMA has issued (~3 points ahead);
+//   * per K step: ONE transform pass (the 5 x 5 patch of the lane's tile read once: 50 ds_read_b128 -- the four wavefronts transform at the
+//     same time and that phase runs at the LDS read bandwidth), then the nine points' 108 MFMAs as one HAND-PLACED instruction stream: one
+//     wavefront per SIMD hides at most six single-issue vector instructions under a 32-cycle MFMA and no packed-fp32 one
+//     (scratch/micro/valu_fill.hip), so every MFMA is followed by its share of the NEXT point's split (44 single-issue VALU over twelve
+//     gaps), a filter refill, an LDS-resident accumulator's store / fetch -- pinned by sched_barrier;
 //   * the epilogue runs in two passes of ALL 36 points x 32 output channels through LDS (147 KB): every wavefront deposits nine blocks in
 //     both passes, every thread owns (tile, 4 couts), reads its 36 values as ds_read_b128 and finishes the 4 x 4 output pixels in one go.
 // STATS / mask / pool epilogue options are those of conv_wino43_kernel (same statistics strips: kpx_conv3x3_wino43_stats_tiles).
@@ -44,11 +46,11 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
                                            // four pixels), 34 columns = 144 slots, padded to 146 so that four rows are 8 (mod 16) slots
 #define W4B_NPIECES 44                     // LDS-DMA pieces of 1 KB per buffer (18 x 146 = 2628 slots, rounded up to 11 pieces per wavefront)
 #define W4B_RAW_BYTES (W4B_NPIECES * 1024) // one raw buffer
-#define W4B_ACC_OFF (2 * W4B_RAW_BYTES)    // [4 wavefronts][4 blocks][4][64 lanes] x 16 B: four of a wavefront's 18 accumulator blocks (units 3, 8, 13, 17 of a K
-                                           // step) live here between K steps and pass through ONE transient block.  18 blocks are 288 registers, the
-                                           // accumulator file has 256: with all of them in registers hipcc spills two blocks to scratch every K step
-                                           // (vector-memory operations in the middle of a counted-vmcnt pipeline) and shuffles a third through VGPRs;
-                                           // with four in LDS 16 accumulator registers are left over for the compiler to park vector registers in
+#define W4B_ACC_OFF (2 * W4B_RAW_BYTES)    // [4 wavefronts][4 blocks][4][64 lanes] x 16 B: four of a wavefront's 18 accumulator blocks (units 3, 9, 13, 17 of a K
+                                           // step) live here between K steps; each is fetched one point before its own, multiplied into, and put back
+                                           // during the point after (never two in registers at once).  18 blocks are 288 registers, the accumulator
+                                           // file has 256: with all of them in registers hipcc spills two blocks to scratch every K step (vector-memory
+                                           // operations in the middle of a counted-vmcnt pipeline)
 #define W4B_NLDS 4
 #define W4B_EPI_BYTES (36 * 32 * 32 * 4)   // P[point][tile][32 couts] fp32
 #define W4B_MAIN_BYTES (W4B_ACC_OFF + 4 * W4B_NLDS * 4096)
@@ -272,7 +274,7 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
 #endif
         else asm("v_sub_f32 %0, %1, %2" : "=v"(x[k]) : "v"(x[k]), "v"(h[k]));      // (asm: never SLP-packed; exact -- the difference fits)
     };
-    auto split_all = [&](const float* v, u32x4* f) {     // a split with no MFMAs to hide under (the first point of a row group)
+    auto split_all = [&](const float* v, u32x4* f) {     // a split with no MFMAs to hide under (the first point of a K step)
         float x[8]; unsigned h[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = v[e];
@@ -354,52 +356,11 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
     // (Walking the K steps in an order rotated from tile to tile, so that the workgroups of a round do not all read the same few KB of U at
     //  the same time, was measured: no change -- the L2 channels are not the limit.  Every tile sums its channels in the same order.)
     //
-    // Schedule of a K step: T single, M single, T pair, M pair, counted wait + barrier (the next step's patch was requested at the top of the
-    // step).  The filter stream is latency bound (six units of look-ahead against ~2 k cycles of loaded L2 latency), so the transforms would
-    // ideally issue BESIDE the multiplies of the previous point group; the rotated loop that does this (M single, T pair | barrier | M pair ||
-    // T single of the next step) was built and spills 11-36 registers per iteration to scratch -- vector-memory operations with vmcnt(0) waits
-    // in the middle of the counted pipeline -- because V of two point groups, the fragment ring and the transform's temporaries are live
-    // together.  Not kept.
-    auto t_single = [&](int buf, float (&vs)[3][8]) {    // patch rows RH + 0, 2, 4
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            f32x4 t[5];
-#pragma unroll
-            for (int m = 0; m < 5; ++m) t[m] = 4.f * W4B_RD(buf, j, 0, m) - 5.f * W4B_RD(buf, j, 2, m) + W4B_RD(buf, j, 4, m);
-            f32x4 o[3];
-            second(t, o);
-#pragma unroll
-            for (int ck = 0; ck < 3; ++ck)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) vs[ck][4 * j + q] = o[ck][q];
-        }
-    };
-    auto t_pair = [&](int buf, float (&vp)[6][8]) {      // patch rows 1..4 (= RH-relative rows 1-RH .. 4-RH)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            f32x4 t1[5], t2[5];
-#pragma unroll
-            for (int m = 0; m < 5; ++m) {
-                const f32x4 d1 = W4B_RD(buf, j, 1 - RH, m), d2 = W4B_RD(buf, j, 2 - RH, m), d3 = W4B_RD(buf, j, 3 - RH, m), d4 = W4B_RD(buf, j, 4 - RH, m);
-                if (RH == 0) {
-                    const f32x4 u = d4 - 4.f * d2, v = d3 - 4.f * d1;
-                    t1[m] = u + v; t2[m] = u - v;
-                } else {
-                    const f32x4 u = d4 - d2, v = d3 - d1;
-                    t1[m] = u + 2.f * v; t2[m] = u - 2.f * v;
-                }
-            }
-            f32x4 o1[3], o2[3];
-            second(t1, o1);
-            second(t2, o2);
-#pragma unroll
-            for (int ck = 0; ck < 3; ++ck)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { vp[ck][4 * j + q] = o1[ck][q]; vp[3 + ck][4 * j + q] = o2[ck][q]; }
-            __builtin_amdgcn_sched_barrier(0);          // (one channel quad at a time: the second quad's temporaries reuse the first's registers)
-        }
-    };
-
+    // Schedule of a K step: request the next step's patch (11 LDS-DMA pieces), transform all nine points (T), split point 0, the nine points'
+    // 108 MFMAs as one hand-placed stream (M), counted wait + barrier.  Measured alternatives, not kept: a rotated loop with T of the next
+    // point group beside M of the previous one spills 11-36 registers per iteration to scratch; the DMA pieces between the reads of T (eleven
+    // more registers live at T's peak: scratch reloads with vmcnt(0)), or two steps ahead in the gaps of points 0..2 with the one barrier after
+    // T (+3 %: a filter fragment loaded behind a piece waits for that piece) -- DESIGN.md 4.2b.
     // both row groups in ONE pass over the patch (rows RH .. RH + 4 read once: 50 instead of 70 ds_read_b128 per K step -- the four wavefronts'
     // transform phases coincide and run at the LDS read bandwidth): v[0..2] the `single` row's points, v[3..8] the pair rows'
     auto t_all = [&](int buf, float (&v)[9][8]) {
