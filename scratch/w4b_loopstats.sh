@@ -10,9 +10,10 @@ hdr=[i for i,l in enumerate(lines) if 'Inner Loop Header' in l]
 for h in hdr:
     # loop end: first s_cbranch back to this label
     lab=lines[h].split(':')[0]
+    tag='Header='+lab.lstrip('.L')          # the loop = the header block + the following blocks marked "in Loop: Header=<it>"
     end=None
     for i in range(h+1,len(lines)):
-        if re.search(r's_c?branch\w* '+re.escape(lab)+r'\b',lines[i]): end=i; break
+        if re.match(r'^\.LBB\d+_\d+:',lines[i]) and tag not in lines[i]: end=i-1; break
     if end is None: continue
     seg=lines[h:end+1]
     cnt=lambda p: sum(1 for l in seg if re.search(p,l))

@@ -7,10 +7,11 @@ want = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 done = 0
 for h in hdr:
     lab = lines[h].split(':')[0]
+    tag = 'Header=' + lab.lstrip('.L')      # the loop = the header block + the following blocks marked "in Loop: Header=<it>"
     end = None
     for i in range(h + 1, len(lines)):
-        if re.search(r's_c?branch\w* ' + re.escape(lab) + r'\b', lines[i]):
-            end = i
+        if re.match(r'^\.LBB\d+_\d+:', lines[i]) and tag not in lines[i]:
+            end = i - 1
             break
     if end is None:
         continue

@@ -499,14 +499,29 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
         for (int lp = 0; lp < 9; ++lp) {
             const int p = 6 * w4b_grid(rh, lp / 3) + w4b_grid(ch, lp % 3);
             float* const Pw = P + (p * 32 + 4 * lh) * 32 + li;
+            // register r of a block is tile row (r & 3) + 8 (r >> 2) + 4 lh, 128 B apart: registers r and r + 2 go out as ONE
+            // ds_write2st64_b32 (two dwords 256 B apart) -- hipcc pairs the stores of a block held in VGPRs by itself, not those of one in AGPRs
+            const int u = 2 * lp + nb;                    // (nb is a run-time loop variable: both forms are written out)
+#define W4B_DEP(blk, cons) do { \
+                const unsigned pa = (unsigned)(size_t)(lds_ptr_t)Pw, pb = pa + 128u; \
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:0 offset1:1" :: "v"(pa), cons((blk)[0]), cons((blk)[2]) : "memory"); \
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:0 offset1:1" :: "v"(pb), cons((blk)[1]), cons((blk)[3]) : "memory"); \
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:4 offset1:5" :: "v"(pa), cons((blk)[4]), cons((blk)[6]) : "memory"); \
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:4 offset1:5" :: "v"(pb), cons((blk)[5]), cons((blk)[7]) : "memory"); \
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:8 offset1:9" :: "v"(pa), cons((blk)[8]), cons((blk)[10]) : "memory"); \
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:8 offset1:9" :: "v"(pb), cons((blk)[9]), cons((blk)[11]) : "memory"); \
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:12 offset1:13" :: "v"(pa), cons((blk)[12]), cons((blk)[14]) : "memory"); \
+                asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:12 offset1:13" :: "v"(pb), cons((blk)[13]), cons((blk)[15]) : "memory"); \
+            } while (0)
             if (nb == 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Pw[((r & 3) + 8 * (r >> 2)) * 32] = w4b_lds_slot(2 * lp) >= 0 ? accl[w4b_lds_slot(2 * lp) & 3][r] : accr[w4b_reg_block(2 * lp)][r];
+                if (w4b_lds_slot(2 * lp) >= 0) W4B_DEP(accl[w4b_lds_slot(2 * lp) & 3], "v"); else W4B_DEP(accr[w4b_reg_block(2 * lp)], "a");
             } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Pw[((r & 3) + 8 * (r >> 2)) * 32] = w4b_lds_slot(2 * lp + 1) >= 0 ? accl[w4b_lds_slot(2 * lp + 1) & 3][r] : accr[w4b_reg_block(2 * lp + 1)][r];
+                if (w4b_lds_slot(2 * lp + 1) >= 0) W4B_DEP(accl[w4b_lds_slot(2 * lp + 1) & 3], "v"); else W4B_DEP(accr[w4b_reg_block(2 * lp + 1)], "a");
             }
+            (void)u;
+#undef W4B_DEP
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the deposits are asm: the compiler's own wait before the barrier does not count them)
         if (nb == 0) W4B_STAMP(4);
         __syncthreads();
         if (nb == 0) W4B_STAMP(5);
