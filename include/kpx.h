@@ -187,7 +187,8 @@ int kpx_conv3x3_wino43_stats_f32(const float* in, int N, int H, int W, int K, in
  * fragment order by kpx_wino43b_filter_transform(_batch)_f32 (kpx_wino43b_u_bytes bytes; descriptors as for
  * kpx_wino_filter_transform_batch_f32), V split in registers after the input transform, six v_mfma_f32_32x32x16_bf16 products per block,
  * fp32 accumulate: the fp32 configuration's arithmetic (error vs float64 as the fp32-MFMA kernel's), not the bf16 mode.  Eligible when
- * H % 16 == 0, W % 32 == 0, K >= 16, K % 4 == 0, Nn > 32, ldin >= K, 16-B alignment.  One entry for every form of the launch: tile_stats
+ * (H % 16 == 0 and W % 32 == 0, or 16 x 16 images in even number: two to a workgroup, no tile_stats), K >= 16, K % 4 == 0, Nn > 32, ldin >= K,
+ * 16-B alignment.  One entry for every form of the launch: tile_stats
  * alone = kpx_conv3x3_wino43_stats_f32's statistics strips (kpx_conv3x3_wino43_stats_tiles); tile_stats + bn_y + bn_beta =
  * kpx_conv3x3_wino43_bnbwd_stats_f32 (no bias / act); mask_y / pool_y = kpx_conv3x3_wino43_ex_f32's options (Nn % 64 == 0); all NULL = the
  * plain convolution.  Replaces the same tf.layers.conv2d call sites (reference models/networks/layers.py:4-10 on

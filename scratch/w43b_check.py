@@ -60,7 +60,7 @@ def t_ms(fn, iters=50, warm=10):
     return e0.elapsed_time(e1) / iters
 
 
-CASES = [(2, 16, 32, 16, 64, 0), (1, 32, 32, 64, 64, 1), (2, 32, 64, 32, 40, 2), (1, 16, 64, 24, 96, 0), (2, 64, 64, 128, 128, 0), (1, 32, 32, 256, 128, 1)]
+CASES = [(2, 16, 16, 64, 64, 1), (4, 16, 16, 40, 72, 0), (2, 16, 32, 16, 64, 0), (1, 32, 32, 64, 64, 1), (2, 32, 64, 32, 40, 2), (1, 16, 64, 24, 96, 0), (2, 64, 64, 128, 128, 0), (1, 32, 32, 256, 128, 1)]
 if len(sys.argv) < 2 or sys.argv[1] != 'time':
     for (n, h, wd, cin, cout, act) in CASES:
         g = torch.Generator().manual_seed(n * 1000 + cin + cout)
@@ -89,8 +89,13 @@ if len(sys.argv) < 2 or sys.argv[1] != 'time':
     y2, _, py, _ = run_new(x, c, w, b, c, 1, mask=m, pool=True)
     want = torch.relu(ref64(x, w, b, 0)) * (m > 0)
     print('mask+relu %.3e  pool %.3e' % (rel(y2, want), rel(py, torch.nn.functional.max_pool2d(want.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))))
+    n, h, wd, c = 4, 16, 16, 64                          # packed 16x16 images with the mask / pool epilogue
+    x = torch.randn(n, h, wd, c, generator=g).to(dev); m = torch.randn(n, h, wd, c, generator=g).to(dev)
+    y2, _, py, _ = run_new(x, c, w, b, c, 1, mask=m, pool=True)
+    want = torch.relu(ref64(x, w, b, 0)) * (m > 0)
+    print('packed: mask+relu %.3e  pool %.3e' % (rel(y2, want), rel(py, torch.nn.functional.max_pool2d(want.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))))
 else:
-    for (n, h, c, co) in [(32, 64, 128, 128), (32, 128, 64, 64), (32, 64, 256, 128), (32, 128, 128, 64), (64, 128, 64, 64), (64, 64, 128, 128), (64, 32, 256, 256), (32, 32, 256, 256), (64, 64, 64, 128)]:
+    for (n, h, c, co) in [(32, 64, 128, 128), (32, 128, 64, 64), (32, 64, 256, 128), (32, 128, 128, 64), (64, 128, 64, 64), (64, 64, 128, 128), (64, 32, 256, 256), (32, 32, 256, 256), (64, 64, 64, 128), (64, 16, 512, 512), (64, 16, 256, 512), (64, 16, 256, 128)]:
         x = torch.randn(n, h, h, c, device=dev); w = torch.randn(3, 3, c, co, device=dev) * 0.03; b = torch.zeros(co, device=dev)
         y, _, _, u = run_new(x, c, w, b, co, 0)
         yo, uo = run_old(x, c, w, b, co, 0)

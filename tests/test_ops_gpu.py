@@ -453,8 +453,9 @@ W43_CASES = [  # n, h, w, cin, cout, act
 
 
 def _w43b_takes(h, w, k, nn):
-    """Launch shapes of the bf16x3 form of F(4x4,3x3) (csrc/conv_wino43b.hip): no packed 16x16 images, gathered channels a multiple of 4."""
-    return h % 16 == 0 and w % 32 == 0 and k >= 16 and k % 4 == 0 and nn >= 33
+    """Launch shapes of the bf16x3 form of F(4x4,3x3) (csrc/conv_wino43b.hip): 16 x 32-pixel regions or 16x16 images packed two to a workgroup
+    (every such case here has an even image count), gathered channels a multiple of 4."""
+    return ((h % 16 == 0 and w % 32 == 0) or (h == 16 and w == 16)) and k >= 16 and k % 4 == 0 and nn >= 33
 
 
 @pytest.mark.parametrize('form', ['bf16x3', 'f32mfma'])
@@ -604,10 +605,19 @@ def test_wino43b_epilogue_options_through_the_c_abi(kpx, dev):
     rc, y3, _, _ = run(xw, 24, 32, wt2, b2, 72, act=2)
     w3 = torch.nn.functional.leaky_relu(conv64(xw.cpu()[..., :24], wt2.cpu(), b2.cpu()), 0.01)
     assert rc == 0 and rel_l2(t2n(y3), w3.numpy()) < 1e-5
-    # rejected: statistics together with mask / pool, the batch-norm form with a bias, 16x16 images, K % 4 != 0
+    # 16x16 images, two to a workgroup (an even number of them): forward with mask + pool; no statistics from that form
+    xp = torch.randn(4, 16, 16, c, generator=g).to(dev); mp = torch.randn(4, 16, 16, c, generator=g).to(dev)
+    rc, yp, _, pp = run(xp, c, c, wt, b, c, act=1, mask=mp, pool=True)
+    assert rc == 0
+    wantp = torch.relu(conv64(xp.cpu(), wt.cpu(), b.cpu())) * (mp.cpu() > 0)
+    assert rel_l2(t2n(yp), wantp.numpy()) < 1e-5
+    assert rel_l2(t2n(pp), torch.nn.functional.max_pool2d(wantp.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).numpy()) < 1e-5
+    assert lib.kpx_conv3x3_wino43_stats_tiles(4, 16, 16) == 0
+    assert lib.kpx_conv3x3_wino43b_eligible(4, 16, 16, 64, 64, 64, x.data_ptr()) == 1 and lib.kpx_conv3x3_wino43b_eligible(3, 16, 16, 64, 64, 64, x.data_ptr()) == 0
+    # rejected: statistics together with mask / pool, the batch-norm form with a bias, K % 4 != 0
     assert run(x, c, c, wt, b, c, mask=m, stats=True)[0] == -1
     assert run(x, c, c, wt, b, c, bn=(z, beta))[0] == -1
-    assert lib.kpx_conv3x3_wino43b_eligible(4, 16, 16, 64, 64, 64, x.data_ptr()) == 0 and lib.kpx_conv3x3_wino43b_eligible(2, 32, 32, 158, 64, 160, x.data_ptr()) == 0
+    assert lib.kpx_conv3x3_wino43b_eligible(2, 32, 32, 158, 64, 160, x.data_ptr()) == 0
     assert lib.kpx_conv3x3_wino43b_eligible(2, 32, 64, 64, 64, 64, x.data_ptr()) == 1
 
 

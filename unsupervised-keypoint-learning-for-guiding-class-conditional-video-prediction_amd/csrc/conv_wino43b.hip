@@ -32,7 +32,8 @@
 //     gaps), a filter refill, an LDS-resident accumulator's store / fetch -- pinned by sched_barrier;
 //   * the epilogue runs in two passes of ALL 36 points x 32 output channels through LDS (147 KB): every wavefront deposits nine blocks in
 //     both passes, every thread owns (tile, 4 couts), reads its 36 values as ds_read_b128 and finishes the 4 x 4 output pixels in one go.
-// STATS / mask / pool epilogue options are those of conv_wino43_kernel (same statistics strips: kpx_conv3x3_wino43_stats_tiles).
+// STATS / mask / pool epilogue options are those of conv_wino43_kernel (same statistics strips: kpx_conv3x3_wino43_stats_tiles); PACK: two 16 x 16
+// images side by side in one 16 x 32 region (VGG19 conv4_*, the 16 x 16 data gradients of the encoders), each with its own zero halo in the patch.
 #include "kpx_common.h"
 #include "kpx_env.h"
 #include <type_traits>
@@ -44,6 +45,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define W4B_OOB 0x7ffffff0                 // voffset beyond any buffer: the load returns / lands as zeros
 #define W4B_ROWSLOTS 146                   // 16-B slots per patch row: pixel column c at slot 4 c + (c >> 2) (four channel quads per pixel, one skew slot per
                                            // four pixels), 34 columns = 144 slots, padded to 146 so that four rows are 8 (mod 16) slots
+#define W4B_ROWSLOTS_PACK 154              // PACK (two 16 x 16 images side by side): image A's 18 patch columns at slots 0..75 of a row, image B's at 76..151 (tile
+                                           // origins 17 tx and 17 tx + 8: the sixteen 16-B columns of a ds_read_b128 group stay distinct), 4 x 154 = 8 (mod 16) too
 #define W4B_NPIECES 44                     // LDS-DMA pieces of 1 KB per buffer (18 x 146 = 2628 slots, rounded up to 11 pieces per wavefront)
 #define W4B_RAW_BYTES (W4B_NPIECES * 1024) // one raw buffer
 #define W4B_ACC_OFF (2 * W4B_RAW_BYTES)    // [4 wavefronts][4 blocks][4][64 lanes] x 16 B: four of a wavefront's 18 accumulator blocks (units 3, 9, 13, 17 of a K
@@ -187,12 +190,13 @@ extern "C" int kpx_debug_w4b_stamps(unsigned long long* buf) { return -(int)hipM
 
 // The K loop of one wavefront role.  RH / CH: which half of the point rows / columns (compile time: the second transform pass selects
 // REGISTERS by column, the first one patch rows).  acc[lp = 3 rk + ck][nb]: local point (row kind rk, column kind ck), 32-cout block nb.
-template <int RH, int CH>
+template <int RH, int CH, bool PACK>
 __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[14], unsigned char* const smem, const int lane, const int wave,
                                          const int n, const int oy0, const int ox0, const int nti, unsigned long long* const dbgp) {
     const int KS = g.Kp >> 4, NB = g.Np >> 5;
     // ---- LDS-DMA of the raw patch: piece wave * 12 + i covers slots 64 (wave * 12 + i) .. + 63 of the buffer
-    const unsigned img_bytes = (unsigned)g.H * g.W * g.ldx * 4u;
+    constexpr int RS = PACK ? W4B_ROWSLOTS_PACK : W4B_ROWSLOTS;
+    const unsigned img_bytes = (unsigned)g.H * g.W * g.ldx * 4u * (PACK ? 2u : 1u);      // PACK: images n and n + 1
     const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.x) + (size_t)n * g.H * g.W * g.ldx, 0, img_bytes, 0x00020000);
     // slot S of row r = S / 146: within the row, slot 17 g + 4 k + q is channel quad q of pixel column 4 g + k (slot 17 g + 16: the skew slot; slots
     // 144, 145: row padding).  Consecutive lanes = the four quads of a pixel (64 contiguous bytes of the tensor) and four consecutive pixels.
@@ -201,11 +205,13 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
 #pragma unroll
     for (int i = 0; i < 11; ++i) {
         const int S = (wave * 11 + i) * 64 + lane;
-        const int row = S / W4B_ROWSLOTS, rs = S - row * W4B_ROWSLOTS, grp = rs / 17, r17 = rs - grp * 17;
+        const int row = S / RS, rs0 = S - row * RS;
+        const int half = PACK && rs0 >= 76 ? 1 : 0, rs = rs0 - 76 * half;               // PACK: which image's half row
+        const int grp = rs / 17, r17 = rs - grp * 17;
         const int col = 4 * grp + (r17 >> 2), q = r17 & 3;
         const int iy = oy0 - 1 + row, ix = ox0 - 1 + col;
-        const bool ok = r17 < 16 && rs < 144 && row < 18 && col < 34 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-        dv[i] = ok ? ((iy * g.W + ix) * g.ldx + q * 4) * 4 : W4B_OOB;
+        const bool ok = r17 < 16 && rs < (PACK ? 76 : 144) && row < 18 && col < (PACK ? 18 : 34) && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        dv[i] = ok ? (((half * g.H + iy) * g.W + ix) * g.ldx + q * 4) * 4 : W4B_OOB;
         if ((KS - 1) * 16 + q * 4 < g.Cin) dtail |= 1u << i;
     }
     auto dma = [&](int s, int buf) {                     // K step s -> raw buffer buf
@@ -240,9 +246,9 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
     // in x and 4 x 146 = 8 (mod 16) slots in y, so the sixteen lanes of every ds_read_b128 group (tiles {0-3, 12-15, 20-27} /
     // {4-11, 16-19, 28-31} of one octet) hit sixteen different 16-B columns of the 256-B bank row: {0..3}, {12..15}, {4..7}, {8..11}.
     const int tile = lane & 31, oct = lane >> 5, ty = tile >> 3, tx = tile & 7;
-    const int rbase = ((4 * ty + RH) * W4B_ROWSLOTS + 17 * tx + 2 * oct) * 16;
+    const int rbase = ((4 * ty + RH) * RS + 17 * tx + (PACK && tx >= 4 ? 8 : 0) + 2 * oct) * 16;
     // patch column CH + m of the tile: slot 4 (CH + m) + ((CH + m) >> 2)
-#define W4B_RD(buf, j, a, m) (*reinterpret_cast<const f32x4*>(smem + (buf) * W4B_RAW_BYTES + rbase + ((a) * W4B_ROWSLOTS + 4 * (CH + (m)) + ((CH + (m)) >> 2) + (j)) * 16))
+#define W4B_RD(buf, j, a, m) (*reinterpret_cast<const f32x4*>(smem + (buf) * W4B_RAW_BYTES + rbase + ((a) * RS + 4 * (CH + (m)) + ((CH + (m)) >> 2) + (j)) * 16))
 
     // the LDS-resident accumulator blocks (this lane's 16 registers of slot k as 4 x 16 B)
     unsigned char* const accsp = smem + W4B_ACC_OFF + wave * (W4B_NLDS * 4096) + lane * 16;
@@ -440,8 +446,9 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
 #undef W4B_RD
 }
 
-template <int STATS>
+template <int STATS, bool PACK = false>
 __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom g) {
+    static_assert(!PACK || STATS == 0, "packed 16 x 16 images: no statistics epilogue (kpx_conv3x3_wino43_stats_tiles is 0 for them)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     int L = kpx_xcd_remap(blockIdx.x, gridDim.x);
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
     const int nti = L % ntc; L /= ntc;
     const int bx = L % g.tiles_x; L /= g.tiles_x;
     const int by = L % g.tiles_y;
-    const int n = L / g.tiles_y;
+    const int n = PACK ? 2 * (L / g.tiles_y) : L / g.tiles_y;      // PACK: tiles_y = tiles_x = 1, the region holds images n and n + 1
     const int oy0 = by * 16, ox0 = bx * 32, n0 = nti * 64;
 
     f32x16 accr[14];                                     // the register-resident accumulator blocks (w4b_reg_block)
@@ -465,10 +472,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
     unsigned long long* const dbgp = nullptr;
 #endif
     const int rh = wave >> 1, ch = wave & 1;
-    if (wave == 0) w4b_kloop<0, 0>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
-    else if (wave == 1) w4b_kloop<0, 1>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
-    else if (wave == 2) w4b_kloop<1, 0>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
-    else w4b_kloop<1, 1>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+    if (wave == 0) w4b_kloop<0, 0, PACK>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+    else if (wave == 1) w4b_kloop<0, 1, PACK>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+    else if (wave == 2) w4b_kloop<1, 0, PACK>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+    else w4b_kloop<1, 1, PACK>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
 
     // ---- epilogue: two passes (one per 32-cout block) of all 36 points through LDS; thread = (tile, 4 couts)
     f32x16 accl[W4B_NLDS];                               // the LDS-resident blocks, before the passes overwrite them
@@ -489,7 +496,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
     const float* const Pr = P + otile * 32 + ocq * 4;
     const float lo = g.act == KPX_ACT_RELU ? 0.f : -__builtin_inff();
     const float slope = g.act == KPX_ACT_LRELU ? 0.01f : 1.f;
-    const int oy = oy0 + 4 * (otile >> 3), ox = ox0 + 4 * (otile & 7);
+    const int oy = oy0 + 4 * (otile >> 3), ox = PACK ? 4 * (otile & 3) : ox0 + 4 * (otile & 7);
+    const int on = PACK ? n + ((otile >> 2) & 1) : n;    // the image of this thread's tile
     const size_t cstr = (size_t)g.ldy, rstr = (size_t)g.W * g.ldy;
 #pragma unroll 1
     for (int nb = 0; nb < 2; ++nb) {
@@ -554,13 +562,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (c0o + q < g.Cout) bv[q] = g.bias[c0o + q];
         }
-        float* const obase = g.y + ((size_t)(n * g.H + oy) * g.W + ox) * g.ldy + c0o;
+        float* const obase = g.y + ((size_t)(on * g.H + oy) * g.W + ox) * g.ldy + c0o;
         const bool fast = (g.ldy & 3) == 0 && ((reinterpret_cast<uintptr_t>(g.y) & 15) == 0) && n0 + 32 * nb + 32 <= g.Cout;     // block-uniform
         f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};
         if (STATS == 2) {
             // data gradient dz of a ReLU'd batch norm's output z (= mask_y): store dz * [z > 0] and reduce sum(dz), sum(dz * (z - beta))
             // (launch preconditions checked by the entry: fast stores, no bias / act)
-            const float* const mbase = g.mask_y + ((size_t)(n * g.H + oy) * g.W + ox) * g.ld_mask + c0o;
+            const float* const mbase = g.mask_y + ((size_t)(on * g.H + oy) * g.W + ox) * g.ld_mask + c0o;
             const size_t mc = (size_t)g.ld_mask, mr = (size_t)g.W * g.ld_mask;
             const f32x4 be = *reinterpret_cast<const f32x4*>(g.bn_beta + c0o);
 #pragma unroll
@@ -590,7 +598,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
                     Y[i][j] = v;
                 }
             if (g.mask_y) {
-                const float* const mbase = g.mask_y + ((size_t)(n * g.H + oy) * g.W + ox) * g.ld_mask + c0o;
+                const float* const mbase = g.mask_y + ((size_t)(on * g.H + oy) * g.W + ox) * g.ld_mask + c0o;
                 const size_t mc = (size_t)g.ld_mask, mr = (size_t)g.W * g.ld_mask;
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
                 for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(obase + i * rstr + j * cstr) = Y[i][j];
             if (g.pool_y) {
                 const int Hp = g.H >> 1, Wp = g.W >> 1;
-                float* const pbase = g.pool_y + ((size_t)(n * Hp + (oy >> 1)) * Wp + (ox >> 1)) * g.ld_pool + c0o;
+                float* const pbase = g.pool_y + ((size_t)(on * Hp + (oy >> 1)) * Wp + (ox >> 1)) * g.ld_pool + c0o;
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -671,8 +679,9 @@ static inline int w4b_lds_bytes() { return W4B_EPI_BYTES > W4B_MAIN_BYTES ? W4B_
 
 extern "C" int kpx_conv3x3_wino43b_eligible(int N, int H, int W, int K, int Nn, int ldin, const void* in_ptr) {
     if (kpx_env()->no_wino || N <= 0) return 0;
-    return H % 16 == 0 && W % 32 == 0 && K >= 16 && K % 4 == 0 && Nn >= 33 && ldin >= K && ldin % 4 == 0 && (((uintptr_t)in_ptr) & 15) == 0 &&
-           (size_t)H * W * ldin * 4 < 0x7fffff00u && (size_t)36 * ((K + 15) & ~15) * ((Nn + 63) & ~63) * 6 < 0x7fffff00u;
+    const bool shape = (H % 16 == 0 && W % 32 == 0) || (H == 16 && W == 16 && N % 2 == 0);      // 16 x 16 images are packed two to a workgroup
+    return shape && K >= 16 && K % 4 == 0 && Nn >= 33 && ldin >= K && ldin % 4 == 0 && (((uintptr_t)in_ptr) & 15) == 0 &&
+           (size_t)H * W * ldin * 8 < 0x7fffff00u && (size_t)36 * ((K + 15) & ~15) * ((Nn + 63) & ~63) * 6 < 0x7fffff00u;
 }
 extern "C" size_t kpx_wino43b_u_bytes(int Cin, int Cout) {
     const size_t a = (size_t)((Cin + 15) & ~15) * ((Cout + 63) & ~63), b = (size_t)((Cout + 15) & ~15) * ((Cin + 63) & ~63);
@@ -711,17 +720,21 @@ extern "C" int kpx_conv3x3_wino43b_f32(const float* in, int N, int H, int W, int
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43b_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, w4b_lds_bytes());
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43b_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, w4b_lds_bytes());
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43b_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, w4b_lds_bytes());
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino43b_kernel<0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, w4b_lds_bytes());
         if (e != hipSuccess) return -(int)e;
     }
     Wino43bGeom g{};
     g.x = in; g.y = out; g.U = U; g.bias = bias;
     g.N = N; g.H = H; g.W = W; g.Cin = K; g.ldx = ldin; g.Cout = Nn; g.ldy = ldout; g.act = act;
     g.Kp = (K + 15) & ~15; g.Np = (Nn + 63) & ~63;
-    g.tiles_y = H / 16; g.tiles_x = W / 32;
+    const bool pack = W == 16;
+    if (pack && tile_stats) return KPX_EINVAL;           // (no statistics epilogue for packed images: kpx_conv3x3_wino43_stats_tiles is 0 for them)
+    g.tiles_y = H / 16; g.tiles_x = pack ? 1 : W / 32;
     g.stats = tile_stats;
     g.mask_y = bnbwd ? bn_y : mask_y; g.ld_mask = bnbwd ? ld_bn_y : ld_mask; g.pool_y = pool_y; g.ld_pool = ld_pool; g.bn_beta = bn_beta;
-    const unsigned blocks = (unsigned)((size_t)N * g.tiles_y * g.tiles_x * (g.Np / 64));
-    if (bnbwd) hipLaunchKernelGGL((conv_wino43b_kernel<2>), dim3(blocks), dim3(256), w4b_lds_bytes(), kpx_stream(stream), g);
+    const unsigned blocks = (unsigned)((size_t)(pack ? N / 2 : N) * g.tiles_y * g.tiles_x * (g.Np / 64));
+    if (pack) hipLaunchKernelGGL((conv_wino43b_kernel<0, true>), dim3(blocks), dim3(256), w4b_lds_bytes(), kpx_stream(stream), g);
+    else if (bnbwd) hipLaunchKernelGGL((conv_wino43b_kernel<2>), dim3(blocks), dim3(256), w4b_lds_bytes(), kpx_stream(stream), g);
     else if (tile_stats) hipLaunchKernelGGL((conv_wino43b_kernel<1>), dim3(blocks), dim3(256), w4b_lds_bytes(), kpx_stream(stream), g);
     else hipLaunchKernelGGL((conv_wino43b_kernel<0>), dim3(blocks), dim3(256), w4b_lds_bytes(), kpx_stream(stream), g);
     return kpx_launch_status();

@@ -591,7 +591,7 @@ def _wino_pretransformed(inp, ld_in, k, w, bias, out, ld_out, nn, act, dgrad, wa
     ent43b = _cached_u(_wino43b_u, w, dgrad) if (WINO43B and ent43 is not None) else None
     if (ent43b is not None and tiles and wgs43 > WINO43_MIN_WORKGROUPS and _wino43b_preferred(n, h, wd, k, nn)
             and lib.kpx_conv3x3_wino43b_eligible(n, h, wd, k, nn, ld_in, inp.data_ptr())):
-        bnbwd = bn_src is not None and dgrad and nn % 64 == 0
+        bnbwd = bn_src is not None and dgrad and nn % 64 == 0 and wd != 16        # (packed 16 x 16 images: no statistics epilogue, as on the fp32-MFMA form)
         slab = None
         if bnbwd or want_stats:
             slab = torch.empty(lib.kpx_conv3x3_wino43_stats_tiles(n, h, wd) * 2 * nn, dtype=torch.float32, device=inp.device)
