@@ -2,7 +2,7 @@
 # instruction mix of the four K-loop bodies of conv_wino43b_kernel<0> (cross-compiled ISA; no GPU)
 cd "$(dirname "$0")/../unsupervised-keypoint-learning-for-guiding-class-conditional-video-prediction_amd/csrc"
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --cuda-device-only $EXTRA -S conv_wino43b.hip -o /tmp/w4b.s 2>/dev/null
-awk '/^_Z19conv_wino43b_kernelILi0EEv11Wino43bGeom:/,/s_endpgm/' /tmp/w4b.s > /tmp/k0.s
+awk '/^_Z19conv_wino43b_kernelILi0ELb0EEv11Wino43bGeom:/,/s_endpgm/' /tmp/w4b.s > /tmp/k0.s
 python3 - <<'PY'
 import re
 lines=open('/tmp/k0.s').read().split('\n')

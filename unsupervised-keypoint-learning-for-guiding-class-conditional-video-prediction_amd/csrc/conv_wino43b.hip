@@ -170,6 +170,10 @@ __global__ __launch_bounds__(256) void wino43b_filter_transform_kernel(const flo
 __constant__ float w4b_AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, -2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 8.f, -8.f, 1.f}};
 
 // unit u = 2 lp + nb of a K step: LDS-resident accumulator slot (0..3) or -1; register block index (0..13) of the others
+// units whose accumulator block lives in VGPRs (VGPR-form MFMA, written as asm: the builtin selects the AGPR form): hipcc allocates 240 AGPRs to
+// 15 blocks and time-shares three of them with these units' blocks through 96 v_accvgpr moves per K step whatever the live ranges are, while
+// 48 VGPRs are free over the whole loop.  (The MFMA that next touches such a block follows two MFMAs later: no hazard the compiler would pad.)
+#define W4B_VFORM(u) ((u) == 16)
 __device__ __forceinline__ constexpr int w4b_lds_slot(int u) { return u == 3 ? 0 : u == 9 ? 1 : u == 13 ? 2 : u == 17 ? 3 : -1; }
 __device__ __forceinline__ constexpr int w4b_reg_block(int u) { return u - (u > 3) - (u > 9) - (u > 13); }
 
@@ -311,6 +315,7 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
         for (int q = 0; q < 12; ++q) {
             const int pr = q >> 1;
             if (q & 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[PA[pr]]), __builtin_bit_cast(bf16x8, ub[sl1][PB[pr]]), c1, 0, 0, 0);
+            else if (W4B_VFORM(u)) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a[PA[pr]]), "v"(ub[sl0][PB[pr]]));
             else c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[PA[pr]]), __builtin_bit_cast(bf16x8, ub[sl0][PB[pr]]), c0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #if defined(W4B_EXP) && (W4B_EXP & 1)
@@ -522,7 +527,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
                 asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:12 offset1:13" :: "v"(pb), cons((blk)[13]), cons((blk)[15]) : "memory"); \
             } while (0)
             if (nb == 0) {
-                if (w4b_lds_slot(2 * lp) >= 0) W4B_DEP(accl[w4b_lds_slot(2 * lp) & 3], "v"); else W4B_DEP(accr[w4b_reg_block(2 * lp)], "a");
+                if (w4b_lds_slot(2 * lp) >= 0) W4B_DEP(accl[w4b_lds_slot(2 * lp) & 3], "v");
+                else if (W4B_VFORM(2 * lp)) W4B_DEP(accr[w4b_reg_block(2 * lp)], "v");
+                else W4B_DEP(accr[w4b_reg_block(2 * lp)], "a");
             } else {
                 if (w4b_lds_slot(2 * lp + 1) >= 0) W4B_DEP(accl[w4b_lds_slot(2 * lp + 1) & 3], "v"); else W4B_DEP(accr[w4b_reg_block(2 * lp + 1)], "a");
             }
