@@ -174,6 +174,9 @@ __constant__ float w4b_AT[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1
 // 15 blocks and time-shares three of them with these units' blocks through 96 v_accvgpr moves per K step whatever the live ranges are, while
 // 48 VGPRs are free over the whole loop.  (The MFMA that next touches such a block follows two MFMAs later: no hazard the compiler would pad.)
 #define W4B_VFORM(u) ((u) == 16)
+#ifndef W4B_VFORM1
+#define W4B_VFORM1(u) (w4b_lds_slot(u) >= 0)
+#endif
 __device__ __forceinline__ constexpr int w4b_lds_slot(int u) { return u == 3 ? 0 : u == 9 ? 1 : u == 13 ? 2 : u == 17 ? 3 : -1; }
 __device__ __forceinline__ constexpr int w4b_reg_block(int u) { return u - (u > 3) - (u > 9) - (u > 13); }
 
@@ -314,7 +317,10 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
 #pragma unroll
         for (int q = 0; q < 12; ++q) {
             const int pr = q >> 1;
-            if (q & 1) c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[PA[pr]]), __builtin_bit_cast(bf16x8, ub[sl1][PB[pr]]), c1, 0, 0, 0);
+            if (q & 1) {
+                if (W4B_VFORM1(u + 1)) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c1) : "v"(a[PA[pr]]), "v"(ub[sl1][PB[pr]]));
+                else c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[PA[pr]]), __builtin_bit_cast(bf16x8, ub[sl1][PB[pr]]), c1, 0, 0, 0);
+            }
             else if (W4B_VFORM(u)) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c0) : "v"(a[PA[pr]]), "v"(ub[sl0][PB[pr]]));
             else c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[PA[pr]]), __builtin_bit_cast(bf16x8, ub[sl0][PB[pr]]), c0, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
