@@ -55,6 +55,16 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
                                            // file has 256: with all of them in registers hipcc spills two blocks to scratch every K step (vector-memory
                                            // operations in the middle of a counted-vmcnt pipeline)
 #define W4B_NLDS 4
+#ifndef W4B_RING
+#define W4B_RING 6                         // filter-fragment ring: units (must divide 18)
+#endif
+#if W4B_RING == 6
+#define W4B_RING3 18                        // fragment loads a full ring holds: the counted waits' argument
+#else
+#define W4B_RING3 27
+#endif
+#define W4B_STR2(x) #x
+#define W4B_STR(x) W4B_STR2(x)
 #define W4B_EPI_BYTES (36 * 32 * 32 * 4)   // P[point][tile][32 couts] fp32
 #define W4B_MAIN_BYTES (W4B_ACC_OFF + 4 * W4B_NLDS * 4096)
 
@@ -238,7 +248,7 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
 #pragma unroll
     for (int lp = 0; lp < 9; ++lp)
         ubase[lp] = __builtin_amdgcn_readfirstlane(((6 * w4b_grid(RH, lp / 3) + w4b_grid(CH, lp % 3)) * KS * NB + 2 * nti) * 3072);
-    u32x4 ub[6][3];
+    u32x4 ub[W4B_RING][3];
     auto uload = [&](int slot, int unit, int koff) {     // unit of the K step at byte offset koff -> ring slot
 #if defined(W4B_EXP) && (W4B_EXP & 2)      // timing experiment: the ring is loaded once (prologue) and never refilled
         if (unit >= 6) return;
@@ -304,11 +314,11 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
                      const f32x16* st, const int st_slot, f32x16* ld, const int ld_slot, const int koff) {
         constexpr int PA[6] = {1, 0, 2, 0, 1, 0}, PB[6] = {1, 2, 0, 1, 0, 0};
         constexpr int S[13] = {0, 4, 8, 12, 16, 20, 24, 28, 32, 35, 38, 41, 44};
-        const int sl0 = u % 6, sl1 = (u + 1) % 6;
+        const int sl0 = u % W4B_RING, sl1 = (u + 1) % W4B_RING;
         // refill sources: unit + 6 of this K step, or unit - 12 of the next one (scalar base; the term's 1 KB steps ride in the immediate offset)
-        const int un0 = u + 6 < 18 ? u + 6 : u - 12, un1 = u + 7 < 18 ? u + 7 : u - 11;
-        const int so0 = ubase[un0 >> 1] + (un0 & 1) * 3072 + (u + 6 < 18 ? koff : koff + ustep);
-        const int so1 = ubase[un1 >> 1] + (un1 & 1) * 3072 + (u + 7 < 18 ? koff : koff + ustep);
+        const int un0 = u + W4B_RING < 18 ? u + W4B_RING : u + W4B_RING - 18, un1 = u + 1 + W4B_RING < 18 ? u + 1 + W4B_RING : u + 1 + W4B_RING - 18;
+        const int so0 = ubase[un0 >> 1] + (un0 & 1) * 3072 + (u + W4B_RING < 18 ? koff : koff + ustep);
+        const int so1 = ubase[un1 >> 1] + (un1 & 1) * 3072 + (u + 1 + W4B_RING < 18 ? koff : koff + ustep);
         float x[8]; unsigned h[8];
         if (xn) {
 #pragma unroll
@@ -411,8 +421,8 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
     // prologue: the first K step's patch, the first six filter units
     dma(0, 0);
 #pragma unroll
-    for (int u = 0; u < 6; ++u) uload(u, u, 0);
-    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");     // the 11 DMA pieces are older than the 18 fragment loads
+    for (int u = 0; u < W4B_RING; ++u) uload(u, u, 0);
+    asm volatile("s_waitcnt vmcnt(" W4B_STR(W4B_RING3) ")" ::: "memory");     // the 11 DMA pieces are older than the 18 fragment loads
     __builtin_amdgcn_s_barrier();
     W4B_STAMP(1);
 
@@ -448,7 +458,7 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(accsp + 3 * 4096 + i * 1024) = f32x4{ctD[4 * i], ctD[4 * i + 1], ctD[4 * i + 2], ctD[4 * i + 3]};
         W4B_KSTAMP(it, 5);
         if (it + 1 < KS) {
-            asm volatile("s_waitcnt vmcnt(18)" ::: "memory");         // the next patch has landed: only the 18 fragment loads issued after its DMA may be in flight
+            asm volatile("s_waitcnt vmcnt(" W4B_STR(W4B_RING3) ")" ::: "memory");         // the next patch has landed: only the 18 fragment loads issued after its DMA may be in flight
             W4B_KSTAMP(it, 6);
             __builtin_amdgcn_s_barrier();
         }
