@@ -205,6 +205,30 @@ extern "C" int kpx_debug_w4b_stamps(unsigned long long* buf) { return -(int)hipM
 #define W4B_USTAMP(k, u) do { } while (0)
 #endif
 
+// Packed-fp32 arithmetic of the transform phase, written out (the phase has no MFMA to disturb): c * a + b with a scalar-pair constant, a +- b.
+// hipcc emits a - b on f32x4 as four v_sub_f32 and the negated products through v_xor sign flips: 316 vector instructions per K step for what is
+// 192 packed ones.  (FMA contraction of 4 e0 - 5 e2 + e4 etc.: the transform rounds once less per term.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned long long w4b_c2(float c) { const unsigned u = __builtin_bit_cast(unsigned, c); return ((unsigned long long)u << 32) | u; }
+__device__ __forceinline__ f32x4 w4b_fma4(unsigned long long c, const f32x4& a, const f32x4& b) {       // c * a + b
+    f32x2 lo, hi;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(f32x2{a[0], a[1]}), "s"(c), "v"(f32x2{b[0], b[1]}));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(f32x2{a[2], a[3]}), "s"(c), "v"(f32x2{b[2], b[3]}));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ f32x4 w4b_add4(const f32x4& a, const f32x4& b) {
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(f32x2{a[0], a[1]}), "v"(f32x2{b[0], b[1]}));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(f32x2{a[2], a[3]}), "v"(f32x2{b[2], b[3]}));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ f32x4 w4b_sub4(const f32x4& a, const f32x4& b) {
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(f32x2{a[0], a[1]}), "v"(f32x2{b[0], b[1]}));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(f32x2{a[2], a[3]}), "v"(f32x2{b[2], b[3]}));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 // The K loop of one wavefront role.  RH / CH: which half of the point rows / columns (compile time: the second transform pass selects
 // REGISTERS by column, the first one patch rows).  acc[lp = 3 rk + ck][nb]: local point (row kind rk, column kind ck), 32-cout block nb.
 template <int RH, int CH, bool PACK>
@@ -368,14 +392,15 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
     // second transform pass over the five column sums t[m] (column CH + m) of one point row: the three points of this wavefront's column half
     //   single (B^T row 0 / 5): 4 t0 - 5 t2 + t4 ;  pair, CH = 0 (rows 1, 2 of B^T on columns 1..4): (t4 - 4 t2) +- (t3 - 4 t1)
     //                                               pair, CH = 1 (rows 3, 4 on columns 1..4 = t0..t3): (t3 - t1) +- 2 (t2 - t0)
+    const unsigned long long k4 = w4b_c2(4.f), km5 = w4b_c2(-5.f), km4 = w4b_c2(-4.f), k2 = w4b_c2(2.f), km2 = w4b_c2(-2.f);
     auto second = [&](const f32x4* t, f32x4* o) {
-        o[0] = 4.f * t[0] - 5.f * t[2] + t[4];
+        o[0] = w4b_fma4(km5, t[2], w4b_fma4(k4, t[0], t[4]));
         if (CH == 0) {
-            const f32x4 u = t[4] - 4.f * t[2], v = t[3] - 4.f * t[1];
-            o[1] = u + v; o[2] = u - v;
+            const f32x4 u = w4b_fma4(km4, t[2], t[4]), v = w4b_fma4(km4, t[1], t[3]);
+            o[1] = w4b_add4(u, v); o[2] = w4b_sub4(u, v);
         } else {
-            const f32x4 u = t[3] - t[1], v = t[2] - t[0];
-            o[1] = u + 2.f * v; o[2] = u - 2.f * v;
+            const f32x4 u = w4b_sub4(t[3], t[1]), v = w4b_sub4(t[2], t[0]);
+            o[1] = w4b_fma4(k2, v, u); o[2] = w4b_fma4(km2, v, u);
         }
     };
 
@@ -397,13 +422,13 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
 #pragma unroll
             for (int m = 0; m < 5; ++m) {
                 const f32x4 e0 = W4B_RD(buf, j, 0, m), e1 = W4B_RD(buf, j, 1, m), e2 = W4B_RD(buf, j, 2, m), e3 = W4B_RD(buf, j, 3, m), e4 = W4B_RD(buf, j, 4, m);
-                ts[m] = 4.f * e0 - 5.f * e2 + e4;
+                ts[m] = w4b_fma4(km5, e2, w4b_fma4(k4, e0, e4));
                 if (RH == 0) {                           // pair rows on patch rows 1..4
-                    const f32x4 u = e4 - 4.f * e2, w = e3 - 4.f * e1;
-                    t1[m] = u + w; t2[m] = u - w;
+                    const f32x4 u = w4b_fma4(km4, e2, e4), w = w4b_fma4(km4, e1, e3);
+                    t1[m] = w4b_add4(u, w); t2[m] = w4b_sub4(u, w);
                 } else {                                 // patch rows 1..4 = relative rows 0..3
-                    const f32x4 u = e3 - e1, w = e2 - e0;
-                    t1[m] = u + 2.f * w; t2[m] = u - 2.f * w;
+                    const f32x4 u = w4b_sub4(e3, e1), w = w4b_sub4(e2, e0);
+                    t1[m] = w4b_fma4(k2, w, u); t2[m] = w4b_fma4(km2, w, u);
                 }
             }
             f32x4 o0[3], o1[3], o2[3];
