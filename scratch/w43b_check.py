@@ -95,7 +95,8 @@ if len(sys.argv) < 2 or sys.argv[1] != 'time':
     want = torch.relu(ref64(x, w, b, 0)) * (m > 0)
     print('packed: mask+relu %.3e  pool %.3e' % (rel(y2, want), rel(py, torch.nn.functional.max_pool2d(want.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))))
 else:
-    for (n, h, c, co) in [(32, 64, 128, 128), (32, 128, 64, 64), (32, 64, 256, 128), (32, 128, 128, 64), (64, 128, 64, 64), (64, 64, 128, 128), (64, 32, 256, 256), (32, 32, 256, 256), (64, 64, 64, 128), (64, 16, 512, 512), (64, 16, 256, 512), (64, 16, 256, 128)]:
+    shapes = [(int(a), int(b), int(c_), int(d)) for a, b, c_, d in (t.split(',') for t in sys.argv[2:])] if len(sys.argv) > 2 else None
+    for (n, h, c, co) in shapes or [(32, 64, 128, 128), (32, 128, 64, 64), (32, 64, 256, 128), (32, 128, 128, 64), (64, 128, 64, 64), (64, 64, 128, 128), (64, 32, 256, 256), (32, 32, 256, 256), (64, 64, 64, 128), (64, 16, 512, 512), (64, 16, 256, 512), (64, 16, 256, 128)]:
         x = torch.randn(n, h, h, c, device=dev); w = torch.randn(3, 3, c, co, device=dev) * 0.03; b = torch.zeros(co, device=dev)
         y, _, _, u = run_new(x, c, w, b, co, 0)
         yo, uo = run_old(x, c, w, b, co, 0)

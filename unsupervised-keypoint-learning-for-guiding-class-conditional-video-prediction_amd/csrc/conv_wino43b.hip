@@ -479,6 +479,8 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
         point(12, accr[w4b_reg_block(12)], ctC, af[0], v[7], af[1], nullptr, 0, nullptr, 0, koff);
         point(14, accr[w4b_reg_block(14)], accr[w4b_reg_block(15)], af[1], v[8], af[0], &ctC, 2, &ctD, 3, koff);
         point(16, accr[w4b_reg_block(16)], ctD, af[0], nullptr, nullptr, nullptr, 0, nullptr, 0, koff);
+        // (the last MFMA on ctD is asm: the compiler does not pad the MFMA-result -> LDS-data hazard behind it.  20 wait states cover a 16-pass MFMA.)
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(accsp + 3 * 4096 + i * 1024) = f32x4{ctD[4 * i], ctD[4 * i + 1], ctD[4 * i + 2], ctD[4 * i + 3]};
         W4B_KSTAMP(it, 5);
