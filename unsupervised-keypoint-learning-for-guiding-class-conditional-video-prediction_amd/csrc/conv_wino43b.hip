@@ -231,8 +231,8 @@ __device__ __forceinline__ f32x4 w4b_sub4(const f32x4& a, const f32x4& b) {
 
 // The K loop of one wavefront role.  RH / CH: which half of the point rows / columns (compile time: the second transform pass selects
 // REGISTERS by column, the first one patch rows).  acc[lp = 3 rk + ck][nb]: local point (row kind rk, column kind ck), 32-cout block nb.
-template <int RH, int CH, bool PACK>
-__device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[14], unsigned char* const smem, const int lane, const int wave,
+template <bool PACK>
+__device__ __forceinline__ void w4b_kloop(const int rh, const int ch, const Wino43bGeom& g, f32x16 (&accr)[14], unsigned char* const smem, const int lane, const int wave,
                                          const int n, const int oy0, const int ox0, const int nti, unsigned long long* const dbgp) {
     const int KS = g.Kp >> 4, NB = g.Np >> 5;
     // ---- LDS-DMA of the raw patch: piece wave * 12 + i covers slots 64 (wave * 12 + i) .. + 63 of the buffer
@@ -271,7 +271,7 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
     int ubase[9];
 #pragma unroll
     for (int lp = 0; lp < 9; ++lp)
-        ubase[lp] = __builtin_amdgcn_readfirstlane(((6 * w4b_grid(RH, lp / 3) + w4b_grid(CH, lp % 3)) * KS * NB + 2 * nti) * 3072);
+        ubase[lp] = __builtin_amdgcn_readfirstlane(((6 * w4b_grid(rh, lp / 3) + w4b_grid(ch, lp % 3)) * KS * NB + 2 * nti) * 3072);
     u32x4 ub[W4B_RING][3];
     auto uload = [&](int slot, int unit, int koff) {     // unit of the K step at byte offset koff -> ring slot
 #if defined(W4B_EXP) && (W4B_EXP & 2)      // timing experiment: the ring is loaded once (prologue) and never refilled
@@ -287,7 +287,7 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
     // in x and 4 x 146 = 8 (mod 16) slots in y, so the sixteen lanes of every ds_read_b128 group (tiles {0-3, 12-15, 20-27} /
     // {4-11, 16-19, 28-31} of one octet) hit sixteen different 16-B columns of the 256-B bank row: {0..3}, {12..15}, {4..7}, {8..11}.
     const int tile = lane & 31, oct = lane >> 5, ty = tile >> 3, tx = tile & 7;
-    const int rbase = ((4 * ty + RH) * RS + 17 * tx + (PACK && tx >= 4 ? 8 : 0) + 2 * oct) * 16;
+    const int rbase = ((4 * ty + rh) * RS + 17 * tx + (PACK && tx >= 4 ? 8 : 0) + 2 * oct) * 16;
     // patch column CH + m of the tile: slot 4 (CH + m) + ((CH + m) >> 2)
 #define W4B_RD(buf, j, a, m) (*reinterpret_cast<const f32x4*>(smem + (buf) * W4B_RAW_BYTES + rbase + ((a) * RS + 4 * (CH + (m)) + ((CH + (m)) >> 2) + (j)) * 16))
 
@@ -393,7 +393,8 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
     //   single (B^T row 0 / 5): 4 t0 - 5 t2 + t4 ;  pair, CH = 0 (rows 1, 2 of B^T on columns 1..4): (t4 - 4 t2) +- (t3 - 4 t1)
     //                                               pair, CH = 1 (rows 3, 4 on columns 1..4 = t0..t3): (t3 - t1) +- 2 (t2 - t0)
     const unsigned long long k4 = w4b_c2(4.f), km5 = w4b_c2(-5.f), km4 = w4b_c2(-4.f), k2 = w4b_c2(2.f), km2 = w4b_c2(-2.f);
-    auto second = [&](const f32x4* t, f32x4* o) {
+    auto second = [&](auto chc, const f32x4* t, f32x4* o) {
+        constexpr int CH = decltype(chc)::value;
         o[0] = w4b_fma4(km5, t[2], w4b_fma4(k4, t[0], t[4]));
         if (CH == 0) {
             const f32x4 u = w4b_fma4(km4, t[2], t[4]), v = w4b_fma4(km4, t[1], t[3]);
@@ -415,7 +416,8 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
     // T (+3 %: a filter fragment loaded behind a piece waits for that piece) -- DESIGN.md 4.2b.
     // both row groups in ONE pass over the patch (rows RH .. RH + 4 read once: 50 instead of 70 ds_read_b128 per K step -- the four wavefronts'
     // transform phases coincide and run at the LDS read bandwidth): v[0..2] the `single` row's points, v[3..8] the pair rows'
-    auto t_all = [&](int buf, float (&v)[9][8]) {
+    auto t_all = [&](auto rhc, auto chc, int buf, float (&v)[9][8]) {
+        constexpr int RH = decltype(rhc)::value, CH = decltype(chc)::value;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             f32x4 ts[5], t1[5], t2[5];
@@ -432,9 +434,9 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
                 }
             }
             f32x4 o0[3], o1[3], o2[3];
-            second(ts, o0);
-            second(t1, o1);
-            second(t2, o2);
+            second(chc, ts, o0);
+            second(chc, t1, o1);
+            second(chc, t2, o2);
 #pragma unroll
             for (int ck = 0; ck < 3; ++ck)
 #pragma unroll
@@ -462,7 +464,13 @@ __device__ __forceinline__ void w4b_kloop(const Wino43bGeom& g, f32x16 (&accr)[1
         W4B_KSTAMP(it, 1);
         __builtin_amdgcn_sched_barrier(0);
         float v[9][8];                                   // V of this wavefront's nine points, this lane's 8 channels
-        t_all(buf, v);
+        {   // the transform is the only role-dependent code of the K loop: the multiply phase below is ONE instruction stream for the four
+            // wavefronts (four copies of it cost 9 % in instruction fetch: with every wavefront on the same role the launch takes 0.0955
+            // instead of 0.1049 ms)
+            const std::integral_constant<int, 0> i0; const std::integral_constant<int, 1> i1;
+            if (rh == 0) { if (ch == 0) t_all(i0, i0, buf, v); else t_all(i0, i1, buf, v); }
+            else { if (ch == 0) t_all(i1, i0, buf, v); else t_all(i1, i1, buf, v); }
+        }
         W4B_KSTAMP(it, 2);
         u32x4 af[2][3];
         split_all(v[0], af[0]);
@@ -520,10 +528,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
     unsigned long long* const dbgp = nullptr;
 #endif
     const int rh = wave >> 1, ch = wave & 1;
-    if (wave == 0) w4b_kloop<0, 0, PACK>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
-    else if (wave == 1) w4b_kloop<0, 1, PACK>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
-    else if (wave == 2) w4b_kloop<1, 0, PACK>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
-    else w4b_kloop<1, 1, PACK>(g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
+    w4b_kloop<PACK>(rh, ch, g, accr, smem, lane, wave, n, oy0, ox0, nti, dbgp);
 
     // ---- epilogue: two passes (one per 32-cout block) of all 36 points through LDS; thread = (tile, 4 couts)
     f32x16 accl[W4B_NLDS];                               // the LDS-resident blocks, before the passes overwrite them
