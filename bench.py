@@ -130,8 +130,8 @@ def _roofline_wino(dev, name, kernel_substr, kernel_desc, reduction, pmc, f43_fw
     alg = flops / (ms * 1e-3) / 1e12
     ach = alg / reduction
     if ran_b:
-        kernel_substr = 'conv_wino43b_kernel<0>'
-        kernel_desc = kernel_desc.replace('conv_wino43_kernel<0, false> F(4x4,3x3)', 'conv_wino43b_kernel<0> F(4x4,3x3), transform-domain GEMMs as bf16x3 = fp32-equivalent on the bf16 pipe,')
+        kernel_substr = 'conv_wino43b_kernel<0, false>'
+        kernel_desc = kernel_desc.replace('conv_wino43_kernel<0, false> F(4x4,3x3)', 'conv_wino43b_kernel<0, false> F(4x4,3x3), transform-domain GEMMs as bf16x3 = fp32-equivalent on the bf16 pipe,')
         pmc = pmc.replace('_wino43_', '_wino43b_')
     peak = 416.7 if ran_b else 157.3
     traffic, src = _pmc_traffic(pmc)

@@ -66,11 +66,11 @@ for f in sorted(glob.glob(O + '/pmc_*/**/*counter_collection.csv', recursive=Tru
                     pmc[tag][r['Counter_Name']].append(float(r['Counter_Value']))
             continue
         if c3:
-            for key, tag in (('conv_wino43_kernel<0, false>', 'wino43_c3'), ('conv_wino43b_kernel<0>', 'wino43b_c3'), ('gauss_fwd', 'render_c3')):
+            for key, tag in (('conv_wino43_kernel<0, false>', 'wino43_c3'), ('conv_wino43b_kernel<0, false>', 'wino43b_c3'), ('gauss_fwd', 'render_c3')):
                 if key in r['Kernel_Name']:
                     pmc[tag][r['Counter_Name']].append(float(r['Counter_Value']))
             continue
-        for key, tag in (('conv_wino_wgrad_kernel<2, 2>', 'wgrad'), ('conv_wino43_kernel<0, false>', 'wino43'), ('conv_wino43b_kernel<0>', 'wino43b'), ('conv_wino_v2_kernel<2, 0>', 'wino'), ('gauss_fwd', 'render'), ('conv_igemm_kernel<128, 128', 'direct'),
+        for key, tag in (('conv_wino_wgrad_kernel<2, 2>', 'wgrad'), ('conv_wino43_kernel<0, false>', 'wino43'), ('conv_wino43b_kernel<0, false>', 'wino43b'), ('conv_wino_v2_kernel<2, 0>', 'wino'), ('gauss_fwd', 'render'), ('conv_igemm_kernel<128, 128', 'direct'),
                          ('conv_gemm3_kernel<128, 128, 2, 4, false, 3,', 'gemm3')):
             if key in r['Kernel_Name']:
                 pmc[tag][r['Counter_Name']].append(float(r['Counter_Value']))
@@ -78,8 +78,8 @@ mean = lambda v: sum(v) / len(v) if v else None
 out = {tag: dict({c: mean(v) for c, v in d.items()}, dispatches={c: len(v) for c, v in d.items()}) for tag, d in pmc.items()}
 json.dump(out, open(O + '/pmc_raw.json', 'w'), indent=1)
 for tag, name, alg, kernel in (('wino43', 'r06_wino43_pmc.json', 134807552, 'conv_wino43_kernel<0, false> F(4x4,3x3) fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1), fp32 MFMA (the roofline_wino43_f32mfma leg)'),
-                               ('wino43b', 'r06_wino43b_pmc.json', 134807552, 'conv_wino43b_kernel<0> F(4x4,3x3) bf16x3 fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)'),
-                               ('wino43b_c3', 'r06_wino43b_c3_pmc.json', 2 * 16 * 128 * 128 * 128 * 4 + 9 * 128 * 128 * 4, 'conv_wino43b_kernel<0> F(4x4,3x3) bf16x3 fwd 3x3 s1 128->128 @128x128 B=16 (translator conv_3_1 of the 256x256 K=40 network)'),
+                               ('wino43b', 'r06_wino43b_pmc.json', 134807552, 'conv_wino43b_kernel<0, false> F(4x4,3x3) bf16x3 fwd 3x3 s1 128->128 @64x64 B=32 (translator conv_3_1)'),
+                               ('wino43b_c3', 'r06_wino43b_c3_pmc.json', 2 * 16 * 128 * 128 * 128 * 4 + 9 * 128 * 128 * 4, 'conv_wino43b_kernel<0, false> F(4x4,3x3) bf16x3 fwd 3x3 s1 128->128 @128x128 B=16 (translator conv_3_1 of the 256x256 K=40 network)'),
                                ('wino', 'r06_wino_pmc.json', 134807552, 'conv_wino_v2_kernel<2, 0> fwd 3x3 s1 128->128 @64x64 B=32'),
                                ('render', 'r06_render_pmc.json', 62922240, 'gauss_fwd_reg_kernel [64,128,128,15], nine rotating 62.9 MB outputs'),
                                ('direct', 'r06_direct_pmc.json', 134807552, 'conv_igemm_kernel<128,128,..> fwd 3x3 s1 128->128 @64x64 B=32 (KPX_NO_WINO=1 KPX_NO_GEMM3=1)'),
