@@ -55,6 +55,10 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
                                            // file has 256: with all of them in registers hipcc spills two blocks to scratch every K step (vector-memory
                                            // operations in the middle of a counted-vmcnt pipeline)
 #define W4B_NLDS 4
+#ifndef W4B_DMA_IN_T
+#define W4B_DMA_IN_T 1                    // the next patch's eleven LDS-DMA pieces between the transform's column groups (texture addresser beside LDS reads /
+                                           // VALU: -2 ... -5 % per launch against all of them before the transform = 0; the offsets then wait in spare AGPRs)
+#endif
 #ifndef W4B_RING
 #define W4B_RING 6                         // filter-fragment ring: units (must divide 18)
 #endif
@@ -255,14 +259,14 @@ __device__ __forceinline__ void w4b_kloop(const int rh, const int ch, const Wino
         dv[i] = ok ? (((half * g.H + iy) * g.W + ix) * g.ldx + q * 4) * 4 : W4B_OOB;
         if ((KS - 1) * 16 + q * 4 < g.Cin) dtail |= 1u << i;
     }
-    auto dma = [&](int s, int buf) {                     // K step s -> raw buffer buf
+    auto dma_piece = [&](int s, int buf, int i) {        // piece i of K step s -> raw buffer buf (past the last K step: zeros into the idle buffer)
         unsigned char* const dst = smem + buf * W4B_RAW_BYTES + wave * 11 * 1024;
-        const bool last = s == KS - 1;
+        const int vo = (s >= KS || (s == KS - 1 && !((dtail >> i) & 1u))) ? W4B_OOB : dv[i];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(dst + i * 1024), 16, vo, s * 64, 0, 0);
+    };
+    auto dma = [&](int s, int buf) {                     // K step s -> raw buffer buf
 #pragma unroll
-        for (int i = 0; i < 11; ++i) {
-            const int vo = (last && !((dtail >> i) & 1u)) ? W4B_OOB : dv[i];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (lds_ptr_t)(dst + i * 1024), 16, vo, s * 64, 0, 0);
-        }
+        for (int i = 0; i < 11; ++i) dma_piece(s, buf, i);
     };
     // ---- filter fragments: unit u = 2 lp + nb of a K step; ring slot u % 6
     const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.U), 0, 36u * (unsigned)(KS * NB) * 3072u, 0x00020000);
@@ -416,7 +420,7 @@ __device__ __forceinline__ void w4b_kloop(const int rh, const int ch, const Wino
     // T (+3 %: a filter fragment loaded behind a piece waits for that piece) -- DESIGN.md 4.2b.
     // both row groups in ONE pass over the patch (rows RH .. RH + 4 read once: 50 instead of 70 ds_read_b128 per K step -- the four wavefronts'
     // transform phases coincide and run at the LDS read bandwidth): v[0..2] the `single` row's points, v[3..8] the pair rows'
-    auto t_all = [&](auto rhc, auto chc, int buf, float (&v)[9][8]) {
+    auto t_all = [&](auto rhc, auto chc, int buf, float (&v)[9][8], const int dstep) {
         constexpr int RH = decltype(rhc)::value, CH = decltype(chc)::value;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -424,6 +428,10 @@ __device__ __forceinline__ void w4b_kloop(const int rh, const int ch, const Wino
 #pragma unroll
             for (int m = 0; m < 5; ++m) {
                 const f32x4 e0 = W4B_RD(buf, j, 0, m), e1 = W4B_RD(buf, j, 1, m), e2 = W4B_RD(buf, j, 2, m), e3 = W4B_RD(buf, j, 3, m), e4 = W4B_RD(buf, j, 4, m);
+#if W4B_DMA_IN_T
+                dma_piece(dstep, buf ^ 1, 5 * j + m);     // the next K step's patch request rides between the column groups of the transform
+                if (j == 1 && m == 4) dma_piece(dstep, buf ^ 1, 10);
+#endif
                 ts[m] = w4b_fma4(km5, e2, w4b_fma4(k4, e0, e4));
                 if (RH == 0) {                           // pair rows on patch rows 1..4
                     const f32x4 u = w4b_fma4(km4, e2, e4), w = w4b_fma4(km4, e1, e3);
@@ -459,7 +467,9 @@ __device__ __forceinline__ void w4b_kloop(const int rh, const int ch, const Wino
         W4B_KSTAMP(it, 0);
 #if defined(W4B_EXP) && (W4B_EXP & 8)
 #else
+#if !W4B_DMA_IN_T
         if (it + 1 < KS) dma(it + 1, buf ^ 1);
+#endif
 #endif
         W4B_KSTAMP(it, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -468,8 +478,8 @@ __device__ __forceinline__ void w4b_kloop(const int rh, const int ch, const Wino
             // wavefronts (four copies of it cost 9 % in instruction fetch: with every wavefront on the same role the launch takes 0.0955
             // instead of 0.1049 ms)
             const std::integral_constant<int, 0> i0; const std::integral_constant<int, 1> i1;
-            if (rh == 0) { if (ch == 0) t_all(i0, i0, buf, v); else t_all(i0, i1, buf, v); }
-            else { if (ch == 0) t_all(i1, i0, buf, v); else t_all(i1, i1, buf, v); }
+            if (rh == 0) { if (ch == 0) t_all(i0, i0, buf, v, it + 1); else t_all(i0, i1, buf, v, it + 1); }
+            else { if (ch == 0) t_all(i1, i0, buf, v, it + 1); else t_all(i1, i1, buf, v, it + 1); }
         }
         W4B_KSTAMP(it, 2);
         u32x4 af[2][3];
