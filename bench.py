@@ -466,7 +466,7 @@ def also_legs(dev):
     change or suppress the headline fields."""
     also = {}
     for name, fn in (('bf16', lambda: _timed_train_leg(dev, 'c1', 'bf16', 10, 3)), ('c3', lambda: _timed_train_leg(dev, 'c3', 'f32', 5, 2)),
-                     ('c4', lambda: _timed_rollout_leg(dev, 3))):
+                     ('c4', lambda: _timed_rollout_leg(dev, 5, warmup=2))):
         t0 = time.perf_counter()
         try:
             also[name] = fn()
