@@ -692,6 +692,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
                         *reinterpret_cast<f32x4*>(pbase + ((size_t)i * Wp + j) * g.ld_pool) = pv;
                     }
             }
+        } else if (fast && g.act != KPX_ACT_LRELU) {
+            // no activation / ReLU (block-uniform): bias + one max per element -- the general form below spends 19 vector instructions per 16-byte
+            // store on the leaky slope (compare, select, multiply per element), 600 per tile
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = Y[i][j] + bv;
+                    if (g.act == KPX_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                    }
+                    if (STATS) { st_s += v; st_q += v * v; }
+                    *reinterpret_cast<f32x4*>(obase + i * rstr + j * cstr) = v;
+                }
         } else if (fast) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
