@@ -658,8 +658,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const Wino43bGeom 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 v = Y[i][j] + bv;
+                    if (g.act == KPX_ACT_RELU) {          // (block-uniform; VGG19's forward: one max per element)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const float z = fmaxf(v[q], lo); v[q] = z > 0.f ? z : z * slope; }
+                        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+                    } else if (g.act == KPX_ACT_LRELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { const float z = v[q]; v[q] = z > 0.f ? z : z * slope; }
+                    }
                     Y[i][j] = v;
                 }
             if (g.mask_y) {
