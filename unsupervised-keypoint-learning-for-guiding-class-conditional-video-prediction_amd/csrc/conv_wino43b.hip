@@ -59,6 +59,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define W4B_DMA_IN_T 1                    // the next patch's eleven LDS-DMA pieces between the transform's column groups (texture addresser beside LDS reads /
                                            // VALU: -2 ... -5 % per launch against all of them before the transform = 0; the offsets then wait in spare AGPRs)
 #endif
+#ifndef W4B_U_AUX
+#define W4B_U_AUX 0                       // cache policy of the filter-fragment loads (measured: 1 = sc0 no change, 2 = nt 10-20 % slower -- every CU re-reads U from L2)
+#endif
 #ifndef W4B_RING
 #define W4B_RING 6                         // filter-fragment ring: units (must divide 18)
 #endif
@@ -284,7 +287,7 @@ __device__ __forceinline__ void w4b_kloop(const int rh, const int ch, const Wino
         const int so = ubase[unit >> 1] + (unit & 1) * 3072 + koff;
 #pragma unroll
         for (int tm = 0; tm < 3; ++tm)
-            ub[slot][tm] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, so + tm * 1024, 0));
+            ub[slot][tm] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, so + tm * 1024, W4B_U_AUX));
     };
 
     // ---- transform read base of this lane: pixel (4 ty + RH, 4 tx + CH) of the patch, channel quad 2 * octet.  Tile origins are 17 slots apart
@@ -371,13 +374,13 @@ __device__ __forceinline__ void w4b_kloop(const int rh, const int ch, const Wino
 #endif
 #if defined(W4B_EXP) && (W4B_EXP & 2)
 #else
-            if (q == 3) ub[sl0][2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane + 2048, so0, 0));
-            if (q == 4) ub[sl1][2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane + 2048, so1, 0));
-            if (q == 7) ub[sl0][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane + 1024, so0, 0));
-            if (q == 8) ub[sl1][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane + 1024, so1, 0));
+            if (q == 3) ub[sl0][2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane + 2048, so0, W4B_U_AUX));
+            if (q == 4) ub[sl1][2] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane + 2048, so1, W4B_U_AUX));
+            if (q == 7) ub[sl0][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane + 1024, so0, W4B_U_AUX));
+            if (q == 8) ub[sl1][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane + 1024, so1, W4B_U_AUX));
             if (q == 11) {
-                ub[sl0][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, so0, 0));
-                ub[sl1][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, so1, 0));
+                ub[sl0][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, so0, W4B_U_AUX));
+                ub[sl1][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsu, ulane, so1, W4B_U_AUX));
             }
 #endif
             if (st && q >= 1 && q <= 4) {
